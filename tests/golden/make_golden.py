@@ -1,0 +1,417 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE NumPy classes.
+
+Runs only in the build container (needs /root/reference); the .npz files it writes are
+committed and travel to the GPU box, this script's inputs (the reference) never do.
+
+The reference imports ``cupy``, ``numba``, ``numba.cuda`` and ``osqp`` unconditionally at
+module top (filter/particle.py:1-6, gaussian_sum_dist/MultivariateGaussianSum.py:2-3,
+controller.py:6) although its NumPy (CPU) classes never call into them.  Those four
+packages are not installed here, so inert placeholder modules are registered first; every
+number written below is computed by the reference's own NumPy code paths
+(ParticleFilter, GaussianSumUnscentedKalmanFilter, MultivariateGaussianSum(library=numpy),
+Bioreactor.homeostatic_DEs / static_outputs, sim_base.get_parts(gpu=False) / get_noise).
+
+Fixture list:
+  G1 model_fg.npz       f, g on 256 states x 4 (u, dt)
+  G2 mixture_pdf.npz    pdf of both mixtures on 256 points (down to exp(-700) underflow)
+  G3 resample.npz       systematic resample cases with recorded r -> ancestor index
+  G4 pf_trace.npz       ParticleFilter N=1024, 10 cycles: inputs, recorded noise/r, states
+  G5 gsukf_trace.npz    GS-UKF N in {1,7,64}: sigma points, predict, update, resample, estimates
+  G6 pf_stat.npz        posterior-mean envelope over independent seeds (statistical parity)
+  G7 constants.npz      mixture constants, inverse covariances, sigma weights, X_ss
+"""
+import os
+import sys
+import types
+
+import numpy
+
+REF = os.environ.get("GSE_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_placeholders():
+    cupy = types.ModuleType("cupy")
+    numba = types.ModuleType("numba")
+    cuda = types.ModuleType("numba.cuda")
+
+    def _passthrough(*args, **kwargs):
+        if len(args) == 1 and callable(args[0]) and not kwargs:
+            return args[0]
+        return lambda fn: fn
+
+    cuda.jit = _passthrough
+    numba.guvectorize = _passthrough
+    numba.cuda = cuda
+    osqp = types.ModuleType("osqp")
+
+    class OSQP:  # MPC is constructed by get_parts but never stepped here
+        def setup(self, *a, **k):
+            pass
+
+        def update(self, *a, **k):
+            pass
+
+        def solve(self):
+            raise RuntimeError("osqp is not available offline")
+
+    osqp.OSQP = OSQP
+    sys.modules.update({"cupy": cupy, "numba": numba, "numba.cuda": cuda, "osqp": osqp})
+
+
+_install_placeholders()
+sys.path.insert(0, REF)
+import sim_base  # noqa: E402  (reference)
+import filter as ref_filter  # noqa: E402  (reference)
+import gaussian_sum_dist as ref_gsd  # noqa: E402
+import model as ref_model  # noqa: E402
+
+f_ref = ref_model.Bioreactor.homeostatic_DEs
+g_ref = ref_model.Bioreactor.static_outputs
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    numpy.savez_compressed(path, **arrays)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrays.items()})
+
+
+def x_ss():
+    bio, _, _, _ = sim_base.get_parts(N_particles=2, gpu=False)
+    return numpy.array(bio.X, dtype=numpy.float64)
+
+
+class Recorder:
+    """Wraps a mixture's draw() so that every returned noise array is kept."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.log = []
+        self._orig = dist.draw
+        dist.draw = self._draw
+
+    def _draw(self, *a, **k):
+        out = self._orig(*a, **k)
+        self.log.append(numpy.array(out, copy=True))
+        return out
+
+
+class RandRecorder:
+    def __init__(self):
+        self.log = []
+        self._orig = numpy.random.rand
+
+    def __enter__(self):
+        def rand(*a):
+            v = self._orig(*a)
+            self.log.append(v)
+            return v
+
+        numpy.random.rand = rand
+        return self
+
+    def __exit__(self, *exc):
+        numpy.random.rand = self._orig
+
+
+# --------------------------------------------------------------------------- G7
+def gen_constants(X):
+    sp, mp = sim_base.get_noise(lib=numpy)
+    gf = ref_filter.GaussianSumUnscentedKalmanFilter(
+        f=f_ref, g=g_ref, N_particles=2, x0=sp, state_pdf=sp, measurement_pdf=mp)
+    save("constants.npz",
+         x_ss=X,
+         state_means=sp.means, state_covs=sp.covariances, state_weights=sp.weights,
+         state_consts=sp._constants, state_inv=sp._inverse_covariances,
+         meas_means=mp.means, meas_covs=mp.covariances, meas_weights=mp.weights,
+         meas_consts=mp._constants, meas_inv=mp._inverse_covariances,
+         w_sigma=gf._w_sigma)
+
+
+# --------------------------------------------------------------------------- G1
+def gen_model(X):
+    rng = numpy.random.default_rng(101)
+    xs = X[None, :] * (1 + 0.3 * rng.uniform(-1, 1, size=(256, 5)))
+    xs[:, 3] = rng.uniform(-0.05, 0.3, size=256)          # Ce is 0 at X_ss
+    xs[:16, 0] *= -1                                        # negative Cg  -> clamp
+    xs[16:32, 2] *= -1                                      # negative Cfa -> clamp
+    xs[32:40, 1] = 0.0                                      # Cx = 0
+    xs[40:48, 0] = 0.0                                      # Cg = 0 (0/(0.01+0))
+    xs[48:56, 4] *= -1                                      # Ch not clamped
+    xs[56:64, 0] = rng.uniform(0, 0.02, size=8)             # near the Monod knee
+    xs[64:96, 4] = rng.uniform(-40, 60, size=32)            # drive theta1_req across its clamps
+    xs32 = xs.astype(numpy.float32)
+    cases = [(numpy.array([0.06, 0.2]), 0.1),
+             (numpy.array([0.05, 0.15]), 1.0),
+             (numpy.array([0.0, 0.0]), 0.1002),
+             (numpy.array([0.0997, 0.1993]), 1.0)]
+    us = numpy.array([c[0] for c in cases])
+    dts = numpy.array([c[1] for c in cases])
+    # f is evaluated on float32 rows exactly as ParticleFilter.predict does (particle.py:65-66)
+    df = numpy.zeros((len(cases), 256, 5), dtype=numpy.float64)
+    gy = numpy.zeros((len(cases), 256, 2), dtype=numpy.float64)
+    x_after = numpy.zeros((len(cases), 256, 5), dtype=numpy.float32)
+    for c, (u, dt) in enumerate(cases):
+        work = xs32.copy()
+        for i in range(256):
+            inc = f_ref(xs32[i], u, dt)
+            df[c, i] = numpy.array([float(v) for v in inc])
+            work[i] += inc
+            gy[c, i] = numpy.array([float(v) for v in g_ref(xs32[i], u)])
+        x_after[c] = work
+    # same states handed over as float64 (the SURVEY's known-answer form)
+    df64 = numpy.zeros_like(df)
+    for c, (u, dt) in enumerate(cases):
+        for i in range(256):
+            df64[c, i] = numpy.array([float(v) for v in f_ref(xs32[i].astype(numpy.float64), u, dt)])
+    save("model_fg.npz", x=xs32, u=us, dt=dts, f_inc=df, f_inc_f64in=df64, g_out=gy, x_after=x_after)
+
+
+# --------------------------------------------------------------------------- G2
+def gen_pdf():
+    sp, mp = sim_base.get_noise(lib=numpy)
+    rng = numpy.random.default_rng(202)
+    # measurement mixture (Nx=2): residuals from tiny to far enough for exp() underflow
+    scale = numpy.concatenate([numpy.full(64, 0.3), numpy.full(64, 5.0),
+                               numpy.full(64, 80.0), numpy.full(64, 1500.0)])
+    e_meas = rng.normal(size=(256, 2)) * scale[:, None]
+    e_meas[:5] = numpy.array([[0.1, 0], [0, -0.1], [3, -2], [30, -40], [0.3, -0.5]])
+    p_meas = mp.pdf(e_meas)
+    # and the float32 route the GPU class takes (particle.py:290-293): es is float32
+    p_meas_f32 = mp.pdf(e_meas.astype(numpy.float32))
+    sd = numpy.sqrt(numpy.array([1e-3, 1e-6, 1e-2, 1e-2, 1e-6]))
+    mult = numpy.concatenate([numpy.full(128, 1.0), numpy.full(64, 6.0), numpy.full(64, 40.0)])
+    e_state = rng.normal(size=(256, 5)) * sd[None, :] * mult[:, None]
+    p_state = sp.pdf(e_state)
+    # non-normalised weights as in tests/ParticleFilter_test.py:41-52
+    toy = ref_gsd.MultivariateGaussianSum(
+        means=numpy.array([[1, 0], [0, -1]]),
+        covariances=numpy.array([[[0.1, 0], [0, 0.1]], [[0.2, 0.01], [0.01, 0.005]]]),
+        weights=numpy.array([0.7, 0.9]), library=numpy)
+    e_toy = rng.normal(size=(64, 2))
+    p_toy = toy.pdf(e_toy)
+    save("mixture_pdf.npz", e_meas=e_meas, p_meas=p_meas, p_meas_f32=p_meas_f32,
+         e_state=e_state, p_state=p_state,
+         toy_means=toy.means, toy_covs=toy.covariances, toy_weights=toy.weights,
+         toy_consts=toy._constants, toy_inv=toy._inverse_covariances, e_toy=e_toy, p_toy=p_toy)
+
+
+# --------------------------------------------------------------------------- G3
+def ref_resample_idx(weights, r):
+    """Runs ParticleFilter.resample (particle.py:85-103) on a filter whose particles are
+    their own row numbers, so that the gathered particles reveal the ancestor index."""
+    n = len(weights)
+    pf = ref_filter.ParticleFilter.__new__(ref_filter.ParticleFilter)
+    pf.N_particles = n
+    pf.particles = numpy.arange(n, dtype=numpy.int64)[:, None].repeat(5, axis=1)
+    pf.weights = numpy.array(weights, copy=True)
+    orig = numpy.random.rand
+    numpy.random.rand = lambda *a: r
+    try:
+        pf.resample()
+    finally:
+        numpy.random.rand = orig
+    return pf.particles[:, 0].copy()
+
+
+def gen_resample():
+    rng = numpy.random.default_rng(303)
+    out = {}
+    cases = []
+    cases.append(("known8", numpy.array([.05, .30, 0, .10, .25, 0, .20, .10]), 0.6964691855978616))
+    cases.append(("uniform8", numpy.full(8, 1 / 8), 0.0))
+    cases.append(("uniform1000", numpy.full(1000, 1 / 1000), 0.37))
+    w = rng.random(1000)
+    cases.append(("random1000", w / w.sum(), rng.random()))
+    w = numpy.zeros(1000)
+    w[617] = 1.0
+    cases.append(("onehot1000", w, 0.5))
+    w = rng.random(4096)
+    w[::2] = 0
+    cases.append(("zeros_interleaved4096", w, rng.random()))
+    w = rng.random(4096) ** 8
+    cases.append(("skewed4096", w, rng.random()))
+    w = numpy.exp(-0.5 * ((numpy.arange(4096) - 1000) / 3.0) ** 2) + 1e-30
+    cases.append(("peaked4096", w, 0.999999))
+    w = rng.random(5000)
+    cases.append(("unnormalised5000", w * 37.5, rng.random()))
+    cases.append(("single1", numpy.array([0.3]), 0.25))
+    w = rng.random(2049)
+    cases.append(("random2049", w, rng.random()))
+    names = []
+    for name, w, r in cases:
+        # weights that are exactly float32-representable, handed to the reference as float64
+        # (the dtype ParticleFilter.weights has after its first resample, particle.py:103)
+        w32 = w.astype(numpy.float32)
+        idx = ref_resample_idx(w32.astype(numpy.float64), float(r))
+        out[name + "_w"] = w32
+        out[name + "_r"] = numpy.float64(r)
+        out[name + "_idx"] = idx
+        names.append(name)
+    out["names"] = numpy.array(names)
+    save("resample.npz", **out)
+
+
+# --------------------------------------------------------------------------- G4
+def plant_step(x_true, u, dt, sp, mp):
+    """A realistic measurement sequence: Euler plant step + state noise, z = g(x) + noise."""
+    x_true = x_true + numpy.array([float(v) for v in f_ref(x_true, u, dt)])
+    x_true = x_true + sp.draw().squeeze().astype(numpy.float64)
+    z = numpy.array([float(v) for v in g_ref(x_true, u)]) + mp.draw().squeeze().astype(numpy.float64)
+    return x_true, z
+
+
+def gen_pf_trace(X, n=1024, cycles=10, seed=404):
+    numpy.random.seed(seed)
+    _, _, _, pf = sim_base.get_parts(N_particles=n, gpu=False)
+    plant_sp, plant_mp = sim_base.get_noise(lib=numpy)
+    rec = Recorder(pf.state_pdf)
+    x_true = X.copy()
+    keys = dict(x0=pf.particles.copy(), w0=pf.weights.copy())
+    us, zs, dts, rs = [], [], [], []
+    p_pred, p_res, w_upd, noises, idxs, est, cov = [], [], [], [], [], [], []
+    for c in range(cycles):
+        u = numpy.array([numpy.random.uniform(0.03, 0.09), numpy.random.uniform(0.1, 0.3)])
+        dt = 0.1 if c % 2 == 0 else 1.0
+        x_true, z = plant_step(x_true, u, dt, plant_sp, plant_mp)
+        pf.predict(u, dt)
+        p_pred.append(pf.particles.copy())
+        noises.append(rec.log[-1])
+        pf.update(u, z)
+        w_upd.append(numpy.array(pf.weights, dtype=numpy.float64))
+        # ancestor index: rerun the reference's own resample on row numbers with the same r
+        with RandRecorder() as rr:
+            pf.resample()
+        r = float(rr.log[-1])
+        idxs.append(ref_resample_idx(w_upd[-1] if c > 0 else pf_weights_f32(w_upd[-1]), r))
+        p_res.append(pf.particles.copy())
+        est.append(numpy.array(pf.point_estimate(), dtype=numpy.float64))
+        cov.append(float(pf.point_covariance()))
+        us.append(u), zs.append(z), dts.append(dt), rs.append(r)
+    keys.update(u=numpy.array(us), z=numpy.array(zs), dt=numpy.array(dts), r=numpy.array(rs),
+                noise=numpy.array(noises), after_predict=numpy.array(p_pred),
+                w_after_update=numpy.array(w_upd), idx=numpy.array(idxs),
+                after_resample=numpy.array(p_res), estimate=numpy.array(est), cov_sv=numpy.array(cov))
+    save("pf_trace.npz", **keys)
+
+
+def pf_weights_f32(w):
+    # in the first cycle ParticleFilter.weights is still float32 (particle.py:50)
+    return numpy.asarray(w, dtype=numpy.float32)
+
+
+# --------------------------------------------------------------------------- G5
+def gen_gsukf(X, seed=505):
+    out = {}
+    for n in (1, 7, 64):
+        numpy.random.seed(seed + n)
+        _, _, _, gf = sim_base.get_parts(N_particles=n, gpu=False, pf=False)
+        plant_sp, plant_mp = sim_base.get_noise(lib=numpy)
+        rec = Recorder(gf.state_pdf)
+        x_true = X.copy()
+        tag = "n%d_" % n
+        out[tag + "means0"] = gf.means.copy()
+        out[tag + "covs0"] = gf.covariances.copy()
+        out[tag + "w0"] = gf.weights.copy()
+        out[tag + "sigmas0"] = gf._get_sigma_points().copy()
+        cyc = 6
+        store = {k: [] for k in ("u", "z", "dt", "r", "noise", "m_pred", "P_pred", "sig_upd", "m_upd",
+                                 "P_upd", "w_upd", "idx", "m_res", "P_res", "est", "cov_sv")}
+        for c in range(cyc):
+            u = numpy.array([numpy.random.uniform(0.03, 0.09), numpy.random.uniform(0.1, 0.3)])
+            dt = 0.1 if c % 2 == 0 else 1.0
+            x_true, z = plant_step(x_true, u, dt, plant_sp, plant_mp)
+            gf.predict(u, dt)
+            store["noise"].append(rec.log[-1])
+            store["m_pred"].append(gf.means.copy())
+            store["P_pred"].append(gf.covariances.copy())
+            store["sig_upd"].append(gf._get_sigma_points().copy())
+            gf.update(u, z)
+            store["m_upd"].append(gf.means.copy())
+            store["P_upd"].append(gf.covariances.copy())
+            store["w_upd"].append(numpy.array(gf.weights, dtype=numpy.float64))
+            w_before = gf.weights.copy()
+            with RandRecorder() as rr:
+                gf.resample()
+            r = float(rr.log[-1])
+            store["idx"].append(ref_resample_idx(w_before, r))
+            store["m_res"].append(gf.means.copy())
+            store["P_res"].append(gf.covariances.copy())
+            store["est"].append(numpy.array(gf.point_estimate(), dtype=numpy.float64))
+            store["cov_sv"].append(float(gf.point_covariance()))
+            store["u"].append(u), store["z"].append(z), store["dt"].append(dt), store["r"].append(r)
+        for k, v in store.items():
+            out[tag + k] = numpy.array(v)
+    # the SURVEY's single-Gaussian known answer (update then noise-free predict)
+    sp, mp = sim_base.get_noise(lib=numpy)
+    x0, _ = sim_base.get_noise(lib=numpy)
+    x0.means = X[None, :].astype(numpy.float32)
+    numpy.random.seed(1)
+    gf = ref_filter.GaussianSumUnscentedKalmanFilter(f=f_ref, g=g_ref, N_particles=2, x0=x0,
+                                                      state_pdf=sp, measurement_pdf=mp)
+    gf.means = numpy.repeat(X[None, :].astype(numpy.float32), 2, axis=0)
+    u = numpy.array([0.06, 0.2])
+    z = numpy.array([280.3, 610.95])
+    gf.update(u, z)
+    out["ka_m_upd"], out["ka_P_upd"], out["ka_w_upd"] = gf.means.copy(), gf.covariances.copy(), gf.weights.copy()
+    zero = numpy.zeros((2, 11, 5), dtype=numpy.float32)
+    sp.draw = lambda *a, **k: zero
+    gf.predict(u, 0.1)
+    out["ka_m_pred"], out["ka_P_pred"] = gf.means.copy(), gf.covariances.copy()
+    out["ka_u"], out["ka_z"] = u, z
+    save("gsukf_trace.npz", **out)
+
+
+# --------------------------------------------------------------------------- G6
+def gen_pf_stat(X, seed=606):
+    """Posterior-mean envelope of the reference PF over independent seeds on ONE fixed
+    (u, z) sequence; the Philox-driven HIP filter must land inside it (3 sigma)."""
+    rng = numpy.random.default_rng(seed)
+    cycles = 30
+    plant_sp, plant_mp = sim_base.get_noise(lib=numpy)
+    numpy.random.seed(seed)
+    x_true = X.copy()
+    us, zs = [], []
+    for c in range(cycles):
+        u = numpy.array([rng.uniform(0.03, 0.09), rng.uniform(0.1, 0.3)])
+        x_true, z = plant_step(x_true, u, 0.1, plant_sp, plant_mp)
+        us.append(u), zs.append(z)
+    us, zs = numpy.array(us), numpy.array(zs)
+    out = dict(u=us, z=zs, dt=numpy.float64(0.1))
+    for n, seeds in ((1024, 48), (8192, 6)):
+        ests = numpy.zeros((seeds, cycles, 5))
+        covs = numpy.zeros((seeds, cycles))
+        for s in range(seeds):
+            numpy.random.seed(7000 + 13 * s + n)
+            _, _, _, pf = sim_base.get_parts(N_particles=n, gpu=False)
+            for c in range(cycles):
+                pf.predict(us[c], 0.1)
+                pf.update(us[c], zs[c])
+                pf.resample()
+                ests[s, c] = pf.point_estimate()
+                covs[s, c] = pf.point_covariance()
+            print("  stat n=%d seed %d/%d" % (n, s + 1, seeds), flush=True)
+        out["est_n%d" % n] = ests
+        out["cov_n%d" % n] = covs
+    save("pf_stat.npz", **out)
+
+
+if __name__ == "__main__":
+    which = set(sys.argv[1:]) or {"constants", "model", "pdf", "resample", "pf", "gsukf", "stat"}
+    Xss = x_ss()
+    print("X_ss =", Xss)
+    if "constants" in which:
+        gen_constants(Xss)
+    if "model" in which:
+        gen_model(Xss)
+    if "pdf" in which:
+        gen_pdf()
+    if "resample" in which:
+        gen_resample()
+    if "pf" in which:
+        gen_pf_trace(Xss)
+    if "gsukf" in which:
+        gen_gsukf(Xss)
+    if "stat" in which:
+        gen_pf_stat(Xss)
