@@ -1,0 +1,110 @@
+"""ctypes binding of libgse_hip.so (the C ABI declared in include/gse.h).
+
+There is no fallback: if the library is missing, or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgse_hip.so")
+
+GSE_NX, GSE_NU, GSE_NY, GSE_NSIGMA = 5, 2, 2, 11
+GSE_MAX_ND, GSE_MAX_B, GSE_TILE = 4, 32, 1024
+GSE_RESAMPLE_TILES_VALID = 1
+
+c_f = ctypes.c_float
+c_d = ctypes.c_double
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_u32 = ctypes.c_uint32
+c_u64 = ctypes.c_uint64
+c_vp = ctypes.c_void_p
+
+
+class Mixture(ctypes.Structure):
+    """struct gse_mixture (include/gse.h)."""
+    _fields_ = [("nd", c_i32), ("nx", c_i32),
+                ("weights", c_f * GSE_MAX_ND),
+                ("consts", c_f * GSE_MAX_ND),
+                ("means", (c_f * GSE_NX) * GSE_MAX_ND),
+                ("chol", ((c_f * GSE_NX) * GSE_NX) * GSE_MAX_ND),
+                ("inv_cov", ((c_d * GSE_NX) * GSE_NX) * GSE_MAX_ND)]
+
+
+class Rng(ctypes.Structure):
+    """struct gse_rng (include/gse.h)."""
+    _fields_ = [("seed", c_u64), ("step", c_u64), ("element_offset", c_u64),
+                ("filter_offset", c_u32), ("reserved", c_u32)]
+
+
+P_MIX = ctypes.POINTER(Mixture)
+P_RNG = ctypes.POINTER(Rng)
+P_D = ctypes.POINTER(c_d)
+P_F = ctypes.POINTER(c_f)
+
+# name -> (restype, argtypes); device pointers are passed as integers (tensor.data_ptr()).
+PROTOTYPES = {
+    "gse_version": (ctypes.c_int, []),
+    "gse_last_error": (ctypes.c_char_p, []),
+    "gse_workspace_bytes": (c_i64, [ctypes.c_int, c_i64]),
+    "gse_pf_predict": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_d, P_MIX, P_RNG, c_vp]),
+    "gse_pf_predict_injected": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_d, c_vp, c_vp]),
+    "gse_pf_update": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_i64, P_D, P_D, P_MIX, c_vp, c_vp]),
+    "gse_pf_resample": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_u32, c_vp, c_vp]),
+    "gse_pf_moments": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
+    "gse_gsukf_sigma_points": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
+    "gse_gsukf_predict": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_F, P_MIX, P_RNG, c_vp, c_vp, c_vp]),
+    "gse_gsukf_update": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, P_D, P_F, P_MIX, c_vp, c_vp, c_vp]),
+    "gse_gsukf_resample": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_u32, c_vp, c_vp]),
+    "gse_gsukf_moments": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
+    "gse_model_f": (ctypes.c_int, [c_vp, c_vp, c_i64, P_D, c_d, c_vp]),
+    "gse_model_g": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "gse_mixture_pdf_f32": (ctypes.c_int, [c_vp, c_i64, P_MIX, c_vp, c_vp]),
+    "gse_mixture_pdf_f64": (ctypes.c_int, [c_vp, c_i64, P_MIX, c_vp, c_vp]),
+    "gse_mixture_draw": (ctypes.c_int, [c_vp, c_i64, c_i64, P_MIX, P_RNG, c_vp]),
+    "gse_cumsum_normalised": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "gse_systematic_index": (ctypes.c_int, [c_vp, c_vp, c_i64, c_d, c_vp]),
+    "gse_rng_raw": (ctypes.c_int, [c_vp, c_i64, P_RNG, c_u32, c_vp]),
+}
+
+_lib = None
+
+
+class GseError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgse_hip.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "gpu_se_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `python gpu_se_amd/build.py`).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().gse_last_error()
+        raise GseError("libgse_hip: error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))
+
+
+def doubles(values, n):
+    """Host array-like -> ctypes double[n]."""
+    vals = [float(v) for v in values]
+    if len(vals) != n:
+        raise ValueError("expected %d values, got %d" % (n, len(vals)))
+    return (c_d * n)(*vals)

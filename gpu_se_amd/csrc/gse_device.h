@@ -1,0 +1,248 @@
+// gse_device.h -- device-side building blocks shared by the gfx950 kernels of libgse_hip.so.
+//
+//   * Philox4x32-10 counter-based RNG held entirely in registers (Salmon et al., SC'11) + Box-Muller
+//   * the bioreactor model: Euler increment f (fp64 arithmetic on fp32 states) and observation g
+//       -- restates Bioreactor.homeostatic_DEs / static_outputs (model/BioreactorModel.py:170-253)
+//   * the 2-d measurement mixture density in fp64 (MultivariateGaussianSum.pdf, MultivariateGaussianSum.py:39-63)
+//   * 64-wide wavefront reductions / scans (fp64) and their 256-thread block forms
+//
+// Written for CDNA4 only: wavefront = 64, no dual paths.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gse.h"
+
+namespace gse {
+
+constexpr int kBlock = 256;               // threads per workgroup (4 wavefronts)
+constexpr int kPerThread = 4;             // particles per thread (one dwordx4 per state row)
+constexpr int kTile = GSE_TILE;           // particles per workgroup = weight-tile size
+static_assert(kBlock * kPerThread == kTile, "tile = block x 4");
+
+// ------------------------------------------------------------------------------------------------
+// Per-filter host inputs, carried in the kernel-argument segment (no H2D copy).
+// ------------------------------------------------------------------------------------------------
+struct FilterIO {
+    double u0, u1;      // inputs Fg_in, Fm_in
+    double z0, z1;      // measurement (update) -- or {r, unused} for resample
+};
+struct FilterIOs {
+    FilterIO f[GSE_MAX_B];
+};
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10
+// ------------------------------------------------------------------------------------------------
+struct RngKey {
+    uint32_t k0, k1;            // seed
+    uint32_t step_lo;           // counter word 2
+    uint32_t hi;                // counter word 3 template: (step_hi & 0xff) << 24 | purpose << 20 | filter0
+    uint64_t elem0;             // global index of element 0
+};
+
+enum : uint32_t { kPurposePrior = 0, kPurposePredict = 1, kPurposeDraw = 2, kPurposeGsukf = 3 };
+
+__host__ __device__ inline RngKey make_rng_key(const gse_rng& r, uint32_t purpose) {
+    RngKey k;
+    k.k0 = (uint32_t)r.seed;
+    k.k1 = (uint32_t)(r.seed >> 32);
+    k.step_lo = (uint32_t)r.step;
+    k.hi = (((uint32_t)(r.step >> 32) & 0xffu) << 24) | ((purpose & 0xfu) << 20) | (r.filter_offset & 0xffffu);
+    k.elem0 = r.element_offset;
+    return k;
+}
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += W0;
+        k1 += W1;
+    }
+}
+
+// The 8 random words of element `elem` (filter `fb` of this call): two Philox blocks, sub = 0, 1.
+__device__ __forceinline__ void rng_words8(const RngKey& key, uint64_t elem, uint32_t fb, uint32_t (&out)[8]) {
+    const uint64_t e = key.elem0 + elem;
+    const uint32_t hi = key.hi + fb;                // filter id lives in the low 16 bits
+#pragma unroll
+    for (uint32_t sub = 0; sub < 2; ++sub) {
+        uint32_t c[4] = {(uint32_t)e, (uint32_t)(e >> 32), key.step_lo, hi | (sub << 16)};
+        philox4x32_10(c, key.k0, key.k1);
+        out[4 * sub + 0] = c[0]; out[4 * sub + 1] = c[1]; out[4 * sub + 2] = c[2]; out[4 * sub + 3] = c[3];
+    }
+}
+
+// Box-Muller on two 32-bit words: u1 = (a + 0.5) / 2^32 in (0, 1], angle = b / 2^32 revolutions.
+// v_sin_f32 / v_cos_f32 take their argument in revolutions, so no 2*pi multiply is needed.
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float u1 = fmaf((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    const float rev = (float)b * 2.3283064365386963e-10f;
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
+    n0 = r * __builtin_amdgcn_cosf(rev);
+    n1 = r * __builtin_amdgcn_sinf(rev);
+}
+
+// Parameters of a Gaussian-sum draw, staged in LDS by each workgroup (component index is per lane).
+struct DrawParams {
+    int32_t nd, nx;
+    float cumw[GSE_MAX_ND];                 // normalised cumulative component weights
+    float mean[GSE_MAX_ND][GSE_NX];
+    float chol[GSE_MAX_ND][15];             // packed lower triangle, row-major: (0,0) (1,0) (1,1) (2,0) ...
+};
+
+// One draw from the mixture for a 5-d state: words -> component + 5 normals -> mean + L n.
+__device__ __forceinline__ void mixture_draw5(const DrawParams& dp, const uint32_t (&wd)[8], float (&out)[5]) {
+    float n[6];
+    box_muller(wd[0], wd[1], n[0], n[1]);
+    box_muller(wd[2], wd[3], n[2], n[3]);
+    box_muller(wd[4], wd[5], n[4], n[5]);
+    const float uc = (float)(wd[7] >> 8) * 5.9604644775390625e-08f;   // [0, 1) with 24 bits
+    int comp = 0;
+#pragma unroll
+    for (int d = 0; d < GSE_MAX_ND - 1; ++d) comp += (d < dp.nd - 1 && uc >= dp.cumw[d]) ? 1 : 0;
+    const float* L = dp.chol[comp];
+    const float* m = dp.mean[comp];
+    int at = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        float acc = m[k];
+#pragma unroll
+        for (int j = 0; j <= k; ++j) acc = fmaf(L[at + j], n[j], acc);
+        at += k + 1;
+        out[k] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bioreactor model.  fp64 arithmetic in the reference's operation order; contraction into FMA is
+// switched off so that the increment is bit-identical to an IEEE evaluation on the host.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bioreactor_increment(const float (&x)[5], double fg, double fm, double dt,
+                                                     double (&dx)[5]) {
+#pragma clang fp contract(off)
+    const double cg_in = 5000.0 / 180.0;
+    const double cg = fmax((double)x[0], 0.0);
+    const double cx = fmax((double)x[1], 0.0);
+    const double cfa = fmax((double)x[2], 0.0);
+    const double ce = fmax((double)x[3], 0.0);
+    const double ch = (double)x[4];
+    const double f_out = fg + fm;
+    const double r_x = 0.0 * cx;
+    const double r_h = 280.0 / 180.0 - cg;
+    const double monod = cg / (1e-2 + cg);
+    const double r_fa = (0.25 / 116.0 * cx * 24.6) * monod;
+    const double th1_max = (0.4 - 0.25) / 180.0 * cx * 24.6;
+    const double th1_req = th1_max - (th1_max / 2000.0 / (0.28 / 180.0) * r_h + 0.01 * ch);
+    const double th1 = fmin(th1_max, fmax(0.0, th1_req)) * monod;
+    const double e_max = 0.025 / 46.0 * cx * 24.6;
+    const double e_req = th1_req - th1_max;
+    const double r_e = fmin(e_max, fmax(0.0, e_req));
+    const double th2_max = (0.1 - 0.025) / 180.0 * cx * 24.6;
+    const double th2_req = th1_req - th1_max - r_e;
+    const double th2 = fmin(th2_max, fmax(0.0, th2_req));
+    const double r_g = -r_fa * (116.0 / 180.0) - th1 - r_e * (46.0 / 180.0) - th2;
+    dx[0] = (fg * cg_in - f_out * cg + r_g) * dt;
+    dx[1] = r_x * dt;
+    dx[2] = (-f_out * cfa + r_fa) * dt;
+    dx[3] = (-f_out * ce + r_e) * dt;
+    dx[4] = r_h * dt;
+}
+
+// x += f(x): one rounding of the fp64 sum to fp32 (what "row_f32 += tuple_f64" does in NumPy).
+__device__ __forceinline__ void bioreactor_step(float (&x)[5], double fg, double fm, double dt) {
+    double dx[5];
+    bioreactor_increment(x, fg, fm, dt, dx);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) x[k] = (float)((double)x[k] + dx[k]);
+}
+
+// g(x) = (Cg*180, Cfa*116) as correctly rounded fp32 products.
+__device__ __forceinline__ void bioreactor_output(float cg, float cfa, float& y0, float& y1) {
+    y0 = cg * 180.0f;
+    y1 = cfa * 116.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Measurement mixture density (Ny = 2), fp64.
+// ------------------------------------------------------------------------------------------------
+struct Pdf2 {
+    int32_t nd, pad;
+    double cw[GSE_MAX_ND];                 // (double) fp32(const_d * weight_d)
+    double mean[GSE_MAX_ND][2];
+    double inv[GSE_MAX_ND][2][2];
+};
+
+__device__ __forceinline__ double mixture_pdf2(const Pdf2& m, double e0, double e1) {
+#pragma clang fp contract(off)
+    double total = 0.0;
+    for (int d = 0; d < m.nd; ++d) {
+        const double a0 = e0 - m.mean[d][0], a1 = e1 - m.mean[d][1];
+        const double t0 = a0 * m.inv[d][0][0] + a1 * m.inv[d][1][0];
+        const double t1 = a0 * m.inv[d][0][1] + a1 * m.inv[d][1][1];
+        const double q = t0 * a0 + t1 * a1;
+        const double term = m.cw[d] * exp(-0.5 * q);
+        total = (d == 0) ? term : total + term;
+    }
+    return total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wavefront / workgroup collectives (fp64).  All lanes of the workgroup must call these.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Inclusive scan across the 64 lanes of a wavefront.
+__device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Sum over the 256-thread workgroup; result valid in every thread.  lds: >= 4 doubles.
+__device__ __forceinline__ double block_sum(double v, double* lds) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();                      // protect lds against a previous use
+    if (lane == 0) lds[wv] = v;
+    __syncthreads();
+    return (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// Exclusive scan over the workgroup of one value per thread; also returns the workgroup total.
+__device__ __forceinline__ double block_exclusive_scan(double v, double* lds, double& total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double inc = wave_inclusive_scan(v, lane);
+    __syncthreads();
+    if (lane == 63) lds[wv] = inc;
+    __syncthreads();
+    double base = 0.0;
+    const double w0 = lds[0], w1 = lds[1], w2 = lds[2], w3 = lds[3];
+    if (wv > 0) base = w0;
+    if (wv > 1) base += w1;
+    if (wv > 2) base += w2;
+    total = ((w0 + w1) + w2) + w3;
+    double exc = __shfl_up(inc, 1, 64);
+    if (lane == 0) exc = 0.0;
+    return base + exc;
+}
+
+}  // namespace gse

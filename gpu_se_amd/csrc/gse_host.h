@@ -1,0 +1,112 @@
+// gse_host.h -- host-side helpers of the C ABI: error reporting, argument checks, kernel-argument packing.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "gse.h"
+#include "gse_device.h"
+
+namespace gse {
+
+// Thread-local message behind gse_last_error().
+char* last_error_buffer();
+int fail(int code, const char* fmt, ...);
+
+#define GSE_REQUIRE(cond, ...)                                        \
+    do {                                                              \
+        if (!(cond)) return ::gse::fail(GSE_ERR_ARG, __VA_ARGS__);    \
+    } while (0)
+
+#define GSE_HIP_CHECK(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return ::gse::fail(GSE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+// After a kernel launch: report launch-time errors without synchronising.
+#define GSE_LAUNCH_CHECK(name)                                                                       \
+    do {                                                                                             \
+        hipError_t e_ = hipGetLastError();                                                           \
+        if (e_ != hipSuccess)                                                                        \
+            return ::gse::fail(GSE_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int64_t tiles_of(int64_t n) { return (n + kTile - 1) / kTile; }
+
+// Common geometry checks for the state-major particle-filter layout.
+int check_pf_geometry(const char* fn, int B, int64_t N, int64_t ld);
+int check_mixture(const char* fn, const gse_mixture* m, int nx);
+
+// Packing of host inputs into kernel-argument structs.
+void pack_io(FilterIOs& io, int B, const double* u, const double* z);
+void pack_draw(DrawParams& dp, const gse_mixture& m);
+void pack_pdf2(Pdf2& p, const gse_mixture& m);
+
+// Workspace carving (all offsets multiples of 256 bytes).
+struct Workspace {
+    double* tile_sums;     // [B][T]
+    double* tile_prefix;   // [B][T + 1]   exclusive prefix of tile sums; [T] = total
+    double* partials;      // [B][kMomentBlocks][kMomentWidth]
+    int64_t bytes;
+};
+constexpr int kMomentBlocks = 512;
+constexpr int kMomentWidth = 48;
+Workspace carve_workspace(void* base, int B, int64_t N);
+
+// ---- shared between gse_pf.hip (definitions) and gse_gsukf.hip ------------------------------------------
+struct ResampleArgs {
+    double r[GSE_MAX_B];
+};
+
+// Payload = what the resample kernel copies from ancestor to offspring.
+struct PfPayload {                    // state-major particle rows
+    const float* __restrict__ in;
+    float* __restrict__ out;
+    int64_t ld;
+    __device__ __forceinline__ void copy(int b, int64_t anc, int64_t j) const {
+        const float* s = in + (int64_t)b * GSE_NX * ld + anc;
+        float* d = out + (int64_t)b * GSE_NX * ld + j;
+        float v[GSE_NX];
+#pragma unroll
+        for (int k = 0; k < GSE_NX; ++k) v[k] = s[k * ld];
+#pragma unroll
+        for (int k = 0; k < GSE_NX; ++k) d[k * ld] = v[k];
+    }
+};
+
+struct GsukfPayload {                 // row-major (mu[5], P[25]) per Gaussian
+    const float* __restrict__ mu_in;
+    const float* __restrict__ P_in;
+    float* __restrict__ mu_out;
+    float* __restrict__ P_out;
+    int64_t N;
+    __device__ __forceinline__ void copy(int b, int64_t anc, int64_t j) const {
+        const float* sm = mu_in + ((int64_t)b * N + anc) * 5;
+        const float* sp = P_in + ((int64_t)b * N + anc) * 25;
+        float* dm = mu_out + ((int64_t)b * N + j) * 5;
+        float* dp = P_out + ((int64_t)b * N + j) * 25;
+        float v[30];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = sm[k];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) v[5 + k] = sp[k];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dm[k] = v[k];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) dp[k] = v[5 + k];
+    }
+};
+
+void launch_tile_sums(const float* w, double* tile_sums, int B, int64_t N, int64_t ldw, int T, hipStream_t st);
+void launch_tile_scan(const double* tile_sums, double* prefix, int B, int T, hipStream_t st);
+void launch_gsukf_resample(const GsukfPayload& pl, const float* w, float* w_out, int32_t* idx, const double* prefix,
+                           int B, int64_t N, int T, const ResampleArgs& ra, hipStream_t st);
+void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
+                           const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, hipStream_t st);
+
+}  // namespace gse

@@ -1,0 +1,108 @@
+// gse_host.hip -- host-side plumbing of the C ABI: error text, argument checks, kernel-argument packing,
+// workspace layout, gse_version / gse_last_error / gse_workspace_bytes.
+#include "gse_host.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace gse {
+
+char* last_error_buffer() {
+    static thread_local char buf[512] = "";
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_pf_geometry(const char* fn, int B, int64_t N, int64_t ld) {
+    GSE_REQUIRE(B >= 1 && B <= GSE_MAX_B, "%s: B = %d is outside 1..%d", fn, B, GSE_MAX_B);
+    GSE_REQUIRE(N >= 1, "%s: N = %lld must be positive", fn, (long long)N);
+    GSE_REQUIRE(ld >= N && (ld & 3) == 0, "%s: ld = %lld must be >= N = %lld and a multiple of 4", fn, (long long)ld,
+                (long long)N);
+    GSE_REQUIRE(tiles_of(N) <= 0x7fffffff / 2, "%s: N = %lld is too large", fn, (long long)N);
+    return GSE_OK;
+}
+
+int check_mixture(const char* fn, const gse_mixture* m, int nx) {
+    GSE_REQUIRE(m->nd >= 1 && m->nd <= GSE_MAX_ND, "%s: mixture has nd = %d, supported 1..%d", fn, m->nd, GSE_MAX_ND);
+    GSE_REQUIRE(m->nx == nx, "%s: mixture has nx = %d, this entry point needs nx = %d", fn, m->nx, nx);
+    return GSE_OK;
+}
+
+void pack_io(FilterIOs& io, int B, const double* u, const double* z) {
+    for (int b = 0; b < B; ++b) {
+        io.f[b].u0 = u ? u[2 * b + 0] : 0.0;
+        io.f[b].u1 = u ? u[2 * b + 1] : 0.0;
+        io.f[b].z0 = z ? z[2 * b + 0] : 0.0;
+        io.f[b].z1 = z ? z[2 * b + 1] : 0.0;
+    }
+}
+
+void pack_draw(DrawParams& dp, const gse_mixture& m) {
+    memset(&dp, 0, sizeof(dp));
+    dp.nd = m.nd;
+    dp.nx = m.nx;
+    double total = 0.0;
+    for (int d = 0; d < m.nd; ++d) total += (double)m.weights[d];
+    double run = 0.0;
+    for (int d = 0; d < m.nd; ++d) {
+        run += (double)m.weights[d];
+        dp.cumw[d] = (float)(run / total);
+        int at = 0;
+        for (int k = 0; k < GSE_NX; ++k) {
+            dp.mean[d][k] = k < m.nx ? m.means[d][k] : 0.f;
+            for (int j = 0; j <= k; ++j) dp.chol[d][at++] = (k < m.nx && j < m.nx) ? m.chol[d][k][j] : 0.f;
+        }
+    }
+    for (int d = m.nd; d < GSE_MAX_ND; ++d) dp.cumw[d] = 2.0f;
+}
+
+void pack_pdf2(Pdf2& p, const gse_mixture& m) {
+    memset(&p, 0, sizeof(p));
+    p.nd = m.nd;
+    for (int d = 0; d < m.nd; ++d) {
+        p.cw[d] = (double)(m.consts[d] * m.weights[d]);          // fp32 product, then widened (MultivariateGaussianSum.py:61)
+        for (int i = 0; i < 2; ++i) {
+            p.mean[d][i] = (double)m.means[d][i];
+            for (int j = 0; j < 2; ++j) p.inv[d][i][j] = m.inv_cov[d][i][j];
+        }
+    }
+}
+
+static int64_t round256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+Workspace carve_workspace(void* base, int B, int64_t N) {
+    const int64_t T = tiles_of(N);
+    Workspace ws;
+    char* p = static_cast<char*>(base);
+    int64_t at = 0;
+    ws.tile_sums = reinterpret_cast<double*>(p + at);
+    at += round256((int64_t)B * T * 8);
+    ws.tile_prefix = reinterpret_cast<double*>(p + at);
+    at += round256((int64_t)B * (T + 1) * 8);
+    ws.partials = reinterpret_cast<double*>(p + at);
+    at += round256((int64_t)B * kMomentBlocks * kMomentWidth * 8);
+    ws.bytes = at;
+    return ws;
+}
+
+}  // namespace gse
+
+extern "C" {
+
+int gse_version(void) { return GSE_VERSION; }
+
+const char* gse_last_error(void) { return gse::last_error_buffer(); }
+
+int64_t gse_workspace_bytes(int B, int64_t N) {
+    if (B < 1 || B > GSE_MAX_B || N < 1) return gse::fail(GSE_ERR_ARG, "gse_workspace_bytes: bad B = %d or N = %lld", B, (long long)N);
+    return gse::carve_workspace(nullptr, B, N).bytes;
+}
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+// gse_rows.hip -- the stand-alone pieces the reference's per-subroutine benchmarks call one at a time
+// (results/pf_openloop/pf_run_seq.py:134-296): row-wise f / g, mixture pdf / draw, normalised cumulative sum,
+// systematic index from a cumulative sum, and the raw RNG words.  The filters themselves use the fused
+// kernels in gse_pf.hip / gse_gsukf.hip; these exist for API completeness and for the parity tests.
+#include "gse_host.h"
+
+#include <string.h>
+
+namespace gse {
+
+// out[i] = f(x[i], u, dt): the Euler INCREMENT, stored fp32 (what f_vectorize returns, particle.py:176-191)
+__global__ __launch_bounds__(kBlock) void model_f_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t M,
+                                                         double fg, double fm, double dt) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    float s[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[k] = x[i * 5 + k];
+    double dx[5];
+    bioreactor_increment(s, fg, fm, dt, dx);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) out[i * 5 + k] = (float)dx[k];
+}
+
+__global__ __launch_bounds__(kBlock) void model_g_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t M) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    float y0, y1;
+    bioreactor_output(x[i * 5 + 0], x[i * 5 + 2], y0, y1);
+    out[i * 2 + 0] = y0;
+    out[i * 2 + 1] = y1;
+}
+
+// General mixture density, nx <= 5, nd <= 4  (MultivariateGaussianSum.py:39-63)
+struct PdfN {
+    int32_t nd, nx;
+    double cw[GSE_MAX_ND];
+    float mean[GSE_MAX_ND][GSE_NX];
+    double inv[GSE_MAX_ND][GSE_NX][GSE_NX];
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void mixture_pdf_kernel(const T* __restrict__ e, double* __restrict__ out, int64_t M,
+                                                             const PdfN m) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    T x[GSE_NX];
+    for (int k = 0; k < m.nx; ++k) x[k] = e[i * m.nx + k];
+    double total = 0.0;
+    for (int d = 0; d < m.nd; ++d) {
+        double a[GSE_NX];
+        // x - mean in the precision of x (fp32 points stay fp32 here, as in the reference), then fp64
+        for (int k = 0; k < m.nx; ++k) a[k] = (double)(x[k] - (T)m.mean[d][k]);
+        double q = 0.0;
+        for (int j = 0; j < m.nx; ++j) {
+            double t = a[0] * m.inv[d][0][j];
+            for (int k = 1; k < m.nx; ++k) t = t + a[k] * m.inv[d][k][j];
+            q = (j == 0) ? t * a[0] : q + t * a[j];
+        }
+        const double term = m.cw[d] * exp(-0.5 * q);
+        total = (d == 0) ? term : total + term;
+    }
+    out[i] = total;
+}
+
+struct DrawArgs {
+    DrawParams draw;
+    RngKey rng;
+};
+
+// out: row-major [M][nx] (ld == 0) or state-major [nx][ld]
+__global__ __launch_bounds__(kBlock) void mixture_draw_kernel(float* __restrict__ out, int64_t M, int64_t ld,
+                                                              const DrawArgs a) {
+    __shared__ DrawParams dp;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.draw);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
+        for (int i = threadIdx.x; i < (int)(sizeof(DrawParams) / 4); i += kBlock) dst[i] = src[i];
+        __syncthreads();
+    }
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    uint32_t wd[8];
+    rng_words8(a.rng, (uint64_t)i, 0u, wd);
+    float e[5];
+    mixture_draw5(dp, wd, e);
+    const int nx = dp.nx;
+    if (ld == 0) {
+        for (int k = 0; k < nx; ++k) out[i * nx + k] = e[k];
+    } else {
+        for (int k = 0; k < nx; ++k) out[(int64_t)k * ld + i] = e[k];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void rng_raw_kernel(uint32_t* __restrict__ out, int64_t M, const RngKey key) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    uint32_t wd[8];
+    rng_words8(key, (uint64_t)i, 0u, wd);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[i * 8 + k] = wd[k];
+}
+
+// c[k] = cumsum(w)[k] / sum(w) from the tile prefix (same arithmetic as the fused resample kernel)
+__global__ __launch_bounds__(kBlock) void cumsum_write_kernel(const float* __restrict__ w, double* __restrict__ c,
+                                                              const double* __restrict__ prefix, int64_t N, int T) {
+    __shared__ double red[4];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const double P0 = prefix[t], P1 = prefix[t + 1], W = prefix[T];
+    const int64_t i0 = (int64_t)t * kTile + (int64_t)tid * kPerThread;
+    float wv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        if (i0 + p < N) wv[p] = w[i0 + p];
+    double s[4];
+    s[0] = (double)wv[0];
+    s[1] = s[0] + (double)wv[1];
+    s[2] = s[1] + (double)wv[2];
+    s[3] = s[2] + (double)wv[3];
+    double total;
+    const double excl = block_exclusive_scan(s[3], red, total);
+    const double top = P1 / W;
+    const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        if (i0 + p < N) c[i0 + p] = (i0 + p == last) ? top : fmin((P0 + (excl + s[p])) / W, top);
+}
+
+// idx[i] = first k with c[k] >= (i + r)/N (CPU semantics, particle.py:96-100), by binary search in global memory
+__global__ __launch_bounds__(kBlock) void systematic_index_kernel(const double* __restrict__ c, int64_t* __restrict__ idx,
+                                                                  int64_t N, double r) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const double u = ((double)i + r) / (double)N;
+    int64_t lo = 0, hi = N - 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (c[mid] < u) lo = mid + 1; else hi = mid;
+    }
+    idx[i] = lo;
+}
+
+static int pack_pdfn(PdfN& p, const gse_mixture& m) {
+    memset(&p, 0, sizeof(p));
+    p.nd = m.nd;
+    p.nx = m.nx;
+    for (int d = 0; d < m.nd; ++d) {
+        p.cw[d] = (double)(m.consts[d] * m.weights[d]);
+        for (int i = 0; i < m.nx; ++i) {
+            p.mean[d][i] = m.means[d][i];
+            for (int j = 0; j < m.nx; ++j) p.inv[d][i][j] = m.inv_cov[d][i][j];
+        }
+    }
+    return 0;
+}
+
+static unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+}  // namespace gse
+
+using namespace gse;
+
+extern "C" {
+
+int gse_model_f(const float* x, float* out, int64_t M, const double* u, double dt, void* stream) {
+    GSE_REQUIRE(x && out && u && M >= 1, "gse_model_f: bad argument");
+    hipLaunchKernelGGL(model_f_kernel, dim3(blocks_for(M)), dim3(kBlock), 0, (hipStream_t)stream, x, out, M, u[0], u[1], dt);
+    GSE_LAUNCH_CHECK("model_f_kernel");
+    return GSE_OK;
+}
+
+int gse_model_g(const float* x, float* out, int64_t M, void* stream) {
+    GSE_REQUIRE(x && out && M >= 1, "gse_model_g: bad argument");
+    hipLaunchKernelGGL(model_g_kernel, dim3(blocks_for(M)), dim3(kBlock), 0, (hipStream_t)stream, x, out, M);
+    GSE_LAUNCH_CHECK("model_g_kernel");
+    return GSE_OK;
+}
+
+static int mixture_pdf_common(const void* e, bool f64, int64_t M, const gse_mixture* m, double* out, void* stream) {
+    GSE_REQUIRE(e && out && m && M >= 1, "gse_mixture_pdf: bad argument");
+    GSE_REQUIRE(m->nd >= 1 && m->nd <= GSE_MAX_ND && m->nx >= 1 && m->nx <= GSE_NX,
+                "gse_mixture_pdf: mixture has nd = %d, nx = %d; supported nd 1..%d, nx 1..%d", m->nd, m->nx, GSE_MAX_ND,
+                GSE_NX);
+    PdfN p;
+    pack_pdfn(p, *m);
+    if (f64)
+        hipLaunchKernelGGL(mixture_pdf_kernel<double>, dim3(blocks_for(M)), dim3(kBlock), 0, (hipStream_t)stream,
+                           (const double*)e, out, M, p);
+    else
+        hipLaunchKernelGGL(mixture_pdf_kernel<float>, dim3(blocks_for(M)), dim3(kBlock), 0, (hipStream_t)stream,
+                           (const float*)e, out, M, p);
+    GSE_LAUNCH_CHECK("mixture_pdf_kernel");
+    return GSE_OK;
+}
+
+int gse_mixture_pdf_f32(const float* e, int64_t M, const gse_mixture* m, double* out, void* stream) {
+    return mixture_pdf_common(e, false, M, m, out, stream);
+}
+
+int gse_mixture_pdf_f64(const double* e, int64_t M, const gse_mixture* m, double* out, void* stream) {
+    return mixture_pdf_common(e, true, M, m, out, stream);
+}
+
+int gse_mixture_draw(float* out, int64_t M, int64_t ld, const gse_mixture* m, const gse_rng* rng, void* stream) {
+    GSE_REQUIRE(out && m && rng && M >= 1, "gse_mixture_draw: bad argument");
+    GSE_REQUIRE(ld == 0 || ld >= M, "gse_mixture_draw: ld = %lld must be 0 (row-major) or >= M", (long long)ld);
+    GSE_REQUIRE(m->nd >= 1 && m->nd <= GSE_MAX_ND && m->nx >= 1 && m->nx <= GSE_NX,
+                "gse_mixture_draw: mixture has nd = %d, nx = %d; supported nd 1..%d, nx 1..%d", m->nd, m->nx, GSE_MAX_ND,
+                GSE_NX);
+    DrawArgs a;
+    pack_draw(a.draw, *m);
+    a.rng = make_rng_key(*rng, kPurposeDraw);
+    hipLaunchKernelGGL(mixture_draw_kernel, dim3(blocks_for(M)), dim3(kBlock), 0, (hipStream_t)stream, out, M, ld, a);
+    GSE_LAUNCH_CHECK("mixture_draw_kernel");
+    return GSE_OK;
+}
+
+int gse_cumsum_normalised(const float* w, double* c, int64_t N, void* workspace, void* stream) {
+    GSE_REQUIRE(w && c && workspace && N >= 1, "gse_cumsum_normalised: bad argument");
+    const int T = (int)tiles_of(N);
+    Workspace ws = carve_workspace(workspace, 1, N);
+    hipStream_t st = (hipStream_t)stream;
+    launch_tile_sums(w, ws.tile_sums, 1, N, N, T, st);
+    GSE_LAUNCH_CHECK("tile_sum_kernel");
+    launch_tile_scan(ws.tile_sums, ws.tile_prefix, 1, T, st);
+    GSE_LAUNCH_CHECK("tile_scan_kernel");
+    hipLaunchKernelGGL(cumsum_write_kernel, dim3(T), dim3(kBlock), 0, st, w, c, ws.tile_prefix, N, T);
+    GSE_LAUNCH_CHECK("cumsum_write_kernel");
+    return GSE_OK;
+}
+
+int gse_systematic_index(const double* c, int64_t* idx, int64_t N, double r, void* stream) {
+    GSE_REQUIRE(c && idx && N >= 1, "gse_systematic_index: bad argument");
+    hipLaunchKernelGGL(systematic_index_kernel, dim3(blocks_for(N)), dim3(kBlock), 0, (hipStream_t)stream, c, idx, N, r);
+    GSE_LAUNCH_CHECK("systematic_index_kernel");
+    return GSE_OK;
+}
+
+int gse_rng_raw(uint32_t* out, int64_t M, const gse_rng* rng, uint32_t purpose, void* stream) {
+    GSE_REQUIRE(out && rng && M >= 1, "gse_rng_raw: bad argument");
+    const RngKey key = make_rng_key(*rng, purpose);
+    hipLaunchKernelGGL(rng_raw_kernel, dim3(blocks_for(M)), dim3(kBlock), 0, (hipStream_t)stream, out, M, key);
+    GSE_LAUNCH_CHECK("rng_raw_kernel");
+    return GSE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+"""Bootstrap particle filter on the MI355X: drop-in for the reference's filter.ParallelParticleFilter
+(filter/particle.py:117-327).  Same constructor, methods and attributes; the device work goes through
+the C ABI of libgse_hip.so (include/gse.h)."""
+import ctypes
+
+import numpy
+import torch
+
+import gpu_se_amd
+from gpu_se_amd import _lib
+from gpu_se_amd.devarray import DevArray, as_device, device, stream_ptr
+from gpu_se_amd.gaussian_sum_dist import DeterministicGaussianSum
+from gpu_se_amd.model import Bioreactor
+
+
+def _require_builtin_model(f, g):
+    """The reference JIT-compiles arbitrary Python f/g with Numba (particle.py:176-208).  Here the model is
+    compiled ahead of time: only the bioreactor functions have kernels, anything else is an error."""
+    if f is not Bioreactor.homeostatic_DEs or g is not Bioreactor.static_outputs:
+        raise NotImplementedError(
+            "gpu_se_amd filters run the built-in bioreactor model only: pass "
+            "f=gpu_se_amd.model.Bioreactor.homeostatic_DEs and g=gpu_se_amd.model.Bioreactor.static_outputs "
+            "(there is no CPU fallback for other callables)")
+
+
+class _KernelLauncher:
+    """Callable that also accepts ``[blocks, threads]`` -- the shape of a Numba kernel launch, which the
+    reference's benchmark scripts use (pf_run_seq.py:282-287).  The launch geometry is chosen by the
+    library, so the subscript is accepted and ignored."""
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    def __getitem__(self, _launch_config):
+        return self._fn
+
+    def __call__(self, *args):
+        return self._fn(*args)
+
+
+def _parallel_resample(cumsum, sample_index, random_number, N_particles):
+    """sample_index[i] = first k with cumsum[k] >= (i + random_number)/N  (particle.py:223-263)."""
+    c = as_device(cumsum, torch.float64)
+    if not (isinstance(sample_index, torch.Tensor) and sample_index.dtype == torch.int64 and sample_index.is_cuda):
+        raise TypeError("sample_index must be an int64 device array")
+    _lib.call("gse_systematic_index", c.data_ptr(), sample_index.data_ptr(), int(N_particles), float(random_number),
+              stream_ptr())
+
+
+class ParallelParticleFilter:
+    """Particle filter class implemented to run on the GPU (MI355X).
+
+    Parameters
+    ----------
+    f : callable
+        The state transition function x_{k+1} += f(x_k, u_k)  -- Bioreactor.homeostatic_DEs
+    g : callable
+        The state observation function y_k = g(x_k, u_k)      -- Bioreactor.static_outputs
+    N_particles : int
+    x0 : MultivariateGaussianSum         the initial distribution
+    state_pdf, measurement_pdf : MultivariateGaussianSum   state and measurement noise
+
+    Attributes
+    ----------
+    particles : device array (N_particles x Nx) fp32 -- a strided view of the state-major storage
+    weights : device array (N_particles) fp32
+    """
+
+    _parallel_resample = _KernelLauncher(_parallel_resample)
+
+    def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, element_offset=0):
+        _require_builtin_model(f, g)
+        _lib.load()
+        self.f = f
+        self.g = g
+        self.N_particles = int(N_particles)
+        self.state_pdf = state_pdf
+        self.measurement_pdf = measurement_pdf
+        n = self.N_particles
+        dev = device()
+        self._ld = -(-n // 4) * 4
+        self._x = torch.zeros((_lib.GSE_NX, self._ld), dtype=torch.float32, device=dev)
+        self._x_alt = torch.zeros_like(self._x)
+        self._w = torch.zeros(self._ld, dtype=torch.float32, device=dev)
+        self._w_alt = torch.zeros_like(self._w)
+        self._ws = torch.empty(_lib.load().gse_workspace_bytes(1, n), dtype=torch.uint8, device=dev)
+        self._moments = torch.empty(26, dtype=torch.float64, device=dev)
+        self._tiles_valid = False
+        self._element_offset = int(element_offset)        # global index of particle 0 (sharded ensembles)
+        self._seed = gpu_se_amd._new_stream_seed()
+        self._step = 0
+        self._host_rng = numpy.random.default_rng(self._seed & 0xFFFFFFFF)
+
+        # particles ~ x0 (particle.py:49), drawn on the device straight into the state-major buffer
+        x0._draw_state_major(self._x, n, self._ld, self._element_offset)
+        self._w[:n] = 1.0 / n                              # (particle.py:50)
+
+        # launch geometry the reference computes and its benchmark scripts read (particle.py:160-174)
+        if n >= 1024:
+            self._tpb, self._bpg = 1024, (n - 1) // 1024 + 1
+        else:
+            self._tpb, self._bpg = 32 * ((n - 1) // 32 + 1), 1
+        self._y_dummy = DevArray.wrap(torch.zeros(_lib.GSE_NY, dtype=torch.float32, device=dev))
+
+    # ------------------------------------------------------------------ attributes
+    @property
+    def particles(self):
+        return DevArray.wrap(self._x[:, :self.N_particles].t())
+
+    @particles.setter
+    def particles(self, value):
+        v = as_device(value, torch.float32)
+        if tuple(v.shape) != (self.N_particles, _lib.GSE_NX):
+            raise ValueError("particles must have shape (%d, %d)" % (self.N_particles, _lib.GSE_NX))
+        self._x[:, :self.N_particles] = v.t()
+
+    @property
+    def weights(self):
+        return DevArray.wrap(self._w[:self.N_particles])
+
+    @weights.setter
+    def weights(self, value):
+        # the benchmark scripts assign a host array here (pf_run_seq.py:124-125)
+        v = as_device(value, torch.float32)
+        if tuple(v.shape) != (self.N_particles,):
+            raise ValueError("weights must have shape (%d,)" % self.N_particles)
+        self._w[:self.N_particles] = v
+        self._tiles_valid = False
+
+    # ------------------------------------------------------------------ the cycle
+    def predict(self, u, dt):
+        """Performs a prediction step on the particles: x_i += f(x_i, u, dt) then x += state noise
+        (particle.py:265-277).  u: (N_inputs) host array-like; dt: float."""
+        uu = _lib.doubles(u, _lib.GSE_NU)
+        n = self.N_particles
+        if isinstance(self.state_pdf, DeterministicGaussianSum):
+            noise = self.state_pdf.draw(n).as_subclass(torch.Tensor)            # (n, Nx) replayed values
+            buf = torch.zeros_like(self._x)
+            buf[:, :n] = noise.reshape(n, _lib.GSE_NX).t()
+            _lib.call("gse_pf_predict_injected", self._x.data_ptr(), self._ld, 1, n, uu, float(dt), buf.data_ptr(),
+                      stream_ptr())
+        else:
+            pod = self.state_pdf._pod()
+            rng = _lib.Rng(seed=self._seed, step=self._step, element_offset=self._element_offset)
+            self._step += 1
+            _lib.call("gse_pf_predict", self._x.data_ptr(), self._ld, 1, n, uu, float(dt), ctypes.byref(pod),
+                      ctypes.byref(rng), stream_ptr())
+
+    def update(self, u, z):
+        """Performs an update step on the particles: w_i *= measurement_pdf(z - g(x_i, u))
+        (particle.py:279-294).  u, z: host array-likes."""
+        uu = _lib.doubles(u, _lib.GSE_NU)
+        zz = _lib.doubles(z, _lib.GSE_NY)
+        pod = self.measurement_pdf._pod()
+        _lib.call("gse_pf_update", self._x.data_ptr(), self._w.data_ptr(), self._ld, 1, self.N_particles, uu, zz,
+                  ctypes.byref(pod), self._ws.data_ptr(), stream_ptr())
+        self._tiles_valid = True
+
+    def resample(self, r=None, return_index=False):
+        """Systematic resample of the particles based on their weights (particle.py:296-316).  The one
+        uniform number comes from a host generator (no device round trip); ``r`` overrides it (tests)."""
+        rr = _lib.doubles([self._host_rng.random() if r is None else r], 1)
+        idx = torch.empty(self._ld, dtype=torch.int32, device=self._x.device) if return_index else None
+        flags = _lib.GSE_RESAMPLE_TILES_VALID if self._tiles_valid else 0
+        _lib.call("gse_pf_resample", self._x.data_ptr(), self._w.data_ptr(), self._x_alt.data_ptr(),
+                  self._w_alt.data_ptr(), idx.data_ptr() if return_index else None, self._ld, 1, self.N_particles,
+                  rr, flags, self._ws.data_ptr(), stream_ptr())
+        self._x, self._x_alt = self._x_alt, self._x
+        self._w, self._w_alt = self._w_alt, self._w
+        self._tiles_valid = False
+        if return_index:
+            return DevArray.wrap(idx[:self.N_particles])
+
+    # ------------------------------------------------------------------ estimates
+    def _moment_sums(self):
+        """(S0, w@x, sum w (x - w@x)(x - w@x)^T) from the device moments (synchronises)."""
+        _lib.call("gse_pf_moments", self._x.data_ptr(), self._w.data_ptr(), self._ld, 1, self.N_particles,
+                  self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
+        m = self._moments.cpu().numpy()
+        return moments_to_mean_cov(m[0], m[1:6], m[6:21], m[21:26])
+
+    def point_estimate(self):
+        """Returns the point estimate of the filter: weights @ particles, host array (5,) (particle.py:318-320)."""
+        return self._moment_sums()[1]
+
+    def point_covariance(self):
+        """Returns the maximum singular value of the filter's covariance (particle.py:322-327)."""
+        cov = self._moment_sums()[2]
+        return numpy.linalg.svd(cov, compute_uv=False)[0]
+
+    # ------------------------------------------------------------------ pieces the benchmark scripts call
+    def f_vectorize(self, particles, u, dt):
+        """out[i] = f(particles[i], u, dt) as a device array (M x Nx) fp32 (particle.py:176-191)."""
+        p = as_device(particles, torch.float32)
+        lead = p.shape[:-1]
+        p2 = p.reshape(-1, _lib.GSE_NX)
+        out = torch.empty_like(p2)
+        _lib.call("gse_model_f", p2.data_ptr(), out.data_ptr(), p2.shape[0], _lib.doubles(u, _lib.GSE_NU), float(dt),
+                  stream_ptr())
+        return DevArray.wrap(out.reshape(lead + (_lib.GSE_NX,)))
+
+    def g_vectorize(self, particles, u, _y_dummy=None):
+        """out[i] = g(particles[i], u) as a device array (M x Ny) fp32 (particle.py:193-208)."""
+        p = as_device(particles, torch.float32)
+        lead = p.shape[:-1]
+        p2 = p.reshape(-1, _lib.GSE_NX)
+        out = torch.empty((p2.shape[0], _lib.GSE_NY), dtype=torch.float32, device=p2.device)
+        _lib.call("gse_model_g", p2.data_ptr(), out.data_ptr(), p2.shape[0], stream_ptr())
+        return DevArray.wrap(out.reshape(lead + (_lib.GSE_NY,)))
+
+
+def moments_to_mean_cov(s0, s1, s2_upper, pivot):
+    """Undo the pivot shift of gse_pf_moments: with d = x - p the kernel returns S0 = sum w, S1 = sum w d,
+    S2 = sum w d d^T.  The reference's quantities (weights are NOT normalised there, particle.py:318-327):
+        mean = w @ x                      = S1 + p S0
+        cov  = sum w (x - mean)(x - mean)^T = S2 - S1 e^T - e S1^T + S0 e e^T,   e = mean - p."""
+    s1 = numpy.asarray(s1, dtype=numpy.float64)
+    pivot = numpy.asarray(pivot, dtype=numpy.float64)
+    nx = len(s1)
+    s2 = numpy.zeros((nx, nx))
+    s2[numpy.triu_indices(nx)] = s2_upper
+    s2 = s2 + s2.T - numpy.diag(numpy.diag(s2))
+    mean = s1 + pivot * s0
+    e = mean - pivot
+    cov = s2 - numpy.outer(s1, e) - numpy.outer(e, s1) + s0 * numpy.outer(e, e)
+    return float(s0), mean, cov

@@ -1,0 +1,184 @@
+/*
+ * gse.h -- C ABI of libgse_hip.so: the MI355X (gfx950) particle-filter / Gaussian-sum-UKF engine.
+ *
+ * The reference (AlgorithmicAmoeba/gpu_se) has no FFI layer: its device boundary is the Python class
+ * API that sim_base.get_parts selects with gpu=True (sim_base.py:89-112).  Each entry point below
+ * replaces the device work behind one method of those classes; the reference site is cited per
+ * function.  The Python mirror of the class API (gpu_se_amd/filter, gpu_se_amd/gaussian_sum_dist,
+ * gpu_se_amd/sim_base) binds these through ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative gse_status otherwise; gse_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - array arguments are caller-owned DEVICE pointers (16-byte aligned) unless marked "host"; nothing is
+ *     retained after the call returns; scalars and the small per-filter inputs (u, z, r) are HOST values
+ *     and travel in the kernel-argument segment -- there is no host->device copy and no synchronisation;
+ *   - the last argument is a hipStream_t (as void*); all work is enqueued asynchronously on it;
+ *   - B independent filters are processed per call (leading dimension everywhere, 1 <= B <= GSE_MAX_B);
+ *   - no function allocates, frees or synchronises: every call is hipGraph-capturable.
+ *
+ * Layouts
+ *   particle filter   x  : [B][5][ld]  fp32, state-major ("SoA"): state k of particle i of filter b at
+ *                          x[(b*5 + k)*ld + i];  ld >= N, ld % 4 == 0 (the padding is never interpreted)
+ *                     w  : [B][ld]     fp32 weights
+ *   GS-UKF            mu : [B][N][5]   fp32,  P : [B][N][5][5] fp32,  w : [B][N] fp32   (row-major "AoS")
+ *   row helpers (gse_model_f/g, gse_mixture_pdf/draw): plain row-major [M][Nx] arrays.
+ */
+#ifndef GSE_H
+#define GSE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSE_VERSION 100          /* 0.1.0 */
+#define GSE_NX 5                 /* bioreactor states  Cg, Cx, Cfa, Ce, Ch  (model/BioreactorModel.py:170) */
+#define GSE_NU 2                 /* inputs             Fg_in, Fm_in                                            */
+#define GSE_NY 2                 /* outputs            Cg*180, Cfa*116     (model/BioreactorModel.py:233) */
+#define GSE_NSIGMA 11            /* 2*Nx + 1 sigma points                  (filter/gs_ukf.py:60)          */
+#define GSE_MAX_ND 4             /* mixture components per Gaussian sum                                     */
+#define GSE_MAX_B 32             /* independent filters per call                                            */
+#define GSE_TILE 1024            /* particles per weight tile (one partial sum per tile)                    */
+
+typedef enum gse_status {
+    GSE_OK = 0,
+    GSE_ERR_ARG = -1,            /* bad argument (null pointer, size, alignment, B, Nd, ...)   */
+    GSE_ERR_HIP = -2,            /* a HIP call failed; message carries hipGetErrorString       */
+    GSE_ERR_UNSUPPORTED = -3
+} gse_status;
+
+/*
+ * A Gaussian sum, as MultivariateGaussianSum holds it (gaussian_sum_dist/MultivariateGaussianSum.py:27-37).
+ * HOST memory, passed by pointer, read during the call only.
+ *   weights/means/consts are the reference's fp32 attributes; inv_cov its fp64 _inverse_covariances;
+ *   chol is the lower Cholesky factor of each (fp32) covariance, used by the draw kernels.
+ * Arrays are dimensioned for GSE_MAX_ND x GSE_NX; only the leading nd x nx part is read.
+ */
+typedef struct gse_mixture {
+    int32_t nd;                                      /* components, 1..GSE_MAX_ND */
+    int32_t nx;                                      /* dimension,  1..GSE_NX     */
+    float   weights[GSE_MAX_ND];
+    float   consts[GSE_MAX_ND];                      /* (2 pi)^(-nx/2) / sqrt(det cov)                      */
+    float   means[GSE_MAX_ND][GSE_NX];
+    float   chol[GSE_MAX_ND][GSE_NX][GSE_NX];        /* lower triangular                                     */
+    double  inv_cov[GSE_MAX_ND][GSE_NX][GSE_NX];
+} gse_mixture;
+
+/* Counter-based RNG stream: Philox4x32-10, key = seed, counter = (element, step, purpose, filter). */
+typedef struct gse_rng {
+    uint64_t seed;
+    uint64_t step;               /* caller increments per call that consumes randomness               */
+    uint64_t element_offset;     /* global index of this call's element 0 (sharded ensembles: rank*N) */
+    uint32_t filter_offset;      /* global id of this call's filter 0                                 */
+    uint32_t reserved;
+} gse_rng;
+
+int         gse_version(void);
+const char *gse_last_error(void);
+
+/* Bytes of device workspace the particle-filter / GS-UKF calls below need for (B, N): per filter the tile
+ * sums, their prefix and the moment partials.  The workspace carries state only BETWEEN gse_*_update and a
+ * gse_*_resample(..., GSE_RESAMPLE_TILES_VALID) that directly follows it. */
+int64_t gse_workspace_bytes(int B, int64_t N);
+
+/* ---------------------------------------------------------------- particle filter ---------------- */
+
+/* ParallelParticleFilter.predict (filter/particle.py:265-277): x_i += f(x_i, u, dt) (Euler increment of
+ * Bioreactor.homeostatic_DEs, fp64 arithmetic, one rounding to fp32), then x_i += a draw from state_pdf
+ * (MultivariateGaussianSum.draw, MultivariateGaussianSum.py:65-97; component i.i.d. per particle).
+ * u: host [B][2]. */
+int gse_pf_predict(float *x, int64_t ld, int B, int64_t N, const double *u, double dt,
+                   const gse_mixture *state_pdf, const gse_rng *rng, void *stream);
+
+/* Same, with the noise supplied: noise is [B][5][ld] fp32, laid out like x.  This is the parity mode -- the
+ * counterpart of running the reference with DeterministicGaussianSum (DeterministicGaussianSum.py:32-65). */
+int gse_pf_predict_injected(float *x, int64_t ld, int B, int64_t N, const double *u, double dt,
+                            const float *noise, void *stream);
+
+/* ParallelParticleFilter.update (filter/particle.py:279-294): w_i *= measurement_pdf.pdf(z - g(x_i, u))
+ * with the mixture density evaluated in fp64 (MultivariateGaussianSum.py:39-63).  Also leaves the per-tile
+ * sums of the new weights in the workspace.  u, z: host [B][2]. */
+int gse_pf_update(const float *x, float *w, int64_t ld, int B, int64_t N, const double *u, const double *z,
+                  const gse_mixture *measurement_pdf, void *workspace, void *stream);
+
+#define GSE_RESAMPLE_TILES_VALID 1u   /* workspace tile sums were left by the preceding gse_*_update on w */
+
+/* ParallelParticleFilter.resample (filter/particle.py:296-316 with _parallel_resample :223-263):
+ * c = cumsum(w) / sum(w) in fp64; ancestor of output j = first k with c_k >= (j + r)/N;
+ * x_out[:, j] = x_in[:, ancestor]; w_out[j] = 1/N.  r: host [B], each in [0,1).
+ * idx (optional, may be NULL): [B][ld] int32 ancestor indices.  x_out / w_out must not alias x_in / w
+ * (a workgroup writes the offspring range of its ancestor tile, which overlaps other tiles' inputs). */
+int gse_pf_resample(const float *x_in, const float *w, float *x_out, float *w_out, int32_t *idx,
+                    int64_t ld, int B, int64_t N, const double *r, uint32_t flags,
+                    void *workspace, void *stream);
+
+/* Moments behind point_estimate / point_covariance (filter/particle.py:318-327), fp64 accumulation:
+ * out [B][26] device = { S0 = sum w, S1[5] = sum w (x - p), S2[15] = upper triangle (row-major) of
+ * sum w (x - p)(x - p)^T, p[5] } with the pivot p = particle 0 (keeps the second moments free of
+ * cancellation).  The host forms  w@x = S1 + p S0  and the covariance from these. */
+int gse_pf_moments(const float *x, const float *w, int64_t ld, int B, int64_t N, double *out,
+                   void *workspace, void *stream);
+
+/* ---------------------------------------------------------------- Gaussian-sum UKF --------------- */
+
+/* Sigma points (filter/gs_ukf.py:332-346): L = chol(P) (retry with P + 1e-10 I for a Gaussian whose
+ * factorisation fails); sigma_0 = mu, sigma_j = mu + L[:, j-1], sigma_{5+j} = mu - L[:, j-1].
+ * sigmas: [B][N][11][5] fp32.  status (optional, may be NULL): device int32[1], incremented once per
+ * Gaussian whose covariance is still not positive definite after the retry (its sigma points are NaN). */
+int gse_gsukf_sigma_points(const float *mu, const float *P, float *sigmas, int B, int64_t N,
+                           int32_t *status, void *stream);
+
+/* ParallelGaussianSumUnscentedKalmanFilter.predict (filter/gs_ukf.py:348-367): sigma points through f,
+ * plus a noise DRAW per sigma point, mean = average(sigma, weights=w_sigma), P = sum_j w_j d_j d_j^T.
+ * w_sigma: host [11] fp32 (gs_ukf.py:62-67).  noise: NULL (Philox draw from state_pdf) or device
+ * [B][N][11][5] fp32 (parity mode).  u: host [B][2]. */
+int gse_gsukf_predict(float *mu, float *P, int B, int64_t N, const double *u, double dt,
+                      const float *w_sigma, const gse_mixture *state_pdf, const gse_rng *rng,
+                      const float *noise, int32_t *status, void *stream);
+
+/* ...update (filter/gs_ukf.py:369-407): per Gaussian eta = g(sigma), P_xy, P_yy (no R), K = P_xy pinv(P_yy)
+ * (CPU class, gs_ukf.py:132), mu += K (z - eta_mean), P -= K P_yy K^T in fp64; then the global update
+ * w *= measurement_pdf.pdf(z - g(mu_new)).  Leaves tile sums of w in the workspace.  u, z: host [B][2]. */
+int gse_gsukf_update(float *mu, float *P, float *w, int B, int64_t N, const double *u, const double *z,
+                     const float *w_sigma, const gse_mixture *measurement_pdf, int32_t *status,
+                     void *workspace, void *stream);
+
+/* ...resample (filter/gs_ukf.py:409-436): as gse_pf_resample, gathering (mu, P) rows. */
+int gse_gsukf_resample(const float *mu_in, const float *P_in, const float *w, float *mu_out, float *P_out,
+                       float *w_out, int32_t *idx, int B, int64_t N, const double *r, uint32_t flags,
+                       void *workspace, void *stream);
+
+/* Moments behind point_estimate / point_covariance (filter/gs_ukf.py:438-449): out [B][46] device =
+ * { S0, S1[5] = sum w (mu - p), S2[15] = upper triangle of sum w (mu - p)(mu - p)^T,
+ *   C[15] = upper triangle of sum w P, p[5] (= mu_0, the pivot), 5 reserved }. */
+int gse_gsukf_moments(const float *mu, const float *P, const float *w, int B, int64_t N, double *out,
+                      void *workspace, void *stream);
+
+/* ---------------------------------------------------------------- row helpers -------------------- */
+/* The pieces the reference's benchmark scripts call one by one (results/pf_openloop/pf_run_seq.py:134-296). */
+
+/* f_vectorize (filter/particle.py:176-191): out[i] = f(x[i], u, dt); x, out: [M][5] fp32; u host [2]. */
+int gse_model_f(const float *x, float *out, int64_t M, const double *u, double dt, void *stream);
+/* g_vectorize (filter/particle.py:193-208): out[i] = g(x[i], u); x: [M][5], out: [M][2] fp32. */
+int gse_model_g(const float *x, float *out, int64_t M, void *stream);
+/* MultivariateGaussianSum.pdf (MultivariateGaussianSum.py:39-63): e [M][nx] fp32 or fp64 -> out [M] fp64. */
+int gse_mixture_pdf_f32(const float *e, int64_t M, const gse_mixture *m, double *out, void *stream);
+int gse_mixture_pdf_f64(const double *e, int64_t M, const gse_mixture *m, double *out, void *stream);
+/* MultivariateGaussianSum.draw (MultivariateGaussianSum.py:65-97): out [M][nx] fp32 (row-major), or with
+ * ld > 0 state-major [nx][ld] (the layout gse_pf_* uses; this is how the filters draw their prior). */
+int gse_mixture_draw(float *out, int64_t M, int64_t ld, const gse_mixture *m, const gse_rng *rng,
+                     void *stream);
+/* torch.cumsum + "/= cumsum[-1]" of resample (filter/particle.py:301-304): w [N] fp32 -> c [N] fp64. */
+int gse_cumsum_normalised(const float *w, double *c, int64_t N, void *workspace, void *stream);
+/* _parallel_resample (filter/particle.py:223-263): idx[i] = first k with c[k] >= (i + r)/N.  idx int64. */
+int gse_systematic_index(const double *c, int64_t *idx, int64_t N, double r, void *stream);
+/* The raw Philox words the draw kernels consume for element i: out [M][8] uint32 (tests pin these against
+ * the published Philox4x32-10 algorithm). */
+int gse_rng_raw(uint32_t *out, int64_t M, const gse_rng *rng, uint32_t purpose, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSE_H */

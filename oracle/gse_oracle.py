@@ -445,3 +445,72 @@ def effective_sample_size(weights):
 
 
 __all__ = [n for n in dir() if not n.startswith("_") and n not in ("math", "np")]
+
+
+# --------------------------------------------------------------------------------------
+# Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11)
+# and the word -> sample mapping of the device draw kernels (gpu_se_amd/csrc/gse_device.h), restated with
+# NumPy integer arithmetic so that the tests can pin the device RNG bit for bit.
+# --------------------------------------------------------------------------------------
+_PHILOX_M0, _PHILOX_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_PHILOX_W0, _PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+_MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(counter, key):
+    """counter: (..., 4) uint32, key: (2,) or (..., 2) uint32 -> (..., 4) uint32."""
+    c = np.asarray(counter, dtype=np.uint64) & _MASK32
+    k = np.broadcast_to(np.asarray(key, dtype=np.uint64) & _MASK32, c.shape[:-1] + (2,)).copy()
+    c0, c1, c2, c3 = c[..., 0], c[..., 1], c[..., 2], c[..., 3]
+    k0, k1 = k[..., 0], k[..., 1]
+    for _ in range(10):
+        p0 = _PHILOX_M0 * c0
+        p1 = _PHILOX_M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & _MASK32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & _MASK32
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0 = (k0 + np.uint64(_PHILOX_W0)) & _MASK32
+        k1 = (k1 + np.uint64(_PHILOX_W1)) & _MASK32
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+RNG_PURPOSE = {"prior": 0, "predict": 1, "draw": 2, "gsukf": 3}
+
+
+def rng_words8(seed, step, purpose, elements, filter_id=0):
+    """The 8 random words per element that the device kernels consume: two Philox blocks with counter
+    (elem_lo, elem_hi, step_lo, (step_hi & 0xff) << 24 | purpose << 20 | sub << 16 | filter), key = seed."""
+    e = np.asarray(elements, dtype=np.uint64)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    out = []
+    for sub in (0, 1):
+        hi = ((((step >> 32) & 0xFF) << 24) | ((purpose & 0xF) << 20) | (filter_id & 0xFFFF)) | (sub << 16)
+        ctr = np.stack([e & _MASK32, e >> np.uint64(32), np.full_like(e, step & 0xFFFFFFFF), np.full_like(e, hi)], axis=-1)
+        out.append(philox4x32_10(ctr, key))
+    return np.concatenate(out, axis=-1)
+
+
+def words_to_draw(words, mixture):
+    """Map (M, 8) words to mixture samples the way mixture_draw5 does (Box-Muller on word pairs (0,1),
+    (2,3), (4,5); component from the top 24 bits of word 7), in fp64 -- the device uses fp32 fast
+    transcendental instructions, so compare with an absolute tolerance of a few 1e-6 sigma."""
+    w = np.asarray(words, dtype=np.uint64)
+    n = np.zeros((w.shape[0], 6))
+    for p in range(3):
+        u1 = (w[:, 2 * p].astype(np.float64) + 0.5) / 2.0 ** 32
+        ang = w[:, 2 * p + 1].astype(np.float64) / 2.0 ** 32
+        r = np.sqrt(-2.0 * np.log(u1))
+        n[:, 2 * p] = r * np.cos(2 * np.pi * ang)
+        n[:, 2 * p + 1] = r * np.sin(2 * np.pi * ang)
+    uc = (w[:, 7] >> np.uint64(8)).astype(np.float64) / 2.0 ** 24
+    cw = np.cumsum(mixture.weights.astype(np.float64))
+    cw = (cw / cw[-1]).astype(np.float32).astype(np.float64)
+    comp = np.zeros(w.shape[0], dtype=np.int64)
+    for d in range(mixture.nd - 1):
+        comp += (uc >= cw[d]).astype(np.int64)
+    out = np.zeros((w.shape[0], mixture.nx))
+    for d in range(mixture.nd):
+        chol = np.linalg.cholesky(mixture.covariances[d].astype(np.float64)).astype(np.float32).astype(np.float64)
+        sel = comp == d
+        out[sel] = mixture.means[d].astype(np.float64) + n[sel, :mixture.nx] @ chol.T
+    return out, comp

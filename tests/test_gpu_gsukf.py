@@ -1,0 +1,140 @@
+"""Parity of the HIP Gaussian-sum UKF against the CPU oracle and the golden vectors (-m gpu)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("no HIP device", allow_module_level=True)
+
+import gpu_se_amd                                            # noqa: E402
+from gpu_se_amd import sim_base                              # noqa: E402
+from gpu_se_amd.filter import ParallelGaussianSumUnscentedKalmanFilter as GSF   # noqa: E402
+from gpu_se_amd.gaussian_sum_dist import DeterministicGaussianSum               # noqa: E402
+from gpu_se_amd.model import Bioreactor                      # noqa: E402
+from oracle import gse_oracle as orc                         # noqa: E402
+from tests.test_oracle_golden import assert_cov_close        # noqa: E402
+
+
+def make(n, means=None, covs=None, deterministic=False):
+    gpu_se_amd.seed(21)
+    state_pdf, measurement_pdf = sim_base.get_noise(deterministic=deterministic)
+    x0, _ = sim_base.get_noise()
+    x0.means += orc.steady_state()[None, :].astype(np.float32)
+    gf = GSF(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, state_pdf, measurement_pdf)
+    if means is not None:
+        gf.means = means
+    if covs is not None:
+        gf.covariances = covs
+    return gf
+
+
+def test_constants(golden):
+    g = golden("constants.npz")
+    gf = make(4)
+    np.testing.assert_array_equal(gf._w_sigma.get(), g["w_sigma"])
+    assert gf._N_sigmas == 11 and gf._Nx == 5 and gf._Ny == 2
+    assert tuple(gf.means.shape) == (4, 5) and tuple(gf.covariances.shape) == (4, 5, 5)
+    np.testing.assert_array_equal(gf.covariances.get()[2], g["state_covs"][0])
+
+
+@pytest.mark.parametrize("n", [1, 7, 64])
+def test_gsukf_trace_per_step(golden, n):
+    """Golden G5: the reference's GS-UKF trace, every step started from the reference's own state with its
+    recorded noise and r."""
+    g = golden("gsukf_trace.npz")
+    t = "n%d_" % n
+    gf = make(n, g[t + "means0"], g[t + "covs0"], deterministic=True)
+    np.testing.assert_allclose(gf._get_sigma_points().get(), g[t + "sigmas0"], rtol=1e-6, atol=1e-9)
+    for c in range(len(g[t + "dt"])):
+        DeterministicGaussianSum.preload(g[t + "noise"][c])
+        gf.predict(g[t + "u"][c], g[t + "dt"][c])
+        np.testing.assert_allclose(gf.means.get(), g[t + "m_pred"][c], rtol=1e-6, atol=1e-8)
+        assert_cov_close(gf.covariances.get(), g[t + "P_pred"][c], 3e-2)
+        gf.means, gf.covariances = g[t + "m_pred"][c], g[t + "P_pred"][c]
+        np.testing.assert_allclose(gf._get_sigma_points().get(), g[t + "sig_upd"][c], rtol=1e-6, atol=1e-9)
+        gf.update(g[t + "u"][c], g[t + "z"][c])
+        np.testing.assert_allclose(gf.means.get(), g[t + "m_upd"][c], rtol=1e-6, atol=1e-8)
+        assert_cov_close(gf.covariances.get(), g[t + "P_upd"][c], 1e-4)
+        np.testing.assert_allclose(gf.weights.get(), g[t + "w_upd"][c], rtol=1e-4)
+        gf.means, gf.covariances, gf.weights = g[t + "m_upd"][c], g[t + "P_upd"][c], g[t + "w_upd"][c]
+        idx = gf.resample(r=float(g[t + "r"][c]), return_index=True).get()
+        w32 = g[t + "w_upd"][c].astype(np.float32).astype(np.float64)
+        np.testing.assert_array_equal(idx, orc.systematic_index(w32, float(g[t + "r"][c])))
+        np.testing.assert_array_equal(idx, g[t + "idx"][c])
+        np.testing.assert_array_equal(gf.means.get(), g[t + "m_res"][c])
+        np.testing.assert_array_equal(gf.covariances.get(), g[t + "P_res"][c])
+        np.testing.assert_allclose(gf.point_estimate(), g[t + "est"][c], rtol=1e-6)
+        np.testing.assert_allclose(gf.point_covariance(), g[t + "cov_sv"][c], rtol=1e-5)
+
+
+@pytest.mark.parametrize("n", [5, 64, 1000])
+def test_gsukf_against_oracle(n):
+    """Same inputs to the HIP path and the NumPy oracle over several free-running cycles with injected noise."""
+    rng = np.random.default_rng(n)
+    sp, mp = orc.bioreactor_noise()
+    xss = orc.steady_state()
+    means = (xss[None, :] + rng.standard_normal((n, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    o = orc.GSUKFOracle(n, None, sp, mp, means=means)
+    gf = make(n, means, deterministic=True)
+    for c in range(3):
+        u = [0.05 + 0.01 * c, 0.2]
+        z = np.array(orc.bioreactor_g(xss)) + [0.2, -0.3]
+        noise = (rng.standard_normal((n, 11, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+        DeterministicGaussianSum.preload(noise)
+        gf.predict(u, 0.1)
+        o.predict(u, 0.1, noise=noise, loop=False)
+        np.testing.assert_allclose(gf.means.get(), o.means, rtol=3e-7, atol=1e-9)
+        assert_cov_close(gf.covariances.get(), o.covariances, 2e-5)
+        gf.means, gf.covariances = o.means, o.covariances
+        gf.update(u, z)
+        o.update(u, z)
+        np.testing.assert_allclose(gf.means.get(), o.means, rtol=3e-7, atol=1e-9)
+        assert_cov_close(gf.covariances.get(), o.covariances, 2e-5)
+        np.testing.assert_allclose(gf.weights.get(), o.weights, rtol=2e-6)
+        gf.means, gf.covariances, gf.weights = o.means, o.covariances, o.weights
+        r = float(rng.random())
+        w32 = np.asarray(o.weights, dtype=np.float32).astype(np.float64)
+        idx = gf.resample(r=r, return_index=True).get()
+        o.weights = w32
+        np.testing.assert_array_equal(idx, o.resample(r=r, loop=False))
+        np.testing.assert_allclose(gf.point_estimate(), o.point_estimate(), rtol=1e-6)
+        np.testing.assert_allclose(gf.point_covariance(), o.point_covariance(), rtol=1e-5)
+
+
+def test_gsukf_known_answer(golden):
+    g = golden("gsukf_trace.npz")
+    xss = orc.steady_state().astype(np.float32)
+    gf = make(2, np.repeat(xss[None], 2, axis=0), deterministic=True)
+    gf.update(g["ka_u"], g["ka_z"])
+    np.testing.assert_allclose(gf.means.get(), g["ka_m_upd"], rtol=1e-6, atol=1e-9)
+    assert_cov_close(gf.covariances.get(), g["ka_P_upd"], 1e-5)
+    np.testing.assert_allclose(gf.weights.get(), g["ka_w_upd"], rtol=1e-6)
+    DeterministicGaussianSum.preload(np.zeros((2, 11, 5), np.float32))
+    gf.means, gf.covariances = g["ka_m_upd"], g["ka_P_upd"]
+    gf.predict(g["ka_u"], 0.1)
+    np.testing.assert_allclose(gf.means.get(), g["ka_m_pred"], rtol=1e-6, atol=1e-8)
+    assert_cov_close(gf.covariances.get(), g["ka_P_pred"], 3e-2)
+
+
+def test_gsukf_philox_cycle_and_errors():
+    gpu_se_amd.seed(5)
+    _, _, _, gf = sim_base.get_parts(N_particles=64, pf=False)
+    xss = orc.steady_state()
+    z = np.array(orc.bioreactor_g(xss))
+    for c in range(20):
+        gf.predict([0.06, 0.2], 0.1)
+        gf.update([0.06, 0.2], z)
+        gf.resample()
+    est = gf.point_estimate()
+    np.testing.assert_allclose(est[[0, 2]], xss[[0, 2]], rtol=2e-3)
+    assert np.isfinite(gf.point_covariance())
+    # a covariance that is not positive definite even after the 1e-10 retry is reported, like the reference's
+    # uncaught LinAlgError / RuntimeError (gs_ukf.py:72-75, :336-339)
+    bad = gf.covariances.get().copy()
+    bad[3] = -np.eye(5, dtype=np.float32)
+    gf.covariances = bad
+    gf.predict([0.06, 0.2], 0.1)
+    with pytest.raises(np.linalg.LinAlgError):
+        gf.point_estimate()

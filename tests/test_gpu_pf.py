@@ -1,0 +1,359 @@
+"""Parity of the HIP particle-filter path against the CPU oracle and the golden vectors.  All calls go
+through the C ABI (ctypes) or the drop-in classes built on it.  Run with -m gpu on an MI355X."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():          # collected everywhere, executed only with a device
+    pytest.skip("no HIP device", allow_module_level=True)
+
+import gpu_se_amd                                            # noqa: E402
+from gpu_se_amd import _lib, sim_base                        # noqa: E402
+from gpu_se_amd.filter import ParallelParticleFilter         # noqa: E402
+from gpu_se_amd.gaussian_sum_dist import DeterministicGaussianSum, MultivariateGaussianSum   # noqa: E402
+from gpu_se_amd.model import Bioreactor                      # noqa: E402
+from oracle import gse_oracle as orc                         # noqa: E402
+from tests.gpu_util import dev, host, padded, stream, to_state_major, workspace   # noqa: E402
+
+
+def test_library_is_the_hip_build():
+    assert gpu_se_amd.version() == 100
+    assert _lib.load()._name.endswith("libgse_hip.so")
+
+
+# ------------------------------------------------------------------------------ RNG
+def test_rng_words_bit_exact():
+    """Device Philox4x32-10 words == the published algorithm restated in NumPy, for several streams."""
+    for seed, step, purpose, off in [(1, 0, 1, 0), (0xDEADBEEFCAFEF00D, 77, 2, 0),
+                                     (12345, (3 << 32) + 5, 3, (1 << 33) + 17)]:
+        m = 3000
+        out = torch.empty((m, 8), dtype=torch.int32, device="cuda")
+        rng = _lib.Rng(seed=seed, step=step, element_offset=off, filter_offset=0)
+        _lib.call("gse_rng_raw", out.data_ptr(), m, ctypes.byref(rng), purpose, stream())
+        got = host(out).view(np.uint32)
+        want = orc.rng_words8(seed, step, purpose, np.arange(m, dtype=np.uint64) + np.uint64(off))
+        np.testing.assert_array_equal(got, want)
+
+
+def test_mixture_draw_matches_word_mapping():
+    """draw() == mean + L n with n = Box-Muller(words); fp32 fast transcendentals vs fp64: 2e-5 sigma."""
+    gpu_se_amd.seed(4242)
+    sp, _ = sim_base.get_noise()
+    osp, _ = orc.bioreactor_noise()
+    m = 100000
+    x = sp.draw(m).get()
+    words = orc.rng_words8(sp._seed, 0, orc.RNG_PURPOSE["draw"], np.arange(m))
+    want, comp = orc.words_to_draw(words, osp)
+    sd = np.sqrt(np.array([np.diag(osp.covariances[c]) for c in comp]))
+    assert np.max(np.abs(x - want) / sd) < 2e-4
+    assert x.dtype == np.float32 and x.shape == (m, 5)
+    # shape handling like the reference: tuple shapes append Nx
+    assert tuple(sp.draw((7, 11)).shape) == (7, 11, 5)
+    assert tuple(sp.draw().shape) == (1, 5)
+
+
+def test_mixture_draw_statistics():
+    gpu_se_amd.seed(99)
+    _, mp = sim_base.get_noise()
+    x = mp.draw(400000).get().astype(np.float64)
+    mean = 0.85 * np.array([0.1, 0]) + 0.15 * np.array([0, -0.1])
+    cov = (0.85 * (np.diag([6e-2, 8e-2]) + np.outer([0.1, 0], [0.1, 0]))
+           + 0.15 * (np.array([[500, 100], [100, 700.]]) + np.outer([0, -0.1], [0, -0.1])) - np.outer(mean, mean))
+    np.testing.assert_allclose(np.cov(x.T), cov, rtol=0.03, atol=0.02)
+    assert np.all(np.abs(x.mean(axis=0) - mean) < 5 * np.sqrt(np.diag(cov) / len(x)))
+
+
+# ------------------------------------------------------------------------------ model f, g, pdf
+def test_model_f_g_rows(golden):
+    g = golden("model_fg.npz")
+    x = dev(g["x"])
+    for c in range(len(g["dt"])):
+        out = torch.empty_like(x)
+        _lib.call("gse_model_f", x.data_ptr(), out.data_ptr(), x.shape[0], _lib.doubles(g["u"][c], 2), float(g["dt"][c]), stream())
+        want = orc.bioreactor_f_vec(g["x"], g["u"][c], g["dt"][c])
+        # bit-exact against the fp64 oracle rounded once to fp32
+        np.testing.assert_array_equal(host(out), want.astype(np.float32))
+        # and within the stated tolerance of the reference's own NumPy evaluation (mixed precision)
+        scale = np.abs(g["f_inc"][c]).max(axis=0, keepdims=True) + 1e-30
+        assert np.max(np.abs(host(out) - g["f_inc"][c]) / scale) < 1e-5
+    y = torch.empty((x.shape[0], 2), dtype=torch.float32, device="cuda")
+    _lib.call("gse_model_g", x.data_ptr(), y.data_ptr(), x.shape[0], stream())
+    np.testing.assert_array_equal(host(y).astype(np.float64), g["g_out"][0])
+
+
+def test_mixture_pdf(golden):
+    g = golden("mixture_pdf.npz")
+    sp, mp = sim_base.get_noise()
+    # fp64 exp on the device vs NumPy's: a few ulp
+    np.testing.assert_allclose(mp.pdf(g["e_meas"]).get(), g["p_meas"], rtol=1e-13, atol=0)
+    np.testing.assert_allclose(mp.pdf(g["e_meas"].astype(np.float32)).get(), g["p_meas_f32"], rtol=1e-13, atol=0)
+    np.testing.assert_allclose(sp.pdf(g["e_state"]).get(), g["p_state"], rtol=1e-11, atol=0)
+    assert (mp.pdf(g["e_meas"]).get() == 0).any()
+    toy = MultivariateGaussianSum(g["toy_means"], g["toy_covs"].astype(np.float64), g["toy_weights"])
+    np.testing.assert_allclose(toy.pdf(g["e_toy"]).get(), g["p_toy"], rtol=1e-5)
+    # single point, host list (tests/MultivariateGaussianSum_test.py)
+    assert tuple(mp.pdf([0.1, 0.0]).shape) == (1,)
+
+
+# ------------------------------------------------------------------------------ predict
+@pytest.mark.parametrize("n", [1, 3, 1000, 1024, 4097])
+def test_predict_injected_bit_exact(n):
+    rng = np.random.default_rng(n)
+    xss = orc.steady_state()
+    x = (xss[None, :] * (1 + 0.2 * rng.uniform(-1, 1, (n, 5)))).astype(np.float32)
+    x[:, 3] = rng.uniform(-0.02, 0.2, n)
+    noise = (rng.standard_normal((n, 5)) * np.sqrt([1e-3, 1e-6, 1e-2, 1e-2, 1e-6])).astype(np.float32)
+    u, dt = [0.047, 0.163], 0.1
+    sp, mp = orc.bioreactor_noise()
+    o = orc.ParticleFilterOracle(n, None, sp, mp, particles=x)
+    o.predict_vec(u, dt, noise=noise)
+    xd, ld = to_state_major(x)
+    nd, _ = to_state_major(noise)
+    _lib.call("gse_pf_predict_injected", xd.data_ptr(), ld, 1, n, _lib.doubles(u, 2), dt, nd.data_ptr(), stream())
+    np.testing.assert_array_equal(host(xd)[:, :n].T, o.particles)
+
+
+def test_predict_rng_matches_word_mapping():
+    """The fused predict kernel = oracle ODE step + the draw mapped from the same Philox words."""
+    n = 5000
+    gpu_se_amd.seed(7)
+    _, _, _, pf = sim_base.get_parts(N_particles=n)
+    x0 = pf.particles.get().copy()
+    u, dt = [0.05, 0.2], 1.0
+    pf.predict(u, dt)
+    osp, omp = orc.bioreactor_noise()
+    o = orc.ParticleFilterOracle(n, None, osp, omp, particles=x0)
+    words = orc.rng_words8(pf._seed, 0, orc.RNG_PURPOSE["predict"], np.arange(n))
+    noise, comp = orc.words_to_draw(words, osp)
+    o.predict_vec(u, dt, noise=noise.astype(np.float32))
+    sd = np.sqrt(np.array([np.diag(osp.covariances[c]) for c in comp]))
+    assert np.max(np.abs(pf.particles.get() - o.particles) / sd) < 1e-3   # fp32 add of a 2e-5-sigma-accurate normal
+
+
+# ------------------------------------------------------------------------------ update
+@pytest.mark.parametrize("n", [1, 5, 1024, 3001])
+def test_update_against_oracle(n):
+    rng = np.random.default_rng(100 + n)
+    xss = orc.steady_state()
+    x = (xss[None, :] * (1 + 0.002 * rng.standard_normal((n, 5)))).astype(np.float32)
+    w = rng.random(n).astype(np.float32)
+    z = np.array(orc.bioreactor_g(xss)) + [0.3, -0.4]
+    sp, mp = orc.bioreactor_noise()
+    o = orc.ParticleFilterOracle(n, None, sp, mp, particles=x)
+    o.weights = w.copy()
+    o.update_vec([0.06, 0.2], z)
+    xd, ld = to_state_major(x)
+    wd = padded(w, ld)
+    ws = workspace(1, n)
+    _, pmp = sim_base.get_noise()
+    pod = pmp._pod()
+    _lib.call("gse_pf_update", xd.data_ptr(), wd.data_ptr(), ld, 1, n, _lib.doubles([0.06, 0.2], 2), _lib.doubles(z, 2),
+              ctypes.byref(pod), ws.data_ptr(), stream())
+    got = host(wd)[:n]
+    # fp64 likelihood (device exp within a few ulp of NumPy's), one rounding to fp32: at most one fp32 ulp apart
+    np.testing.assert_allclose(got, o.weights, rtol=1.2e-7, atol=0)
+    # the tile sums left in the workspace are the fp64 sums of the new fp32 weights
+    t = -(-n // 1024)
+    sums = host(ws[:8 * t].view(torch.float64))
+    want = [got[i * 1024:(i + 1) * 1024].astype(np.float64).sum() for i in range(t)]
+    np.testing.assert_allclose(sums, want, rtol=1e-14)
+
+
+# ------------------------------------------------------------------------------ resample
+def run_resample(w, r, x=None, tiles_valid=False):
+    n = len(w)
+    if x is None:
+        x = np.arange(n, dtype=np.float32)[:, None] + np.arange(5, dtype=np.float32)[None, :] * 0.125
+    xd, ld = to_state_major(x)
+    wd = padded(np.asarray(w, dtype=np.float32), ld)
+    xo = torch.full_like(xd, float("nan"))
+    wo = torch.full_like(wd, float("nan"))
+    idx = torch.full((ld,), -1, dtype=torch.int32, device="cuda")
+    ws = workspace(1, n)
+    _lib.call("gse_pf_resample", xd.data_ptr(), wd.data_ptr(), xo.data_ptr(), wo.data_ptr(), idx.data_ptr(), ld, 1, n,
+              _lib.doubles([r], 1), 0, ws.data_ptr(), stream())
+    return host(idx)[:n], host(xo)[:, :n].T, host(wo)[:n], x
+
+
+def test_resample_golden_indices(golden):
+    """Ancestor indices are integer work: bit-exact against the reference's own resample (golden) and the oracle."""
+    g = golden("resample.npz")
+    for name in g["names"]:
+        w, r = g[name + "_w"], float(g[name + "_r"])
+        idx, xo, wo, x = run_resample(w, r)
+        np.testing.assert_array_equal(idx, g[name + "_idx"], err_msg=str(name))
+        np.testing.assert_array_equal(idx, orc.systematic_index(w.astype(np.float64), r), err_msg=str(name))
+        np.testing.assert_array_equal(xo, x[idx], err_msg=str(name))
+        np.testing.assert_array_equal(wo, np.full(len(w), np.float32(1.0 / len(w))))
+
+
+@pytest.mark.parametrize("n", [2, 1023, 1025, 2048, 5000, 65536 + 3])
+def test_resample_random_weights_vs_oracle(n):
+    rng = np.random.default_rng(n)
+    for kind in range(4):
+        w = rng.random(n).astype(np.float32)
+        if kind == 1:
+            w = (w ** 12).astype(np.float32)
+        if kind == 2:
+            w[rng.random(n) < 0.7] = 0
+            w[n // 2] = 1
+        if kind == 3:
+            w = np.exp(-0.5 * ((np.arange(n) - 0.3 * n) / (0.01 * n + 1)) ** 2).astype(np.float32)
+        r = float(rng.random())
+        idx, xo, wo, x = run_resample(w, r)
+        want = orc.systematic_index(w.astype(np.float64), r)
+        # the device scans tile-wise, the oracle left to right: their fp64 cumulative sums may differ in the
+        # last bit, which can move an ancestor by one only when a threshold lands within ~1e-16 of a
+        # cumulative value -- none expected at these sizes
+        np.testing.assert_array_equal(idx, want)
+        np.testing.assert_array_equal(xo, x[idx])
+
+
+def test_resample_degenerate_weights():
+    n = 3000
+    for w in (np.zeros(n, np.float32), np.full(n, np.nan, np.float32)):
+        idx, xo, wo, x = run_resample(w, 0.3)
+        np.testing.assert_array_equal(idx, np.zeros(n, dtype=np.int32))     # the CPU class's sweep never advances
+        np.testing.assert_array_equal(xo, np.repeat(x[:1], n, axis=0))
+    w = np.zeros(n, np.float32)
+    w[-1] = 5.0
+    idx, *_ = run_resample(w, 0.999)
+    np.testing.assert_array_equal(idx, np.full(n, n - 1))
+    with pytest.raises(_lib.GseError):
+        run_resample(np.ones(8, np.float32), 1.0)                            # r outside [0, 1)
+
+
+def test_resample_full_size_properties():
+    """N = 2^20 (BASELINE config 2): size-independent properties of systematic resampling."""
+    n = 1 << 20
+    rng = np.random.default_rng(20)
+    w = rng.random(n).astype(np.float32) ** 3
+    r = float(rng.random())
+    idx, xo, wo, x = run_resample(w, r)
+    assert np.all(np.diff(idx) >= 0) and idx.min() >= 0 and idx.max() < n          # sorted, in range
+    counts = np.bincount(idx, minlength=n)
+    expect = w.astype(np.float64) / w.astype(np.float64).sum() * n
+    assert np.all(np.abs(counts - expect) < 1.0 + 1e-6)                            # |count - N w| < 1
+    np.testing.assert_array_equal(xo, x[idx])
+    want = orc.systematic_index(w.astype(np.float64), r)
+    assert np.sum(idx != want) <= 2                                                 # ties on the last bit only
+    # uniform weights, any r: identity
+    idx, *_ = run_resample(np.full(n, 1.0 / n, np.float32), 0.5)
+    np.testing.assert_array_equal(idx, np.arange(n))
+
+
+# ------------------------------------------------------------------------------ moments
+@pytest.mark.parametrize("n", [1, 7, 1024, 50001])
+def test_moments(n):
+    rng = np.random.default_rng(n + 5)
+    xss = orc.steady_state()
+    x = (xss[None, :] + rng.standard_normal((n, 5)) * np.sqrt([1e-3, 1e-6, 1e-2, 1e-2, 1e-6])).astype(np.float32)
+    w = (rng.random(n) / n).astype(np.float32)
+    sp, mp = orc.bioreactor_noise()
+    o = orc.ParticleFilterOracle(n, None, sp, mp, particles=x)
+    o.weights = w.astype(np.float64)
+    gpu_se_amd.seed(1)
+    _, _, _, pf = sim_base.get_parts(N_particles=n)
+    pf.particles = x
+    pf.weights = w
+    np.testing.assert_allclose(pf.point_estimate(), o.point_estimate(), rtol=1e-12)
+    if n > 1:
+        np.testing.assert_allclose(pf.point_covariance(), o.point_covariance(), rtol=1e-9)
+
+
+# ------------------------------------------------------------------------------ the class, golden trace
+def make_filter(n, particles, deterministic=False):
+    gpu_se_amd.seed(11)
+    state_pdf, measurement_pdf = sim_base.get_noise(deterministic=deterministic)
+    x0, _ = sim_base.get_noise()
+    pf = ParallelParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, state_pdf, measurement_pdf)
+    pf.particles = particles
+    return pf
+
+
+def test_pf_trace_per_step(golden):
+    """The reference's own 10-cycle trace (golden G4), each step started from the reference's state with its
+    recorded noise and r, through the drop-in class: particles to one fp32 rounding, weights 2e-6,
+    ancestors exact."""
+    g = golden("pf_trace.npz")
+    n = len(g["w0"])
+    pf = make_filter(n, g["x0"], deterministic=True)
+    for c in range(len(g["dt"])):
+        DeterministicGaussianSum.preload(g["noise"][c])
+        pf.predict(g["u"][c], g["dt"][c])
+        np.testing.assert_allclose(pf.particles.get(), g["after_predict"][c], rtol=5e-7, atol=2e-9)
+        pf.particles = g["after_predict"][c]
+        pf.update(g["u"][c], g["z"][c])
+        np.testing.assert_allclose(pf.weights.get(), g["w_after_update"][c], rtol=2e-6)
+        pf.weights = g["w_after_update"][c]
+        idx = pf.resample(r=float(g["r"][c]), return_index=True)
+        w32 = g["w_after_update"][c].astype(np.float32).astype(np.float64)
+        np.testing.assert_array_equal(idx.get(), orc.systematic_index(w32, float(g["r"][c])))
+        # vs the reference's ancestors (it resampled fp64 weights; ours are their fp32 roundings): flips only where
+        # a threshold falls within 6e-8 relative of a cumulative weight
+        assert np.sum(idx.get() != g["idx"][c]) <= 2
+        pf.particles = g["after_resample"][c]
+        np.testing.assert_allclose(pf.point_estimate(), g["estimate"][c], rtol=1e-6)
+        np.testing.assert_allclose(pf.point_covariance(), g["cov_sv"][c], rtol=1e-5)
+
+
+def test_api_surface():
+    gpu_se_amd.seed(3)
+    bioreactor, lin_model, K, pf = sim_base.get_parts(N_particles=2000)
+    np.testing.assert_allclose(bioreactor.X, orc.steady_state(), rtol=1e-12)
+    assert tuple(pf.particles.shape) == (2000, 5) and pf.particles.dtype == torch.float32
+    assert tuple(pf.weights.shape) == (2000,)
+    assert pf.N_particles == 2000 and pf._tpb == 1024 and pf._bpg == 2
+    u, z = [0.06, 0.2], np.array([280.1, 611.0])
+    pf.predict(u, 0.1)
+    pf.update(u, z)
+    pf.resample()
+    est = pf.point_estimate()
+    assert est.shape == (5,) and np.all(np.isfinite(est))
+    assert np.isfinite(pf.point_covariance())
+    # pieces the benchmark scripts use (pf_run_seq.py:172, :223, :282-287)
+    inc = pf.f_vectorize(pf.particles, u, 1.0)
+    assert tuple(inc.shape) == (2000, 5)
+    ys = pf.g_vectorize(pf.particles, u, pf._y_dummy)
+    np.testing.assert_array_equal(ys.get(), orc.bioreactor_g_vec(pf.particles.get()))
+    w = np.random.default_rng(0).random(2000)
+    pf.weights = w / w.sum()                       # host array assignment (pf_run_seq.py:124-125)
+    c = torch.empty(2000, dtype=torch.float64, device="cuda")
+    _lib.call("gse_cumsum_normalised", pf.weights.data_ptr(), c.data_ptr(), 2000, pf._ws.data_ptr(), stream())
+    w32 = pf.weights.get().astype(np.float64)
+    np.testing.assert_allclose(host(c), np.cumsum(w32) / w32.sum(), rtol=1e-14)
+    sample_index = torch.zeros(2000, dtype=torch.int64, device="cuda")
+    ParallelParticleFilter._parallel_resample[pf._bpg, pf._tpb](c, sample_index, 0.25, 2000)
+    np.testing.assert_array_equal(host(sample_index), orc.systematic_index(w32, 0.25))
+    with pytest.raises(NotImplementedError):
+        ParallelParticleFilter(lambda x, u, dt: x, Bioreactor.static_outputs, 8, *[sim_base.get_noise()[0]] * 2,
+                               sim_base.get_noise()[1])
+
+
+def test_statistical_parity_with_reference(golden):
+    """Philox-driven HIP filter vs the reference's NumPy filter (MT19937) on one fixed (u, z) sequence: the
+    posterior mean must fall inside the envelope of the reference's own seed-to-seed scatter (golden G6)."""
+    g = golden("pf_stat.npz")
+    for n, key in ((1024, "est_n1024"), (8192, "est_n8192")):
+        ref = g[key]                                     # (seeds, cycles, 5)
+        mu, sd = ref.mean(axis=0), ref.std(axis=0, ddof=1)
+        runs = []
+        for s in range(8):
+            gpu_se_amd.seed(1000 + s)
+            _, _, _, pf = sim_base.get_parts(N_particles=n)
+            est = []
+            for c in range(len(g["u"])):
+                pf.predict(g["u"][c], float(g["dt"]))
+                pf.update(g["u"][c], g["z"][c])
+                pf.resample()
+                est.append(pf.point_estimate())
+            runs.append(np.array(est))
+        runs = np.array(runs)
+        zscore = (runs.mean(axis=0) - mu) / (sd * np.sqrt(1 / 8 + 1 / ref.shape[0]) + 1e-9)
+        zscore = zscore[:, [0, 2, 3, 4]]                 # Cx has no dynamics and no information: skip
+        assert np.mean(np.abs(zscore) < 3.5) > 0.97, np.abs(zscore).max()
+        assert np.abs(zscore).max() < 6
