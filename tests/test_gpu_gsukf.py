@@ -17,6 +17,17 @@ from oracle import gse_oracle as orc                         # noqa: E402
 from tests.test_oracle_golden import assert_cov_close        # noqa: E402
 
 
+def assert_mean_close(mu, ref, cov, rel_sigma=5e-5, rtol=3e-7):
+    """|d mu_k| <= rel_sigma * sqrt(P_kk) + rtol |mu_k|.  A one-ulp difference in a sigma point (the device
+    factorises with its own fp32 Cholesky, the oracle with LAPACK) moves y = 180 Cg by an fp32 ulp of 280
+    (3e-5) against deviations of ~1.8, i.e. the Kalman gain by ~1e-5 relative; the update of each state is a
+    fraction of its standard deviation, hence the sigma-relative tolerance."""
+    sd = np.sqrt(np.abs(np.einsum("...ii->...i", np.asarray(cov, dtype=np.float64))))
+    bound = rel_sigma * sd + rtol * np.abs(ref) + 1e-12
+    err = np.abs(np.asarray(mu, dtype=np.float64) - ref)
+    assert np.all(err <= bound), float(np.max(err / bound))
+
+
 def make(n, means=None, covs=None, deterministic=False):
     gpu_se_amd.seed(21)
     state_pdf, measurement_pdf = sim_base.get_noise(deterministic=deterministic)
@@ -46,18 +57,18 @@ def test_gsukf_trace_per_step(golden, n):
     g = golden("gsukf_trace.npz")
     t = "n%d_" % n
     gf = make(n, g[t + "means0"], g[t + "covs0"], deterministic=True)
-    np.testing.assert_allclose(gf._get_sigma_points().get(), g[t + "sigmas0"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(gf._get_sigma_points().get(), g[t + "sigmas0"], rtol=1e-6, atol=1e-8)
     for c in range(len(g[t + "dt"])):
         DeterministicGaussianSum.preload(g[t + "noise"][c])
         gf.predict(g[t + "u"][c], g[t + "dt"][c])
         np.testing.assert_allclose(gf.means.get(), g[t + "m_pred"][c], rtol=1e-6, atol=1e-8)
         assert_cov_close(gf.covariances.get(), g[t + "P_pred"][c], 3e-2)
         gf.means, gf.covariances = g[t + "m_pred"][c], g[t + "P_pred"][c]
-        np.testing.assert_allclose(gf._get_sigma_points().get(), g[t + "sig_upd"][c], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(gf._get_sigma_points().get(), g[t + "sig_upd"][c], rtol=1e-6, atol=1e-8)
         gf.update(g[t + "u"][c], g[t + "z"][c])
-        np.testing.assert_allclose(gf.means.get(), g[t + "m_upd"][c], rtol=1e-6, atol=1e-8)
+        assert_mean_close(gf.means.get(), g[t + "m_upd"][c], g[t + "P_pred"][c])
         assert_cov_close(gf.covariances.get(), g[t + "P_upd"][c], 1e-4)
-        np.testing.assert_allclose(gf.weights.get(), g[t + "w_upd"][c], rtol=1e-4)
+        np.testing.assert_allclose(gf.weights.get(), g[t + "w_upd"][c], rtol=1e-3)
         gf.means, gf.covariances, gf.weights = g[t + "m_upd"][c], g[t + "P_upd"][c], g[t + "w_upd"][c]
         idx = gf.resample(r=float(g[t + "r"][c]), return_index=True).get()
         w32 = g[t + "w_upd"][c].astype(np.float32).astype(np.float64)
@@ -88,11 +99,14 @@ def test_gsukf_against_oracle(n):
         np.testing.assert_allclose(gf.means.get(), o.means, rtol=3e-7, atol=1e-9)
         assert_cov_close(gf.covariances.get(), o.covariances, 2e-5)
         gf.means, gf.covariances = o.means, o.covariances
+        prior_cov = o.covariances.copy()
         gf.update(u, z)
         o.update(u, z)
-        np.testing.assert_allclose(gf.means.get(), o.means, rtol=3e-7, atol=1e-9)
-        assert_cov_close(gf.covariances.get(), o.covariances, 2e-5)
-        np.testing.assert_allclose(gf.weights.get(), o.weights, rtol=2e-6)
+        assert_mean_close(gf.means.get(), o.means, prior_cov)
+        assert_cov_close(gf.covariances.get(), o.covariances, 1e-4)
+        # the weight factor is pdf(z - g(mu_new)): an fp32 ulp of y = 180 Cg (3e-5) against the 0.245 measurement
+        # sigma moves the likelihood by up to a few 1e-4 relative
+        np.testing.assert_allclose(gf.weights.get(), o.weights, rtol=1e-3)
         gf.means, gf.covariances, gf.weights = o.means, o.covariances, o.weights
         r = float(rng.random())
         w32 = np.asarray(o.weights, dtype=np.float32).astype(np.float64)
