@@ -472,23 +472,17 @@ int gse_gsukf_resample(const float* mu_in, const float* P_in, const float* w, fl
     if (int rc = check_gsukf("gse_gsukf_resample", B, N)) return rc;
     GSE_REQUIRE(mu_in && P_in && w && mu_out && P_out && w_out && r && workspace, "gse_gsukf_resample: null argument");
     GSE_REQUIRE(mu_in != mu_out && P_in != P_out && w != w_out, "gse_gsukf_resample: outputs must not alias inputs");
-    (void)flags;                                   // tile sums are always recomputed for the Gaussian bank
+    // (tile sums are always recomputed for the Gaussian bank: GSE_RESAMPLE_TILES_VALID is ignored)
     ResampleArgs ra;
     for (int b = 0; b < B; ++b) {
         GSE_REQUIRE(r[b] >= 0.0 && r[b] < 1.0, "gse_gsukf_resample: r[%d] = %g is outside [0, 1)", b, r[b]);
         ra.r[b] = r[b];
     }
-    const int T = (int)tiles_of(N);
     Workspace ws = carve_workspace(workspace, B, N);
     hipStream_t st = (hipStream_t)stream;
-    launch_tile_sums(w, ws.tile_sums, B, N, N, T, st);
-    GSE_LAUNCH_CHECK("tile_sum_kernel");
-    launch_tile_scan(ws.tile_sums, ws.tile_prefix, B, T, st);
-    GSE_LAUNCH_CHECK("tile_scan_kernel");
+    if (int rc = launch_cumsum(w, N, B, N, flags & ~GSE_RESAMPLE_TILES_VALID, nullptr, ws, ws.cumsum, st)) return rc;
     GsukfPayload pl{mu_in, P_in, mu_out, P_out, N};
-    launch_gsukf_resample(pl, w, w_out, idx, ws.tile_prefix, B, N, T, ra, st);
-    GSE_LAUNCH_CHECK("resample_kernel<gsukf>");
-    return GSE_OK;
+    return launch_gsukf_gather(pl, w_out, idx, B, N, ra, ws, st);
 }
 
 int gse_gsukf_moments(const float* mu, const float* P, const float* w, int B, int64_t N, double* out, void* workspace,

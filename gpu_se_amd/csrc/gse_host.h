@@ -52,6 +52,8 @@ struct Workspace {
     double* tile_sums;     // [B][T]
     double* tile_prefix;   // [B][T + 1]   exclusive prefix of tile sums; [T] = total
     double* partials;      // [B][kMomentBlocks][kMomentWidth]
+    double* totals;        // [B]          sum of the weights of each filter
+    double* cumsum;        // [B][N]       normalised cumulative weights
     int64_t bytes;
 };
 constexpr int kMomentBlocks = 512;
@@ -102,10 +104,10 @@ struct GsukfPayload {                 // row-major (mu[5], P[25]) per Gaussian
     }
 };
 
-void launch_tile_sums(const float* w, double* tile_sums, int B, int64_t N, int64_t ldw, int T, hipStream_t st);
-void launch_tile_scan(const double* tile_sums, double* prefix, int B, int T, hipStream_t st);
-void launch_gsukf_resample(const GsukfPayload& pl, const float* w, float* w_out, int32_t* idx, const double* prefix,
-                           int B, int64_t N, int T, const ResampleArgs& ra, hipStream_t st);
+int launch_cumsum(const float* w, int64_t ldw, int B, int64_t N, uint32_t flags, double* island, const Workspace& ws,
+                  double* c_out, hipStream_t st);
+int launch_gsukf_gather(const GsukfPayload& pl, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra,
+                        const Workspace& ws, hipStream_t st);
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
                            const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, hipStream_t st);
 

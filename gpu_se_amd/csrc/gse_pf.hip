@@ -175,52 +175,77 @@ __global__ __launch_bounds__(kBlock) void tile_scan_kernel(const double* __restr
 // ------------------------------------------------------------------------------------------------
 // systematic resample
 // ------------------------------------------------------------------------------------------------
-// #{ j in [0, N) : fl(fl(j + r) / N) <= y }  -- evaluated with exactly the reference's expression for u_j
-// (filter/particle.py:97 / :247): closed-form estimate, then exact fix-up by direct comparison.
-__device__ __forceinline__ int64_t count_thresholds_le(double y, double r, int64_t N) {
-    const double Nd = (double)N;
-    double est = floor(y * Nd - r) + 1.0;
-    est = fmin(fmax(est, 0.0), Nd);                       // NaN-safe clamp
-    int64_t j = (int64_t)est;
-    while (j > 0 && ((double)(j - 1) + r) / Nd > y) --j;
-    while (j < N && ((double)j + r) / Nd <= y) ++j;
-    return j;
+// Two kernels, both perfectly balanced whatever the weights look like (a degenerate posterior -- a handful of
+// particles carrying all the weight -- is the normal state of this filter, see tests/test_oracle_golden.py):
+//
+//   cumsum_kernel   one workgroup per tile of 1024 ANCESTORS: tile prefix (from the tile sums the update kernel
+//                   left behind) + fp64 scan of the tile's weights -> normalised cumulative weights c[k], fp64,
+//                   monotone, c[N-1] = 1.                                     r 4 B, w 8 B per particle
+//   gather_kernel   one workgroup per tile of 1024 OUTPUTS: two 64-ary wavefront searches bracket the tile's
+//                   ancestor span in c[], the span is staged in LDS, every output finds its ancestor
+//                   (first k with c[k] >= (j + r)/N, the reference's comparison verbatim) by binary search in
+//                   LDS and copies it; stores are contiguous in j.           r 8 + 20 B, w 24 B per particle
+//
+// Tile prefix computed inside the cumsum kernel (T <= 4096 tiles): every workgroup scans the T tile sums itself
+// -- identical code on identical data, hence identical bits in every workgroup -- and picks out
+//   Pfx(t), Pfx(t+1), Pfx(T) = total,   Pfx(q) = excl[q / m] + s[(q/m)*m] + ... + s[q-1]
+// (thread j owns chunk [j*m, (j+1)*m); excl = workgroup exclusive scan of the chunk sums).  Larger T: a scan
+// kernel of its own writes the prefix once.
+constexpr int kInlinePrefixMaxT = 4096;
+
+__device__ __forceinline__ void inline_tile_prefix(const double* __restrict__ s, int T, int t, double* red,
+                                                   double* out3) {
+    const int m = (T + kBlock - 1) / kBlock;
+    const int lo = threadIdx.x * m;
+    const int hi = min(lo + m, T);
+    double chunk = 0.0;
+    for (int q = lo; q < hi; ++q) chunk += s[q];
+    double total;
+    const double excl = block_exclusive_scan(chunk, red, total);
+    if (t >= lo && t < hi) {
+        double run = excl;
+        for (int q = lo; q < t; ++q) run += s[q];
+        out3[0] = run;
+    }
+    if (t + 1 < T) {
+        if (t + 1 >= lo && t + 1 < hi) {
+            double run = excl;
+            for (int q = lo; q <= t; ++q) run += s[q];
+            out3[1] = run;
+        }
+    } else if (threadIdx.x == 0) {
+        out3[1] = total;
+    }
+    if (threadIdx.x == 0) out3[2] = total;
+    __syncthreads();
 }
 
-template <class Payload>
-__global__ __launch_bounds__(kBlock) void resample_kernel(const Payload pl, const float* __restrict__ w,
-                                                          float* __restrict__ w_out, int32_t* __restrict__ idx_out,
-                                                          const double* __restrict__ tile_prefix, int64_t N,
-                                                          int64_t ldw, int T, const ResampleArgs ra) {
-    __shared__ double sc[kTile];          // normalised cumulative weights of this tile
+// tile_src: kInlinePrefix ? tile sums [B][T] : exclusive tile prefix [B][T + 1] (from tile_scan_kernel).
+// c: [B][N] fp64.  totals: [B] fp64 (sum of the weights).  island: optional [2][B] shard bookkeeping.
+template <bool kInlinePrefix>
+__global__ __launch_bounds__(kBlock) void cumsum_kernel(const float* __restrict__ w, double* __restrict__ c,
+                                                        const double* __restrict__ tile_src,
+                                                        double* __restrict__ totals, double* __restrict__ island,
+                                                        int64_t N, int64_t ldw, int T) {
     __shared__ double red[4];
-    __shared__ int64_t bounds[2];
-
+    __shared__ double pfx[3];
     const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
-    const double* pf = tile_prefix + (int64_t)b * (T + 1);
-    const double P0 = pf[t], P1 = pf[t + 1], W = pf[T];
-    const double r = ra.r[b];
-    const int64_t k0 = (int64_t)t * kTile;
-    const int cnt = (int)min((int64_t)kTile, N - k0);
-    const float w_uniform = (float)(1.0 / (double)N);
-    float* wo = w_out + (int64_t)b * ldw;
-    int32_t* io = idx_out ? idx_out + (int64_t)b * ldw : nullptr;
-
-    // Weights that do not sum to a positive finite number: the reference's normalised cumsum is all-NaN and
-    // its sweep never advances (filter/particle.py:98), so every offspring copies particle 0.
-    if (!(W > 0.0) || !(W < INFINITY)) {
-        if (t == 0) {
-            for (int64_t j = tid; j < N; j += kBlock) {
-                pl.copy(b, 0, j);
-                wo[j] = w_uniform;
-                if (io) io[j] = 0;
-            }
-        }
-        return;
+    double P0, P1, W;
+    if (kInlinePrefix) {
+        inline_tile_prefix(tile_src + (int64_t)b * T, T, t, red, pfx);
+        P0 = pfx[0]; P1 = pfx[1]; W = pfx[2];
+    } else {
+        const double* pf = tile_src + (int64_t)b * (T + 1);
+        P0 = pf[t]; P1 = pf[t + 1]; W = pf[T];
     }
-
-    // 1. fp64 inclusive scan of the tile's weights: 4 per thread in registers, then across the workgroup.
-    const int64_t i0 = k0 + (int64_t)tid * kPerThread;
+    if (t == 0 && tid == 0) {
+        totals[b] = W;
+        if (island) {                          // shard bookkeeping: accumulated log-weight and this cycle's sum
+            island[b] += log(W);
+            island[gridDim.y + b] = W;
+        }
+    }
+    const int64_t i0 = (int64_t)t * kTile + (int64_t)tid * kPerThread;
     const float4 wv = load_weights4(w + (int64_t)b * ldw, i0, N, ldw);
     double s[kPerThread];
     s[0] = (i0 + 0 < N) ? (double)wv.x : 0.0;
@@ -229,37 +254,119 @@ __global__ __launch_bounds__(kBlock) void resample_kernel(const Payload pl, cons
     s[3] = s[2] + ((i0 + 3 < N) ? (double)wv.w : 0.0);
     double tile_total;
     const double excl = block_exclusive_scan(s[3], red, tile_total);
-
-    // 2. normalised cumulative sums into LDS; the tile's last entry is pinned to prefix[t+1]/W, the value the
-    //    next tile uses as its lower boundary, so the partition of the outputs among tiles is exact.
+    // The tile's last entry is pinned to prefix[t+1]/W and everything before it clamped to that value, so the
+    // array is monotone across tiles although prefix and in-tile sums associate differently; c[N-1] = W/W = 1.
     const double top = P1 / W;
+    const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
+    double* cb = c + (int64_t)b * N;
+    double v[kPerThread];
 #pragma unroll
-    for (int p = 0; p < kPerThread; ++p) {
-        const int q = tid * kPerThread + p;
-        if (q < cnt) sc[q] = (q == cnt - 1) ? top : fmin((P0 + (excl + s[p])) / W, top);
+    for (int p = 0; p < kPerThread; ++p) v[p] = (i0 + p == last) ? top : fmin((P0 + (excl + s[p])) / W, top);
+    if (i0 + 3 < N && (N & 1) == 0) {          // 16-byte aligned pairs
+        *reinterpret_cast<double2*>(cb + i0) = make_double2(v[0], v[1]);
+        *reinterpret_cast<double2*>(cb + i0 + 2) = make_double2(v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p)
+            if (i0 + p < N) cb[i0 + p] = v[p];
     }
-    if (tid == 0) bounds[0] = (t == 0) ? 0 : count_thresholds_le(P0 / W, r, N);
-    if (tid == 64) bounds[1] = (t == T - 1) ? N : count_thresholds_le(top, r, N);
-    __syncthreads();
-    const int64_t o0 = bounds[0], o1 = bounds[1];
+}
 
-    // 3. every output slot of this tile's range finds its ancestor by binary search in LDS and gathers it.
+// First k in [0, N) with c[k] >= u, found by one wavefront: every round the 64 lanes probe 64 evenly spaced
+// elements of the remaining range and a ballot picks the sub-range (4 rounds of one L2 access for N <= 2^24,
+// instead of 24 dependent ones).  Returns N - 1 if no element qualifies (cannot happen for u <= c[N-1] = 1).
+__device__ __forceinline__ int64_t wave_search_ge(const double* __restrict__ c, int64_t N, double u, int lane) {
+    int64_t lo = 0, hi = N;                                   // answer in [lo, hi)
+    while (true) {
+        const int64_t n = hi - lo;
+        const int64_t step = (n + 63) >> 6;
+        const int64_t probe = min(lo + (int64_t)(lane + 1) * step, hi) - 1;
+        const bool ge = c[probe] >= u;
+        const unsigned long long mask = __ballot(ge);
+        if (mask == 0ull) return N - 1;
+        const int first = __ffsll((long long)mask) - 1;
+        const int64_t nlo = lo + (int64_t)first * step;
+        const int64_t nhi = min(lo + (int64_t)(first + 1) * step, hi);
+        if (step == 1) return nlo;
+        lo = nlo;
+        hi = nhi;
+    }
+}
+
+constexpr int kSpanMax = 2048;            // ancestors staged in LDS per output tile (16 KiB)
+
+template <class Payload>
+__global__ __launch_bounds__(kBlock) void gather_kernel(const Payload pl, const double* __restrict__ c,
+                                                        const double* __restrict__ totals, float* __restrict__ w_out,
+                                                        int32_t* __restrict__ idx_out, int64_t N, int64_t ldw,
+                                                        const ResampleArgs ra) {
+    __shared__ double seg[kSpanMax];
+    __shared__ int64_t span[2];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t j0 = (int64_t)blockIdx.x * kTile;
+    const int64_t j1 = min(j0 + kTile, N);
+    const double r = ra.r[b];
     const double Nd = (double)N;
-    for (int64_t j = o0 + tid; j < o1; j += kBlock) {
-        const double u = ((double)j + r) / Nd;
-        int lo = 0, hi = cnt - 1;
-#pragma unroll
-        for (int it = 0; it < 10; ++it) {                 // 2^10 = kTile
-            const int mid = (lo + hi) >> 1;
-            const bool open = lo < hi;
-            const bool less = open && (sc[mid] < u);
-            lo = less ? mid + 1 : lo;
-            hi = (open && !less) ? mid : hi;
+    const double W = totals[b];
+    const double* cb = c + (int64_t)b * N;
+    const float w_uniform = (float)(1.0 / Nd);
+    float* wo = w_out + (int64_t)b * ldw;
+    int32_t* io = idx_out ? idx_out + (int64_t)b * ldw : nullptr;
+
+    // Weights that do not sum to a positive finite number: the reference's normalised cumsum is all-NaN and its
+    // sweep never advances (filter/particle.py:98), so every offspring copies particle 0.
+    if (!(W > 0.0) || !(W < INFINITY)) {
+        for (int64_t j = j0 + tid; j < j1; j += kBlock) {
+            pl.copy(b, 0, j);
+            wo[j] = w_uniform;
+            if (io) io[j] = 0;
         }
-        const int64_t anc = k0 + lo;
-        pl.copy(b, anc, j);
-        wo[j] = w_uniform;
-        if (io) io[j] = (int32_t)anc;
+        return;
+    }
+
+    // 1. bracket the ancestors of this output tile: wavefront 0 searches for the first output, wavefront 1 for the last
+    if (wv < 2) {
+        const int64_t j = (wv == 0) ? j0 : j1 - 1;
+        const int64_t k = wave_search_ge(cb, N, ((double)j + r) / Nd, lane);
+        if (lane == 0) span[wv] = k;
+    }
+    __syncthreads();
+    const int64_t klo = span[0], khi = span[1];
+    const int64_t len = khi - klo + 1;
+
+    if (len <= kSpanMax) {
+        // 2a. stage c[klo..khi] in LDS, binary search there (<= 11 steps)
+        for (int q = tid; q < (int)len; q += kBlock) seg[q] = cb[klo + q];
+        __syncthreads();
+        for (int64_t j = j0 + tid; j < j1; j += kBlock) {
+            const double u = ((double)j + r) / Nd;
+            int lo = 0, hi = (int)len - 1;
+#pragma unroll
+            for (int it = 0; it < 11; ++it) {             // 2^11 = kSpanMax
+                const int mid = (lo + hi) >> 1;
+                const bool open = lo < hi;
+                const bool less = open && (seg[mid] < u);
+                lo = less ? mid + 1 : lo;
+                hi = (open && !less) ? mid : hi;
+            }
+            const int64_t anc = klo + lo;
+            pl.copy(b, anc, j);
+            wo[j] = w_uniform;
+            if (io) io[j] = (int32_t)anc;
+        }
+    } else {
+        // 2b. the tile's ancestors are spread over a long stretch of (nearly) weightless particles: search c[] itself
+        for (int64_t j = j0 + tid; j < j1; j += kBlock) {
+            const double u = ((double)j + r) / Nd;
+            int64_t lo = klo, hi = khi;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (cb[mid] < u) lo = mid + 1; else hi = mid;
+            }
+            pl.copy(b, lo, j);
+            wo[j] = w_uniform;
+            if (io) io[j] = (int32_t)lo;
+        }
     }
 }
 
@@ -334,17 +441,35 @@ __global__ __launch_bounds__(kBlock) void moments_finish_kernel(const double* __
 }
 
 // Exposed to gse_gsukf.hip
-void launch_tile_sums(const float* w, double* tile_sums, int B, int64_t N, int64_t ldw, int T, hipStream_t st) {
-    hipLaunchKernelGGL(tile_sum_kernel, dim3(T, B), dim3(kBlock), 0, st, w, tile_sums, N, ldw, T);
+// Normalised cumulative weights of B filters into ws.cumsum (+ totals); shared by PF, GS-UKF and gse_cumsum_normalised.
+int launch_cumsum(const float* w, int64_t ldw, int B, int64_t N, uint32_t flags, double* island, const Workspace& ws,
+                  double* c_out, hipStream_t st) {
+    const int T = (int)tiles_of(N);
+    if (!(flags & GSE_RESAMPLE_TILES_VALID)) {
+        hipLaunchKernelGGL(tile_sum_kernel, dim3(T, B), dim3(kBlock), 0, st, w, ws.tile_sums, N, ldw, T);
+        GSE_LAUNCH_CHECK("tile_sum_kernel");
+    }
+    if (T <= kInlinePrefixMaxT && !(flags & GSE_RESAMPLE_SEPARATE_SCAN)) {
+        hipLaunchKernelGGL(cumsum_kernel<true>, dim3(T, B), dim3(kBlock), 0, st, w, c_out, ws.tile_sums, ws.totals, island,
+                           N, ldw, T);
+    } else {
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(B), dim3(kBlock), 0, st, ws.tile_sums, ws.tile_prefix, T);
+        GSE_LAUNCH_CHECK("tile_scan_kernel");
+        hipLaunchKernelGGL(cumsum_kernel<false>, dim3(T, B), dim3(kBlock), 0, st, w, c_out, ws.tile_prefix, ws.totals,
+                           island, N, ldw, T);
+    }
+    GSE_LAUNCH_CHECK("cumsum_kernel");
+    return GSE_OK;
 }
-void launch_tile_scan(const double* tile_sums, double* prefix, int B, int T, hipStream_t st) {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(B), dim3(kBlock), 0, st, tile_sums, prefix, T);
+
+int launch_gsukf_gather(const GsukfPayload& pl, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra,
+                        const Workspace& ws, hipStream_t st) {
+    hipLaunchKernelGGL(gather_kernel<GsukfPayload>, dim3((unsigned)tiles_of(N), B), dim3(kBlock), 0, st, pl, ws.cumsum,
+                       ws.totals, w_out, idx, N, N, ra);
+    GSE_LAUNCH_CHECK("gather_kernel<gsukf>");
+    return GSE_OK;
 }
-void launch_gsukf_resample(const GsukfPayload& pl, const float* w, float* w_out, int32_t* idx, const double* prefix,
-                           int B, int64_t N, int T, const ResampleArgs& ra, hipStream_t st) {
-    hipLaunchKernelGGL(resample_kernel<GsukfPayload>, dim3(T, B), dim3(kBlock), 0, st, pl, w, w_out, idx, prefix, N, N,
-                       T, ra);
-}
+
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
                            const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, hipStream_t st) {
     hipLaunchKernelGGL(moments_finish_kernel, dim3(B), dim3(kBlock), 0, st, partials, nblk, width, out, out_stride,
@@ -410,7 +535,7 @@ int gse_pf_update(const float* x, float* w, int64_t ld, int B, int64_t N, const 
 }
 
 int gse_pf_resample(const float* x_in, const float* w, float* x_out, float* w_out, int32_t* idx, int64_t ld, int B,
-                    int64_t N, const double* r, uint32_t flags, void* workspace, void* stream) {
+                    int64_t N, const double* r, uint32_t flags, double* island, void* workspace, void* stream) {
     if (int rc = check_pf_geometry("gse_pf_resample", B, N, ld)) return rc;
     GSE_REQUIRE(x_in && w && x_out && w_out && r && workspace, "gse_pf_resample: null argument");
     GSE_REQUIRE(x_in != x_out && w != w_out, "gse_pf_resample: x_out / w_out must not alias x_in / w");
@@ -422,19 +547,13 @@ int gse_pf_resample(const float* x_in, const float* w, float* x_out, float* w_ou
         GSE_REQUIRE(r[b] >= 0.0 && r[b] < 1.0, "gse_pf_resample: r[%d] = %g is outside [0, 1)", b, r[b]);
         ra.r[b] = r[b];
     }
-    const int T = (int)tiles_of(N);
     Workspace ws = carve_workspace(workspace, B, N);
     hipStream_t st = (hipStream_t)stream;
-    if (!(flags & GSE_RESAMPLE_TILES_VALID)) {
-        launch_tile_sums(w, ws.tile_sums, B, N, ld, T, st);
-        GSE_LAUNCH_CHECK("tile_sum_kernel");
-    }
-    launch_tile_scan(ws.tile_sums, ws.tile_prefix, B, T, st);
-    GSE_LAUNCH_CHECK("tile_scan_kernel");
+    if (int rc = launch_cumsum(w, ld, B, N, flags, island, ws, ws.cumsum, st)) return rc;
     PfPayload pl{x_in, x_out, ld};
-    hipLaunchKernelGGL(resample_kernel<PfPayload>, dim3(T, B), dim3(kBlock), 0, st, pl, w, w_out, idx, ws.tile_prefix, N,
-                       ld, T, ra);
-    GSE_LAUNCH_CHECK("resample_kernel");
+    hipLaunchKernelGGL(gather_kernel<PfPayload>, dim3((unsigned)tiles_of(N), B), dim3(kBlock), 0, st, pl, ws.cumsum,
+                       ws.totals, w_out, idx, N, ld, ra);
+    GSE_LAUNCH_CHECK("gather_kernel");
     return GSE_OK;
 }
 

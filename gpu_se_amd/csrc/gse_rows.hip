@@ -102,31 +102,6 @@ __global__ __launch_bounds__(kBlock) void rng_raw_kernel(uint32_t* __restrict__ 
     for (int k = 0; k < 8; ++k) out[i * 8 + k] = wd[k];
 }
 
-// c[k] = cumsum(w)[k] / sum(w) from the tile prefix (same arithmetic as the fused resample kernel)
-__global__ __launch_bounds__(kBlock) void cumsum_write_kernel(const float* __restrict__ w, double* __restrict__ c,
-                                                              const double* __restrict__ prefix, int64_t N, int T) {
-    __shared__ double red[4];
-    const int t = blockIdx.x, tid = threadIdx.x;
-    const double P0 = prefix[t], P1 = prefix[t + 1], W = prefix[T];
-    const int64_t i0 = (int64_t)t * kTile + (int64_t)tid * kPerThread;
-    float wv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-        if (i0 + p < N) wv[p] = w[i0 + p];
-    double s[4];
-    s[0] = (double)wv[0];
-    s[1] = s[0] + (double)wv[1];
-    s[2] = s[1] + (double)wv[2];
-    s[3] = s[2] + (double)wv[3];
-    double total;
-    const double excl = block_exclusive_scan(s[3], red, total);
-    const double top = P1 / W;
-    const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-        if (i0 + p < N) c[i0 + p] = (i0 + p == last) ? top : fmin((P0 + (excl + s[p])) / W, top);
-}
-
 // idx[i] = first k with c[k] >= (i + r)/N (CPU semantics, particle.py:96-100), by binary search in global memory
 __global__ __launch_bounds__(kBlock) void systematic_index_kernel(const double* __restrict__ c, int64_t* __restrict__ idx,
                                                                   int64_t N, double r) {
@@ -218,16 +193,8 @@ int gse_mixture_draw(float* out, int64_t M, int64_t ld, const gse_mixture* m, co
 
 int gse_cumsum_normalised(const float* w, double* c, int64_t N, void* workspace, void* stream) {
     GSE_REQUIRE(w && c && workspace && N >= 1, "gse_cumsum_normalised: bad argument");
-    const int T = (int)tiles_of(N);
     Workspace ws = carve_workspace(workspace, 1, N);
-    hipStream_t st = (hipStream_t)stream;
-    launch_tile_sums(w, ws.tile_sums, 1, N, N, T, st);
-    GSE_LAUNCH_CHECK("tile_sum_kernel");
-    launch_tile_scan(ws.tile_sums, ws.tile_prefix, 1, T, st);
-    GSE_LAUNCH_CHECK("tile_scan_kernel");
-    hipLaunchKernelGGL(cumsum_write_kernel, dim3(T), dim3(kBlock), 0, st, w, c, ws.tile_prefix, N, T);
-    GSE_LAUNCH_CHECK("cumsum_write_kernel");
-    return GSE_OK;
+    return launch_cumsum(w, N, 1, N, 0, nullptr, ws, c, (hipStream_t)stream);
 }
 
 int gse_systematic_index(const double* c, int64_t* idx, int64_t N, double r, void* stream) {

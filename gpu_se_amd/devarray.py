@@ -29,7 +29,15 @@ def device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def stream_ptr():
+try:                                    # raw hipStream_t of torch's current stream without building a Stream object
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:                  # pragma: no cover
+    _raw_stream = None
+
+
+def stream_ptr(index=None):
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device() if index is None else index)
     return torch.cuda.current_stream().cuda_stream
 
 

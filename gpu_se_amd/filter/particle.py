@@ -86,10 +86,20 @@ class ParallelParticleFilter:
         self._ws = torch.empty(_lib.load().gse_workspace_bytes(1, n), dtype=torch.uint8, device=dev)
         self._moments = torch.empty(26, dtype=torch.float64, device=dev)
         self._tiles_valid = False
+        self._island = None                                 # [2][1] fp64 shard bookkeeping (ShardedParticleFilter)
         self._element_offset = int(element_offset)        # global index of particle 0 (sharded ensembles)
         self._seed = gpu_se_amd._new_stream_seed()
         self._step = 0
         self._host_rng = numpy.random.default_rng(self._seed & 0xFFFFFFFF)
+        # persistent argument buffers: a call only rewrites a few doubles (keeps the host side of a launch short)
+        lib = _lib.load()
+        self._c_u = (_lib.c_d * _lib.GSE_NU)()
+        self._c_z = (_lib.c_d * _lib.GSE_NY)()
+        self._c_r = (_lib.c_d * 1)()
+        self._c_rng = _lib.Rng(seed=self._seed, step=0, element_offset=self._element_offset)
+        self._c_rng_ref = ctypes.byref(self._c_rng)
+        self._fn_predict, self._fn_update, self._fn_resample = lib.gse_pf_predict, lib.gse_pf_update, lib.gse_pf_resample
+        self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
 
         # particles ~ x0 (particle.py:49), drawn on the device straight into the state-major buffer
         x0._draw_state_major(self._x, n, self._ld, self._element_offset)
@@ -131,40 +141,50 @@ class ParallelParticleFilter:
     def predict(self, u, dt):
         """Performs a prediction step on the particles: x_i += f(x_i, u, dt) then x += state noise
         (particle.py:265-277).  u: (N_inputs) host array-like; dt: float."""
-        uu = _lib.doubles(u, _lib.GSE_NU)
         n = self.N_particles
         if isinstance(self.state_pdf, DeterministicGaussianSum):
+            uu = _lib.doubles(u, _lib.GSE_NU)
             noise = self.state_pdf.draw(n).as_subclass(torch.Tensor)            # (n, Nx) replayed values
             buf = torch.zeros_like(self._x)
             buf[:, :n] = noise.reshape(n, _lib.GSE_NX).t()
             _lib.call("gse_pf_predict_injected", self._x.data_ptr(), self._ld, 1, n, uu, float(dt), buf.data_ptr(),
                       stream_ptr())
         else:
-            pod = self.state_pdf._pod()
-            rng = _lib.Rng(seed=self._seed, step=self._step, element_offset=self._element_offset)
+            cu = self._c_u
+            cu[0], cu[1] = u
+            self._c_rng.step = self._step
             self._step += 1
-            _lib.call("gse_pf_predict", self._x.data_ptr(), self._ld, 1, n, uu, float(dt), ctypes.byref(pod),
-                      ctypes.byref(rng), stream_ptr())
+            rc = self._fn_predict(self._x.data_ptr(), self._ld, 1, n, cu, dt, ctypes.byref(self.state_pdf._pod()),
+                                  self._c_rng_ref, stream_ptr(self._dev_index))
+            if rc:
+                _lib.check(rc)
 
     def update(self, u, z):
         """Performs an update step on the particles: w_i *= measurement_pdf(z - g(x_i, u))
         (particle.py:279-294).  u, z: host array-likes."""
-        uu = _lib.doubles(u, _lib.GSE_NU)
-        zz = _lib.doubles(z, _lib.GSE_NY)
-        pod = self.measurement_pdf._pod()
-        _lib.call("gse_pf_update", self._x.data_ptr(), self._w.data_ptr(), self._ld, 1, self.N_particles, uu, zz,
-                  ctypes.byref(pod), self._ws.data_ptr(), stream_ptr())
+        cu, cz = self._c_u, self._c_z
+        cu[0], cu[1] = u
+        cz[0], cz[1] = z
+        rc = self._fn_update(self._x.data_ptr(), self._w.data_ptr(), self._ld, 1, self.N_particles, cu, cz,
+                             ctypes.byref(self.measurement_pdf._pod()), self._ws.data_ptr(), stream_ptr(self._dev_index))
+        if rc:
+            _lib.check(rc)
         self._tiles_valid = True
 
     def resample(self, r=None, return_index=False):
         """Systematic resample of the particles based on their weights (particle.py:296-316).  The one
         uniform number comes from a host generator (no device round trip); ``r`` overrides it (tests)."""
-        rr = _lib.doubles([self._host_rng.random() if r is None else r], 1)
+        rr = self._c_r
+        rr[0] = self._host_rng.random() if r is None else r
         idx = torch.empty(self._ld, dtype=torch.int32, device=self._x.device) if return_index else None
         flags = _lib.GSE_RESAMPLE_TILES_VALID if self._tiles_valid else 0
-        _lib.call("gse_pf_resample", self._x.data_ptr(), self._w.data_ptr(), self._x_alt.data_ptr(),
-                  self._w_alt.data_ptr(), idx.data_ptr() if return_index else None, self._ld, 1, self.N_particles,
-                  rr, flags, self._ws.data_ptr(), stream_ptr())
+        rc = self._fn_resample(self._x.data_ptr(), self._w.data_ptr(), self._x_alt.data_ptr(),
+                               self._w_alt.data_ptr(), idx.data_ptr() if return_index else None, self._ld, 1,
+                               self.N_particles, rr, flags,
+                               self._island.data_ptr() if self._island is not None else None, self._ws.data_ptr(),
+                               stream_ptr(self._dev_index))
+        if rc:
+            _lib.check(rc)
         self._x, self._x_alt = self._x_alt, self._x
         self._w, self._w_alt = self._w_alt, self._w
         self._tiles_valid = False
@@ -172,12 +192,20 @@ class ParallelParticleFilter:
             return DevArray.wrap(idx[:self.N_particles])
 
     # ------------------------------------------------------------------ estimates
-    def _moment_sums(self):
-        """(S0, w@x, sum w (x - w@x)(x - w@x)^T) from the device moments (synchronises)."""
+    def _raw_moments(self):
+        """(S0, S1 = sum w d, S2 = sum w d d^T (5x5), pivot) with d = x - pivot, from the device (synchronises)."""
         _lib.call("gse_pf_moments", self._x.data_ptr(), self._w.data_ptr(), self._ld, 1, self.N_particles,
                   self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
         m = self._moments.cpu().numpy()
-        return moments_to_mean_cov(m[0], m[1:6], m[6:21], m[21:26])
+        s2 = numpy.zeros((_lib.GSE_NX, _lib.GSE_NX))
+        s2[numpy.triu_indices(_lib.GSE_NX)] = m[6:21]
+        s2 = s2 + s2.T - numpy.diag(numpy.diag(s2))
+        return float(m[0]), m[1:6].copy(), s2, m[21:26].copy()
+
+    def _moment_sums(self):
+        """(S0, w@x, sum w (x - w@x)(x - w@x)^T) -- the reference's un-normalised quantities."""
+        s0, s1, s2, pivot = self._raw_moments()
+        return moments_to_mean_cov(s0, s1, s2[numpy.triu_indices(_lib.GSE_NX)], pivot)
 
     def point_estimate(self):
         """Returns the point estimate of the filter: weights @ particles, host array (5,) (particle.py:318-320)."""

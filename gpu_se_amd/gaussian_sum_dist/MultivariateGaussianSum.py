@@ -47,7 +47,18 @@ class MultivariateGaussianSum:
 
     # ------------------------------------------------------------------ C-ABI view
     def _pod(self):
-        """struct gse_mixture built from the CURRENT attribute values."""
+        """struct gse_mixture for the CURRENT attribute values.  The attributes are plain arrays that callers may
+        change in place at any time, so the struct is cached against their bytes (three tiny arrays)."""
+        key = (numpy.asarray(self.means).tobytes(), numpy.asarray(self.weights).tobytes(),
+               numpy.asarray(self.covariances).tobytes())
+        cached = self.__dict__.get("_pod_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        pod = self._build_pod()
+        self._pod_cache = (key, pod)
+        return pod
+
+    def _build_pod(self):
         m = _lib.Mixture()
         m.nd, m.nx = self._Nd, self._Nx
         means = numpy.asarray(self.means, dtype=numpy.float32).reshape(self._Nd, self._Nx)

@@ -104,14 +104,19 @@ int gse_pf_update(const float *x, float *w, int64_t ld, int B, int64_t N, const 
                   const gse_mixture *measurement_pdf, void *workspace, void *stream);
 
 #define GSE_RESAMPLE_TILES_VALID 1u   /* workspace tile sums were left by the preceding gse_*_update on w */
+#define GSE_RESAMPLE_SEPARATE_SCAN 2u /* scan the tile sums in a kernel of its own even when N is small enough
+                                         (<= 4096 tiles) for the resample kernel to do it itself (test hook) */
 
 /* ParallelParticleFilter.resample (filter/particle.py:296-316 with _parallel_resample :223-263):
  * c = cumsum(w) / sum(w) in fp64; ancestor of output j = first k with c_k >= (j + r)/N;
  * x_out[:, j] = x_in[:, ancestor]; w_out[j] = 1/N.  r: host [B], each in [0,1).
  * idx (optional, may be NULL): [B][ld] int32 ancestor indices.  x_out / w_out must not alias x_in / w
- * (a workgroup writes the offspring range of its ancestor tile, which overlaps other tiles' inputs). */
+ * (a workgroup writes the offspring range of its ancestor tile, which overlaps other tiles' inputs).
+ * island (optional, may be NULL): device fp64 [2][B], the bookkeeping of a SHARDED ensemble whose shards resample
+ * locally: island[0][b] += log(sum of w of filter b) (the shard's accumulated log-weight, never reset by the
+ * library), island[1][b] = that sum itself (what the ranks all-reduce for the global weight normalisation). */
 int gse_pf_resample(const float *x_in, const float *w, float *x_out, float *w_out, int32_t *idx,
-                    int64_t ld, int B, int64_t N, const double *r, uint32_t flags,
+                    int64_t ld, int B, int64_t N, const double *r, uint32_t flags, double *island,
                     void *workspace, void *stream);
 
 /* Moments behind point_estimate / point_covariance (filter/particle.py:318-327), fp64 accumulation:

@@ -46,7 +46,7 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     with pytest.raises(lib.GseError, match="multiple of 4"):
         lib.call("gse_pf_predict_injected", 16, 7, 1, 7, lib.doubles([0, 0], 2), 0.1, 16, None)
     with pytest.raises(lib.GseError, match=r"outside \[0, 1\)"):
-        lib.call("gse_pf_resample", 16, 32, 48, 64, None, 8, 1, 8, lib.doubles([1.5], 1), 0, 80, None)
+        lib.call("gse_pf_resample", 16, 32, 48, 64, None, 8, 1, 8, lib.doubles([1.5], 1), 0, None, 80, None)
 
 
 def test_moments_to_mean_cov():

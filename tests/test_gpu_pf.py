@@ -165,7 +165,7 @@ def test_update_against_oracle(n):
 
 
 # ------------------------------------------------------------------------------ resample
-def run_resample(w, r, x=None, tiles_valid=False):
+def run_resample(w, r, x=None, flags=0):
     n = len(w)
     if x is None:
         x = np.arange(n, dtype=np.float32)[:, None] + np.arange(5, dtype=np.float32)[None, :] * 0.125
@@ -176,7 +176,7 @@ def run_resample(w, r, x=None, tiles_valid=False):
     idx = torch.full((ld,), -1, dtype=torch.int32, device="cuda")
     ws = workspace(1, n)
     _lib.call("gse_pf_resample", xd.data_ptr(), wd.data_ptr(), xo.data_ptr(), wo.data_ptr(), idx.data_ptr(), ld, 1, n,
-              _lib.doubles([r], 1), 0, ws.data_ptr(), stream())
+              _lib.doubles([r], 1), flags, None, ws.data_ptr(), stream())
     return host(idx)[:n], host(xo)[:, :n].T, host(wo)[:n], x
 
 
@@ -245,6 +245,21 @@ def test_resample_full_size_properties():
     # uniform weights, any r: identity
     idx, *_ = run_resample(np.full(n, 1.0 / n, np.float32), 0.5)
     np.testing.assert_array_equal(idx, np.arange(n))
+
+
+def test_resample_scan_paths_agree():
+    """The tile prefix is computed inside the resample kernel up to 4096 tiles and by a scan kernel of its own
+    beyond; both must give the oracle's ancestors (the two differ at most in the last bit of a cumulative sum)."""
+    rng = np.random.default_rng(77)
+    for n in (5000, (1 << 18) + 11, 4100 * 1024 + 3):           # the last one has > 4096 tiles
+        w = (rng.random(n) ** 2).astype(np.float32)
+        r = float(rng.random())
+        want = orc.systematic_index(w.astype(np.float64), r)
+        for flags in (0, _lib.GSE_RESAMPLE_SEPARATE_SCAN):
+            idx, xo, wo, x = run_resample(w, r, flags=flags)
+            assert np.sum(idx != want) <= 2, (n, flags)
+            assert np.all(np.diff(idx) >= 0)
+            np.testing.assert_array_equal(xo, x[idx])
 
 
 # ------------------------------------------------------------------------------ moments
@@ -358,3 +373,30 @@ def test_statistical_parity_with_reference(golden):
         zscore = zscore[:, [0, 2, 3, 4]]                 # Cx has no dynamics and no information: skip
         assert np.mean(np.abs(zscore) < 3.5) > 0.97, np.abs(zscore).max()
         assert np.abs(zscore).max() < 6
+
+
+def test_sharded_filter_single_rank_bookkeeping():
+    """ShardedParticleFilter on one rank: the device-side island bookkeeping (log-weight accumulation, last
+    weight sum) and the normalised posterior merge."""
+    from gpu_se_amd.distributed import ShardedParticleFilter
+    gpu_se_amd.seed(31)
+    spf = ShardedParticleFilter.from_get_parts(n_local=6000)
+    xss = orc.steady_state()
+    z = np.array(orc.bioreactor_g(xss)) + [0.1, 0.2]
+    log_acc = 0.0
+    for c in range(3):
+        spf.predict([0.06, 0.2], 0.1)
+        spf.update([0.06, 0.2], z)
+        w = spf.local.weights.get().astype(np.float64)
+        x = spf.local.particles.get().astype(np.float64)
+        if c == 2:
+            want_mean = (w / w.sum()) @ x
+            np.testing.assert_allclose(spf.point_estimate(), want_mean, rtol=1e-9)
+            dd = x - want_mean
+            want_cov = dd.T @ (dd * (w / w.sum())[:, None])
+            np.testing.assert_allclose(spf.point_covariance(), np.linalg.svd(want_cov, compute_uv=False)[0], rtol=1e-6)
+        spf.resample()
+        log_acc += np.log(w.sum())
+        isl = host(spf.local._island)
+        np.testing.assert_allclose(isl[0, 0], log_acc, rtol=1e-12)
+        np.testing.assert_allclose(isl[1, 0], w.sum(), rtol=1e-13)
