@@ -157,28 +157,38 @@ def main():
 
     result = None
     if rank == 0:
-        # ---- per-method device time (HIP events on the launch stream), rank 0 only, local filter
+        # ---- per-kernel device time (HIP events on the launch stream), rank 0 only, local filter.  In steady state
+        #      a cycle is two launches: cumsum_kernel (resample, first half) and pf_step_kernel<gather,predict,update>.
         lp = pf.local
+        lp._flush()
         reps = max(50, min(steps, 400))
         per = {}
-        per["predict"] = time_method_events(torch, lambda i: lp.predict(io[i % len(io)][0], dt), reps)
-        per["update"] = time_method_events(torch, lambda i: lp.update(*io[i % len(io)]), reps)
 
-        def upd_res(i):
-            lp.update(*io[i % len(io)])
+        def one_step(i):
+            u, z = io[i % len(io)]
+            lp._pend_gather = True
+            lp.predict(u, dt)
+            lp.update(u, z)
+        lp.resample()
+        lp._flush()
+        per["step"] = time_method_events(torch, one_step, reps)
+
+        def one_cumsum(i):
             lp.resample()
-        both = time_method_events(torch, upd_res, reps)
-        per["resample"] = both - per["update"]                  # resample as it runs in the cycle (tile sums valid)
-        dom = max(per, key=lambda k: per[k])
-        achieved = ALG_BYTES[dom] * n / per[dom] / 1e9
-        cycle_dev = sum(per.values())
-        roofline = {"bound": "hbm", "kernel": {"predict": "pf_predict_kernel", "update": "pf_update_kernel",
-                                               "resample": "resample_kernel"}[dom],
+            lp._pend_gather = False
+        per["cumsum"] = time_method_events(torch, one_cumsum, reps)
+        lp._pend_gather = False
+        per["cycle"] = time_method_events(torch, cycle, reps)
+        pf.wait_collectives()
+        alg = {"step": 128, "cumsum": 12}                       # SURVEY 8d bytes / particle attributed to each kernel
+        dom = "step"
+        achieved = alg[dom] * n / per[dom] / 1e9
+        roofline = {"bound": "hbm", "kernel": "pf_step_kernel<gather,predict,update>",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes_per_particle": ALG_BYTES[dom],
+                    "algorithmic_bytes_per_particle": alg[dom],
                     "device_us": {k: round(v * 1e6, 2) for k, v in per.items()},
-                    "cycle_frac_of_140B_roofline": round(140.0 * n / cycle_dev / 1e9 / HBM_PEAK_GBS, 4)}
+                    "cycle_frac_of_140B_roofline": round(140.0 * n / per["cycle"] / 1e9 / HBM_PEAK_GBS, 4)}
         value = world * steps / elapsed
         result = {
             "metric": "PF steps/sec (predict+update+resample) @ N particles, bioreactor model",

@@ -56,8 +56,11 @@ __host__ __device__ inline RngKey make_rng_key(const gse_rng& r, uint32_t purpos
 
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    // one 32x32 -> 64 multiply per product (v_mad_u64_u32) instead of a mul_hi / mul_lo pair
+    const uint64_t p0 = (uint64_t)M0 * (uint64_t)c[0];
+    const uint64_t p1 = (uint64_t)M1 * (uint64_t)c[2];
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
     c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
 }
@@ -184,10 +187,15 @@ struct Pdf2 {
     double inv[GSE_MAX_ND][2][2];
 };
 
+// kNd > 0 fixes the number of components at compile time (the bioreactor's mixtures have 2): with a run-time count
+// the compiler keeps the parameters of all GSE_MAX_ND components live (28 fp64 values), which overflows the scalar
+// registers in the fused kernels.  kNd = 0 reads m.nd.
+template <int kNd>
 __device__ __forceinline__ double mixture_pdf2(const Pdf2& m, double e0, double e1) {
 #pragma clang fp contract(off)
     double total = 0.0;
-    for (int d = 0; d < m.nd; ++d) {
+    const int nd = kNd > 0 ? kNd : m.nd;
+    for (int d = 0; d < nd; ++d) {
         const double a0 = e0 - m.mean[d][0], a1 = e1 - m.mean[d][1];
         const double t0 = a0 * m.inv[d][0][0] + a1 * m.inv[d][1][0];
         const double t1 = a0 * m.inv[d][0][1] + a1 * m.inv[d][1][1];
@@ -243,6 +251,76 @@ __device__ __forceinline__ double block_exclusive_scan(double v, double* lds, do
     double exc = __shfl_up(inc, 1, 64);
     if (lane == 0) exc = 0.0;
     return base + exc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight rows and searches in the normalised cumulative weights
+// ------------------------------------------------------------------------------------------------
+using v4f = float __attribute__((ext_vector_type(4)));     // a native 4 x fp32 register tuple (asm operands)
+
+// Sum of a thread's 4 weights (entries at or beyond N count as zero) -- the same expression wherever tile sums
+// are formed.
+__device__ __forceinline__ double masked_sum4(float w0, float w1, float w2, float w3, int64_t i0, int64_t N) {
+    double s = 0.0;
+    if (i0 + 0 < N) s = (double)w0;
+    if (i0 + 1 < N) s += (double)w1;
+    if (i0 + 2 < N) s += (double)w2;
+    if (i0 + 3 < N) s += (double)w3;
+    return s;
+}
+
+// Four consecutive weights starting at element i0 (a multiple of 4) of a row; entries at or beyond N read as 0.
+// Rows with ld % 4 == 0 are 16-byte aligned and padded (one dwordx4); otherwise (row-major GS-UKF weights of
+// filter b > 0) the row start is only dword aligned and has no padding, so the loads are scalar.
+__device__ __forceinline__ float4 load_weights4(const float* __restrict__ row, int64_t i0, int64_t N, int64_t ldw) {
+    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i0 >= N) return wv;
+    if ((ldw & 3) == 0) {
+        wv = *reinterpret_cast<const float4*>(row + i0);
+    } else {
+        wv.x = row[i0];
+        if (i0 + 1 < N) wv.y = row[i0 + 1];
+        if (i0 + 2 < N) wv.z = row[i0 + 2];
+        if (i0 + 3 < N) wv.w = row[i0 + 3];
+    }
+    return wv;
+}
+
+// First k in [0, N) with c[k] >= u, found by one wavefront: every round the 64 lanes probe 64 evenly spaced
+// elements of the remaining range and a ballot picks the sub-range (4 rounds of one L2 access for N <= 2^24,
+// instead of 24 dependent ones).  Returns N - 1 if no element qualifies (cannot happen for u <= c[N-1] = 1).
+__device__ __forceinline__ int64_t wave_search_ge(const double* __restrict__ c, int64_t N, double u, int lane) {
+    int64_t lo = 0, hi = N;                                   // answer in [lo, hi)
+    while (true) {
+        const int64_t n = hi - lo;
+        const int64_t step = (n + 63) >> 6;
+        const int64_t probe = min(lo + (int64_t)(lane + 1) * step, hi) - 1;
+        const bool ge = c[probe] >= u;
+        const unsigned long long mask = __ballot(ge);
+        if (mask == 0ull) return N - 1;
+        const int first = __ffsll((long long)mask) - 1;
+        const int64_t nlo = lo + (int64_t)first * step;
+        const int64_t nhi = min(lo + (int64_t)(first + 1) * step, hi);
+        if (step == 1) return nlo;
+        lo = nlo;
+        hi = nhi;
+    }
+}
+
+constexpr int kSpanMax = 2048;            // cumulative weights staged in LDS per tile of 1024 outputs (16 KiB)
+
+// Ancestor of one output with threshold u among the staged span seg[0..len): first q with seg[q] >= u.
+__device__ __forceinline__ int span_search(const double* seg, int len, double u) {
+    int lo = 0, hi = len - 1;
+#pragma unroll
+    for (int it = 0; it < 11; ++it) {             // 2^11 = kSpanMax
+        const int mid = (lo + hi) >> 1;
+        const bool open = lo < hi;
+        const bool less = open && (seg[mid] < u);
+        lo = less ? mid + 1 : lo;
+        hi = (open && !less) ? mid : hi;
+    }
+    return lo;
 }
 
 }  // namespace gse

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void gsukf_update_kernel(float* __restrict_
         // global update: w *= pdf(z - g(mu_new))
         float y0, y1;
         bioreactor_output(mnew[0], mnew[2], y0, y1);
-        const double lik = mixture_pdf2(a.pdf, z0 - (double)y0, z1 - (double)y1);
+        const double lik = mixture_pdf2<0>(a.pdf, z0 - (double)y0, z1 - (double)y1);
         w[gi] = (float)((double)w[gi] * lik);
     }
 }

@@ -3,139 +3,222 @@
 // One workgroup = 256 threads = 4 wavefronts owns one TILE of 1024 consecutive particles of one filter;
 // every thread owns 4 consecutive particles, so each state row is read and written with one dwordx4 per
 // lane (1 KiB per wave-instruction, fully coalesced) from the state-major layout x[b][k][i].
-// Everything here is HBM-bound streaming work (140 algorithmic bytes / particle / cycle); the
-// kernels keep one pass per method and no intermediate arrays:
+// Everything here is HBM-bound streaming work (140 algorithmic bytes / particle / cycle), and at
+// N = 2^20 one kernel is a single generation of workgroups (4 tiles per CU), so every launch costs a fixed
+// 3.5-5 us of ramp-up / latency chain whatever it computes.  The design therefore minimises LAUNCHES and passes:
 //
-//   predict   r 20 B + w 20 B   ODE step (fp64 in registers) + Philox/Box-Muller mixture draw, fused
-//   update    r 8 B + rw 8 B    only the two observed state rows are read; likelihood in fp64;
-//                               workgroup sum of the new weights -> one tile sum (feeds resample)
-//   resample  r 4 + 20, w 24 B  tile prefix -> in-LDS fp64 scan of the tile's weights -> each output slot
-//                               binary-searches its ancestor in LDS -> gather; no cumsum / index array in HBM
+//   pf_step_kernel<gather, predict, update>   ONE fused pass over the particles that does any subset of
+//        gather    the offspring's ancestor (resample, second half): 64-ary wavefront search + LDS binary search
+//                  in the normalised cumulative weights, then an indexed read of the 5 state rows
+//        predict   ODE step (fp64 in registers) + Philox/Box-Muller mixture draw (no memory: hides the loads)
+//        update    likelihood in fp64, w *= pdf, workgroup sum of the new weights -> one tile sum
+//   cumsum_kernel   tile prefix + fp64 scan of the weights -> normalised cumulative weights (resample, first half)
+//
+// The steady-state cycle  resample -> predict -> update  is two launches: cumsum, then step<gather,predict,update>
+// (r 8 + 20 B, w 24 B per particle, nothing else touches HBM).  The classic one-method-one-kernel entry points are
+// the same kernel with a single stage enabled.
 #include "gse_host.h"
 
 namespace gse {
 
 // ------------------------------------------------------------------------------------------------
-// predict
+// the fused step
 // ------------------------------------------------------------------------------------------------
-struct PredictArgs {
-    FilterIOs io;
-    DrawParams draw;
+struct StepArgs {
+    FilterIOs io;          // u, z per filter
+    ResampleArgs ra;       // r per filter
+    DrawParams draw;       // state noise (predict)
+    Pdf2 pdf;              // measurement noise (update)
     RngKey rng;
     double dt;
 };
 
-template <bool kInjected>
-__global__ __launch_bounds__(kBlock) void pf_predict_kernel(float* __restrict__ x, const float* __restrict__ noise,
-                                                            int64_t N, int64_t ld, const PredictArgs a) {
+#ifndef GSE_STEP_MIN_WAVES
+#define GSE_STEP_MIN_WAVES 4     // waves per SIMD the register allocator must leave room for (tuning knob)
+#endif
+
+#define GSE_LOAD_DWORD(dst, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#define GSE_LOAD_DWORDX4(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+
+template <bool kGather, bool kPredict, bool kInjected, bool kUpdate, int kNd>
+__global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(const float* __restrict__ x_in, float* __restrict__ x_out,
+                                                         const float* __restrict__ w_in, float* __restrict__ w_out,
+                                                         const float* __restrict__ noise, int32_t* __restrict__ idx_out,
+                                                         const double* __restrict__ c, const double* __restrict__ totals,
+                                                         double* __restrict__ tile_sums, int64_t N, int64_t ld, int T,
+                                                         const StepArgs a) {
     __shared__ DrawParams dp;
-    if (!kInjected) {
+    __shared__ double seg[kGather ? kSpanMax : 1];
+    __shared__ int64_t span[2];
+    __shared__ double red[4];
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t i0 = ((int64_t)blockIdx.x * kBlock + tid) * kPerThread;      // first of this thread's 4 particles
+    const bool live = i0 < N;
+    const double Nd = (double)N;
+    const float w_uniform = (float)(1.0 / Nd);
+    const float* xin_b = x_in + (int64_t)b * GSE_NX * ld;
+
+    if (kPredict && !kInjected) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.draw);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
-        for (int i = threadIdx.x; i < (int)(sizeof(DrawParams) / 4); i += kBlock) dst[i] = src[i];
-        __syncthreads();
-    }
-    const int b = blockIdx.y;
-    const int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kPerThread;
-    if (i0 >= N) return;
-    float* xb = x + (int64_t)b * GSE_NX * ld + i0;
-    const double fg = a.io.f[b].u0, fm = a.io.f[b].u1;
-
-    float4 row[GSE_NX];
-#pragma unroll
-    for (int k = 0; k < GSE_NX; ++k) row[k] = *reinterpret_cast<const float4*>(xb + k * ld);
-    float4 nz[GSE_NX];
-    if (kInjected) {
-        const float* nb = noise + (int64_t)b * GSE_NX * ld + i0;
-#pragma unroll
-        for (int k = 0; k < GSE_NX; ++k) nz[k] = *reinterpret_cast<const float4*>(nb + k * ld);
+        for (int i = tid; i < (int)(sizeof(DrawParams) / 4); i += kBlock) dst[i] = src[i];
     }
 
+    // ---- gather: ancestors of this thread's 4 outputs -------------------------------------------------
+    int32_t anc[kPerThread] = {0, 0, 0, 0};
+    if (kGather) {
+        const double W = totals[b];
+        const double r = a.ra.r[b];
+        // Weights that do not sum to a positive finite number: the reference's normalised cumsum is all-NaN and its
+        // sweep never advances (filter/particle.py:98), so every offspring copies particle 0 (anc stays 0).
+        if ((W > 0.0) && (W < INFINITY)) {
+            const double* cb = c + (int64_t)b * N;
+            const int64_t j0 = (int64_t)blockIdx.x * kTile;
+            const int64_t j1 = min(j0 + kTile, N);
+            if (wv < 2) {       // bracket the tile's ancestors: wavefront 0 takes the first output, wavefront 1 the last
+                const int64_t j = (wv == 0) ? j0 : j1 - 1;
+                const int64_t k = wave_search_ge(cb, N, ((double)j + r) / Nd, lane);
+                if (lane == 0) span[wv] = k;
+            }
+            __syncthreads();
+            const int64_t klo = span[0], khi = span[1];
+            const int64_t len = khi - klo + 1;
+            if (len <= kSpanMax) {
+                for (int q = tid; q < (int)len; q += kBlock) seg[q] = cb[klo + q];
+                __syncthreads();
 #pragma unroll
-    for (int p = 0; p < kPerThread; ++p) {
-        float s[GSE_NX];
+                for (int p = 0; p < kPerThread; ++p)
+                    anc[p] = (int32_t)klo + span_search(seg, (int)len, ((double)(i0 + p) + r) / Nd);
+            } else {
+                // the tile's ancestors are spread over a long stretch of (nearly) weightless particles: search c[] itself
 #pragma unroll
-        for (int k = 0; k < GSE_NX; ++k) s[k] = reinterpret_cast<const float*>(&row[k])[p];
-        bioreactor_step(s, fg, fm, a.dt);
-        float e[GSE_NX];
-        if (kInjected) {
-#pragma unroll
-            for (int k = 0; k < GSE_NX; ++k) e[k] = reinterpret_cast<const float*>(&nz[k])[p];
-        } else {
-            uint32_t wd[8];
-            rng_words8(a.rng, (uint64_t)(i0 + p), (uint32_t)b, wd);
-            mixture_draw5(dp, wd, e);
+                for (int p = 0; p < kPerThread; ++p) {
+                    const double u = ((double)(i0 + p) + r) / Nd;
+                    int64_t lo = klo, hi = khi;
+                    while (lo < hi) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (cb[mid] < u) lo = mid + 1; else hi = mid;
+                    }
+                    anc[p] = (int32_t)lo;
+                }
+            }
         }
-#pragma unroll
-        for (int k = 0; k < GSE_NX; ++k) reinterpret_cast<float*>(&row[k])[p] = s[k] + e[k];
     }
-#pragma unroll
-    for (int k = 0; k < GSE_NX; ++k) *reinterpret_cast<float4*>(xb + k * ld) = row[k];
-}
+    if (kPredict && !kInjected) __syncthreads();        // dp staged
 
-// ------------------------------------------------------------------------------------------------
-// update
-// ------------------------------------------------------------------------------------------------
-struct UpdateArgs {
-    FilterIOs io;
-    Pdf2 pdf;
-};
-
-// Sum of a thread's 4 weights (entries at or beyond N count as zero) -- the same expression in the update
-// kernel and in the standalone tile-sum kernel.
-__device__ __forceinline__ double masked_sum4(const float4& w, int64_t i0, int64_t N) {
-    double s = 0.0;
-    if (i0 + 0 < N) s = (double)w.x;
-    if (i0 + 1 < N) s += (double)w.y;
-    if (i0 + 2 < N) s += (double)w.z;
-    if (i0 + 3 < N) s += (double)w.w;
-    return s;
-}
-
-__global__ __launch_bounds__(kBlock) void pf_update_kernel(const float* __restrict__ x, float* __restrict__ w,
-                                                           double* __restrict__ tile_sums, int64_t N, int64_t ld,
-                                                           int T, const UpdateArgs a) {
-    __shared__ double red[4];
-    const int b = blockIdx.y;
-    const int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kPerThread;
     double mine = 0.0;
-    if (i0 < N) {
-        const float* xb = x + (int64_t)b * GSE_NX * ld + i0;
-        float* wb = w + (int64_t)b * ld + i0;
-        const float4 cg = *reinterpret_cast<const float4*>(xb);                 // state row 0
-        const float4 cfa = *reinterpret_cast<const float4*>(xb + 2 * ld);       // state row 2
-        float4 wv = *reinterpret_cast<const float4*>(wb);
+    if (live) {
+        // ---- issue every load now; the RNG arithmetic below needs no memory and hides their latency.  (Plain loads
+        //      get sunk below the RNG by the compiler to save registers, which serialises "RNG, then wait for HBM";
+        //      the asm statements pin the issue point and the wait is tied to the registers -- guide 5.7.)
+        float g[kPerThread][GSE_NX];          // gathered rows (kGather)
+        v4f r0, r1, r2, r3, r4;               // contiguous rows (!kGather)
+        if (kGather) {
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p)
+#pragma unroll
+                for (int k = 0; k < GSE_NX; ++k) GSE_LOAD_DWORD(g[p][k], xin_b + k * ld + anc[p]);
+        } else {
+            const float* xb = xin_b + i0;
+            GSE_LOAD_DWORDX4(r0, xb);
+            GSE_LOAD_DWORDX4(r1, xb + ld);
+            GSE_LOAD_DWORDX4(r2, xb + 2 * ld);
+            GSE_LOAD_DWORDX4(r3, xb + 3 * ld);
+            GSE_LOAD_DWORDX4(r4, xb + 4 * ld);
+        }
+        float4 wv4 = make_float4(w_uniform, w_uniform, w_uniform, w_uniform);
+        if (kUpdate && !kGather) wv4 = *reinterpret_cast<const float4*>(w_in + (int64_t)b * ld + i0);
+        float4 nz[GSE_NX];
+        if (kPredict && kInjected) {
+            const float* nb = noise + (int64_t)b * GSE_NX * ld + i0;
+#pragma unroll
+            for (int k = 0; k < GSE_NX; ++k) nz[k] = *reinterpret_cast<const float4*>(nb + k * ld);
+        }
+
+        // ---- two halves of two particles each (keeps the live register set small): the noise of a half is drawn
+        //      first -- registers only -- and the first half's draw is what hides the latency of the loads above.
+        v4f row[GSE_NX];
+        const double fg = a.io.f[b].u0, fm = a.io.f[b].u1;
         const double z0 = a.io.f[b].z0, z1 = a.io.f[b].z1;
 #pragma unroll
-        for (int p = 0; p < kPerThread; ++p) {
-            float y0, y1;
-            bioreactor_output(reinterpret_cast<const float*>(&cg)[p], reinterpret_cast<const float*>(&cfa)[p], y0, y1);
-            const double lik = mixture_pdf2(a.pdf, z0 - (double)y0, z1 - (double)y1);
-            float& wp = reinterpret_cast<float*>(&wv)[p];
-            wp = (float)((double)wp * lik);
+        for (int h = 0; h < 2; ++h) {
+            float e[2][GSE_NX];
+            if (kPredict) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int p = 2 * h + q;
+                    if (kInjected) {
+#pragma unroll
+                        for (int k = 0; k < GSE_NX; ++k) e[q][k] = reinterpret_cast<const float*>(&nz[k])[p];
+                    } else {
+                        uint32_t wd[8];
+                        rng_words8(a.rng, (uint64_t)(i0 + p), (uint32_t)b, wd);
+                        mixture_draw5(dp, wd, e[q]);
+                    }
+                }
+            }
+            if (h == 0) {
+                // the state rows must have landed now
+                if (kGather) {
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[0][2]), "+v"(g[0][3]), "+v"(g[0][4]),
+                                   "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[1][2]), "+v"(g[1][3]), "+v"(g[1][4]),
+                                   "+v"(g[2][0]), "+v"(g[2][1]), "+v"(g[2][2]), "+v"(g[2][3]), "+v"(g[2][4]),
+                                   "+v"(g[3][0]), "+v"(g[3][1]), "+v"(g[3][2]), "+v"(g[3][3]), "+v"(g[3][4])::"memory");
+#pragma unroll
+                    for (int p = 0; p < kPerThread; ++p)
+#pragma unroll
+                        for (int k = 0; k < GSE_NX; ++k) row[k][p] = g[p][k];
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4)::"memory");
+                    row[0] = r0; row[1] = r1; row[2] = r2; row[3] = r3; row[4] = r4;
+                }
+            }
+            // predict: ODE step + noise;  update: likelihood of the (new) state
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int p = 2 * h + q;
+                if (kPredict) {
+                    float s[GSE_NX];
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) s[k] = row[k][p];
+                    bioreactor_step(s, fg, fm, a.dt);
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) row[k][p] = s[k] + e[q][k];
+                }
+            }
         }
-        *reinterpret_cast<float4*>(wb) = wv;
-        mine = masked_sum4(wv, i0, N);
-    }
-    const double total = block_sum(mine, red);
-    if (threadIdx.x == 0) tile_sums[(int64_t)b * T + blockIdx.x] = total;
-}
+        // the new state goes out now (contiguous in the particle index: one dwordx4 per row), ahead of the update phase
+        if (kGather || kPredict) {
+            float* xb = x_out + (int64_t)b * GSE_NX * ld + i0;
+#pragma unroll
+            for (int k = 0; k < GSE_NX; ++k) *reinterpret_cast<v4f*>(xb + k * ld) = row[k];
+        }
+        // update as a phase of its own: the ODE and the likelihood each need ~20 fp64 constants; interleaving them per
+        // particle keeps both sets live, overflows the scalar registers and spills ~100 VGPRs
+        __builtin_amdgcn_sched_barrier(0);
+        if (kUpdate) {
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) {
+                float y0, y1;
+                bioreactor_output(row[0][p], row[2][p], y0, y1);
+                const double lik = mixture_pdf2<kNd>(a.pdf, z0 - (double)y0, z1 - (double)y1);
+                float& wp = reinterpret_cast<float*>(&wv4)[p];
+                wp = (float)((double)wp * lik);
+            }
+        }
 
-// Four consecutive weights starting at element i0 (a multiple of 4) of a row; entries at or beyond N read as 0.
-// Rows with ld % 4 == 0 are 16-byte aligned and padded (one dwordx4); otherwise (row-major GS-UKF weights of
-// filter b > 0) the row start is only dword aligned and has no padding, so the loads are scalar.
-__device__ __forceinline__ float4 load_weights4(const float* __restrict__ row, int64_t i0, int64_t N, int64_t ldw) {
-    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i0 >= N) return wv;
-    if ((ldw & 3) == 0) {
-        wv = *reinterpret_cast<const float4*>(row + i0);
-    } else {
-        wv.x = row[i0];
-        if (i0 + 1 < N) wv.y = row[i0 + 1];
-        if (i0 + 2 < N) wv.z = row[i0 + 2];
-        if (i0 + 3 < N) wv.w = row[i0 + 3];
+        // ---- weights, ancestor indices
+        if (kGather || kUpdate) *reinterpret_cast<float4*>(w_out + (int64_t)b * ld + i0) = wv4;
+        if (kGather && idx_out)
+            *reinterpret_cast<int4*>(idx_out + (int64_t)b * ld + i0) = make_int4(anc[0], anc[1], anc[2], anc[3]);
+        if (kUpdate) mine = masked_sum4(wv4.x, wv4.y, wv4.z, wv4.w, i0, N);
     }
-    return wv;
+    if (kUpdate) {
+        const double total = block_sum(mine, red);
+        if (tid == 0) tile_sums[(int64_t)b * T + blockIdx.x] = total;
+    }
 }
 
 // Tile sums for a resample that does not directly follow an update (weights assigned by the caller).
@@ -145,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void tile_sum_kernel(const float* __restric
     const int b = blockIdx.y;
     const int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kPerThread;
     const float4 wv = load_weights4(w + (int64_t)b * ldw, i0, N, ldw);
-    const double mine = masked_sum4(wv, i0, N);
+    const double mine = masked_sum4(wv.x, wv.y, wv.z, wv.w, i0, N);
     const double total = block_sum(mine, red);
     if (threadIdx.x == 0) tile_sums[(int64_t)b * T + blockIdx.x] = total;
 }
@@ -181,10 +264,11 @@ __global__ __launch_bounds__(kBlock) void tile_scan_kernel(const double* __restr
 //   cumsum_kernel   one workgroup per tile of 1024 ANCESTORS: tile prefix (from the tile sums the update kernel
 //                   left behind) + fp64 scan of the tile's weights -> normalised cumulative weights c[k], fp64,
 //                   monotone, c[N-1] = 1.                                     r 4 B, w 8 B per particle
-//   gather_kernel   one workgroup per tile of 1024 OUTPUTS: two 64-ary wavefront searches bracket the tile's
-//                   ancestor span in c[], the span is staged in LDS, every output finds its ancestor
-//                   (first k with c[k] >= (j + r)/N, the reference's comparison verbatim) by binary search in
-//                   LDS and copies it; stores are contiguous in j.           r 8 + 20 B, w 24 B per particle
+//   gather          one workgroup per tile of 1024 OUTPUTS: two 64-ary wavefront searches bracket the tile's
+//   (stage of        ancestor span in c[], the span is staged in LDS, every output finds its ancestor
+//   pf_step_kernel;  (first k with c[k] >= (j + r)/N, the reference's comparison verbatim) by binary search in
+//   gather_kernel    LDS and copies it; stores are contiguous in j.           r 8 + 20 B, w 24 B per particle
+//   for GS-UKF rows)
 //
 // Tile prefix computed inside the cumsum kernel (T <= 4096 tiles): every workgroup scans the T tile sums itself
 // -- identical code on identical data, hence identical bits in every workgroup -- and picks out
@@ -272,29 +356,6 @@ __global__ __launch_bounds__(kBlock) void cumsum_kernel(const float* __restrict_
     }
 }
 
-// First k in [0, N) with c[k] >= u, found by one wavefront: every round the 64 lanes probe 64 evenly spaced
-// elements of the remaining range and a ballot picks the sub-range (4 rounds of one L2 access for N <= 2^24,
-// instead of 24 dependent ones).  Returns N - 1 if no element qualifies (cannot happen for u <= c[N-1] = 1).
-__device__ __forceinline__ int64_t wave_search_ge(const double* __restrict__ c, int64_t N, double u, int lane) {
-    int64_t lo = 0, hi = N;                                   // answer in [lo, hi)
-    while (true) {
-        const int64_t n = hi - lo;
-        const int64_t step = (n + 63) >> 6;
-        const int64_t probe = min(lo + (int64_t)(lane + 1) * step, hi) - 1;
-        const bool ge = c[probe] >= u;
-        const unsigned long long mask = __ballot(ge);
-        if (mask == 0ull) return N - 1;
-        const int first = __ffsll((long long)mask) - 1;
-        const int64_t nlo = lo + (int64_t)first * step;
-        const int64_t nhi = min(lo + (int64_t)(first + 1) * step, hi);
-        if (step == 1) return nlo;
-        lo = nlo;
-        hi = nhi;
-    }
-}
-
-constexpr int kSpanMax = 2048;            // ancestors staged in LDS per output tile (16 KiB)
-
 template <class Payload>
 __global__ __launch_bounds__(kBlock) void gather_kernel(const Payload pl, const double* __restrict__ c,
                                                         const double* __restrict__ totals, float* __restrict__ w_out,
@@ -340,15 +401,7 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const Payload pl, const 
         __syncthreads();
         for (int64_t j = j0 + tid; j < j1; j += kBlock) {
             const double u = ((double)j + r) / Nd;
-            int lo = 0, hi = (int)len - 1;
-#pragma unroll
-            for (int it = 0; it < 11; ++it) {             // 2^11 = kSpanMax
-                const int mid = (lo + hi) >> 1;
-                const bool open = lo < hi;
-                const bool less = open && (seg[mid] < u);
-                lo = less ? mid + 1 : lo;
-                hi = (open && !less) ? mid : hi;
-            }
+            const int lo = span_search(seg, (int)len, u);
             const int64_t anc = klo + lo;
             pl.copy(b, anc, j);
             wo[j] = w_uniform;
@@ -483,78 +536,143 @@ using namespace gse;
 // ================================================================================================
 // C ABI
 // ================================================================================================
+namespace {
+
+template <bool G, bool P, bool I, bool U>
+void launch_step(dim3 grid, hipStream_t st, const float* x_in, float* x_out, const float* w_in, float* w_out,
+                 const float* noise, int32_t* idx, const Workspace& ws, int64_t N, int64_t ld, int T, const StepArgs& a) {
+    if (U && a.pdf.nd == 2)         // the common case gets the kernel with the component count folded in
+        hipLaunchKernelGGL((pf_step_kernel<G, P, I, U, U ? 2 : 0>), grid, dim3(kBlock), 0, st, x_in, x_out, w_in, w_out,
+                           noise, idx, ws.cumsum, ws.totals, ws.tile_sums, N, ld, T, a);
+    else
+        hipLaunchKernelGGL((pf_step_kernel<G, P, I, U, 0>), grid, dim3(kBlock), 0, st, x_in, x_out, w_in, w_out, noise,
+                           idx, ws.cumsum, ws.totals, ws.tile_sums, N, ld, T, a);
+}
+
+// The one place that validates and dispatches a fused step.
+int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, float* w_out, int32_t* idx, int64_t ld,
+            int B, int64_t N, const double* u, double dt, const double* z, const double* r, const gse_mixture* state_pdf,
+            const gse_rng* rng, const float* noise, const gse_mixture* measurement_pdf, void* workspace, void* stream,
+            const char* fn) {
+    if (int rc = check_pf_geometry(fn, B, N, ld)) return rc;
+    const bool G = ops & GSE_OP_GATHER, P = ops & GSE_OP_PREDICT, U = ops & GSE_OP_UPDATE;
+    GSE_REQUIRE(ops != 0 && (ops & ~(GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE)) == 0, "%s: bad ops mask 0x%x", fn, ops);
+    GSE_REQUIRE(x_in && aligned16(x_in), "%s: x_in must be a 16-byte aligned device pointer", fn);
+    GSE_REQUIRE((workspace && aligned16(workspace)) || !(ops & (GSE_OP_GATHER | GSE_OP_UPDATE)),
+                "%s: gather / update need a 16-byte aligned device workspace", fn);
+    GSE_REQUIRE(N < ((int64_t)1 << 31), "%s: N must be below 2^31", fn);
+    StepArgs a;
+    pack_io(a.io, B, (P ? u : nullptr), (U ? z : nullptr));
+    if (G) {
+        GSE_REQUIRE(x_out && w_out && r, "%s: gather needs x_out, w_out and r", fn);
+        GSE_REQUIRE(x_out != x_in && aligned16(x_out) && aligned16(w_out), "%s: x_out must be a separate aligned buffer", fn);
+        GSE_REQUIRE(!U || !w_in || w_in != w_out, "%s: w_out must not alias w_in when gathering", fn);
+        for (int b = 0; b < B; ++b) {
+            GSE_REQUIRE(r[b] >= 0.0 && r[b] < 1.0, "%s: r[%d] = %g is outside [0, 1)", fn, b, r[b]);
+            a.ra.r[b] = r[b];
+        }
+    }
+    if (P) {
+        GSE_REQUIRE(u, "%s: predict needs u", fn);
+        GSE_REQUIRE(x_out && aligned16(x_out), "%s: predict needs an aligned x_out (may equal x_in without gather)", fn);
+        GSE_REQUIRE(G || x_out == x_in, "%s: without gather the step is in place: x_out must equal x_in", fn);
+        if (noise) {
+            GSE_REQUIRE(aligned16(noise), "%s: noise must be 16-byte aligned", fn);
+            a.draw = DrawParams{};
+            a.rng = RngKey{};
+        } else {
+            GSE_REQUIRE(state_pdf && rng, "%s: predict needs state_pdf and rng (or injected noise)", fn);
+            if (int rc = check_mixture(fn, state_pdf, GSE_NX)) return rc;
+            GSE_REQUIRE((rng->element_offset & 3u) == 0, "%s: rng element_offset must be a multiple of 4", fn);
+            pack_draw(a.draw, *state_pdf);
+            a.rng = make_rng_key(*rng, kPurposePredict);
+        }
+    }
+    if (U) {
+        GSE_REQUIRE(z && measurement_pdf && w_out && aligned16(w_out), "%s: update needs z, measurement_pdf and w_out", fn);
+        GSE_REQUIRE(G || (w_in && aligned16(w_in)), "%s: update without gather needs w_in", fn);
+        if (int rc = check_mixture(fn, measurement_pdf, GSE_NY)) return rc;
+        pack_pdf2(a.pdf, *measurement_pdf);
+    }
+    a.dt = dt;
+    const bool I = P && noise != nullptr;
+    const int T = (int)tiles_of(N);
+    const Workspace ws = carve_workspace(workspace, B, N);
+    const dim3 grid((unsigned)T, (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+#define GSE_STEP_CASE(g, p, i, uu)                                                                        \
+    if (G == g && P == p && I == i && U == uu) {                                                          \
+        launch_step<g, p, i, uu>(grid, st, x_in, x_out, w_in, w_out, noise, idx, ws, N, ld, T, a);        \
+    } else
+    GSE_STEP_CASE(false, true, false, false)
+    GSE_STEP_CASE(false, true, true, false)
+    GSE_STEP_CASE(false, false, false, true)
+    GSE_STEP_CASE(false, true, false, true)
+    GSE_STEP_CASE(false, true, true, true)
+    GSE_STEP_CASE(true, false, false, false)
+    GSE_STEP_CASE(true, true, false, false)
+    GSE_STEP_CASE(true, true, true, false)
+    GSE_STEP_CASE(true, false, false, true)
+    GSE_STEP_CASE(true, true, false, true)
+    GSE_STEP_CASE(true, true, true, true)
+    { return fail(GSE_ERR_ARG, "%s: unsupported stage combination 0x%x", fn, ops); }
+#undef GSE_STEP_CASE
+    GSE_LAUNCH_CHECK("pf_step_kernel");
+    return GSE_OK;
+}
+
+}  // namespace
+
 extern "C" {
+
+int gse_pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, float* w_out, int32_t* idx, int64_t ld,
+                int B, int64_t N, const double* u, double dt, const double* z, const double* r,
+                const gse_mixture* state_pdf, const gse_rng* rng, const float* noise, const gse_mixture* measurement_pdf,
+                void* workspace, void* stream) {
+    return pf_step(ops, x_in, x_out, w_in, w_out, idx, ld, B, N, u, dt, z, r, state_pdf, rng, noise, measurement_pdf,
+                   workspace, stream, "gse_pf_step");
+}
 
 int gse_pf_predict(float* x, int64_t ld, int B, int64_t N, const double* u, double dt, const gse_mixture* state_pdf,
                    const gse_rng* rng, void* stream) {
-    if (int rc = check_pf_geometry("gse_pf_predict", B, N, ld)) return rc;
-    GSE_REQUIRE(x && u && state_pdf && rng, "gse_pf_predict: null argument");
-    GSE_REQUIRE(aligned16(x), "gse_pf_predict: x must be 16-byte aligned");
-    if (int rc = check_mixture("gse_pf_predict", state_pdf, GSE_NX)) return rc;
-    PredictArgs a;
-    pack_io(a.io, B, u, nullptr);
-    pack_draw(a.draw, *state_pdf);
-    a.rng = make_rng_key(*rng, kPurposePredict);
-    a.dt = dt;
-    hipLaunchKernelGGL(pf_predict_kernel<false>, dim3((unsigned)tiles_of(N), B), dim3(kBlock), 0, (hipStream_t)stream, x,
-                       (const float*)nullptr, N, ld, a);
-    GSE_LAUNCH_CHECK("pf_predict_kernel");
-    return GSE_OK;
+    GSE_REQUIRE(state_pdf && rng, "gse_pf_predict: null argument");
+    return pf_step(GSE_OP_PREDICT, x, x, nullptr, nullptr, nullptr, ld, B, N, u, dt, nullptr, nullptr, state_pdf, rng,
+                   nullptr, nullptr, nullptr, stream, "gse_pf_predict");
 }
 
 int gse_pf_predict_injected(float* x, int64_t ld, int B, int64_t N, const double* u, double dt, const float* noise,
                             void* stream) {
-    if (int rc = check_pf_geometry("gse_pf_predict_injected", B, N, ld)) return rc;
-    GSE_REQUIRE(x && u && noise, "gse_pf_predict_injected: null argument");
-    GSE_REQUIRE(aligned16(x) && aligned16(noise), "gse_pf_predict_injected: x, noise must be 16-byte aligned");
-    PredictArgs a;
-    pack_io(a.io, B, u, nullptr);
-    a.draw = DrawParams{};
-    a.rng = RngKey{};
-    a.dt = dt;
-    hipLaunchKernelGGL(pf_predict_kernel<true>, dim3((unsigned)tiles_of(N), B), dim3(kBlock), 0, (hipStream_t)stream, x,
-                       noise, N, ld, a);
-    GSE_LAUNCH_CHECK("pf_predict_kernel<injected>");
-    return GSE_OK;
+    GSE_REQUIRE(noise, "gse_pf_predict_injected: null argument");
+    return pf_step(GSE_OP_PREDICT, x, x, nullptr, nullptr, nullptr, ld, B, N, u, dt, nullptr, nullptr, nullptr, nullptr,
+                   noise, nullptr, nullptr, stream, "gse_pf_predict_injected");
 }
 
 int gse_pf_update(const float* x, float* w, int64_t ld, int B, int64_t N, const double* u, const double* z,
                   const gse_mixture* measurement_pdf, void* workspace, void* stream) {
-    if (int rc = check_pf_geometry("gse_pf_update", B, N, ld)) return rc;
-    GSE_REQUIRE(x && w && u && z && measurement_pdf && workspace, "gse_pf_update: null argument");
-    GSE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(workspace), "gse_pf_update: pointers must be 16-byte aligned");
-    if (int rc = check_mixture("gse_pf_update", measurement_pdf, GSE_NY)) return rc;
-    UpdateArgs a;
-    pack_io(a.io, B, u, z);
-    pack_pdf2(a.pdf, *measurement_pdf);
-    const int T = (int)tiles_of(N);
-    Workspace ws = carve_workspace(workspace, B, N);
-    hipLaunchKernelGGL(pf_update_kernel, dim3(T, B), dim3(kBlock), 0, (hipStream_t)stream, x, w, ws.tile_sums, N, ld, T, a);
-    GSE_LAUNCH_CHECK("pf_update_kernel");
-    return GSE_OK;
+    (void)u;                                         // g does not depend on the inputs (static_outputs ignores u)
+    GSE_REQUIRE(w, "gse_pf_update: null argument");
+    return pf_step(GSE_OP_UPDATE, x, nullptr, w, w, nullptr, ld, B, N, nullptr, 0.0, z, nullptr, nullptr, nullptr, nullptr,
+                   measurement_pdf, workspace, stream, "gse_pf_update");
+}
+
+int gse_pf_resample_begin(const float* w, int64_t ld, int B, int64_t N, uint32_t flags, double* island, void* workspace,
+                          void* stream) {
+    if (int rc = check_pf_geometry("gse_pf_resample_begin", B, N, ld)) return rc;
+    GSE_REQUIRE(w && workspace && aligned16(w) && aligned16(workspace), "gse_pf_resample_begin: bad pointer");
+    const Workspace ws = carve_workspace(workspace, B, N);
+    return launch_cumsum(w, ld, B, N, flags, island, ws, ws.cumsum, (hipStream_t)stream);
 }
 
 int gse_pf_resample(const float* x_in, const float* w, float* x_out, float* w_out, int32_t* idx, int64_t ld, int B,
                     int64_t N, const double* r, uint32_t flags, double* island, void* workspace, void* stream) {
+    GSE_REQUIRE(w && w_out && w != w_out, "gse_pf_resample: w_out must be a buffer separate from w");
+    GSE_REQUIRE(x_in && x_out && x_in != x_out && r, "gse_pf_resample: x_out must be a buffer separate from x_in; r is required");
     if (int rc = check_pf_geometry("gse_pf_resample", B, N, ld)) return rc;
-    GSE_REQUIRE(x_in && w && x_out && w_out && r && workspace, "gse_pf_resample: null argument");
-    GSE_REQUIRE(x_in != x_out && w != w_out, "gse_pf_resample: x_out / w_out must not alias x_in / w");
-    GSE_REQUIRE(aligned16(x_in) && aligned16(w) && aligned16(x_out) && aligned16(w_out) && aligned16(workspace),
-                "gse_pf_resample: pointers must be 16-byte aligned");
-    GSE_REQUIRE(N < (int64_t)1 << 31, "gse_pf_resample: N must be below 2^31");
-    ResampleArgs ra;
-    for (int b = 0; b < B; ++b) {
+    for (int b = 0; b < B; ++b)
         GSE_REQUIRE(r[b] >= 0.0 && r[b] < 1.0, "gse_pf_resample: r[%d] = %g is outside [0, 1)", b, r[b]);
-        ra.r[b] = r[b];
-    }
-    Workspace ws = carve_workspace(workspace, B, N);
-    hipStream_t st = (hipStream_t)stream;
-    if (int rc = launch_cumsum(w, ld, B, N, flags, island, ws, ws.cumsum, st)) return rc;
-    PfPayload pl{x_in, x_out, ld};
-    hipLaunchKernelGGL(gather_kernel<PfPayload>, dim3((unsigned)tiles_of(N), B), dim3(kBlock), 0, st, pl, ws.cumsum,
-                       ws.totals, w_out, idx, N, ld, ra);
-    GSE_LAUNCH_CHECK("gather_kernel");
-    return GSE_OK;
+    if (int rc = gse_pf_resample_begin(w, ld, B, N, flags, island, workspace, stream)) return rc;
+    return pf_step(GSE_OP_GATHER, x_in, x_out, nullptr, w_out, idx, ld, B, N, nullptr, 0.0, nullptr, r, nullptr, nullptr,
+                   nullptr, nullptr, workspace, stream, "gse_pf_resample");
 }
 
 int gse_pf_moments(const float* x, const float* w, int64_t ld, int B, int64_t N, double* out, void* workspace,

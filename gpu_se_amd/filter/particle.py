@@ -98,7 +98,12 @@ class ParallelParticleFilter:
         self._c_r = (_lib.c_d * 1)()
         self._c_rng = _lib.Rng(seed=self._seed, step=0, element_offset=self._element_offset)
         self._c_rng_ref = ctypes.byref(self._c_rng)
-        self._fn_predict, self._fn_update, self._fn_resample = lib.gse_pf_predict, lib.gse_pf_update, lib.gse_pf_resample
+        self._fn_step, self._fn_resample_begin = lib.gse_pf_step, lib.gse_pf_resample_begin
+        self._pend_gather = False
+        self._pend_predict = None
+        self._want_index = False
+        self._last_index = None
+        self.lazy = True                                    # False: every method launches its own kernel at once
         self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
 
         # particles ~ x0 (particle.py:49), drawn on the device straight into the state-major buffer
@@ -112,9 +117,72 @@ class ParallelParticleFilter:
             self._tpb, self._bpg = 32 * ((n - 1) // 32 + 1), 1
         self._y_dummy = DevArray.wrap(torch.zeros(_lib.GSE_NY, dtype=torch.float32, device=dev))
 
+    # ------------------------------------------------------------------ deferred stages
+    # resample() and predict() do not launch their particle pass at once: resample() computes the cumulative
+    # weights (one small kernel) and leaves the gather pending, predict() leaves the model step pending; the next
+    # update() then runs gather + predict + update as ONE fused pass (gse_pf_step).  Anything that looks at the
+    # particles or weights in between first flushes what is pending with the same kernel, so every result is what
+    # the eager sequence of calls would have produced.
+    def _flush(self):
+        if self._pend_gather or self._pend_predict is not None:
+            self._launch_step(update=None)
+
+    def _launch_step(self, update):
+        """Run the pending gather / predict stages, plus an update if ``update`` = (u, z) is given."""
+        ops = 0
+        n = self.N_particles
+        gather = self._pend_gather
+        x_in = self._x
+        x_out = self._x_alt if gather else self._x
+        w_in = self._w
+        w_out = self._w_alt if gather else self._w
+        idx_ptr = None
+        if gather:
+            ops |= _lib.GSE_OP_GATHER
+            if self._want_index:
+                self._last_index = torch.empty(self._ld, dtype=torch.int32, device=self._x.device)
+                idx_ptr = self._last_index.data_ptr()
+        pod_state = rng_ref = noise_ptr = None
+        dt = 0.0
+        cu = self._c_u
+        if self._pend_predict is not None:
+            ops |= _lib.GSE_OP_PREDICT
+            u, dt = self._pend_predict
+            cu[0], cu[1] = u
+            if isinstance(self.state_pdf, DeterministicGaussianSum):
+                noise = self.state_pdf.draw(n).as_subclass(torch.Tensor)            # (n, Nx) replayed values
+                buf = torch.zeros_like(self._x)
+                buf[:, :n] = noise.reshape(n, _lib.GSE_NX).t()
+                self._noise_buf = buf
+                noise_ptr = buf.data_ptr()
+            else:
+                pod_state = ctypes.byref(self.state_pdf._pod())
+                self._c_rng.step = self._step
+                self._step += 1
+                rng_ref = self._c_rng_ref
+        pod_meas = None
+        cz = self._c_z
+        if update is not None:
+            ops |= _lib.GSE_OP_UPDATE
+            cz[0], cz[1] = update[1]
+            pod_meas = ctypes.byref(self.measurement_pdf._pod())
+        rc = self._fn_step(ops, x_in.data_ptr(), x_out.data_ptr(), w_in.data_ptr(), w_out.data_ptr(), idx_ptr, self._ld, 1,
+                           n, cu, dt, cz, self._c_r, pod_state, rng_ref, noise_ptr, pod_meas, self._ws.data_ptr(),
+                           stream_ptr(self._dev_index))
+        if rc:
+            _lib.check(rc)
+        if gather:
+            self._x, self._x_alt = self._x_alt, self._x
+            self._w, self._w_alt = self._w_alt, self._w
+        self._pend_gather = False
+        self._pend_predict = None
+        if update is not None:
+            self._tiles_valid = True
+
     # ------------------------------------------------------------------ attributes
     @property
     def particles(self):
+        self._flush()
         return DevArray.wrap(self._x[:, :self.N_particles].t())
 
     @particles.setter
@@ -122,10 +190,12 @@ class ParallelParticleFilter:
         v = as_device(value, torch.float32)
         if tuple(v.shape) != (self.N_particles, _lib.GSE_NX):
             raise ValueError("particles must have shape (%d, %d)" % (self.N_particles, _lib.GSE_NX))
+        self._flush()
         self._x[:, :self.N_particles] = v.t()
 
     @property
     def weights(self):
+        self._flush()
         return DevArray.wrap(self._w[:self.N_particles])
 
     @weights.setter
@@ -134,66 +204,51 @@ class ParallelParticleFilter:
         v = as_device(value, torch.float32)
         if tuple(v.shape) != (self.N_particles,):
             raise ValueError("weights must have shape (%d,)" % self.N_particles)
+        self._flush()
         self._w[:self.N_particles] = v
         self._tiles_valid = False
 
     # ------------------------------------------------------------------ the cycle
     def predict(self, u, dt):
         """Performs a prediction step on the particles: x_i += f(x_i, u, dt) then x += state noise
-        (particle.py:265-277).  u: (N_inputs) host array-like; dt: float."""
-        n = self.N_particles
-        if isinstance(self.state_pdf, DeterministicGaussianSum):
-            uu = _lib.doubles(u, _lib.GSE_NU)
-            noise = self.state_pdf.draw(n).as_subclass(torch.Tensor)            # (n, Nx) replayed values
-            buf = torch.zeros_like(self._x)
-            buf[:, :n] = noise.reshape(n, _lib.GSE_NX).t()
-            _lib.call("gse_pf_predict_injected", self._x.data_ptr(), self._ld, 1, n, uu, float(dt), buf.data_ptr(),
-                      stream_ptr())
-        else:
-            cu = self._c_u
-            cu[0], cu[1] = u
-            self._c_rng.step = self._step
-            self._step += 1
-            rc = self._fn_predict(self._x.data_ptr(), self._ld, 1, n, cu, dt, ctypes.byref(self.state_pdf._pod()),
-                                  self._c_rng_ref, stream_ptr(self._dev_index))
-            if rc:
-                _lib.check(rc)
+        (particle.py:265-277).  u: (N_inputs) host array-like; dt: float.  Deferred -- see above."""
+        if self._pend_predict is not None:
+            self._flush()                                   # two predicts in a row: run the first one now
+        u0, u1 = u
+        self._pend_predict = ((float(u0), float(u1)), float(dt))
+        if not self.lazy:
+            self._flush()
 
     def update(self, u, z):
         """Performs an update step on the particles: w_i *= measurement_pdf(z - g(x_i, u))
-        (particle.py:279-294).  u, z: host array-likes."""
-        cu, cz = self._c_u, self._c_z
-        cu[0], cu[1] = u
-        cz[0], cz[1] = z
-        rc = self._fn_update(self._x.data_ptr(), self._w.data_ptr(), self._ld, 1, self.N_particles, cu, cz,
-                             ctypes.byref(self.measurement_pdf._pod()), self._ws.data_ptr(), stream_ptr(self._dev_index))
-        if rc:
-            _lib.check(rc)
-        self._tiles_valid = True
+        (particle.py:279-294).  u, z: host array-likes.  Runs the pending resample-gather and predict in the same
+        pass."""
+        self._launch_step(update=(u, z))
 
     def resample(self, r=None, return_index=False):
         """Systematic resample of the particles based on their weights (particle.py:296-316).  The one
-        uniform number comes from a host generator (no device round trip); ``r`` overrides it (tests)."""
-        rr = self._c_r
-        rr[0] = self._host_rng.random() if r is None else r
-        idx = torch.empty(self._ld, dtype=torch.int32, device=self._x.device) if return_index else None
+        uniform number comes from a host generator (no device round trip); ``r`` overrides it (tests).  The
+        cumulative weights are computed now; the copy of the ancestors is deferred -- see above."""
+        self._flush()
+        self._c_r[0] = self._host_rng.random() if r is None else r
         flags = _lib.GSE_RESAMPLE_TILES_VALID if self._tiles_valid else 0
-        rc = self._fn_resample(self._x.data_ptr(), self._w.data_ptr(), self._x_alt.data_ptr(),
-                               self._w_alt.data_ptr(), idx.data_ptr() if return_index else None, self._ld, 1,
-                               self.N_particles, rr, flags,
-                               self._island.data_ptr() if self._island is not None else None, self._ws.data_ptr(),
-                               stream_ptr(self._dev_index))
+        rc = self._fn_resample_begin(self._w.data_ptr(), self._ld, 1, self.N_particles, flags,
+                                     self._island.data_ptr() if self._island is not None else None,
+                                     self._ws.data_ptr(), stream_ptr(self._dev_index))
         if rc:
             _lib.check(rc)
-        self._x, self._x_alt = self._x_alt, self._x
-        self._w, self._w_alt = self._w_alt, self._w
         self._tiles_valid = False
+        self._pend_gather = True
+        self._want_index = bool(return_index)
+        if return_index or not self.lazy:
+            self._flush()
         if return_index:
-            return DevArray.wrap(idx[:self.N_particles])
+            return DevArray.wrap(self._last_index[:self.N_particles])
 
     # ------------------------------------------------------------------ estimates
     def _raw_moments(self):
         """(S0, S1 = sum w d, S2 = sum w d d^T (5x5), pivot) with d = x - pivot, from the device (synchronises)."""
+        self._flush()
         _lib.call("gse_pf_moments", self._x.data_ptr(), self._w.data_ptr(), self._ld, 1, self.N_particles,
                   self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
         m = self._moments.cpu().numpy()
@@ -221,7 +276,7 @@ class ParallelParticleFilter:
         """out[i] = f(particles[i], u, dt) as a device array (M x Nx) fp32 (particle.py:176-191)."""
         p = as_device(particles, torch.float32)
         lead = p.shape[:-1]
-        p2 = p.reshape(-1, _lib.GSE_NX)
+        p2 = p.reshape(-1, _lib.GSE_NX).contiguous()
         out = torch.empty_like(p2)
         _lib.call("gse_model_f", p2.data_ptr(), out.data_ptr(), p2.shape[0], _lib.doubles(u, _lib.GSE_NU), float(dt),
                   stream_ptr())

@@ -119,6 +119,28 @@ int gse_pf_resample(const float *x_in, const float *w, float *x_out, float *w_ou
                     int64_t ld, int B, int64_t N, const double *r, uint32_t flags, double *island,
                     void *workspace, void *stream);
 
+/* First half of a resample only: the normalised cumulative weights (and the weight sum) go to the workspace, where a
+ * following gse_pf_step(GSE_OP_GATHER | ...) finds them.  flags / island as for gse_pf_resample. */
+int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t flags, double *island,
+                          void *workspace, void *stream);
+
+/* One fused pass over the particles that performs any subset, in this order, of
+ *   GSE_OP_GATHER   second half of resample: offspring j copies its ancestor (needs gse_pf_resample_begin on the same
+ *                   workspace first; r as for gse_pf_resample); the offspring weight is 1/N;
+ *   GSE_OP_PREDICT  gse_pf_predict (noise == NULL: Philox draw from state_pdf) or gse_pf_predict_injected (noise given);
+ *   GSE_OP_UPDATE   gse_pf_update (leaves the tile sums of the new weights in the workspace).
+ * It computes exactly what the separate calls compute, with one launch and one trip of the state through HBM; the
+ * steady-state cycle resample -> predict -> update is gse_pf_resample_begin + ONE gse_pf_step of all three stages.
+ * With GATHER: x_out, w_out are separate buffers, w_in is not read.  Without: in place (x_out == x_in; w_out may
+ * equal w_in).  Arguments of stages that are not requested may be NULL. */
+#define GSE_OP_GATHER  1u
+#define GSE_OP_PREDICT 2u
+#define GSE_OP_UPDATE  4u
+int gse_pf_step(uint32_t ops, const float *x_in, float *x_out, const float *w_in, float *w_out, int32_t *idx,
+                int64_t ld, int B, int64_t N, const double *u, double dt, const double *z, const double *r,
+                const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,
+                const gse_mixture *measurement_pdf, void *workspace, void *stream);
+
 /* Moments behind point_estimate / point_covariance (filter/particle.py:318-327), fp64 accumulation:
  * out [B][26] device = { S0 = sum w, S1[5] = sum w (x - p), S2[15] = upper triangle (row-major) of
  * sum w (x - p)(x - p)^T, p[5] } with the pivot p = particle 0 (keeps the second moments free of

@@ -400,3 +400,78 @@ def test_sharded_filter_single_rank_bookkeeping():
         isl = host(spf.local._island)
         np.testing.assert_allclose(isl[0, 0], log_acc, rtol=1e-12)
         np.testing.assert_allclose(isl[1, 0], w.sum(), rtol=1e-13)
+
+
+# ------------------------------------------------------------------------------ fused / deferred execution
+def _two_filters(n, seed):
+    out = []
+    for lazy in (True, False):
+        gpu_se_amd.seed(seed)
+        _, _, _, pf = sim_base.get_parts(N_particles=n)
+        pf.lazy = lazy
+        out.append(pf)
+    return out
+
+
+@pytest.mark.parametrize("n", [7, 1024, 5003, 1 << 17])
+def test_fused_cycle_equals_eager_calls(n):
+    """resample / predict / update deferred into ONE fused pass must give bit-identical particles and weights to the
+    same calls executed one kernel each (lazy=False), for any interleaving of calls and accessors."""
+    fused, eager = _two_filters(n, 77)
+    np.testing.assert_array_equal(fused.particles.get(), eager.particles.get())
+    xss = orc.steady_state()
+    rng = np.random.default_rng(n)
+    for c in range(6):
+        u = [rng.uniform(0.03, 0.09), rng.uniform(0.1, 0.3)]
+        z = np.array(orc.bioreactor_g(xss)) + rng.normal(0, 0.3, 2)
+        r = float(rng.random())
+        for pf in (fused, eager):
+            pf.predict(u, 0.1)
+            if c == 2:
+                pf.predict(u, 0.05)                # two predicts in a row
+            pf.update(u, z)
+            if c == 3:
+                pf.update(u, z)                    # two updates in a row
+            pf.resample(r=r)
+            if c == 4:
+                pf.point_estimate()                # estimate between resample and predict (closed loop order)
+        if c in (0, 3, 5):
+            np.testing.assert_array_equal(fused.particles.get(), eager.particles.get())
+            np.testing.assert_array_equal(fused.weights.get(), eager.weights.get())
+    np.testing.assert_array_equal(fused.point_estimate(), eager.point_estimate())
+
+
+def test_fused_step_against_oracle():
+    """gather + predict(injected) + update in one launch (gse_pf_step) vs the oracle's three separate steps."""
+    n = 6000
+    rng = np.random.default_rng(8)
+    xss = orc.steady_state()
+    x = (xss[None, :] * (1 + 0.01 * rng.standard_normal((n, 5)))).astype(np.float32)
+    x[:, 3] = rng.uniform(0, 0.05, n)
+    w = (rng.random(n) ** 4).astype(np.float32)
+    noise = (rng.standard_normal((n, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    u, dt, r = [0.055, 0.21], 0.1, 0.3721
+    z = np.array(orc.bioreactor_g(xss)) + [0.15, -0.2]
+    sp, mp = orc.bioreactor_noise()
+    o = orc.ParticleFilterOracle(n, None, sp, mp, particles=x)
+    o.weights = w.astype(np.float64)
+    idx_want = o.resample(r=r, loop=False)
+    o.weights = np.full(n, np.float32(1.0 / n), dtype=np.float32)          # the device keeps fp32 weights
+    o.predict_vec(u, dt, noise=noise)
+    o.update_vec(u, z)
+
+    xd, ld = to_state_major(x)
+    wd = padded(w, ld)
+    nd, _ = to_state_major(noise)
+    xo, wo = torch.full_like(xd, float("nan")), torch.full_like(wd, float("nan"))
+    idx = torch.full((ld,), -1, dtype=torch.int32, device="cuda")
+    ws = workspace(1, n)
+    _, pmp = sim_base.get_noise()
+    pod = pmp._pod()
+    _lib.call("gse_pf_resample_begin", wd.data_ptr(), ld, 1, n, 0, None, ws.data_ptr(), stream())
+    _lib.call("gse_pf_step", _lib.GSE_OP_GATHER | _lib.GSE_OP_PREDICT | _lib.GSE_OP_UPDATE, xd.data_ptr(), xo.data_ptr(),
+              wd.data_ptr(), wo.data_ptr(), idx.data_ptr(), ld, 1, n, _lib.doubles(u, 2), dt, _lib.doubles(z, 2),
+              _lib.doubles([r], 1), None, None, nd.data_ptr(), ctypes.byref(pod), ws.data_ptr(), stream())
+    np.testing.assert_array_equal(host(idx)[:n], idx_want)
+    np.testing.assert_array_equal(host(xo)[:, :n].T, o.particles)
+    np.testing.assert_allclose(host(wo)[:n], o.weights, rtol=1.2e-7)

@@ -1,6 +1,6 @@
 # micro-benchmark of the host side of one cycle (run on the GPU box)
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import gpu_se_amd
 from gpu_se_amd import sim_base
