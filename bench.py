@@ -174,6 +174,7 @@ def main():
         per["step"] = time_method_events(torch, one_step, reps)
 
         def one_cumsum(i):
+            lp._tiles_valid = True                              # as in the cycle: tile sums left by the update stage
             lp.resample()
             lp._pend_gather = False
         per["cumsum"] = time_method_events(torch, one_cumsum, reps)

@@ -39,6 +39,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd[1:1] = os.environ.get("GSE_CXXFLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

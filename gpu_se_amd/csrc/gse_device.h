@@ -103,7 +103,9 @@ struct DrawParams {
     float cumw[GSE_MAX_ND];                 // normalised cumulative component weights
     float mean[GSE_MAX_ND][GSE_NX];
     float chol[GSE_MAX_ND][15];             // packed lower triangle, row-major: (0,0) (1,0) (1,1) (2,0) ...
+    float pad[2];                           // sizeof = 352, a multiple of 16 (LDS carve alignment)
 };
+static_assert(sizeof(DrawParams) % 16 == 0, "DrawParams must keep LDS offsets 16-byte aligned");
 
 // One draw from the mixture for a 5-d state: words -> component + 5 normals -> mean + L n.
 __device__ __forceinline__ void mixture_draw5(const DrawParams& dp, const uint32_t (&wd)[8], float (&out)[5]) {

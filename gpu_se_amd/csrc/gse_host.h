@@ -53,6 +53,7 @@ struct Workspace {
     double* tile_prefix;   // [B][T + 1]   exclusive prefix of tile sums; [T] = total
     double* partials;      // [B][kMomentBlocks][kMomentWidth]
     double* totals;        // [B]          sum of the weights of each filter
+    double* tops;          // [B][T]       normalised cumulative weight at the end of each tile
     double* cumsum;        // [B][N]       normalised cumulative weights
     int64_t bytes;
 };

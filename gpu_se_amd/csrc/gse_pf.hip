@@ -19,6 +19,8 @@
 // the same kernel with a single stage enabled.
 #include "gse_host.h"
 
+#include <stdlib.h>
+
 namespace gse {
 
 // ------------------------------------------------------------------------------------------------
@@ -37,27 +39,41 @@ struct StepArgs {
 #define GSE_STEP_MIN_WAVES 4     // waves per SIMD the register allocator must leave room for (tuning knob)
 #endif
 
+#ifndef GSE_GATHER_STRIDED
+#define GSE_GATHER_STRIDED 1     // gather variants: a thread's 4 outputs are 256 apart (1) or consecutive (0)
+#endif
+
 #define GSE_LOAD_DWORD(dst, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 #define GSE_LOAD_DWORDX4(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 
+// Particle <-> thread mapping.  Without gather a thread owns 4 CONSECUTIVE particles (one dwordx4 per state row).
+// With gather the reads are indexed anyway, so a thread owns 4 outputs 256 apart: for each of them the 64 lanes of a
+// wavefront then touch consecutive outputs and (near-)consecutive ancestors -- every dword load / store instruction
+// covers whole cache lines, where the consecutive mapping would use a quarter of each line it touches.
 template <bool kGather, bool kPredict, bool kInjected, bool kUpdate, int kNd>
-__global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(const float* __restrict__ x_in, float* __restrict__ x_out,
-                                                         const float* __restrict__ w_in, float* __restrict__ w_out,
-                                                         const float* __restrict__ noise, int32_t* __restrict__ idx_out,
-                                                         const double* __restrict__ c, const double* __restrict__ totals,
-                                                         double* __restrict__ tile_sums, int64_t N, int64_t ld, int T,
-                                                         const StepArgs a) {
+__global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
+    const float* __restrict__ x_in, float* __restrict__ x_out, const float* __restrict__ w_in, float* __restrict__ w_out,
+    const float* __restrict__ noise, int32_t* __restrict__ idx_out, const double* __restrict__ c,
+    const double* __restrict__ totals, const double* __restrict__ tops, double* __restrict__ tile_sums, int64_t N,
+    int64_t ld, int T, int tops_in_lds, const StepArgs a) {
     __shared__ DrawParams dp;
-    __shared__ double seg[kGather ? kSpanMax : 1];
+    __shared__ double seg[kGather ? kSpanMax : 2];
+    __shared__ float wtile[(kGather && kUpdate) ? kTile : 4];
     __shared__ int64_t span[2];
     __shared__ double red[4];
+    extern __shared__ double tops_s[];        // [T] when tops_in_lds (dynamic; statics above total a multiple of 16 B)
 
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t i0 = ((int64_t)blockIdx.x * kBlock + tid) * kPerThread;      // first of this thread's 4 particles
-    const bool live = i0 < N;
+    const int64_t tile0 = (int64_t)blockIdx.x * kTile;
+    const int64_t i0 = tile0 + (int64_t)tid * kPerThread;       // consecutive mapping: first of this thread's 4
     const double Nd = (double)N;
     const float w_uniform = (float)(1.0 / Nd);
     const float* xin_b = x_in + (int64_t)b * GSE_NX * ld;
+
+    // index of this thread's p-th particle
+    int64_t jp[kPerThread];
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p) jp[p] = (kGather && GSE_GATHER_STRIDED) ? tile0 + tid + (int64_t)p * kBlock : i0 + p;
 
     if (kPredict && !kInjected) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.draw);
@@ -74,27 +90,51 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(con
         // sweep never advances (filter/particle.py:98), so every offspring copies particle 0 (anc stays 0).
         if ((W > 0.0) && (W < INFINITY)) {
             const double* cb = c + (int64_t)b * N;
-            const int64_t j0 = (int64_t)blockIdx.x * kTile;
+            const int64_t j0 = tile0;
             const int64_t j1 = min(j0 + kTile, N);
-            if (wv < 2) {       // bracket the tile's ancestors: wavefront 0 takes the first output, wavefront 1 the last
-                const int64_t j = (wv == 0) ? j0 : j1 - 1;
-                const int64_t k = wave_search_ge(cb, N, ((double)j + r) / Nd, lane);
-                if (lane == 0) span[wv] = k;
+            int64_t klo, khi;
+            if (tops_in_lds) {
+                // first level in LDS: the T tile-end values (8 KiB at N = 2^20) arrive in one coalesced round trip and
+                // two threads binary-search them; the second level is the staging below.
+                const double* tb = tops + (int64_t)b * T;
+                for (int q = tid; q < T; q += kBlock) tops_s[q] = tb[q];
+                __syncthreads();
+                if (tid == 0 || tid == 64) {
+                    const int64_t j = (tid == 0) ? j0 : j1 - 1;
+                    const double u = ((double)j + r) / Nd;
+                    int lo = 0, hi = T - 1;                    // first tile whose end value is >= u
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (tops_s[mid] < u) lo = mid + 1; else hi = mid;
+                    }
+                    span[tid >> 6] = lo;
+                }
+                __syncthreads();
+                const int64_t tlo = span[0], thi = span[1];
+                klo = tlo * kTile;
+                khi = min((thi + 1) * (int64_t)kTile, N) - 1;
+            } else {
+                if (wv < 2) {   // bracket the tile's ancestors: wavefront 0 takes the first output, wavefront 1 the last
+                    const int64_t j = (wv == 0) ? j0 : j1 - 1;
+                    const int64_t k = wave_search_ge(cb, N, ((double)j + r) / Nd, lane);
+                    if (lane == 0) span[wv] = k;
+                }
+                __syncthreads();
+                klo = span[0];
+                khi = span[1];
             }
-            __syncthreads();
-            const int64_t klo = span[0], khi = span[1];
             const int64_t len = khi - klo + 1;
             if (len <= kSpanMax) {
                 for (int q = tid; q < (int)len; q += kBlock) seg[q] = cb[klo + q];
                 __syncthreads();
 #pragma unroll
                 for (int p = 0; p < kPerThread; ++p)
-                    anc[p] = (int32_t)klo + span_search(seg, (int)len, ((double)(i0 + p) + r) / Nd);
+                    anc[p] = (int32_t)klo + span_search(seg, (int)len, ((double)jp[p] + r) / Nd);
             } else {
                 // the tile's ancestors are spread over a long stretch of (nearly) weightless particles: search c[] itself
 #pragma unroll
                 for (int p = 0; p < kPerThread; ++p) {
-                    const double u = ((double)(i0 + p) + r) / Nd;
+                    const double u = ((double)jp[p] + r) / Nd;
                     int64_t lo = klo, hi = khi;
                     while (lo < hi) {
                         const int64_t mid = (lo + hi) >> 1;
@@ -107,7 +147,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(con
     }
     if (kPredict && !kInjected) __syncthreads();        // dp staged
 
-    double mine = 0.0;
+    // a thread is live if it owns at least one particle (its first one)
+    const bool live = jp[0] < N;
+    float wnew[kPerThread] = {w_uniform, w_uniform, w_uniform, w_uniform};
     if (live) {
         // ---- issue every load now; the RNG arithmetic below needs no memory and hides their latency.  (Plain loads
         //      get sunk below the RNG by the compiler to save registers, which serialises "RNG, then wait for HBM";
@@ -127,13 +169,25 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(con
             GSE_LOAD_DWORDX4(r3, xb + 3 * ld);
             GSE_LOAD_DWORDX4(r4, xb + 4 * ld);
         }
-        float4 wv4 = make_float4(w_uniform, w_uniform, w_uniform, w_uniform);
-        if (kUpdate && !kGather) wv4 = *reinterpret_cast<const float4*>(w_in + (int64_t)b * ld + i0);
-        float4 nz[GSE_NX];
+        if (kUpdate && !kGather) {
+            const float4 w4 = *reinterpret_cast<const float4*>(w_in + (int64_t)b * ld + i0);
+            wnew[0] = w4.x; wnew[1] = w4.y; wnew[2] = w4.z; wnew[3] = w4.w;
+        }
+        float nz[kPerThread][GSE_NX];
         if (kPredict && kInjected) {
-            const float* nb = noise + (int64_t)b * GSE_NX * ld + i0;
+            const float* nb = noise + (int64_t)b * GSE_NX * ld;
+            if (kGather) {
 #pragma unroll
-            for (int k = 0; k < GSE_NX; ++k) nz[k] = *reinterpret_cast<const float4*>(nb + k * ld);
+                for (int p = 0; p < kPerThread; ++p)
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) nz[p][k] = (jp[p] < N) ? nb[k * ld + jp[p]] : 0.f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < GSE_NX; ++k) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(nb + k * ld + i0);
+                    nz[0][k] = t4.x; nz[1][k] = t4.y; nz[2][k] = t4.z; nz[3][k] = t4.w;
+                }
+            }
         }
 
         // ---- two halves of two particles each (keeps the live register set small): the noise of a half is drawn
@@ -150,10 +204,10 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(con
                     const int p = 2 * h + q;
                     if (kInjected) {
 #pragma unroll
-                        for (int k = 0; k < GSE_NX; ++k) e[q][k] = reinterpret_cast<const float*>(&nz[k])[p];
+                        for (int k = 0; k < GSE_NX; ++k) e[q][k] = nz[p][k];
                     } else {
                         uint32_t wd[8];
-                        rng_words8(a.rng, (uint64_t)(i0 + p), (uint32_t)b, wd);
+                        rng_words8(a.rng, (uint64_t)jp[p], (uint32_t)b, wd);
                         mixture_draw5(dp, wd, e[q]);
                     }
                 }
@@ -175,7 +229,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(con
                     row[0] = r0; row[1] = r1; row[2] = r2; row[3] = r3; row[4] = r4;
                 }
             }
-            // predict: ODE step + noise;  update: likelihood of the (new) state
+            // predict: ODE step + noise
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int p = 2 * h + q;
@@ -189,8 +243,16 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(con
                 }
             }
         }
-        // the new state goes out now (contiguous in the particle index: one dwordx4 per row), ahead of the update phase
-        if (kGather || kPredict) {
+        // the new state goes out now, ahead of the update phase
+        if (kGather) {
+            float* xb = x_out + (int64_t)b * GSE_NX * ld;
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p)
+                if (jp[p] < N) {
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) xb[k * ld + jp[p]] = row[k][p];
+                }
+        } else if (kPredict) {
             float* xb = x_out + (int64_t)b * GSE_NX * ld + i0;
 #pragma unroll
             for (int k = 0; k < GSE_NX; ++k) *reinterpret_cast<v4f*>(xb + k * ld) = row[k];
@@ -204,18 +266,35 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(con
                 float y0, y1;
                 bioreactor_output(row[0][p], row[2][p], y0, y1);
                 const double lik = mixture_pdf2<kNd>(a.pdf, z0 - (double)y0, z1 - (double)y1);
-                float& wp = reinterpret_cast<float*>(&wv4)[p];
-                wp = (float)((double)wp * lik);
+                wnew[p] = (float)((double)wnew[p] * lik);
             }
         }
 
         // ---- weights, ancestor indices
-        if (kGather || kUpdate) *reinterpret_cast<float4*>(w_out + (int64_t)b * ld + i0) = wv4;
-        if (kGather && idx_out)
-            *reinterpret_cast<int4*>(idx_out + (int64_t)b * ld + i0) = make_int4(anc[0], anc[1], anc[2], anc[3]);
-        if (kUpdate) mine = masked_sum4(wv4.x, wv4.y, wv4.z, wv4.w, i0, N);
+        if (kGather) {
+            float* wb = w_out + (int64_t)b * ld;
+            int32_t* ib = idx_out ? idx_out + (int64_t)b * ld : nullptr;
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p)
+                if (jp[p] < N) {
+                    wb[jp[p]] = wnew[p];
+                    if (ib) ib[jp[p]] = anc[p];
+                }
+        } else if (kUpdate) {
+            *reinterpret_cast<float4*>(w_out + (int64_t)b * ld + i0) = make_float4(wnew[0], wnew[1], wnew[2], wnew[3]);
+        }
     }
     if (kUpdate) {
+        // tile sum of the new weights, always formed in the same order (4 consecutive per thread, then the workgroup
+        // tree) so that fused and separate launches leave bit-identical sums; the strided mapping goes through LDS.
+        if (kGather && GSE_GATHER_STRIDED) {
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) wtile[tid + p * kBlock] = wnew[p];
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) wnew[p] = wtile[tid * kPerThread + p];
+        }
+        const double mine = masked_sum4(wnew[0], wnew[1], wnew[2], wnew[3], i0, N);
         const double total = block_sum(mine, red);
         if (tid == 0) tile_sums[(int64_t)b * T + blockIdx.x] = total;
     }
@@ -309,8 +388,8 @@ __device__ __forceinline__ void inline_tile_prefix(const double* __restrict__ s,
 template <bool kInlinePrefix>
 __global__ __launch_bounds__(kBlock) void cumsum_kernel(const float* __restrict__ w, double* __restrict__ c,
                                                         const double* __restrict__ tile_src,
-                                                        double* __restrict__ totals, double* __restrict__ island,
-                                                        int64_t N, int64_t ldw, int T) {
+                                                        double* __restrict__ totals, double* __restrict__ tops,
+                                                        double* __restrict__ island, int64_t N, int64_t ldw, int T) {
     __shared__ double red[4];
     __shared__ double pfx[3];
     const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
@@ -341,6 +420,7 @@ __global__ __launch_bounds__(kBlock) void cumsum_kernel(const float* __restrict_
     // The tile's last entry is pinned to prefix[t+1]/W and everything before it clamped to that value, so the
     // array is monotone across tiles although prefix and in-tile sums associate differently; c[N-1] = W/W = 1.
     const double top = P1 / W;
+    if (tid == 0) tops[(int64_t)b * T + t] = top;       // compact copy of c at the tile ends: the gather's first-level index
     const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
     double* cb = c + (int64_t)b * N;
     double v[kPerThread];
@@ -503,13 +583,13 @@ int launch_cumsum(const float* w, int64_t ldw, int B, int64_t N, uint32_t flags,
         GSE_LAUNCH_CHECK("tile_sum_kernel");
     }
     if (T <= kInlinePrefixMaxT && !(flags & GSE_RESAMPLE_SEPARATE_SCAN)) {
-        hipLaunchKernelGGL(cumsum_kernel<true>, dim3(T, B), dim3(kBlock), 0, st, w, c_out, ws.tile_sums, ws.totals, island,
-                           N, ldw, T);
+        hipLaunchKernelGGL(cumsum_kernel<true>, dim3(T, B), dim3(kBlock), 0, st, w, c_out, ws.tile_sums, ws.totals, ws.tops,
+                           island, N, ldw, T);
     } else {
         hipLaunchKernelGGL(tile_scan_kernel, dim3(B), dim3(kBlock), 0, st, ws.tile_sums, ws.tile_prefix, T);
         GSE_LAUNCH_CHECK("tile_scan_kernel");
         hipLaunchKernelGGL(cumsum_kernel<false>, dim3(T, B), dim3(kBlock), 0, st, w, c_out, ws.tile_prefix, ws.totals,
-                           island, N, ldw, T);
+                           ws.tops, island, N, ldw, T);
     }
     GSE_LAUNCH_CHECK("cumsum_kernel");
     return GSE_OK;
@@ -541,12 +621,18 @@ namespace {
 template <bool G, bool P, bool I, bool U>
 void launch_step(dim3 grid, hipStream_t st, const float* x_in, float* x_out, const float* w_in, float* w_out,
                  const float* noise, int32_t* idx, const Workspace& ws, int64_t N, int64_t ld, int T, const StepArgs& a) {
+    // First-level index of the gather: GSE_TOPS=1 stages the T tile-end values in LDS (one round trip) instead of the
+    // 64-ary wavefront search of c[] (four).  Measured on MI355X at N = 2^20 the LDS variant is SLOWER in the fused
+    // kernel (30.7 vs 26.2 us: more LDS, two more barriers, 16 KiB staged instead of ~8), so it is off by default.
+    static const char* tops_env = getenv("GSE_TOPS");
+    const int tops_in_lds = (G && T <= kInlinePrefixMaxT && tops_env && tops_env[0] == '1') ? 1 : 0;
+    const size_t dyn = tops_in_lds ? (size_t)T * sizeof(double) : 0;
     if (U && a.pdf.nd == 2)         // the common case gets the kernel with the component count folded in
-        hipLaunchKernelGGL((pf_step_kernel<G, P, I, U, U ? 2 : 0>), grid, dim3(kBlock), 0, st, x_in, x_out, w_in, w_out,
-                           noise, idx, ws.cumsum, ws.totals, ws.tile_sums, N, ld, T, a);
+        hipLaunchKernelGGL((pf_step_kernel<G, P, I, U, U ? 2 : 0>), grid, dim3(kBlock), dyn, st, x_in, x_out, w_in, w_out,
+                           noise, idx, ws.cumsum, ws.totals, ws.tops, ws.tile_sums, N, ld, T, tops_in_lds, a);
     else
-        hipLaunchKernelGGL((pf_step_kernel<G, P, I, U, 0>), grid, dim3(kBlock), 0, st, x_in, x_out, w_in, w_out, noise,
-                           idx, ws.cumsum, ws.totals, ws.tile_sums, N, ld, T, a);
+        hipLaunchKernelGGL((pf_step_kernel<G, P, I, U, 0>), grid, dim3(kBlock), dyn, st, x_in, x_out, w_in, w_out, noise,
+                           idx, ws.cumsum, ws.totals, ws.tops, ws.tile_sums, N, ld, T, tops_in_lds, a);
 }
 
 // The one place that validates and dispatches a fused step.

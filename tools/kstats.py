@@ -1,5 +1,6 @@
 """Print a compact per-kernel table from a rocprofv3 *_kernel_stats.csv (or a directory containing one)."""
-import csv, glob, os, sys
+import csv, glob, os, signal, sys
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)
 path = sys.argv[1]
 if os.path.isdir(path):
     path = sorted(glob.glob(os.path.join(path, "**", "*kernel_stats.csv"), recursive=True))[0]
