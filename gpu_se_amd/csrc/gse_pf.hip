@@ -44,6 +44,9 @@ struct StepArgs {
 #endif
 
 #define GSE_LOAD_DWORD(dst, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+// scalar base (uniform row pointer) + 32-bit byte offset per lane
+#define GSE_LOAD_DWORD_S(dst, voff, sbase) \
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
 #define GSE_LOAD_DWORDX4(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 
 // Particle <-> thread mapping.  Without gather a thread owns 4 CONSECUTIVE particles (one dwordx4 per state row).
@@ -70,10 +73,13 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     const float w_uniform = (float)(1.0 / Nd);
     const float* xin_b = x_in + (int64_t)b * GSE_NX * ld;
 
-    // index of this thread's p-th particle
-    int64_t jp[kPerThread];
+    // index of this thread's p-th particle (N < 2^31 is checked by the host: 32-bit offsets from uniform row pointers
+    // let the loads and stores use the scalar-base + 32-bit-offset form instead of a 64-bit address per access)
+    uint32_t jp[kPerThread];
 #pragma unroll
-    for (int p = 0; p < kPerThread; ++p) jp[p] = (kGather && GSE_GATHER_STRIDED) ? tile0 + tid + (int64_t)p * kBlock : i0 + p;
+    for (int p = 0; p < kPerThread; ++p)
+        jp[p] = (uint32_t)((kGather && GSE_GATHER_STRIDED) ? tile0 + tid + (int64_t)p * kBlock : i0 + p);
+    const uint32_t Nu = (uint32_t)N;
 
     if (kPredict && !kInjected) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.draw);
@@ -148,19 +154,19 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     if (kPredict && !kInjected) __syncthreads();        // dp staged
 
     // a thread is live if it owns at least one particle (its first one)
-    const bool live = jp[0] < N;
+    const bool live = jp[0] < Nu;
     float wnew[kPerThread] = {w_uniform, w_uniform, w_uniform, w_uniform};
     if (live) {
         // ---- issue every load now; the RNG arithmetic below needs no memory and hides their latency.  (Plain loads
         //      get sunk below the RNG by the compiler to save registers, which serialises "RNG, then wait for HBM";
         //      the asm statements pin the issue point and the wait is tied to the registers -- guide 5.7.)
-        float g[kPerThread][GSE_NX];          // gathered rows (kGather)
+        float g[2][GSE_NX];                   // gathered rows of the current half (kGather)
         v4f r0, r1, r2, r3, r4;               // contiguous rows (!kGather)
         if (kGather) {
 #pragma unroll
-            for (int p = 0; p < kPerThread; ++p)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int k = 0; k < GSE_NX; ++k) GSE_LOAD_DWORD(g[p][k], xin_b + k * ld + anc[p]);
+                for (int k = 0; k < GSE_NX; ++k) GSE_LOAD_DWORD_S(g[q][k], (uint32_t)anc[q] * 4u, xin_b + k * ld);
         } else {
             const float* xb = xin_b + i0;
             GSE_LOAD_DWORDX4(r0, xb);
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
                 for (int p = 0; p < kPerThread; ++p)
 #pragma unroll
-                    for (int k = 0; k < GSE_NX; ++k) nz[p][k] = (jp[p] < N) ? nb[k * ld + jp[p]] : 0.f;
+                    for (int k = 0; k < GSE_NX; ++k) nz[p][k] = (jp[p] < Nu) ? (nb + k * ld)[jp[p]] : 0.f;
             } else {
 #pragma unroll
                 for (int k = 0; k < GSE_NX; ++k) {
@@ -193,6 +199,8 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         // ---- two halves of two particles each (keeps the live register set small): the noise of a half is drawn
         //      first -- registers only -- and the first half's draw is what hides the latency of the loads above.
         v4f row[GSE_NX];
+        float gq[2][GSE_NX];
+        float obs0[kPerThread], obs2[kPerThread];     // Cg, Cfa of the (new) state: all the update needs
         const double fg = a.io.f[b].u0, fm = a.io.f[b].u1;
         const double z0 = a.io.f[b].z0, z1 = a.io.f[b].z1;
 #pragma unroll
@@ -212,47 +220,56 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                     }
                 }
             }
-            if (h == 0) {
-                // the state rows must have landed now
-                if (kGather) {
-                    asm volatile("s_waitcnt vmcnt(0)"
-                                 : "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[0][2]), "+v"(g[0][3]), "+v"(g[0][4]),
-                                   "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[1][2]), "+v"(g[1][3]), "+v"(g[1][4]),
-                                   "+v"(g[2][0]), "+v"(g[2][1]), "+v"(g[2][2]), "+v"(g[2][3]), "+v"(g[2][4]),
-                                   "+v"(g[3][0]), "+v"(g[3][1]), "+v"(g[3][2]), "+v"(g[3][3]), "+v"(g[3][4])::"memory");
+            // the state rows of this half must have landed now; with gather, the other half's loads are issued right
+            // behind the wait so that they fly during this half's ODE step and the next draw
+            if (kGather) {
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[0][2]), "+v"(g[0][3]), "+v"(g[0][4]),
+                               "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[1][2]), "+v"(g[1][3]), "+v"(g[1][4])::"memory");
 #pragma unroll
-                    for (int p = 0; p < kPerThread; ++p)
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int k = 0; k < GSE_NX; ++k) row[k][p] = g[p][k];
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4)::"memory");
-                    row[0] = r0; row[1] = r1; row[2] = r2; row[3] = r3; row[4] = r4;
+                    for (int k = 0; k < GSE_NX; ++k) gq[q][k] = g[q][k];
+                if (h == 0) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int k = 0; k < GSE_NX; ++k)
+                            GSE_LOAD_DWORD_S(g[q][k], (uint32_t)anc[2 + q] * 4u, xin_b + k * ld);
                 }
+            } else if (h == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4)::"memory");
+                row[0] = r0; row[1] = r1; row[2] = r2; row[3] = r3; row[4] = r4;
             }
-            // predict: ODE step + noise
+            // predict: ODE step + noise.  With gather the particle's new state goes out at once (dword stores,
+            // contiguous across the wavefront) and only the two observed states stay in registers for the update.
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int p = 2 * h + q;
-                if (kPredict) {
-                    float s[GSE_NX];
+                float s[GSE_NX];
 #pragma unroll
-                    for (int k = 0; k < GSE_NX; ++k) s[k] = row[k][p];
+                for (int k = 0; k < GSE_NX; ++k) s[k] = kGather ? gq[q][k] : row[k][p];
+                if (kPredict) {
                     bioreactor_step(s, fg, fm, a.dt);
 #pragma unroll
-                    for (int k = 0; k < GSE_NX; ++k) row[k][p] = s[k] + e[q][k];
+                    for (int k = 0; k < GSE_NX; ++k) s[k] += e[q][k];
                 }
+                if (kGather) {
+                    if (jp[p] < Nu) {
+                        float* xb = x_out + (int64_t)b * GSE_NX * ld;
+#pragma unroll
+                        for (int k = 0; k < GSE_NX; ++k) (xb + k * ld)[jp[p]] = s[k];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) row[k][p] = s[k];
+                }
+                obs0[p] = s[0];
+                obs2[p] = s[2];
             }
         }
-        // the new state goes out now, ahead of the update phase
-        if (kGather) {
-            float* xb = x_out + (int64_t)b * GSE_NX * ld;
-#pragma unroll
-            for (int p = 0; p < kPerThread; ++p)
-                if (jp[p] < N) {
-#pragma unroll
-                    for (int k = 0; k < GSE_NX; ++k) xb[k * ld + jp[p]] = row[k][p];
-                }
-        } else if (kPredict) {
+        // the new state goes out now, ahead of the update phase (consecutive mapping: one dwordx4 per row)
+        if (!kGather && kPredict) {
             float* xb = x_out + (int64_t)b * GSE_NX * ld + i0;
 #pragma unroll
             for (int k = 0; k < GSE_NX; ++k) *reinterpret_cast<v4f*>(xb + k * ld) = row[k];
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p) {
                 float y0, y1;
-                bioreactor_output(row[0][p], row[2][p], y0, y1);
+                bioreactor_output(obs0[p], obs2[p], y0, y1);
                 const double lik = mixture_pdf2<kNd>(a.pdf, z0 - (double)y0, z1 - (double)y1);
                 wnew[p] = (float)((double)wnew[p] * lik);
             }
@@ -276,7 +293,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             int32_t* ib = idx_out ? idx_out + (int64_t)b * ld : nullptr;
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p)
-                if (jp[p] < N) {
+                if (jp[p] < Nu) {
                     wb[jp[p]] = wnew[p];
                     if (ib) ib[jp[p]] = anc[p];
                 }
