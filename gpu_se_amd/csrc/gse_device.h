@@ -291,13 +291,14 @@ __device__ __forceinline__ float4 load_weights4(const float* __restrict__ row, i
 // First k in [0, N) with c[k] >= u, found by one wavefront: every round the 64 lanes probe 64 evenly spaced
 // elements of the remaining range and a ballot picks the sub-range (4 rounds of one L2 access for N <= 2^24,
 // instead of 24 dependent ones).  Returns N - 1 if no element qualifies (cannot happen for u <= c[N-1] = 1).
-__device__ __forceinline__ int64_t wave_search_ge(const double* __restrict__ c, int64_t N, double u, int lane) {
+template <class Value>     // Value: k -> c[k]
+__device__ __forceinline__ int64_t wave_search_ge(Value value, int64_t N, double u, int lane) {
     int64_t lo = 0, hi = N;                                   // answer in [lo, hi)
     while (true) {
         const int64_t n = hi - lo;
         const int64_t step = (n + 63) >> 6;
         const int64_t probe = min(lo + (int64_t)(lane + 1) * step, hi) - 1;
-        const bool ge = c[probe] >= u;
+        const bool ge = value(probe) >= u;
         const unsigned long long mask = __ballot(ge);
         if (mask == 0ull) return N - 1;
         const int first = __ffsll((long long)mask) - 1;

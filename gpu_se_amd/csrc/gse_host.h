@@ -53,7 +53,8 @@ struct Workspace {
     double* tile_prefix;   // [B][T + 1]   exclusive prefix of tile sums; [T] = total
     double* partials;      // [B][kMomentBlocks][kMomentWidth]
     double* totals;        // [B]          sum of the weights of each filter
-    double* tops;          // [B][T]       normalised cumulative weight at the end of each tile
+    double* scan_sums[2];  // [B][T]       tile sums that go with scan[slot]
+    double* scan[2];       // [B][N]       tile-local inclusive scans of the weights (GSE_OP_SCAN_OUT / _IN), two slots
     double* cumsum;        // [B][N]       normalised cumulative weights
     int64_t bytes;
 };

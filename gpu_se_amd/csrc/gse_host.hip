@@ -90,8 +90,12 @@ Workspace carve_workspace(void* base, int B, int64_t N) {
     at += round256((int64_t)B * kMomentBlocks * kMomentWidth * 8);
     ws.totals = reinterpret_cast<double*>(p + at);
     at += round256((int64_t)B * 8);
-    ws.tops = reinterpret_cast<double*>(p + at);
-    at += round256((int64_t)B * T * 8);
+    for (int k = 0; k < 2; ++k) {
+        ws.scan_sums[k] = reinterpret_cast<double*>(p + at);
+        at += round256((int64_t)B * T * 8);
+        ws.scan[k] = reinterpret_cast<double*>(p + at);
+        at += round256((int64_t)B * N * 8);
+    }
     ws.cumsum = reinterpret_cast<double*>(p + at);
     at += round256((int64_t)B * N * 8);
     ws.bytes = at;

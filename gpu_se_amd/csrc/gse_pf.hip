@@ -39,6 +39,9 @@ struct StepArgs {
 #define GSE_STEP_MIN_WAVES 4     // waves per SIMD the register allocator must leave room for (tuning knob)
 #endif
 
+#ifndef GSE_STAGGER
+#define GSE_STAGGER 1            // gather variants: half of the workgroups draw their noise before the memory phases
+#endif
 #ifndef GSE_GATHER_STRIDED
 #define GSE_GATHER_STRIDED 1     // gather variants: a thread's 4 outputs are 256 apart (1) or consecutive (0)
 #endif
@@ -53,18 +56,30 @@ struct StepArgs {
 // With gather the reads are indexed anyway, so a thread owns 4 outputs 256 apart: for each of them the 64 lanes of a
 // wavefront then touch consecutive outputs and (near-)consecutive ancestors -- every dword load / store instruction
 // covers whole cache lines, where the consecutive mapping would use a quarter of each line it touches.
-template <bool kGather, bool kPredict, bool kInjected, bool kUpdate, int kNd>
+//
+// kScan: where the gather finds the cumulative weights and what the update leaves behind for the NEXT gather.
+//   bit 0 (SCAN_IN)   c[k] is not read from a materialised array (cumsum_kernel) but formed on the fly as
+//                     (Pfx[tile(k)] + L[k]) / W  from the tile sums and the tile-local inclusive scans L that the update
+//                     stage of the PREVIOUS step wrote; the tile prefix Pfx (T + 1 values) is computed by every workgroup
+//                     into LDS.  Same arithmetic, same bits as cumsum_kernel.
+//   bit 1 (SCAN_OUT)  the update stage also writes L and the tile sums of the new weights (8 B / particle).
+// With both bits the steady-state cycle is ONE launch: no cumsum kernel, no second pass over the weights.
+template <bool kGather, bool kPredict, bool kInjected, bool kUpdate, int kNd, int kScan>
 __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     const float* __restrict__ x_in, float* __restrict__ x_out, const float* __restrict__ w_in, float* __restrict__ w_out,
     const float* __restrict__ noise, int32_t* __restrict__ idx_out, const double* __restrict__ c,
-    const double* __restrict__ totals, const double* __restrict__ tops, double* __restrict__ tile_sums, int64_t N,
-    int64_t ld, int T, int tops_in_lds, const StepArgs a) {
+    const double* __restrict__ totals, double* __restrict__ tile_sums, const double* __restrict__ scan_in_sums,
+    const double* __restrict__ scan_in, double* __restrict__ scan_out_sums, double* __restrict__ scan_out,
+    double* __restrict__ island, int64_t N, int64_t ld, int T, const StepArgs a) {
+    constexpr bool kScanIn = (kScan & 1) != 0, kScanOut = (kScan & 2) != 0;
+    static_assert(!kScanIn || kGather, "SCAN_IN belongs to the gather stage");
+    static_assert(!kScanOut || kUpdate, "SCAN_OUT belongs to the update stage");
     __shared__ DrawParams dp;
     __shared__ double seg[kGather ? kSpanMax : 2];
-    __shared__ float wtile[(kGather && kUpdate) ? kTile : 4];
+    __shared__ float wtile[((kGather && kUpdate) || kScanOut) ? kTile : 4];
     __shared__ int64_t span[2];
     __shared__ double red[4];
-    extern __shared__ double tops_s[];        // [T] when tops_in_lds (dynamic; statics above total a multiple of 16 B)
+    extern __shared__ double pfx_s[];         // [T + 1] with SCAN_IN (dynamic; statics above total a multiple of 16 B)
 
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t tile0 = (int64_t)blockIdx.x * kTile;
@@ -87,51 +102,77 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         for (int i = tid; i < (int)(sizeof(DrawParams) / 4); i += kBlock) dst[i] = src[i];
     }
 
+    // ---- noise: Philox + Box-Muller, registers only.  At N = 2^20 all workgroups of a launch are resident at once and
+    //      march through the same phases together, so while they wait on memory (tile prefix, searches, staging,
+    //      gather) no wavefront on the CU has arithmetic to do.  The draw is the one block of arithmetic that depends
+    //      on nothing: half of the workgroups do it up front, the other half between issuing their state loads and
+    //      using them, so that on every CU one group computes while the other waits.
+    float e[kPerThread][GSE_NX];
+    auto draw_all = [&]() {
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p) {
+            uint32_t wd[8];
+            rng_words8(a.rng, (uint64_t)jp[p], (uint32_t)b, wd);
+            mixture_draw5(dp, wd, e[p]);
+        }
+    };
+    constexpr bool kDraw = kPredict && !kInjected;
+    const bool draw_early = kDraw && kGather && GSE_STAGGER && ((((blockIdx.x >> 8) ^ blockIdx.x) & 1) != 0);
+    if (kDraw) __syncthreads();                          // dp staged
+    if (draw_early) draw_all();
+
     // ---- gather: ancestors of this thread's 4 outputs -------------------------------------------------
     int32_t anc[kPerThread] = {0, 0, 0, 0};
     if (kGather) {
-        const double W = totals[b];
+        double W;
+        if (kScanIn) {
+            // tile prefix into LDS: thread j owns chunk [j*m, (j+1)*m) of the tile sums (as inline_tile_prefix)
+            const double* sums = scan_in_sums + (int64_t)b * T;
+            const int m = (T + kBlock - 1) / kBlock;
+            const int qlo = tid * m, qhi = min(qlo + m, T);
+            double chunk = 0.0;
+            for (int q = qlo; q < qhi; ++q) chunk += sums[q];
+            double total;
+            double run = block_exclusive_scan(chunk, red, total);
+            for (int q = qlo; q < qhi; ++q) {
+                pfx_s[q] = run;
+                run += sums[q];
+            }
+            if (tid == 0) pfx_s[T] = total;
+            __syncthreads();
+            W = pfx_s[T];
+            if (island && blockIdx.x == 0 && tid == 0) {   // shard bookkeeping (see gse_pf_resample)
+                island[b] += log(W);
+                island[gridDim.y + b] = W;
+            }
+        } else {
+            W = totals[b];
+        }
         const double r = a.ra.r[b];
         // Weights that do not sum to a positive finite number: the reference's normalised cumsum is all-NaN and its
         // sweep never advances (filter/particle.py:98), so every offspring copies particle 0 (anc stays 0).
         if ((W > 0.0) && (W < INFINITY)) {
-            const double* cb = c + (int64_t)b * N;
+            const double* cb = kScanIn ? scan_in + (int64_t)b * N : c + (int64_t)b * N;
+            // normalised cumulative weight of ancestor k
+            auto cval = [&](int64_t k) -> double {
+                if (!kScanIn) return cb[k];
+                const int t = (int)(k / kTile);
+                const double top = pfx_s[t + 1] / W;
+                const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
+                return (k == last) ? top : fmin((pfx_s[t] + cb[k]) / W, top);
+            };
             const int64_t j0 = tile0;
             const int64_t j1 = min(j0 + kTile, N);
-            int64_t klo, khi;
-            if (tops_in_lds) {
-                // first level in LDS: the T tile-end values (8 KiB at N = 2^20) arrive in one coalesced round trip and
-                // two threads binary-search them; the second level is the staging below.
-                const double* tb = tops + (int64_t)b * T;
-                for (int q = tid; q < T; q += kBlock) tops_s[q] = tb[q];
-                __syncthreads();
-                if (tid == 0 || tid == 64) {
-                    const int64_t j = (tid == 0) ? j0 : j1 - 1;
-                    const double u = ((double)j + r) / Nd;
-                    int lo = 0, hi = T - 1;                    // first tile whose end value is >= u
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (tops_s[mid] < u) lo = mid + 1; else hi = mid;
-                    }
-                    span[tid >> 6] = lo;
-                }
-                __syncthreads();
-                const int64_t tlo = span[0], thi = span[1];
-                klo = tlo * kTile;
-                khi = min((thi + 1) * (int64_t)kTile, N) - 1;
-            } else {
-                if (wv < 2) {   // bracket the tile's ancestors: wavefront 0 takes the first output, wavefront 1 the last
-                    const int64_t j = (wv == 0) ? j0 : j1 - 1;
-                    const int64_t k = wave_search_ge(cb, N, ((double)j + r) / Nd, lane);
-                    if (lane == 0) span[wv] = k;
-                }
-                __syncthreads();
-                klo = span[0];
-                khi = span[1];
+            if (wv < 2) {       // bracket the tile's ancestors: wavefront 0 takes the first output, wavefront 1 the last
+                const int64_t j = (wv == 0) ? j0 : j1 - 1;
+                const int64_t k = wave_search_ge(cval, N, ((double)j + r) / Nd, lane);
+                if (lane == 0) span[wv] = k;
             }
+            __syncthreads();
+            const int64_t klo = span[0], khi = span[1];
             const int64_t len = khi - klo + 1;
             if (len <= kSpanMax) {
-                for (int q = tid; q < (int)len; q += kBlock) seg[q] = cb[klo + q];
+                for (int q = tid; q < (int)len; q += kBlock) seg[q] = cval(klo + q);
                 __syncthreads();
 #pragma unroll
                 for (int p = 0; p < kPerThread; ++p)
@@ -144,15 +185,13 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                     int64_t lo = klo, hi = khi;
                     while (lo < hi) {
                         const int64_t mid = (lo + hi) >> 1;
-                        if (cb[mid] < u) lo = mid + 1; else hi = mid;
+                        if (cval(mid) < u) lo = mid + 1; else hi = mid;
                     }
                     anc[p] = (int32_t)lo;
                 }
             }
         }
     }
-    if (kPredict && !kInjected) __syncthreads();        // dp staged
-
     // a thread is live if it owns at least one particle (its first one)
     const bool live = jp[0] < Nu;
     float wnew[kPerThread] = {w_uniform, w_uniform, w_uniform, w_uniform};
@@ -205,19 +244,13 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         const double z0 = a.io.f[b].z0, z1 = a.io.f[b].z1;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            float e[2][GSE_NX];
-            if (kPredict) {
+            if (h == 0) {
+                if (kDraw && !draw_early) draw_all();
+                if (kPredict && kInjected) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int p = 2 * h + q;
-                    if (kInjected) {
+                    for (int p = 0; p < kPerThread; ++p)
 #pragma unroll
-                        for (int k = 0; k < GSE_NX; ++k) e[q][k] = nz[p][k];
-                    } else {
-                        uint32_t wd[8];
-                        rng_words8(a.rng, (uint64_t)jp[p], (uint32_t)b, wd);
-                        mixture_draw5(dp, wd, e[q]);
-                    }
+                        for (int k = 0; k < GSE_NX; ++k) e[p][k] = nz[p][k];
                 }
             }
             // the state rows of this half must have landed now; with gather, the other half's loads are issued right
@@ -252,7 +285,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                 if (kPredict) {
                     bioreactor_step(s, fg, fm, a.dt);
 #pragma unroll
-                    for (int k = 0; k < GSE_NX; ++k) s[k] += e[q][k];
+                    for (int k = 0; k < GSE_NX; ++k) s[k] += e[p][k];
                 }
                 if (kGather) {
                     if (jp[p] < Nu) {
@@ -311,9 +344,29 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p) wnew[p] = wtile[tid * kPerThread + p];
         }
-        const double mine = masked_sum4(wnew[0], wnew[1], wnew[2], wnew[3], i0, N);
-        const double total = block_sum(mine, red);
+        // (the tile sum is DEFINED as the total of the workgroup scan of the per-thread sums -- tile_scan_total -- in
+        // every kernel that forms one, so one reduction serves both the sum and the tile-local scan)
+        double sc[kPerThread];
+        sc[0] = (i0 + 0 < N) ? (double)wnew[0] : 0.0;
+        sc[1] = sc[0] + ((i0 + 1 < N) ? (double)wnew[1] : 0.0);
+        sc[2] = sc[1] + ((i0 + 2 < N) ? (double)wnew[2] : 0.0);
+        sc[3] = sc[2] + ((i0 + 3 < N) ? (double)wnew[3] : 0.0);
+        double total;
+        const double excl = block_exclusive_scan(sc[3], red, total);
         if (tid == 0) tile_sums[(int64_t)b * T + blockIdx.x] = total;
+        if (kScanOut) {
+            // tile-local inclusive scan of the new weights, the expression cumsum_kernel uses: L = excl + s_p
+            if (tid == 0) scan_out_sums[(int64_t)b * T + blockIdx.x] = total;
+            double* lb = scan_out + (int64_t)b * N;
+            if (i0 + 3 < N && (N & 1) == 0) {
+                *reinterpret_cast<double2*>(lb + i0) = make_double2(excl + sc[0], excl + sc[1]);
+                *reinterpret_cast<double2*>(lb + i0 + 2) = make_double2(excl + sc[2], excl + sc[3]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < kPerThread; ++p)
+                    if (i0 + p < N) lb[i0 + p] = excl + sc[p];
+            }
+        }
     }
 }
 
@@ -325,7 +378,8 @@ __global__ __launch_bounds__(kBlock) void tile_sum_kernel(const float* __restric
     const int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kPerThread;
     const float4 wv = load_weights4(w + (int64_t)b * ldw, i0, N, ldw);
     const double mine = masked_sum4(wv.x, wv.y, wv.z, wv.w, i0, N);
-    const double total = block_sum(mine, red);
+    double total;
+    block_exclusive_scan(mine, red, total);
     if (threadIdx.x == 0) tile_sums[(int64_t)b * T + blockIdx.x] = total;
 }
 
@@ -405,8 +459,8 @@ __device__ __forceinline__ void inline_tile_prefix(const double* __restrict__ s,
 template <bool kInlinePrefix>
 __global__ __launch_bounds__(kBlock) void cumsum_kernel(const float* __restrict__ w, double* __restrict__ c,
                                                         const double* __restrict__ tile_src,
-                                                        double* __restrict__ totals, double* __restrict__ tops,
-                                                        double* __restrict__ island, int64_t N, int64_t ldw, int T) {
+                                                        double* __restrict__ totals, double* __restrict__ island,
+                                                        int64_t N, int64_t ldw, int T) {
     __shared__ double red[4];
     __shared__ double pfx[3];
     const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
@@ -437,7 +491,6 @@ __global__ __launch_bounds__(kBlock) void cumsum_kernel(const float* __restrict_
     // The tile's last entry is pinned to prefix[t+1]/W and everything before it clamped to that value, so the
     // array is monotone across tiles although prefix and in-tile sums associate differently; c[N-1] = W/W = 1.
     const double top = P1 / W;
-    if (tid == 0) tops[(int64_t)b * T + t] = top;       // compact copy of c at the tile ends: the gather's first-level index
     const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
     double* cb = c + (int64_t)b * N;
     double v[kPerThread];
@@ -485,7 +538,7 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const Payload pl, const 
     // 1. bracket the ancestors of this output tile: wavefront 0 searches for the first output, wavefront 1 for the last
     if (wv < 2) {
         const int64_t j = (wv == 0) ? j0 : j1 - 1;
-        const int64_t k = wave_search_ge(cb, N, ((double)j + r) / Nd, lane);
+        const int64_t k = wave_search_ge([&](int64_t q) { return cb[q]; }, N, ((double)j + r) / Nd, lane);
         if (lane == 0) span[wv] = k;
     }
     __syncthreads();
@@ -600,13 +653,13 @@ int launch_cumsum(const float* w, int64_t ldw, int B, int64_t N, uint32_t flags,
         GSE_LAUNCH_CHECK("tile_sum_kernel");
     }
     if (T <= kInlinePrefixMaxT && !(flags & GSE_RESAMPLE_SEPARATE_SCAN)) {
-        hipLaunchKernelGGL(cumsum_kernel<true>, dim3(T, B), dim3(kBlock), 0, st, w, c_out, ws.tile_sums, ws.totals, ws.tops,
-                           island, N, ldw, T);
+        hipLaunchKernelGGL(cumsum_kernel<true>, dim3(T, B), dim3(kBlock), 0, st, w, c_out, ws.tile_sums, ws.totals, island,
+                           N, ldw, T);
     } else {
         hipLaunchKernelGGL(tile_scan_kernel, dim3(B), dim3(kBlock), 0, st, ws.tile_sums, ws.tile_prefix, T);
         GSE_LAUNCH_CHECK("tile_scan_kernel");
         hipLaunchKernelGGL(cumsum_kernel<false>, dim3(T, B), dim3(kBlock), 0, st, w, c_out, ws.tile_prefix, ws.totals,
-                           ws.tops, island, N, ldw, T);
+                           island, N, ldw, T);
     }
     GSE_LAUNCH_CHECK("cumsum_kernel");
     return GSE_OK;
@@ -635,31 +688,73 @@ using namespace gse;
 // ================================================================================================
 namespace {
 
+struct StepLaunch {
+    dim3 grid;
+    hipStream_t st;
+    const float* x_in; float* x_out; const float* w_in; float* w_out; const float* noise; int32_t* idx;
+    const Workspace* ws;
+    double* island;
+    int64_t N, ld;
+    int T, slot_in, slot_out;
+    const StepArgs* a;
+};
+
+template <bool G, bool P, bool I, bool U, int ND, int S>
+void step_go(const StepLaunch& L) {
+    const Workspace& ws = *L.ws;
+    const size_t dyn = (S & 1) ? (size_t)(L.T + 1) * sizeof(double) : 0;
+    hipLaunchKernelGGL((pf_step_kernel<G, P, I, U, ND, S>), L.grid, dim3(kBlock), dyn, L.st, L.x_in, L.x_out, L.w_in, L.w_out,
+                       L.noise, L.idx, ws.cumsum, ws.totals, ws.tile_sums, ws.scan_sums[L.slot_in], ws.scan[L.slot_in],
+                       ws.scan_sums[L.slot_out], ws.scan[L.slot_out], L.island, L.N, L.ld, L.T, *L.a);
+}
+
+// Run-time stage flags -> template instance.  Instantiated: every stage combination; the component count folded in
+// (ND = 2) for update stages; the scan modes only for the Philox (not injected-noise) variants with ND = 2.
+template <bool G, bool P, bool I, bool U, int ND>
+bool step_pick_scan(int scan, const StepLaunch& L) {
+    constexpr bool kScanOk = !I && (!U || ND == 2);
+    if (scan == 0) { step_go<G, P, I, U, ND, 0>(L); return true; }
+    if constexpr (kScanOk && G) if (scan == 1) { step_go<G, P, I, U, ND, 1>(L); return true; }
+    if constexpr (kScanOk && U) if (scan == 2) { step_go<G, P, I, U, ND, 2>(L); return true; }
+    if constexpr (kScanOk && G && U) if (scan == 3) { step_go<G, P, I, U, ND, 3>(L); return true; }
+    return false;
+}
 template <bool G, bool P, bool I, bool U>
-void launch_step(dim3 grid, hipStream_t st, const float* x_in, float* x_out, const float* w_in, float* w_out,
-                 const float* noise, int32_t* idx, const Workspace& ws, int64_t N, int64_t ld, int T, const StepArgs& a) {
-    // First-level index of the gather: GSE_TOPS=1 stages the T tile-end values in LDS (one round trip) instead of the
-    // 64-ary wavefront search of c[] (four).  Measured on MI355X at N = 2^20 the LDS variant is SLOWER in the fused
-    // kernel (30.7 vs 26.2 us: more LDS, two more barriers, 16 KiB staged instead of ~8), so it is off by default.
-    static const char* tops_env = getenv("GSE_TOPS");
-    const int tops_in_lds = (G && T <= kInlinePrefixMaxT && tops_env && tops_env[0] == '1') ? 1 : 0;
-    const size_t dyn = tops_in_lds ? (size_t)T * sizeof(double) : 0;
-    if (U && a.pdf.nd == 2)         // the common case gets the kernel with the component count folded in
-        hipLaunchKernelGGL((pf_step_kernel<G, P, I, U, U ? 2 : 0>), grid, dim3(kBlock), dyn, st, x_in, x_out, w_in, w_out,
-                           noise, idx, ws.cumsum, ws.totals, ws.tops, ws.tile_sums, N, ld, T, tops_in_lds, a);
-    else
-        hipLaunchKernelGGL((pf_step_kernel<G, P, I, U, 0>), grid, dim3(kBlock), dyn, st, x_in, x_out, w_in, w_out, noise,
-                           idx, ws.cumsum, ws.totals, ws.tops, ws.tile_sums, N, ld, T, tops_in_lds, a);
+bool step_pick_nd(bool nd2, int scan, const StepLaunch& L) {
+    if constexpr (U) {
+        if (nd2) return step_pick_scan<G, P, I, U, 2>(scan, L);
+    }
+    return step_pick_scan<G, P, I, U, 0>(scan, L);
+}
+template <bool G, bool P, bool I>
+bool step_pick_u(bool u, bool nd2, int scan, const StepLaunch& L) {
+    if constexpr (G || P) {
+        if (!u) return step_pick_nd<G, P, I, false>(nd2, scan, L);
+    }
+    return u ? step_pick_nd<G, P, I, true>(nd2, scan, L) : false;
+}
+template <bool G>
+bool step_pick_p(bool p, bool i, bool u, bool nd2, int scan, const StepLaunch& L) {
+    if (p) return i ? step_pick_u<G, true, true>(u, nd2, scan, L) : step_pick_u<G, true, false>(u, nd2, scan, L);
+    return step_pick_u<G, false, false>(u, nd2, scan, L);
 }
 
 // The one place that validates and dispatches a fused step.
 int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, float* w_out, int32_t* idx, int64_t ld,
             int B, int64_t N, const double* u, double dt, const double* z, const double* r, const gse_mixture* state_pdf,
-            const gse_rng* rng, const float* noise, const gse_mixture* measurement_pdf, void* workspace, void* stream,
-            const char* fn) {
+            const gse_rng* rng, const float* noise, const gse_mixture* measurement_pdf, double* island, void* workspace,
+            void* stream, const char* fn) {
     if (int rc = check_pf_geometry(fn, B, N, ld)) return rc;
     const bool G = ops & GSE_OP_GATHER, P = ops & GSE_OP_PREDICT, U = ops & GSE_OP_UPDATE;
-    GSE_REQUIRE(ops != 0 && (ops & ~(GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE)) == 0, "%s: bad ops mask 0x%x", fn, ops);
+    const uint32_t known = GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE | GSE_OP_SCAN_IN | GSE_OP_SCAN_OUT |
+                           GSE_OP_SCAN_IN_SLOT1 | GSE_OP_SCAN_OUT_SLOT1;
+    GSE_REQUIRE((ops & (GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE)) != 0 && (ops & ~known) == 0,
+                "%s: bad ops mask 0x%x", fn, ops);
+    const int scan = ((ops & GSE_OP_SCAN_IN) ? 1 : 0) | ((ops & GSE_OP_SCAN_OUT) ? 2 : 0);
+    GSE_REQUIRE(!(scan & 1) || G, "%s: GSE_OP_SCAN_IN needs GSE_OP_GATHER", fn);
+    GSE_REQUIRE(!(scan & 2) || U, "%s: GSE_OP_SCAN_OUT needs GSE_OP_UPDATE", fn);
+    GSE_REQUIRE(scan == 0 || tiles_of(N) <= kInlinePrefixMaxT, "%s: the scan modes support at most %d tiles (N <= %d)", fn,
+                kInlinePrefixMaxT, kInlinePrefixMaxT * kTile);
     GSE_REQUIRE(x_in && aligned16(x_in), "%s: x_in must be a 16-byte aligned device pointer", fn);
     GSE_REQUIRE((workspace && aligned16(workspace)) || !(ops & (GSE_OP_GATHER | GSE_OP_UPDATE)),
                 "%s: gather / update need a 16-byte aligned device workspace", fn);
@@ -701,25 +796,21 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const bool I = P && noise != nullptr;
     const int T = (int)tiles_of(N);
     const Workspace ws = carve_workspace(workspace, B, N);
-    const dim3 grid((unsigned)T, (unsigned)B);
-    hipStream_t st = (hipStream_t)stream;
-#define GSE_STEP_CASE(g, p, i, uu)                                                                        \
-    if (G == g && P == p && I == i && U == uu) {                                                          \
-        launch_step<g, p, i, uu>(grid, st, x_in, x_out, w_in, w_out, noise, idx, ws, N, ld, T, a);        \
-    } else
-    GSE_STEP_CASE(false, true, false, false)
-    GSE_STEP_CASE(false, true, true, false)
-    GSE_STEP_CASE(false, false, false, true)
-    GSE_STEP_CASE(false, true, false, true)
-    GSE_STEP_CASE(false, true, true, true)
-    GSE_STEP_CASE(true, false, false, false)
-    GSE_STEP_CASE(true, true, false, false)
-    GSE_STEP_CASE(true, true, true, false)
-    GSE_STEP_CASE(true, false, false, true)
-    GSE_STEP_CASE(true, true, false, true)
-    GSE_STEP_CASE(true, true, true, true)
-    { return fail(GSE_ERR_ARG, "%s: unsupported stage combination 0x%x", fn, ops); }
-#undef GSE_STEP_CASE
+    StepLaunch L;
+    L.grid = dim3((unsigned)T, (unsigned)B);
+    L.st = (hipStream_t)stream;
+    L.x_in = x_in; L.x_out = x_out; L.w_in = w_in; L.w_out = w_out; L.noise = noise; L.idx = idx;
+    L.ws = &ws;
+    L.island = island;
+    L.N = N; L.ld = ld; L.T = T;
+    L.slot_in = (ops & GSE_OP_SCAN_IN_SLOT1) ? 1 : 0;
+    L.slot_out = (ops & GSE_OP_SCAN_OUT_SLOT1) ? 1 : 0;
+    L.a = &a;
+    GSE_REQUIRE(!(scan == 3) || L.slot_in != L.slot_out, "%s: SCAN_IN and SCAN_OUT must use different slots", fn);
+    const bool nd2 = U && a.pdf.nd == 2;
+    const bool ok = G ? step_pick_p<true>(P, I, U, nd2, scan, L) : step_pick_p<false>(P, I, U, nd2, scan, L);
+    if (!ok) return fail(GSE_ERR_UNSUPPORTED, "%s: stage combination 0x%x is not available (scan modes need the Philox "
+                         "draw and a 2-component measurement mixture)", fn, ops);
     GSE_LAUNCH_CHECK("pf_step_kernel");
     return GSE_OK;
 }
@@ -731,23 +822,23 @@ extern "C" {
 int gse_pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, float* w_out, int32_t* idx, int64_t ld,
                 int B, int64_t N, const double* u, double dt, const double* z, const double* r,
                 const gse_mixture* state_pdf, const gse_rng* rng, const float* noise, const gse_mixture* measurement_pdf,
-                void* workspace, void* stream) {
+                double* island, void* workspace, void* stream) {
     return pf_step(ops, x_in, x_out, w_in, w_out, idx, ld, B, N, u, dt, z, r, state_pdf, rng, noise, measurement_pdf,
-                   workspace, stream, "gse_pf_step");
+                   island, workspace, stream, "gse_pf_step");
 }
 
 int gse_pf_predict(float* x, int64_t ld, int B, int64_t N, const double* u, double dt, const gse_mixture* state_pdf,
                    const gse_rng* rng, void* stream) {
     GSE_REQUIRE(state_pdf && rng, "gse_pf_predict: null argument");
     return pf_step(GSE_OP_PREDICT, x, x, nullptr, nullptr, nullptr, ld, B, N, u, dt, nullptr, nullptr, state_pdf, rng,
-                   nullptr, nullptr, nullptr, stream, "gse_pf_predict");
+                   nullptr, nullptr, nullptr, nullptr, stream, "gse_pf_predict");
 }
 
 int gse_pf_predict_injected(float* x, int64_t ld, int B, int64_t N, const double* u, double dt, const float* noise,
                             void* stream) {
     GSE_REQUIRE(noise, "gse_pf_predict_injected: null argument");
     return pf_step(GSE_OP_PREDICT, x, x, nullptr, nullptr, nullptr, ld, B, N, u, dt, nullptr, nullptr, nullptr, nullptr,
-                   noise, nullptr, nullptr, stream, "gse_pf_predict_injected");
+                   noise, nullptr, nullptr, nullptr, stream, "gse_pf_predict_injected");
 }
 
 int gse_pf_update(const float* x, float* w, int64_t ld, int B, int64_t N, const double* u, const double* z,
@@ -755,7 +846,7 @@ int gse_pf_update(const float* x, float* w, int64_t ld, int B, int64_t N, const 
     (void)u;                                         // g does not depend on the inputs (static_outputs ignores u)
     GSE_REQUIRE(w, "gse_pf_update: null argument");
     return pf_step(GSE_OP_UPDATE, x, nullptr, w, w, nullptr, ld, B, N, nullptr, 0.0, z, nullptr, nullptr, nullptr, nullptr,
-                   measurement_pdf, workspace, stream, "gse_pf_update");
+                   measurement_pdf, nullptr, workspace, stream, "gse_pf_update");
 }
 
 int gse_pf_resample_begin(const float* w, int64_t ld, int B, int64_t N, uint32_t flags, double* island, void* workspace,
@@ -775,7 +866,7 @@ int gse_pf_resample(const float* x_in, const float* w, float* x_out, float* w_ou
         GSE_REQUIRE(r[b] >= 0.0 && r[b] < 1.0, "gse_pf_resample: r[%d] = %g is outside [0, 1)", b, r[b]);
     if (int rc = gse_pf_resample_begin(w, ld, B, N, flags, island, workspace, stream)) return rc;
     return pf_step(GSE_OP_GATHER, x_in, x_out, nullptr, w_out, idx, ld, B, N, nullptr, 0.0, nullptr, r, nullptr, nullptr,
-                   nullptr, nullptr, workspace, stream, "gse_pf_resample");
+                   nullptr, nullptr, nullptr, workspace, stream, "gse_pf_resample");
 }
 
 int gse_pf_moments(const float* x, const float* w, int64_t ld, int B, int64_t N, double* out, void* workspace,

@@ -106,13 +106,19 @@ class ShardedParticleFilter:
         self.local.predict(u, dt)
 
     def update(self, u, z):
+        """Local update.  The launch that carries the update also executes a pending resample-gather, which is where
+        the shard's log-weight absorbs the weight sum; with more than one rank that sum is then all-reduced
+        asynchronously (RCCL) -- nothing waits for it until wait_collectives() / an estimate."""
+        resampled = self.local._pend_gather
         self.local.update(u, z)
+        if resampled:
+            self._reduce_weight_sum()
 
     def resample(self, r=None):
-        """Local systematic resample; the shard's log-weight absorbs the sum of its weights on the device.  With
-        more than one rank the global weight sum of this cycle is all-reduced asynchronously (RCCL); nothing
-        waits for it until wait_collectives() / an estimate."""
+        """Local systematic resample (island filter); see update() for the bookkeeping."""
         self.local.resample(r=r)
+
+    def _reduce_weight_sum(self):
         if self.world > 1:
             self.wait_collectives()
             if self._merge_device.type == "cuda":

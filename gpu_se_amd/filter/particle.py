@@ -100,6 +100,9 @@ class ParallelParticleFilter:
         self._c_rng_ref = ctypes.byref(self._c_rng)
         self._fn_step, self._fn_resample_begin = lib.gse_pf_step, lib.gse_pf_resample_begin
         self._pend_gather = False
+        self._gather_slot = None                            # slot of the scans a pending gather reads (None: cumsum array)
+        self._scan_slot = None                              # slot holding scans of the CURRENT weights, if any
+        self._scan_capable = (-(-n // _lib.GSE_TILE)) <= _lib.GSE_SCAN_MAX_TILES
         self._pend_predict = None
         self._want_index = False
         self._last_index = None
@@ -129,6 +132,12 @@ class ParallelParticleFilter:
 
     def _launch_step(self, update):
         """Run the pending gather / predict stages, plus an update if ``update`` = (u, z) is given."""
+        injected = self._pend_predict is not None and isinstance(self.state_pdf, DeterministicGaussianSum)
+        if injected and self._pend_gather and self._gather_slot is not None:
+            # the injected-noise kernels have no scan variants: run the gather on its own first
+            pend, self._pend_predict = self._pend_predict, None
+            self._launch_step(update=None)
+            self._pend_predict = pend
         ops = 0
         n = self.N_particles
         gather = self._pend_gather
@@ -139,6 +148,8 @@ class ParallelParticleFilter:
         idx_ptr = None
         if gather:
             ops |= _lib.GSE_OP_GATHER
+            if self._gather_slot is not None:
+                ops |= _lib.GSE_OP_SCAN_IN | (_lib.GSE_OP_SCAN_IN_SLOT1 if self._gather_slot else 0)
             if self._want_index:
                 self._last_index = torch.empty(self._ld, dtype=torch.int32, device=self._x.device)
                 idx_ptr = self._last_index.data_ptr()
@@ -149,7 +160,7 @@ class ParallelParticleFilter:
             ops |= _lib.GSE_OP_PREDICT
             u, dt = self._pend_predict
             cu[0], cu[1] = u
-            if isinstance(self.state_pdf, DeterministicGaussianSum):
+            if injected:
                 noise = self.state_pdf.draw(n).as_subclass(torch.Tensor)            # (n, Nx) replayed values
                 buf = torch.zeros_like(self._x)
                 buf[:, :n] = noise.reshape(n, _lib.GSE_NX).t()
@@ -162,12 +173,18 @@ class ParallelParticleFilter:
                 rng_ref = self._c_rng_ref
         pod_meas = None
         cz = self._c_z
+        scan_out = None
         if update is not None:
             ops |= _lib.GSE_OP_UPDATE
             cz[0], cz[1] = update[1]
             pod_meas = ctypes.byref(self.measurement_pdf._pod())
+            if self._scan_capable and not injected and self.measurement_pdf._Nd == 2:
+                # leave the tile-local scans of the new weights behind: the next resample then needs no kernel
+                scan_out = 1 if (gather and self._gather_slot == 0) else 0
+                ops |= _lib.GSE_OP_SCAN_OUT | (_lib.GSE_OP_SCAN_OUT_SLOT1 if scan_out else 0)
         rc = self._fn_step(ops, x_in.data_ptr(), x_out.data_ptr(), w_in.data_ptr(), w_out.data_ptr(), idx_ptr, self._ld, 1,
-                           n, cu, dt, cz, self._c_r, pod_state, rng_ref, noise_ptr, pod_meas, self._ws.data_ptr(),
+                           n, cu, dt, cz, self._c_r, pod_state, rng_ref, noise_ptr, pod_meas,
+                           self._island.data_ptr() if self._island is not None else None, self._ws.data_ptr(),
                            stream_ptr(self._dev_index))
         if rc:
             _lib.check(rc)
@@ -175,9 +192,11 @@ class ParallelParticleFilter:
             self._x, self._x_alt = self._x_alt, self._x
             self._w, self._w_alt = self._w_alt, self._w
         self._pend_gather = False
+        self._gather_slot = None
         self._pend_predict = None
         if update is not None:
             self._tiles_valid = True
+            self._scan_slot = scan_out
 
     # ------------------------------------------------------------------ attributes
     @property
@@ -207,6 +226,7 @@ class ParallelParticleFilter:
         self._flush()
         self._w[:self.N_particles] = v
         self._tiles_valid = False
+        self._scan_slot = None
 
     # ------------------------------------------------------------------ the cycle
     def predict(self, u, dt):
@@ -231,13 +251,19 @@ class ParallelParticleFilter:
         cumulative weights are computed now; the copy of the ancestors is deferred -- see above."""
         self._flush()
         self._c_r[0] = self._host_rng.random() if r is None else r
-        flags = _lib.GSE_RESAMPLE_TILES_VALID if self._tiles_valid else 0
-        rc = self._fn_resample_begin(self._w.data_ptr(), self._ld, 1, self.N_particles, flags,
-                                     self._island.data_ptr() if self._island is not None else None,
-                                     self._ws.data_ptr(), stream_ptr(self._dev_index))
-        if rc:
-            _lib.check(rc)
+        if self.lazy and self._scan_slot is not None:
+            # the preceding update left the tile-local scans of these weights in the workspace: nothing to launch
+            self._gather_slot = self._scan_slot
+        else:
+            flags = _lib.GSE_RESAMPLE_TILES_VALID if self._tiles_valid else 0
+            rc = self._fn_resample_begin(self._w.data_ptr(), self._ld, 1, self.N_particles, flags,
+                                         self._island.data_ptr() if self._island is not None else None,
+                                         self._ws.data_ptr(), stream_ptr(self._dev_index))
+            if rc:
+                _lib.check(rc)
+            self._gather_slot = None
         self._tiles_valid = False
+        self._scan_slot = None
         self._pend_gather = True
         self._want_index = bool(return_index)
         if return_index or not self.lazy:

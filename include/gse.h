@@ -132,14 +132,26 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
  * It computes exactly what the separate calls compute, with one launch and one trip of the state through HBM; the
  * steady-state cycle resample -> predict -> update is gse_pf_resample_begin + ONE gse_pf_step of all three stages.
  * With GATHER: x_out, w_out are separate buffers, w_in is not read.  Without: in place (x_out == x_in; w_out may
- * equal w_in).  Arguments of stages that are not requested may be NULL. */
+ * equal w_in).  Arguments of stages that are not requested may be NULL.
+ *
+ * Single-launch cycle (N <= 4096 * GSE_TILE, Philox draw, 2-component measurement mixture):
+ *   GSE_OP_SCAN_OUT  (with UPDATE)  also leave the tile-local inclusive scans of the new weights and their tile sums in
+ *                    workspace slot 0 (or 1 with GSE_OP_SCAN_OUT_SLOT1): 8 B per particle;
+ *   GSE_OP_SCAN_IN   (with GATHER)  take the cumulative weights from slot 0 (1 with GSE_OP_SCAN_IN_SLOT1) instead of
+ *                    from gse_pf_resample_begin: c[k] = (tile prefix + scan[k]) / sum, the same arithmetic and bits.
+ * Alternating the slots, update -> resample -> predict -> update -> ... is ONE launch per cycle and the weights are
+ * never re-read.  island: as for gse_pf_resample, maintained by the GATHER stage when GSE_OP_SCAN_IN is set. */
 #define GSE_OP_GATHER  1u
 #define GSE_OP_PREDICT 2u
 #define GSE_OP_UPDATE  4u
+#define GSE_OP_SCAN_IN 8u
+#define GSE_OP_SCAN_OUT 16u
+#define GSE_OP_SCAN_IN_SLOT1 32u
+#define GSE_OP_SCAN_OUT_SLOT1 64u
 int gse_pf_step(uint32_t ops, const float *x_in, float *x_out, const float *w_in, float *w_out, int32_t *idx,
                 int64_t ld, int B, int64_t N, const double *u, double dt, const double *z, const double *r,
                 const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,
-                const gse_mixture *measurement_pdf, void *workspace, void *stream);
+                const gse_mixture *measurement_pdf, double *island, void *workspace, void *stream);
 
 /* Moments behind point_estimate / point_covariance (filter/particle.py:318-327), fp64 accumulation:
  * out [B][26] device = { S0 = sum w, S1[5] = sum w (x - p), S2[15] = upper triangle (row-major) of

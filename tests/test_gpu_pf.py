@@ -396,6 +396,7 @@ def test_sharded_filter_single_rank_bookkeeping():
             want_cov = dd.T @ (dd * (w / w.sum())[:, None])
             np.testing.assert_allclose(spf.point_covariance(), np.linalg.svd(want_cov, compute_uv=False)[0], rtol=1e-6)
         spf.resample()
+        spf.local._flush()                     # the gather (deferred) is where the bookkeeping happens
         log_acc += np.log(w.sum())
         isl = host(spf.local._island)
         np.testing.assert_allclose(isl[0, 0], log_acc, rtol=1e-12)
@@ -471,7 +472,7 @@ def test_fused_step_against_oracle():
     _lib.call("gse_pf_resample_begin", wd.data_ptr(), ld, 1, n, 0, None, ws.data_ptr(), stream())
     _lib.call("gse_pf_step", _lib.GSE_OP_GATHER | _lib.GSE_OP_PREDICT | _lib.GSE_OP_UPDATE, xd.data_ptr(), xo.data_ptr(),
               wd.data_ptr(), wo.data_ptr(), idx.data_ptr(), ld, 1, n, _lib.doubles(u, 2), dt, _lib.doubles(z, 2),
-              _lib.doubles([r], 1), None, None, nd.data_ptr(), ctypes.byref(pod), ws.data_ptr(), stream())
+              _lib.doubles([r], 1), None, None, nd.data_ptr(), ctypes.byref(pod), None, ws.data_ptr(), stream())
     np.testing.assert_array_equal(host(idx)[:n], idx_want)
     np.testing.assert_array_equal(host(xo)[:, :n].T, o.particles)
     np.testing.assert_allclose(host(wo)[:n], o.weights, rtol=1.2e-7)
