@@ -157,39 +157,21 @@ def main():
 
     result = None
     if rank == 0:
-        # ---- per-kernel device time (HIP events on the launch stream), rank 0 only, local filter.  In steady state
-        #      a cycle is two launches: cumsum_kernel (resample, first half) and pf_step_kernel<gather,predict,update>.
+        # ---- device time of the cycle's kernel (HIP events on the launch stream), rank 0 only, local filter.  In steady
+        #      state one cycle is ONE launch, pf_step_kernel<gather, predict, update, scan in+out>: resample() and
+        #      predict() only record their arguments, update() launches the fused pass.
         lp = pf.local
-        lp._flush()
         reps = max(50, min(steps, 400))
-        per = {}
-
-        def one_step(i):
-            u, z = io[i % len(io)]
-            lp._pend_gather = True
-            lp.predict(u, dt)
-            lp.update(u, z)
-        lp.resample()
-        lp._flush()
-        per["step"] = time_method_events(torch, one_step, reps)
-
-        def one_cumsum(i):
-            lp._tiles_valid = True                              # as in the cycle: tile sums left by the update stage
-            lp.resample()
-            lp._pend_gather = False
-        per["cumsum"] = time_method_events(torch, one_cumsum, reps)
-        lp._pend_gather = False
-        per["cycle"] = time_method_events(torch, cycle, reps)
+        per = {"cycle": time_method_events(torch, cycle, reps)}
         pf.wait_collectives()
-        alg = {"step": 128, "cumsum": 12}                       # SURVEY 8d bytes / particle attributed to each kernel
-        dom = "step"
-        achieved = alg[dom] * n / per[dom] / 1e9
-        roofline = {"bound": "hbm", "kernel": "pf_step_kernel<gather,predict,update>",
+        dom = "cycle"
+        achieved = 140.0 * n / per[dom] / 1e9
+        roofline = {"bound": "hbm", "kernel": "pf_step_kernel<gather,predict,update,scan>",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes_per_particle": alg[dom],
+                    "algorithmic_bytes_per_particle": 140,
                     "device_us": {k: round(v * 1e6, 2) for k, v in per.items()},
-                    "cycle_frac_of_140B_roofline": round(140.0 * n / per["cycle"] / 1e9 / HBM_PEAK_GBS, 4)}
+                    "note": "one launch per cycle; achieved = 140 B x N / average launch-to-launch device time"}
         value = world * steps / elapsed
         result = {
             "metric": "PF steps/sec (predict+update+resample) @ N particles, bioreactor model",

@@ -310,7 +310,26 @@ __device__ __forceinline__ int64_t wave_search_ge(Value value, int64_t N, double
     }
 }
 
-constexpr int kSpanMax = 2048;            // cumulative weights staged in LDS per tile of 1024 outputs (16 KiB)
+// Smallest fp64 x >= 0 with fl(x / W) >= u  (W > 0 finite).  x -> fl(x / W) is monotone non-decreasing, so for any
+// key:  fl(key / W) >= u  <=>  key >= this value.  Start from u * W and walk by single ulps (a few steps at most).
+__device__ __forceinline__ double smallest_with_quotient_ge(double u, double W) {
+    if (!(u > 0.0)) return 0.0;                       // fl(0 / W) = 0 >= u
+    double x = u * W;
+    if (!(x < INFINITY)) return x;
+    // down while the predecessor still satisfies the predicate, then up until the predicate holds
+    for (int it = 0; it < 8; ++it) {
+        const double y = __longlong_as_double(__double_as_longlong(x) - 1);     // next below (x > 0)
+        if (x > 0.0 && y / W >= u) x = y; else break;
+    }
+    for (int it = 0; it < 8; ++it) {
+        if (x / W >= u) break;
+        x = __longlong_as_double(__double_as_longlong(x) + 1);                   // next above
+    }
+    return x;
+}
+
+constexpr int kSpanMax = 2048;            // cumulative weights staged in LDS per pass (16 KiB)
+constexpr int kSpanPasses = 8;            // spans up to kSpanPasses * kSpanMax ancestors are bisected in LDS
 
 // Ancestor of one output with threshold u among the staged span seg[0..len): first q with seg[q] >= u.
 __device__ __forceinline__ int span_search(const double* seg, int len, double u) {

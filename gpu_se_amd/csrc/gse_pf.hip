@@ -153,39 +153,74 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         // sweep never advances (filter/particle.py:98), so every offspring copies particle 0 (anc stays 0).
         if ((W > 0.0) && (W < INFINITY)) {
             const double* cb = kScanIn ? scan_in + (int64_t)b * N : c + (int64_t)b * N;
-            // normalised cumulative weight of ancestor k
-            auto cval = [&](int64_t k) -> double {
+            // The search key of ancestor k and the threshold of an output.
+            //   materialised c[] : key = c[k] (normalised),                 threshold = u = (j + r) / N
+            //   SCAN_IN          : key = min(Pfx[t] + L[k], Pfx[t+1]) (NOT divided by W; the tile's last element is
+            //                      Pfx[t+1]),                               threshold = tau(u)
+            // where tau(u) is the smallest fp64 x with fl(x / W) >= u.  Because x -> fl(x / W) is monotone,
+            // fl(key / W) >= u  <=>  key >= tau(u): the ancestor found is EXACTLY the one the normalised comparison
+            // gives, and no probe of the search needs a division.
+            auto key = [&](int64_t k) -> double {
                 if (!kScanIn) return cb[k];
                 const int t = (int)(k / kTile);
-                const double top = pfx_s[t + 1] / W;
                 const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
-                return (k == last) ? top : fmin((pfx_s[t] + cb[k]) / W, top);
+                return (k == last) ? pfx_s[t + 1] : fmin(pfx_s[t] + cb[k], pfx_s[t + 1]);
+            };
+            auto threshold = [&](uint32_t j) -> double {
+                const double u = ((double)j + r) / Nd;
+                return kScanIn ? smallest_with_quotient_ge(u, W) : u;
             };
             const int64_t j0 = tile0;
             const int64_t j1 = min(j0 + kTile, N);
             if (wv < 2) {       // bracket the tile's ancestors: wavefront 0 takes the first output, wavefront 1 the last
                 const int64_t j = (wv == 0) ? j0 : j1 - 1;
-                const int64_t k = wave_search_ge(cval, N, ((double)j + r) / Nd, lane);
+                const int64_t k = wave_search_ge(key, N, threshold((uint32_t)j), lane);
                 if (lane == 0) span[wv] = k;
             }
             __syncthreads();
             const int64_t klo = span[0], khi = span[1];
             const int64_t len = khi - klo + 1;
-            if (len <= kSpanMax) {
-                for (int q = tid; q < (int)len; q += kBlock) seg[q] = cval(klo + q);
-                __syncthreads();
+            double thr[kPerThread];
 #pragma unroll
-                for (int p = 0; p < kPerThread; ++p)
-                    anc[p] = (int32_t)klo + span_search(seg, (int)len, ((double)jp[p] + r) / Nd);
+            for (int p = 0; p < kPerThread; ++p) thr[p] = threshold(jp[p]);
+            if (len <= (int64_t)kSpanPasses * kSpanMax) {
+                // Stage the span in LDS, kSpanMax keys at a time (one pass in the common case; the ancestors of a tile
+                // of 1024 outputs span ~1000 particles at the median and < 8192 in the tail even when the effective
+                // sample size is 0.01 % of N), and bisect there.  An output is resolved in the pass whose last key
+                // reaches its threshold.
+                bool open[kPerThread] = {true, true, true, true};
+                for (int64_t base = klo; base <= khi; base += kSpanMax) {            // workgroup-uniform
+                    const int cnt = (int)min((int64_t)kSpanMax, khi - base + 1);
+                    if (base != klo) __syncthreads();                                // previous pass fully read
+                    for (int q = tid; q < cnt; q += kBlock) seg[q] = key(base + q);
+                    __syncthreads();
+                    const double top = seg[cnt - 1];
+                    const bool final_pass = base + cnt > khi;
+#pragma unroll
+                    for (int p = 0; p < kPerThread; ++p)
+                        if (open[p] && (thr[p] <= top || final_pass)) {
+                            anc[p] = (int32_t)base + span_search(seg, cnt, thr[p]);
+                            open[p] = false;
+                        }
+                }
             } else {
-                // the tile's ancestors are spread over a long stretch of (nearly) weightless particles: search c[] itself
+                // A longer stretch of (nearly) weightless particles: search the keys in memory.  With SCAN_IN the tile
+                // is found first in the LDS prefix (no memory access), then 10 probes inside the tile.
 #pragma unroll
                 for (int p = 0; p < kPerThread; ++p) {
-                    const double u = ((double)jp[p] + r) / Nd;
                     int64_t lo = klo, hi = khi;
+                    if (kScanIn) {
+                        int tl = (int)(klo / kTile), th = (int)(khi / kTile);     // first tile whose end value >= thr
+                        while (tl < th) {
+                            const int mid = (tl + th) >> 1;
+                            if (pfx_s[mid + 1] < thr[p]) tl = mid + 1; else th = mid;
+                        }
+                        lo = max(lo, (int64_t)tl * kTile);
+                        hi = min(hi, min((int64_t)(tl + 1) * kTile, N) - 1);
+                    }
                     while (lo < hi) {
                         const int64_t mid = (lo + hi) >> 1;
-                        if (cval(mid) < u) lo = mid + 1; else hi = mid;
+                        if (key(mid) < thr[p]) lo = mid + 1; else hi = mid;
                     }
                     anc[p] = (int32_t)lo;
                 }

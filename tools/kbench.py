@@ -36,9 +36,16 @@ def timed(name, fn):
     print("%-28s device %.2f us   host %.2f us" % (name, e0.elapsed_time(e1) / reps * 1e3, host * 1e6), flush=True)
 
 
+import bench
+io = bench.make_inputs(reps + 60, 1.0)
+state = {"i": 0}
+
+
 def cycle():
-    pf.predict(u, 0.1)
-    pf.update(u, z)
+    uu, zz = io[state["i"] % len(io)]
+    state["i"] += 1
+    pf.predict(uu, 1.0)
+    pf.update(uu, zz)
     pf.resample()
 
 
@@ -49,4 +56,6 @@ timed("update", lambda: pf.update(u, z))
 w = np.random.default_rng(0).random(n)
 pf.weights = w / w.sum()
 timed("resample(random w, +tile sums)", lambda: pf.resample())
-timed("cycle", cycle)
+gpu_se_amd.seed(2)
+_, _, _, pf = sim_base.get_parts(N_particles=n)
+timed("cycle (plant-tracking inputs)", cycle)
