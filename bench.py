@@ -57,6 +57,16 @@ def make_inputs(steps, dt, seed=0):
     return out
 
 
+def pmc_traffic(n):
+    """HBM bytes per launch of the cycle kernel from the committed PMC profile (rocprofv3 cannot run inside this
+    process): profiles/pmc_traffic.json, valid for N = 2^20; None otherwise."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if n != 1 << 20 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh).get("traffic_bytes_per_launch")
+
+
 def time_method_events(torch, fn, reps):
     """Average device time of one call of fn, HIP events on the stream the kernels are launched on."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -114,14 +124,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("GSE_FORCE_DIST") == "1"      # the latter: exercise RCCL with one rank
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n = int(round(2 ** args.log2_particles))
     gpu_se_amd.seed(1234)
     from gpu_se_amd.distributed import ShardedParticleFilter
-    pf = ShardedParticleFilter.from_get_parts(n_local=n, group=dist.group.WORLD if world > 1 else None)
+    pf = ShardedParticleFilter.from_get_parts(n_local=n, group=dist.group.WORLD if use_dist else None)
     steps, warmup = args.steps, args.warmup
     dt = 1.0                                                    # pf_run_seq.py:48
     io = make_inputs(steps + warmup, dt)
@@ -168,7 +181,7 @@ def main():
         achieved = 140.0 * n / per[dom] / 1e9
         roofline = {"bound": "hbm", "kernel": "pf_step_kernel<gather,predict,update,scan>",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n),
                     "algorithmic_bytes_per_particle": 140,
                     "device_us": {k: round(v * 1e6, 2) for k, v in per.items()},
                     "note": "one launch per cycle; achieved = 140 B x N / average launch-to-launch device time"}
@@ -182,7 +195,9 @@ def main():
             "config": {"workload": "ParallelParticleFilter HIP, N=2^%g particles per GPU, systematic resample "
                                    "(BASELINE config 2)" % args.log2_particles,
                        "particles_per_gpu": n, "total_particles": n * world, "dt": dt,
-                       "parallelism": "particle shards x%d, island resampling, async all-reduce of the weight sum" % world
+                       "parallelism": "particle shards x%d, island resampling, async RCCL all-reduce of the weight sum every "
+                                      "%d cycles, posterior merge (all-reduce of 22 doubles per rank) at estimates"
+                                      % (world, pf.reduce_every)
                        if world > 1 else "single GPU"},
             "particles_per_s": round(value * n, 1),
             "roofline": roofline,
@@ -198,7 +213,7 @@ def main():
                 "vectorised_numpy_cycles_per_s": round(1.0 / (vec * scale), 4),
                 "host": "%d logical cpus" % (os.cpu_count() or 0)}
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return result

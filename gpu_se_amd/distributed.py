@@ -68,7 +68,8 @@ class ShardedParticleFilter:
     because shards cannot share one un-normalised weight scale without the exchange this design avoids.
     """
 
-    def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, group=None, merge_device=None):
+    def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, group=None, merge_device=None,
+                 reduce_every=8):
         self.group = group
         self.world = dist.get_world_size(group) if group is not None else 1
         self.rank = dist.get_rank(group) if group is not None else 0
@@ -86,6 +87,11 @@ class ShardedParticleFilter:
         self._merge_device = merge_device or (dev if backend in (None, "nccl") else torch.device("cpu"))
         self._wsum = torch.zeros(1, dtype=torch.float64, device=self._merge_device)
         self._pending = None
+        # The weight-sum all-reduce is bookkeeping (island weights travel as log-weights and are only combined when
+        # an estimate is asked for), so it is issued every reduce_every-th resample: a torch.distributed call costs
+        # ~25 us of host time, more than a whole cycle of device work at N = 2^20.
+        self.reduce_every = max(1, int(reduce_every))
+        self._resamples = 0
 
     @classmethod
     def from_get_parts(cls, n_local, group=None):
@@ -112,14 +118,16 @@ class ShardedParticleFilter:
         resampled = self.local._pend_gather
         self.local.update(u, z)
         if resampled:
-            self._reduce_weight_sum()
+            self._resamples += 1
+            if self._resamples % self.reduce_every == 0:
+                self._reduce_weight_sum()
 
     def resample(self, r=None):
         """Local systematic resample (island filter); see update() for the bookkeeping."""
         self.local.resample(r=r)
 
     def _reduce_weight_sum(self):
-        if self.world > 1:
+        if self.group is not None:
             self.wait_collectives()
             if self._merge_device.type == "cuda":
                 self._wsum = self.local._island[1]                 # contiguous [1] view written by the kernel
@@ -140,7 +148,7 @@ class ShardedParticleFilter:
 
     def _merged(self):
         row = self._local_row()
-        if self.world == 1:
+        if self.group is None:
             return merge_rows(row[None, :], self._pivot)
         self.wait_collectives()
         buf = torch.zeros((self.world, MERGE_WIDTH), dtype=torch.float64, device=self._merge_device)

@@ -476,3 +476,52 @@ def test_fused_step_against_oracle():
     np.testing.assert_array_equal(host(idx)[:n], idx_want)
     np.testing.assert_array_equal(host(xo)[:, :n].T, o.particles)
     np.testing.assert_allclose(host(wo)[:n], o.weights, rtol=1.2e-7)
+
+
+# ------------------------------------------------------------------------------ batches of independent filters
+def test_batch_of_filters_equals_single_filters():
+    """B independent filters in one launch (leading dimension of every array; per-filter u, z, r, Philox stream) give,
+    filter by filter, bit-identical results to B separate single-filter calls -- over two fused single-launch cycles."""
+    B, n = 3, 2500
+    ld = -(-n // 4) * 4
+    rng = np.random.default_rng(4)
+    xss = orc.steady_state()
+    x0 = (xss[None, None, :] * (1 + 0.01 * rng.standard_normal((B, n, 5)))).astype(np.float32)
+    sp, mp = sim_base.get_noise()
+    pod_s, pod_m = sp._pod(), mp._pod()
+    us = rng.uniform([0.03, 0.1], [0.09, 0.3], size=(2, B, 2))
+    zs = np.array(orc.bioreactor_g(xss))[None, None, :] + rng.normal(0, 0.3, size=(2, B, 2))
+    rs = rng.random((2, B))
+    OPS = _lib.GSE_OP_PREDICT | _lib.GSE_OP_UPDATE | _lib.GSE_OP_SCAN_OUT
+
+    def run(filters, nb):
+        """filters: list of filter ids handled by this call sequence (one call with nb = len(filters))."""
+        xb = np.full((nb, 5, ld), np.nan, np.float32)
+        for i, f in enumerate(filters):
+            xb[i, :, :n] = x0[f].T
+        xd = dev(xb)
+        xa = torch.empty_like(xd)
+        wd = torch.zeros((nb, ld), dtype=torch.float32, device="cuda")
+        wd[:, :n] = 1.0 / n
+        wa = torch.empty_like(wd)
+        ws = workspace(nb, n)
+        fl = lambda a: _lib.doubles(np.asarray(a).ravel(), np.asarray(a).size)
+        # cycle 0: predict + update (+ scans out, slot 0)
+        r0 = _lib.Rng(seed=99, step=0, element_offset=0, filter_offset=filters[0])
+        _lib.call("gse_pf_step", OPS, xd.data_ptr(), xd.data_ptr(), wd.data_ptr(), wd.data_ptr(), None, ld, nb, n,
+                  fl(us[0, filters]), 0.1, fl(zs[0, filters]), None, ctypes.byref(pod_s), ctypes.byref(r0), None,
+                  ctypes.byref(pod_m), None, ws.data_ptr(), stream())
+        # cycle 1: gather (scans in, slot 0) + predict + update (scans out, slot 1) -- one launch
+        r1 = _lib.Rng(seed=99, step=1, element_offset=0, filter_offset=filters[0])
+        _lib.call("gse_pf_step", OPS | _lib.GSE_OP_GATHER | _lib.GSE_OP_SCAN_IN | _lib.GSE_OP_SCAN_OUT_SLOT1,
+                  xd.data_ptr(), xa.data_ptr(), wd.data_ptr(), wa.data_ptr(), None, ld, nb, n, fl(us[1, filters]), 0.1,
+                  fl(zs[1, filters]), fl(rs[1, filters]), ctypes.byref(pod_s), ctypes.byref(r1), None,
+                  ctypes.byref(pod_m), None, ws.data_ptr(), stream())
+        return host(xa)[:, :, :n], host(wa)[:, :n]
+
+    xb, wb = run([0, 1, 2], 3)
+    for f in range(B):
+        x1, w1 = run([f], 1)
+        np.testing.assert_array_equal(xb[f], x1[0])
+        np.testing.assert_array_equal(wb[f], w1[0])
+    assert not np.array_equal(xb[0], xb[1])
