@@ -90,6 +90,10 @@ def load():
         raise ImportError(
             "gpu_se_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `python gpu_se_amd/build.py`).  There is no CPU fallback." % LIB_PATH)
+    # torch first: it brings its own HIP runtime (torch/lib/libamdhip64.so), and the buffers and streams handed to the
+    # kernels live in that runtime.  Loading libgse_hip.so before torch would bind it to the system copy of the
+    # runtime instead -- a second runtime in the process, which sees no device ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
