@@ -79,7 +79,7 @@ class ShardedParticleFilter:
         dev = self.local._x.device
         self.local._island = torch.zeros((2, 1), dtype=torch.float64, device=dev)
         # a shard's prior weight is its share of the particles
-        self.local._island[0, 0] = float(numpy.log(n_local / self.N_particles))
+        self.local._island[0, 0] = float(numpy.log(n_local / self.N_particles))   # [2][B = 1]
         self._pivot = numpy.asarray(x0.weights, dtype=numpy.float64) @ numpy.asarray(x0.means, dtype=numpy.float64) \
             / float(numpy.sum(x0.weights))
         # the collective runs where the backend wants its tensors: device for nccl/RCCL, host for gloo (CPU tests)

@@ -68,34 +68,36 @@ class ParallelParticleFilter:
 
     _parallel_resample = _KernelLauncher(_parallel_resample)
 
-    def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, element_offset=0):
+    def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, element_offset=0, _batch=1):
         _require_builtin_model(f, g)
-        _lib.load()
+        lib = _lib.load()
         self.f = f
         self.g = g
         self.N_particles = int(N_particles)
         self.state_pdf = state_pdf
         self.measurement_pdf = measurement_pdf
         n = self.N_particles
+        B = self._B = int(_batch)                           # independent filters sharing every launch (1 for this class)
+        if not 1 <= B <= _lib.GSE_MAX_B:
+            raise ValueError("batch size must be in 1..%d" % _lib.GSE_MAX_B)
         dev = device()
         self._ld = -(-n // 4) * 4
-        self._x = torch.zeros((_lib.GSE_NX, self._ld), dtype=torch.float32, device=dev)
+        self._x = torch.zeros((B, _lib.GSE_NX, self._ld), dtype=torch.float32, device=dev)
         self._x_alt = torch.zeros_like(self._x)
-        self._w = torch.zeros(self._ld, dtype=torch.float32, device=dev)
+        self._w = torch.zeros((B, self._ld), dtype=torch.float32, device=dev)
         self._w_alt = torch.zeros_like(self._w)
-        self._ws = torch.empty(_lib.load().gse_workspace_bytes(1, n), dtype=torch.uint8, device=dev)
-        self._moments = torch.empty(26, dtype=torch.float64, device=dev)
+        self._ws = torch.empty(lib.gse_workspace_bytes(B, n), dtype=torch.uint8, device=dev)
+        self._moments = torch.empty((B, 26), dtype=torch.float64, device=dev)
         self._tiles_valid = False
-        self._island = None                                 # [2][1] fp64 shard bookkeeping (ShardedParticleFilter)
+        self._island = None                                 # [2][B] fp64 shard bookkeeping (ShardedParticleFilter)
         self._element_offset = int(element_offset)        # global index of particle 0 (sharded ensembles)
         self._seed = gpu_se_amd._new_stream_seed()
         self._step = 0
         self._host_rng = numpy.random.default_rng(self._seed & 0xFFFFFFFF)
         # persistent argument buffers: a call only rewrites a few doubles (keeps the host side of a launch short)
-        lib = _lib.load()
-        self._c_u = (_lib.c_d * _lib.GSE_NU)()
-        self._c_z = (_lib.c_d * _lib.GSE_NY)()
-        self._c_r = (_lib.c_d * 1)()
+        self._c_u = (_lib.c_d * (_lib.GSE_NU * B))()
+        self._c_z = (_lib.c_d * (_lib.GSE_NY * B))()
+        self._c_r = (_lib.c_d * B)()
         self._c_rng = _lib.Rng(seed=self._seed, step=0, element_offset=self._element_offset)
         self._c_rng_ref = ctypes.byref(self._c_rng)
         self._fn_step, self._fn_resample_begin = lib.gse_pf_step, lib.gse_pf_resample_begin
@@ -110,8 +112,9 @@ class ParallelParticleFilter:
         self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
 
         # particles ~ x0 (particle.py:49), drawn on the device straight into the state-major buffer
-        x0._draw_state_major(self._x, n, self._ld, self._element_offset)
-        self._w[:n] = 1.0 / n                              # (particle.py:50)
+        for b in range(B):
+            x0._draw_state_major(self._x[b], n, self._ld, self._element_offset, filter_offset=b)
+        self._w[:, :n] = 1.0 / n                           # (particle.py:50)
 
         # launch geometry the reference computes and its benchmark scripts read (particle.py:160-174)
         if n >= 1024:
@@ -119,6 +122,21 @@ class ParallelParticleFilter:
         else:
             self._tpb, self._bpg = 32 * ((n - 1) // 32 + 1), 1
         self._y_dummy = DevArray.wrap(torch.zeros(_lib.GSE_NY, dtype=torch.float32, device=dev))
+
+    # -- per-filter host inputs -> the persistent ctypes buffers ([B][2]; one row is broadcast to all filters)
+    def _fill(self, buf, values, width):
+        B = self._B
+        if B == 1:
+            if width == 2:
+                buf[0], buf[1] = values
+            else:
+                buf[0] = values
+            return
+        a = numpy.broadcast_to(numpy.asarray(values, dtype=numpy.float64).reshape(-1, width) if width > 1
+                               else numpy.asarray(values, dtype=numpy.float64).reshape(-1, 1), (B, width))
+        flat = a.ravel()
+        for i in range(B * width):
+            buf[i] = flat[i]
 
     # ------------------------------------------------------------------ deferred stages
     # resample() and predict() do not launch their particle pass at once: resample() computes the cumulative
@@ -151,7 +169,7 @@ class ParallelParticleFilter:
             if self._gather_slot is not None:
                 ops |= _lib.GSE_OP_SCAN_IN | (_lib.GSE_OP_SCAN_IN_SLOT1 if self._gather_slot else 0)
             if self._want_index:
-                self._last_index = torch.empty(self._ld, dtype=torch.int32, device=self._x.device)
+                self._last_index = torch.empty((self._B, self._ld), dtype=torch.int32, device=self._x.device)
                 idx_ptr = self._last_index.data_ptr()
         pod_state = rng_ref = noise_ptr = None
         dt = 0.0
@@ -159,11 +177,11 @@ class ParallelParticleFilter:
         if self._pend_predict is not None:
             ops |= _lib.GSE_OP_PREDICT
             u, dt = self._pend_predict
-            cu[0], cu[1] = u
+            self._fill(cu, u, _lib.GSE_NU)
             if injected:
-                noise = self.state_pdf.draw(n).as_subclass(torch.Tensor)            # (n, Nx) replayed values
+                noise = self.state_pdf.draw((self._B, n)).as_subclass(torch.Tensor)  # (B, n, Nx) replayed values
                 buf = torch.zeros_like(self._x)
-                buf[:, :n] = noise.reshape(n, _lib.GSE_NX).t()
+                buf[:, :, :n] = noise.reshape(self._B, n, _lib.GSE_NX).transpose(1, 2)
                 self._noise_buf = buf
                 noise_ptr = buf.data_ptr()
             else:
@@ -176,14 +194,14 @@ class ParallelParticleFilter:
         scan_out = None
         if update is not None:
             ops |= _lib.GSE_OP_UPDATE
-            cz[0], cz[1] = update[1]
+            self._fill(cz, update[1], _lib.GSE_NY)
             pod_meas = ctypes.byref(self.measurement_pdf._pod())
             if self._scan_capable and not injected and self.measurement_pdf._Nd == 2:
                 # leave the tile-local scans of the new weights behind: the next resample then needs no kernel
                 scan_out = 1 if (gather and self._gather_slot == 0) else 0
                 ops |= _lib.GSE_OP_SCAN_OUT | (_lib.GSE_OP_SCAN_OUT_SLOT1 if scan_out else 0)
-        rc = self._fn_step(ops, x_in.data_ptr(), x_out.data_ptr(), w_in.data_ptr(), w_out.data_ptr(), idx_ptr, self._ld, 1,
-                           n, cu, dt, cz, self._c_r, pod_state, rng_ref, noise_ptr, pod_meas,
+        rc = self._fn_step(ops, x_in.data_ptr(), x_out.data_ptr(), w_in.data_ptr(), w_out.data_ptr(), idx_ptr, self._ld,
+                           self._B, n, cu, dt, cz, self._c_r, pod_state, rng_ref, noise_ptr, pod_meas,
                            self._island.data_ptr() if self._island is not None else None, self._ws.data_ptr(),
                            stream_ptr(self._dev_index))
         if rc:
@@ -202,29 +220,27 @@ class ParallelParticleFilter:
     @property
     def particles(self):
         self._flush()
-        return DevArray.wrap(self._x[:, :self.N_particles].t())
+        v = self._x[:, :, :self.N_particles].transpose(1, 2)            # (B, N, Nx) strided view
+        return DevArray.wrap(v[0] if self._B == 1 else v)
 
     @particles.setter
     def particles(self, value):
-        v = as_device(value, torch.float32)
-        if tuple(v.shape) != (self.N_particles, _lib.GSE_NX):
-            raise ValueError("particles must have shape (%d, %d)" % (self.N_particles, _lib.GSE_NX))
+        v = as_device(value, torch.float32).reshape(self._B, self.N_particles, _lib.GSE_NX)
         self._flush()
-        self._x[:, :self.N_particles] = v.t()
+        self._x[:, :, :self.N_particles] = v.transpose(1, 2)
 
     @property
     def weights(self):
         self._flush()
-        return DevArray.wrap(self._w[:self.N_particles])
+        v = self._w[:, :self.N_particles]
+        return DevArray.wrap(v[0] if self._B == 1 else v)
 
     @weights.setter
     def weights(self, value):
         # the benchmark scripts assign a host array here (pf_run_seq.py:124-125)
-        v = as_device(value, torch.float32)
-        if tuple(v.shape) != (self.N_particles,):
-            raise ValueError("weights must have shape (%d,)" % self.N_particles)
+        v = as_device(value, torch.float32).reshape(self._B, self.N_particles)
         self._flush()
-        self._w[:self.N_particles] = v
+        self._w[:, :self.N_particles] = v
         self._tiles_valid = False
         self._scan_slot = None
 
@@ -234,8 +250,12 @@ class ParallelParticleFilter:
         (particle.py:265-277).  u: (N_inputs) host array-like; dt: float.  Deferred -- see above."""
         if self._pend_predict is not None:
             self._flush()                                   # two predicts in a row: run the first one now
-        u0, u1 = u
-        self._pend_predict = ((float(u0), float(u1)), float(dt))
+        if self._B == 1:
+            u0, u1 = u
+            u = (float(u0), float(u1))
+        else:
+            u = numpy.array(u, dtype=numpy.float64)
+        self._pend_predict = (u, float(dt))
         if not self.lazy:
             self._flush()
 
@@ -250,13 +270,16 @@ class ParallelParticleFilter:
         uniform number comes from a host generator (no device round trip); ``r`` overrides it (tests).  The
         cumulative weights are computed now; the copy of the ancestors is deferred -- see above."""
         self._flush()
-        self._c_r[0] = self._host_rng.random() if r is None else r
+        if self._B == 1:
+            self._c_r[0] = self._host_rng.random() if r is None else r
+        else:
+            self._fill(self._c_r, self._host_rng.random(self._B) if r is None else r, 1)
         if self.lazy and self._scan_slot is not None:
             # the preceding update left the tile-local scans of these weights in the workspace: nothing to launch
             self._gather_slot = self._scan_slot
         else:
             flags = _lib.GSE_RESAMPLE_TILES_VALID if self._tiles_valid else 0
-            rc = self._fn_resample_begin(self._w.data_ptr(), self._ld, 1, self.N_particles, flags,
+            rc = self._fn_resample_begin(self._w.data_ptr(), self._ld, self._B, self.N_particles, flags,
                                          self._island.data_ptr() if self._island is not None else None,
                                          self._ws.data_ptr(), stream_ptr(self._dev_index))
             if rc:
@@ -269,24 +292,34 @@ class ParallelParticleFilter:
         if return_index or not self.lazy:
             self._flush()
         if return_index:
-            return DevArray.wrap(self._last_index[:self.N_particles])
+            v = self._last_index[:, :self.N_particles]
+            return DevArray.wrap(v[0] if self._B == 1 else v)
 
     # ------------------------------------------------------------------ estimates
-    def _raw_moments(self):
-        """(S0, S1 = sum w d, S2 = sum w d d^T (5x5), pivot) with d = x - pivot, from the device (synchronises)."""
+    def _raw_moments_all(self):
+        """Per filter (S0, S1 = sum w d, S2 = sum w d d^T (5x5), pivot) with d = x - pivot (synchronises)."""
         self._flush()
-        _lib.call("gse_pf_moments", self._x.data_ptr(), self._w.data_ptr(), self._ld, 1, self.N_particles,
+        _lib.call("gse_pf_moments", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
                   self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
         m = self._moments.cpu().numpy()
-        s2 = numpy.zeros((_lib.GSE_NX, _lib.GSE_NX))
-        s2[numpy.triu_indices(_lib.GSE_NX)] = m[6:21]
-        s2 = s2 + s2.T - numpy.diag(numpy.diag(s2))
-        return float(m[0]), m[1:6].copy(), s2, m[21:26].copy()
+        out = []
+        for b in range(self._B):
+            s2 = numpy.zeros((_lib.GSE_NX, _lib.GSE_NX))
+            s2[numpy.triu_indices(_lib.GSE_NX)] = m[b, 6:21]
+            s2 = s2 + s2.T - numpy.diag(numpy.diag(s2))
+            out.append((float(m[b, 0]), m[b, 1:6].copy(), s2, m[b, 21:26].copy()))
+        return out
+
+    def _raw_moments(self):
+        return self._raw_moments_all()[0]
+
+    def _moment_sums_all(self):
+        """Per filter (S0, w@x, sum w (x - w@x)(x - w@x)^T) -- the reference's un-normalised quantities."""
+        return [moments_to_mean_cov(s0, s1, s2[numpy.triu_indices(_lib.GSE_NX)], pivot)
+                for s0, s1, s2, pivot in self._raw_moments_all()]
 
     def _moment_sums(self):
-        """(S0, w@x, sum w (x - w@x)(x - w@x)^T) -- the reference's un-normalised quantities."""
-        s0, s1, s2, pivot = self._raw_moments()
-        return moments_to_mean_cov(s0, s1, s2[numpy.triu_indices(_lib.GSE_NX)], pivot)
+        return self._moment_sums_all()[0]
 
     def point_estimate(self):
         """Returns the point estimate of the filter: weights @ particles, host array (5,) (particle.py:318-320)."""
@@ -316,6 +349,33 @@ class ParallelParticleFilter:
         out = torch.empty((p2.shape[0], _lib.GSE_NY), dtype=torch.float32, device=p2.device)
         _lib.call("gse_model_g", p2.data_ptr(), out.data_ptr(), p2.shape[0], stream_ptr())
         return DevArray.wrap(out.reshape(lead + (_lib.GSE_NY,)))
+
+
+class BatchedParticleFilter(ParallelParticleFilter):
+    """B independent particle filters (same model and noise, separate particles, inputs, measurements and random
+    streams) advanced by the same kernel launches -- the batch dimension of the C ABI.  This is how independent
+    closed-loop rollouts (the Monte-Carlo repetitions of results/pf_closedloop/bioreactor_performance_pf.py:104-118)
+    share a GPU.  Methods as ParallelParticleFilter with a leading batch axis: u (B, 2) or (2,), z (B, 2);
+    particles (B, N, 5); weights (B, N); point_estimate() -> (B, 5); point_covariance() -> (B,)."""
+
+    def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, batch):
+        super().__init__(f, g, N_particles, x0, state_pdf, measurement_pdf, _batch=batch)
+
+    @property
+    def batch(self):
+        return self._B
+
+    def point_estimate(self):
+        return numpy.array([m[1] for m in self._moment_sums_all()])
+
+    def point_covariance(self):
+        return numpy.array([numpy.linalg.svd(m[2], compute_uv=False)[0] for m in self._moment_sums_all()])
+
+    def estimates(self):
+        """(point estimates (B, 5), covariance sizes (B,)) from ONE device pass and one synchronisation."""
+        ms = self._moment_sums_all()
+        return (numpy.array([m[1] for m in ms]),
+                numpy.array([numpy.linalg.svd(m[2], compute_uv=False)[0] for m in ms]))
 
 
 def moments_to_mean_cov(s0, s1, s2_upper, pivot):

@@ -73,8 +73,9 @@ class MultivariateGaussianSum:
                     m.inv_cov[d][i][j] = float(self._inverse_covariances[d, i, j])
         return m
 
-    def _rng(self, element_offset=0):
-        r = _lib.Rng(seed=self._seed, step=self._draws, element_offset=element_offset, filter_offset=0, reserved=0)
+    def _rng(self, element_offset=0, filter_offset=0):
+        r = _lib.Rng(seed=self._seed, step=self._draws, element_offset=element_offset, filter_offset=filter_offset,
+                     reserved=0)
         self._draws += 1
         return r
 
@@ -114,7 +115,7 @@ class MultivariateGaussianSum:
         _lib.call("gse_mixture_draw", out.data_ptr(), size, 0, ctypes.byref(pod), ctypes.byref(rng), stream_ptr())
         return DevArray.wrap(out.reshape(shape + (self._Nx,)))
 
-    def _draw_state_major(self, out, n, ld, element_offset=0):
+    def _draw_state_major(self, out, n, ld, element_offset=0, filter_offset=0):
         """Draw n samples straight into a state-major [Nx][ld] buffer (how the filters draw their prior)."""
-        pod, rng = self._pod(), self._rng(element_offset)
+        pod, rng = self._pod(), self._rng(element_offset, filter_offset)
         _lib.call("gse_mixture_draw", out.data_ptr(), n, ld, ctypes.byref(pod), ctypes.byref(rng), stream_ptr())

@@ -84,3 +84,173 @@ def get_realistic_io(rng, x_ref):
     else:
         y = y + numpy.array([0.0, -0.1]) + numpy.linalg.cholesky(numpy.array([[500., 100.], [100., 700.]])) @ rng.standard_normal(2)
     return u, y
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Closed loop (sim_base.py:164-309).  The estimator runs on the device; the plant, its noise and the bookkeeping are
+# scalar host work exactly as in the reference.  The MPC of the reference (controller.py, OSQP) is out of scope: the
+# controller is a pluggable callable, and the default is what the reference's loop applies whenever its QP solve
+# raises (sim_base.py:264-273): hold u = [0.06, 0.2].
+# ----------------------------------------------------------------------------------------------------------------
+_OUTPUTS = [0, 2]            # lin_model.outputs after select_subset (sim_base.py:69-73): Cg, Cfa
+_INPUTS = [0, 1]
+_U_FALLBACK = numpy.array([0.06, 0.2])
+_STATE_NOISE = (numpy.zeros((2, 5)),
+                numpy.array([numpy.diag([1e-4, 1e-7, 1e-3, 1e-3, 1e-7]), numpy.diag([1e-3, 1e-6, 1e-2, 1e-2, 1e-6])]),
+                numpy.array([0.75, 0.25]))
+_MEAS_NOISE = (numpy.array([[1e-1, 0], [0, -1e-1]]),
+               numpy.array([[[6e-2, 0], [0, 8e-2]], [[500, 100], [100, 700]]]),
+               numpy.array([0.85, 0.15]))
+
+
+def _host_mixture_draw(rng, mixture, size):
+    """size draws of a Gaussian sum on the host (the plant's own noise; the reference pulls these through the device
+    class and .get(), sim_base.py:281-284 -- a host generator gives the same distribution without two syncs a tick)."""
+    means, covs, weights = mixture
+    comp = rng.choice(len(weights), size=size, p=weights / weights.sum())
+    chol = numpy.linalg.cholesky(covs)
+    z = rng.standard_normal((size, means.shape[1]))
+    return means[comp] + numpy.einsum("nij,nj->ni", chol[comp], z)
+
+
+def performance(ys, r, ts):
+    """Integral of the time-weighted squared error, summed over the outputs (sim_base.py:164-185; Simpson's rule --
+    scipy.integrate.simps of the reference is scipy.integrate.simpson today)."""
+    import scipy.integrate
+    se = (numpy.asarray(ys) - numpy.asarray(r)) ** 2
+    return float(sum(scipy.integrate.simpson(se_ax * ts, x=ts) for se_ax in numpy.rollaxis(se, 1)))
+
+
+def hold_controller(x_estimate, u_previous, y_measured):
+    """The input the reference falls back to when its MPC step fails (sim_base.py:271-273)."""
+    return _U_FALLBACK.copy()
+
+
+class Simulation:
+    """Holds details of a closed-loop simulation (sim_base.py:207-309): plant + estimator (+ controller).
+
+    Parameters as in the reference; ``controller`` is a callable (x_estimate, u_previous, y_measured) -> u replacing
+    the reference's MPC object, ``seed`` seeds the plant's noise."""
+
+    def __init__(self, N_particles, dt_control, dt_predict, end_time=50, pf=True, controller=None, seed=0):
+        self.ts = numpy.linspace(0, end_time, int(end_time * 10))
+        self.dt = self.ts[1]
+        self.dt_control = dt_control
+        self.dt_predict = dt_predict
+        self.bioreactor, self.lin_model, self.K, self.f = get_parts(dt_control=dt_control, N_particles=N_particles, pf=pf)
+        self.controller = controller or hold_controller
+        self._rng = numpy.random.default_rng(seed)
+
+        self.us = [_U_FALLBACK.copy()]
+        self.xs = [self.bioreactor.X.copy()]
+        self.ys = [self.bioreactor.outputs(self.us[-1])]
+        self.ys_meas = [self.bioreactor.outputs(self.us[-1])]
+        self.xs_f = [self.f.point_estimate()]
+        self.ys_f = [numpy.array(model.Bioreactor.static_outputs(self.xs_f[-1], self.us[-1]))]
+        self.covariance_point_size = [self.f.point_covariance()]
+        self.performance = None
+        self.predict_count, self.update_count = 0, 0
+
+    def simulate(self):
+        """Performs a simulation using the simulation parameters (sim_base.py:243-309)."""
+        t_next_control, t_next_predict = 0, 0
+        for t in self.ts[1:]:
+            if t > t_next_predict:
+                self.f.predict(self.us[-1], self.dt)
+                self.predict_count += 1
+                t_next_predict += self.dt_predict
+            if t > t_next_control:
+                self.f.update(self.us[-1], self.ys_meas[-1][_OUTPUTS])
+                self.f.resample()
+                self.update_count += 1
+                self.xs_f.append(self.f.point_estimate())
+                u = numpy.asarray(self.controller(self.xs_f[-1], self.us[-1], self.ys_meas[-1]), dtype=numpy.float64)
+                self.us.append(u.copy())
+                t_next_control += self.dt_control
+            else:
+                self.us.append(self.us[-1])
+
+            self.bioreactor.step(self.dt, self.us[-1])
+            self.bioreactor.X += _host_mixture_draw(self._rng, _STATE_NOISE, 1)[0]
+            outputs = self.bioreactor.outputs(self.us[-1])
+            self.ys.append(outputs.copy())
+            outputs[_OUTPUTS] += _host_mixture_draw(self._rng, _MEAS_NOISE, 1)[0]
+            self.ys_meas.append(outputs)
+            self.xs.append(self.bioreactor.X.copy())
+            estimate = self.f.point_estimate()
+            self.ys_f.append(numpy.array(model.Bioreactor.static_outputs(estimate, self.us[-1])))
+            self.covariance_point_size.append(self.f.point_covariance())
+
+        for name in ("us", "xs", "ys", "ys_meas", "xs_f", "ys_f", "covariance_point_size"):
+            setattr(self, name, numpy.array(getattr(self, name)))
+        self.performance = performance(self.ys[:, _OUTPUTS], self.ys_f, self.ts)
+
+
+class BatchedSimulation:
+    """B independent closed loops advanced together: the Monte-Carlo repetitions of the reference's closed-loop
+    performance study (results/pf_closedloop/bioreactor_performance_pf.py:104-118, a sequential Python loop there)
+    become the batch dimension of every kernel launch.  Plants are vectorised NumPy on the host; per tick there is one
+    fused estimator launch and one synchronisation (the estimates of all rollouts)."""
+
+    def __init__(self, batch, N_particles, dt_control, dt_predict, end_time=50, controller=None, seed=0):
+        self.B = int(batch)
+        self.ts = numpy.linspace(0, end_time, int(end_time * 10))
+        self.dt = self.ts[1]
+        self.dt_control, self.dt_predict = dt_control, dt_predict
+        xss = model.Bioreactor.find_SS(numpy.array([0.06, 0.2]), numpy.array([260 / 180, 640 / 24.6, 1000 / 116, 0, 0]))
+        state_pdf, measurement_pdf = get_noise()
+        x0, _ = get_noise()
+        x0.means += numpy.asarray(xss[numpy.newaxis, :], dtype=numpy.float32)
+        self.f = _filter.BatchedParticleFilter(model.Bioreactor.homeostatic_DEs, model.Bioreactor.static_outputs,
+                                               N_particles, x0, state_pdf, measurement_pdf, batch=self.B)
+        self.controller = controller or hold_controller
+        self._rng = numpy.random.default_rng(seed)
+        self.X = numpy.repeat(xss[None, :], self.B, axis=0)
+        self.us = [numpy.repeat(_U_FALLBACK[None, :], self.B, axis=0)]
+        self.xs, self.ys, self.ys_f, self.covariance_point_size = [self.X.copy()], [], [], []
+        self.ys.append(self._outputs())
+        self.ys_meas = [self.ys[-1].copy()]
+        est, cov = self.f.estimates()
+        self.xs_f = [est]
+        self.ys_f.append(numpy.stack([est[:, 0] * 180, est[:, 2] * 116], axis=1))
+        self.covariance_point_size.append(cov)
+        self.performance = None
+
+    def _outputs(self):
+        return self.X * numpy.array([180, 24.6, 116, 46, 1])
+
+    def _plant_step(self, u):
+        dX = numpy.array([model.Bioreactor.homeostatic_DEs(self.X[b], u[b], 1) for b in range(self.B)])
+        self.X = self.X + dX * self.dt
+        self.X[:, :4] = numpy.maximum(self.X[:, :4], 0)
+
+    def simulate(self):
+        t_next_control, t_next_predict = 0, 0
+        for t in self.ts[1:]:
+            if t > t_next_predict:
+                self.f.predict(self.us[-1], self.dt)
+                t_next_predict += self.dt_predict
+            if t > t_next_control:
+                self.f.update(self.us[-1], self.ys_meas[-1][:, _OUTPUTS])
+                self.f.resample()
+                est = self.f.point_estimate()
+                self.xs_f.append(est)
+                u = numpy.array([self.controller(est[b], self.us[-1][b], self.ys_meas[-1][b]) for b in range(self.B)])
+                self.us.append(u)
+                t_next_control += self.dt_control
+            else:
+                self.us.append(self.us[-1])
+            self._plant_step(self.us[-1])
+            self.X += _host_mixture_draw(self._rng, _STATE_NOISE, self.B)
+            out = self._outputs()
+            self.ys.append(out.copy())
+            out[:, _OUTPUTS] += _host_mixture_draw(self._rng, _MEAS_NOISE, self.B)
+            self.ys_meas.append(out)
+            self.xs.append(self.X.copy())
+            est, cov = self.f.estimates()
+            self.ys_f.append(numpy.stack([est[:, 0] * 180, est[:, 2] * 116], axis=1))
+            self.covariance_point_size.append(cov)
+        for name in ("us", "xs", "ys", "ys_meas", "xs_f", "ys_f", "covariance_point_size"):
+            setattr(self, name, numpy.array(getattr(self, name)))
+        self.performance = numpy.array([performance(self.ys[:, b][:, _OUTPUTS], self.ys_f[:, b], self.ts)
+                                        for b in range(self.B)])

@@ -1,0 +1,82 @@
+"""Closed-loop driver and the batch of filters behind it, -m gpu."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("no HIP device", allow_module_level=True)
+
+import gpu_se_amd                                            # noqa: E402
+from gpu_se_amd import sim_base                              # noqa: E402
+from gpu_se_amd.filter import BatchedParticleFilter, ParallelParticleFilter   # noqa: E402
+from gpu_se_amd.model import Bioreactor                      # noqa: E402
+from oracle import gse_oracle as orc                         # noqa: E402
+
+
+def _parts(seed):
+    gpu_se_amd.seed(seed)
+    sp, mp = sim_base.get_noise()
+    x0, _ = sim_base.get_noise()
+    x0.means += orc.steady_state()[None, :].astype(np.float32)
+    return x0, sp, mp
+
+
+def test_batched_filter_with_one_filter_equals_the_plain_class():
+    n = 3000
+    a = ParallelParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, *_parts(5))
+    b = BatchedParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, *_parts(5), batch=1)
+    z = np.array(orc.bioreactor_g(orc.steady_state())) + [0.1, -0.2]
+    for c in range(4):
+        for f in (a, b):
+            f.predict([0.05, 0.2], 0.1)
+            f.update([0.05, 0.2], z)
+            f.resample(r=0.25 + 0.1 * c)
+    np.testing.assert_array_equal(a.particles.get(), b.particles.get())
+    np.testing.assert_array_equal(a.point_estimate(), b.point_estimate()[0])
+
+
+def test_batched_filter_tracks_per_filter_measurements():
+    """Three filters in one batch, each fed its own measurement: every estimate follows ITS measurement."""
+    n, B = 1 << 14, 3
+    f = BatchedParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, *_parts(9), batch=B)
+    assert tuple(f.particles.shape) == (B, n, 5) and tuple(f.weights.shape) == (B, n)
+    xss = orc.steady_state()
+    shift = np.array([-0.004, 0.0, 0.004])
+    z = np.stack([(xss[0] + shift) * 180, np.full(B, xss[2] * 116)], axis=1)
+    u = np.repeat([[0.06, 0.2]], B, axis=0)
+    for c in range(15):
+        f.predict(u, 0.1)
+        f.update(u, z)
+        f.resample()
+    est, cov = f.estimates()
+    assert est.shape == (B, 5) and cov.shape == (B,)
+    np.testing.assert_allclose(est[:, 0], xss[0] + shift, atol=1.2e-3)
+    assert est[0, 0] < est[1, 0] < est[2, 0]
+
+
+def test_closed_loop_simulation_tracks_the_plant():
+    gpu_se_amd.seed(1)
+    sim = sim_base.Simulation(N_particles=1 << 14, dt_control=0.1, dt_predict=0.1, end_time=6, seed=3)
+    sim.simulate()
+    steps = len(sim.ts)
+    assert sim.xs.shape == (steps, 5) and sim.ys_f.shape == (steps, 2) and sim.us.shape == (steps, 2)
+    assert sim.predict_count == steps - 1 and sim.update_count == steps - 1
+    # the estimate at tick t has seen the measurement of tick t-1 (then the plant moves on by a step plus state noise
+    # of 1.8-5.7 mg/L): compare it with the plant output it was told about
+    err = np.abs(sim.ys_f[5:] - sim.ys[4:-1, [0, 2]])
+    assert np.median(err[:, 0]) < 0.6 and np.median(err[:, 1]) < 0.8          # mg/L; measurement sigma is 0.25 / 0.28
+    assert np.isfinite(sim.performance) and np.all(np.isfinite(sim.covariance_point_size))
+
+
+def test_batched_closed_loops():
+    gpu_se_amd.seed(2)
+    sim = sim_base.BatchedSimulation(batch=4, N_particles=1 << 13, dt_control=0.1, dt_predict=0.1, end_time=4, seed=7)
+    sim.simulate()
+    steps = len(sim.ts)
+    assert sim.xs.shape == (steps, 4, 5) and sim.ys_f.shape == (steps, 4, 2)
+    assert sim.performance.shape == (4,) and np.all(np.isfinite(sim.performance))
+    err = np.abs(sim.ys_f[5:] - sim.ys[4:-1][:, :, [0, 2]])
+    assert np.median(err[..., 0]) < 0.6
+    assert len(np.unique(np.round(sim.performance, 6))) == 4                      # independent rollouts
