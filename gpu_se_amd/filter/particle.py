@@ -109,6 +109,7 @@ class ParallelParticleFilter:
         self._want_index = False
         self._last_index = None
         self.lazy = True                                    # False: every method launches its own kernel at once
+        self._moments_host = None                           # cached device moments (cleared by anything that changes x, w)
         self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
 
         # particles ~ x0 (particle.py:49), drawn on the device straight into the state-major buffer
@@ -127,10 +128,9 @@ class ParallelParticleFilter:
     def _fill(self, buf, values, width):
         B = self._B
         if B == 1:
-            if width == 2:
-                buf[0], buf[1] = values
-            else:
-                buf[0] = values
+            flat = numpy.asarray(values, dtype=numpy.float64).reshape(-1)
+            for i in range(width):
+                buf[i] = flat[i]
             return
         a = numpy.broadcast_to(numpy.asarray(values, dtype=numpy.float64).reshape(-1, width) if width > 1
                                else numpy.asarray(values, dtype=numpy.float64).reshape(-1, 1), (B, width))
@@ -212,6 +212,7 @@ class ParallelParticleFilter:
         self._pend_gather = False
         self._gather_slot = None
         self._pend_predict = None
+        self._moments_host = None
         if update is not None:
             self._tiles_valid = True
             self._scan_slot = scan_out
@@ -228,6 +229,7 @@ class ParallelParticleFilter:
         v = as_device(value, torch.float32).reshape(self._B, self.N_particles, _lib.GSE_NX)
         self._flush()
         self._x[:, :, :self.N_particles] = v.transpose(1, 2)
+        self._moments_host = None
 
     @property
     def weights(self):
@@ -243,6 +245,7 @@ class ParallelParticleFilter:
         self._w[:, :self.N_particles] = v
         self._tiles_valid = False
         self._scan_slot = None
+        self._moments_host = None
 
     # ------------------------------------------------------------------ the cycle
     def predict(self, u, dt):
@@ -251,7 +254,7 @@ class ParallelParticleFilter:
         if self._pend_predict is not None:
             self._flush()                                   # two predicts in a row: run the first one now
         if self._B == 1:
-            u0, u1 = u
+            u0, u1 = numpy.asarray(u, dtype=numpy.float64).reshape(-1)
             u = (float(u0), float(u1))
         else:
             u = numpy.array(u, dtype=numpy.float64)
@@ -296,19 +299,23 @@ class ParallelParticleFilter:
             return DevArray.wrap(v[0] if self._B == 1 else v)
 
     # ------------------------------------------------------------------ estimates
-    def _raw_moments_all(self):
-        """Per filter (S0, S1 = sum w d, S2 = sum w d d^T (5x5), pivot) with d = x - pivot (synchronises)."""
+    def _raw_moments_arrays(self):
+        """(S0 (B,), S1 (B, 5), S2 (B, 5, 5), pivot (B, 5)) with d = x - pivot, from the device (synchronises)."""
         self._flush()
-        _lib.call("gse_pf_moments", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
-                  self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
-        m = self._moments.cpu().numpy()
-        out = []
-        for b in range(self._B):
-            s2 = numpy.zeros((_lib.GSE_NX, _lib.GSE_NX))
-            s2[numpy.triu_indices(_lib.GSE_NX)] = m[b, 6:21]
-            s2 = s2 + s2.T - numpy.diag(numpy.diag(s2))
-            out.append((float(m[b, 0]), m[b, 1:6].copy(), s2, m[b, 21:26].copy()))
-        return out
+        if self._moments_host is None:                      # nothing changed since the last estimate: reuse it
+            _lib.call("gse_pf_moments", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
+                      self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
+            self._moments_host = self._moments.cpu().numpy()
+        m = self._moments_host
+        iu = numpy.triu_indices(_lib.GSE_NX)
+        s2 = numpy.zeros((self._B, _lib.GSE_NX, _lib.GSE_NX))
+        s2[:, iu[0], iu[1]] = m[:, 6:21]
+        s2[:, iu[1], iu[0]] = m[:, 6:21]
+        return m[:, 0].copy(), m[:, 1:6].copy(), s2, m[:, 21:26].copy()
+
+    def _raw_moments_all(self):
+        s0, s1, s2, pv = self._raw_moments_arrays()
+        return [(float(s0[b]), s1[b], s2[b], pv[b]) for b in range(self._B)]
 
     def _raw_moments(self):
         return self._raw_moments_all()[0]
@@ -365,17 +372,21 @@ class BatchedParticleFilter(ParallelParticleFilter):
     def batch(self):
         return self._B
 
+    def estimates(self):
+        """(point estimates (B, 5), covariance sizes (B,)) from ONE device pass and one synchronisation; the pivot
+        shift of moments_to_mean_cov, vectorised over the batch."""
+        s0, s1, s2, pv = self._raw_moments_arrays()
+        mean = s1 + pv * s0[:, None]
+        e = mean - pv
+        cov = (s2 - s1[:, :, None] * e[:, None, :] - e[:, :, None] * s1[:, None, :]
+               + s0[:, None, None] * e[:, :, None] * e[:, None, :])
+        return mean, numpy.linalg.svd(cov, compute_uv=False)[:, 0]
+
     def point_estimate(self):
-        return numpy.array([m[1] for m in self._moment_sums_all()])
+        return self.estimates()[0]
 
     def point_covariance(self):
-        return numpy.array([numpy.linalg.svd(m[2], compute_uv=False)[0] for m in self._moment_sums_all()])
-
-    def estimates(self):
-        """(point estimates (B, 5), covariance sizes (B,)) from ONE device pass and one synchronisation."""
-        ms = self._moment_sums_all()
-        return (numpy.array([m[1] for m in ms]),
-                numpy.array([numpy.linalg.svd(m[2], compute_uv=False)[0] for m in ms]))
+        return self.estimates()[1]
 
 
 def moments_to_mean_cov(s0, s1, s2_upper, pivot):

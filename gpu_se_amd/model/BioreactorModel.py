@@ -54,6 +54,28 @@ class Bioreactor:
                 r_h * dt)
 
     @staticmethod
+    def homeostatic_DEs_rows(X, U, dt=1):
+        """homeostatic_DEs for B plants at once: X (B, 5), U (B, 2) -> increments (B, 5); NumPy, same expressions
+        (the host side of BatchedSimulation)."""
+        X = numpy.asarray(X, dtype=numpy.float64)
+        U = numpy.asarray(U, dtype=numpy.float64)
+        cg, cx, cfa, ce = (numpy.maximum(X[:, k], 0.0) for k in range(4))
+        ch = X[:, 4]
+        fg, fm = U[:, 0], U[:, 1]
+        outflow = fg + fm
+        sat = cg / (1e-2 + cg)
+        r_h = 280 / 180 - cg
+        r_fa = 0.25 / 116 * cx * 24.6 * sat
+        cap1 = (0.4 - 0.25) / 180 * cx * 24.6
+        want1 = cap1 - (cap1 / 2000 / (0.28 / 180) * r_h + 0.01 * ch)
+        th1 = numpy.minimum(cap1, numpy.maximum(0.0, want1)) * sat
+        r_e = numpy.minimum(0.025 / 46 * cx * 24.6, numpy.maximum(0.0, want1 - cap1))
+        th2 = numpy.minimum((0.1 - 0.025) / 180 * cx * 24.6, numpy.maximum(0.0, want1 - cap1 - r_e))
+        r_g = -r_fa * (116 / 180) - th1 - r_e * (46 / 180) - th2
+        return numpy.stack([(fg * (5000 / 180) - outflow * cg + r_g) * dt, 0.0 * cx * dt,
+                            (-outflow * cfa + r_fa) * dt, (-outflow * ce + r_e) * dt, r_h * dt], axis=1)
+
+    @staticmethod
     def static_outputs(x, u):
         """(mass of glucose, mass of fumaric acid) = (Cg*180, Cfa*116)."""
         return x[0] * 180, x[2] * 116

@@ -220,7 +220,7 @@ class BatchedSimulation:
         return self.X * numpy.array([180, 24.6, 116, 46, 1])
 
     def _plant_step(self, u):
-        dX = numpy.array([model.Bioreactor.homeostatic_DEs(self.X[b], u[b], 1) for b in range(self.B)])
+        dX = model.Bioreactor.homeostatic_DEs_rows(self.X, u, 1)
         self.X = self.X + dX * self.dt
         self.X[:, :4] = numpy.maximum(self.X[:, :4], 0)
 

@@ -80,6 +80,11 @@ def test_host_model_matches_oracle():
         x[3] = rng.uniform(-0.1, 0.3)
         u = rng.uniform(0, 0.2, 2)
         np.testing.assert_allclose(Bioreactor.homeostatic_DEs(x, u, 0.3), orc.bioreactor_f(x, u, 0.3), rtol=1e-12, atol=1e-15)
+    X = xss[None, :] * (1 + 0.3 * rng.uniform(-1, 1, (20, 5)))
+    U = rng.uniform(0, 0.2, (20, 2))
+    rows = Bioreactor.homeostatic_DEs_rows(X, U, 0.3)
+    for i in range(20):
+        np.testing.assert_allclose(rows[i], Bioreactor.homeostatic_DEs(X[i], U[i], 0.3), rtol=1e-13, atol=1e-16)
     assert Bioreactor.static_outputs(xss, None) == (xss[0] * 180, xss[2] * 116)
     b = Bioreactor(xss)
     b.step(0.1, [0.06, 0.2])
