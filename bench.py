@@ -123,13 +123,22 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    # rehearsal on a one-GPU box: GSE_BENCH_REHEARSAL=1 maps every rank to device 0 and uses gloo for the collectives
+    rehearsal = os.environ.get("GSE_BENCH_REHEARSAL") == "1"
+    backend = "gloo" if rehearsal else "nccl"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("GSE_FORCE_DIST") == "1"      # the latter: exercise RCCL with one rank
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     n = int(round(2 ** args.log2_particles))
     gpu_se_amd.seed(1234)
@@ -162,7 +171,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     est = pf.point_estimate()                                   # merges the shards (all-reduce of the moments)
@@ -174,9 +183,14 @@ def main():
         #      state one cycle is ONE launch, pf_step_kernel<gather, predict, update, scan in+out>: resample() and
         #      predict() only record their arguments, update() launches the fused pass.
         lp = pf.local
+
+        def local_cycle(i):                 # rank 0 only: the local filter, no collective (other ranks are at the barrier)
+            u, z = io[i % len(io)]
+            lp.predict(u, dt)
+            lp.update(u, z)
+            lp.resample()
         reps = max(50, min(steps, 400))
-        per = {"cycle": time_method_events(torch, cycle, reps)}
-        pf.wait_collectives()
+        per = {"cycle": time_method_events(torch, local_cycle, reps)}
         dom = "cycle"
         achieved = 140.0 * n / per[dom] / 1e9
         roofline = {"bound": "hbm", "kernel": "pf_step_kernel<gather,predict,update,scan>",

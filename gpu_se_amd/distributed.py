@@ -129,8 +129,9 @@ class ShardedParticleFilter:
     def _reduce_weight_sum(self):
         if self.group is not None:
             self.wait_collectives()
+            # a buffer of its own: the next launch rewrites island[1] while the collective may still be in flight
             if self._merge_device.type == "cuda":
-                self._wsum = self.local._island[1]                 # contiguous [1] view written by the kernel
+                self._wsum.copy_(self.local._island[1])
             else:
                 self._wsum = self.local._island[1].cpu()
             self._pending = dist.all_reduce(self._wsum, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

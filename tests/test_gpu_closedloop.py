@@ -80,3 +80,49 @@ def test_batched_closed_loops():
     err = np.abs(sim.ys_f[5:] - sim.ys[4:-1][:, :, [0, 2]])
     assert np.median(err[..., 0]) < 0.6
     assert len(np.unique(np.round(sim.performance, 6))) == 4                      # independent rollouts
+
+
+# ------------------------------------------------------------------------------ sharded filter across two ranks
+def _sharded_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks share the one GPU of the test box
+    torch.cuda.set_device(0)
+    import gpu_se_amd as g
+    from gpu_se_amd.distributed import ShardedParticleFilter
+    g.seed(77)
+    spf = ShardedParticleFilter.from_get_parts(n_local=1 << 15, group=dist.group.WORLD)
+    spf.reduce_every = 2
+    xss = orc.steady_state()
+    z = np.array(orc.bioreactor_g(xss)) + [0.3, -0.2]
+    for c in range(6):
+        spf.predict([0.06, 0.2], 0.1)
+        spf.update([0.06, 0.2], z)
+        spf.resample()
+    spf.wait_collectives()
+    est = spf.point_estimate()
+    cov = spf.point_covariance()
+    lo = spf.local._element_offset
+    out[rank] = (est, float(cov), lo, float(spf.local._island[0, 0].item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_filter_two_ranks_share_one_posterior():
+    """Two processes (gloo group, both on the test box's GPU), each owning half of the particles with its own Philox
+    sub-stream: after the merge both report the SAME posterior, and it sits where a single filter puts it."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    manager = mp.Manager()
+    out = manager.dict()
+    mp.spawn(_sharded_worker, args=(2, port, out), nprocs=2, join=True)
+    (e0, c0, lo0, l0), (e1, c1, lo1, l1) = out[0], out[1]
+    np.testing.assert_array_equal(e0, e1)
+    assert c0 == c1 and lo0 == 0 and lo1 == 1 << 15 and l0 != l1
+    xss = orc.steady_state()
+    assert abs(e0[0] * 180 - (xss[0] * 180 + 0.3)) < 0.4          # follows the measurement (sigma 0.245)
