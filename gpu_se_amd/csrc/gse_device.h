@@ -328,14 +328,18 @@ __device__ __forceinline__ double smallest_with_quotient_ge(double u, double W) 
     return x;
 }
 
-constexpr int kSpanMax = 2048;            // cumulative weights staged in LDS per pass (16 KiB)
+#ifndef GSE_SPAN_MAX
+#define GSE_SPAN_MAX 2048
+#endif
+constexpr int kSpanMax = GSE_SPAN_MAX;    // cumulative weights staged in LDS per pass (8 B each)
+static_assert(kSpanMax <= 4096, "span_search bisects 12 times");
 constexpr int kSpanPasses = 8;            // spans up to kSpanPasses * kSpanMax ancestors are bisected in LDS
 
 // Ancestor of one output with threshold u among the staged span seg[0..len): first q with seg[q] >= u.
 __device__ __forceinline__ int span_search(const double* seg, int len, double u) {
     int lo = 0, hi = len - 1;
 #pragma unroll
-    for (int it = 0; it < 11; ++it) {             // 2^11 = kSpanMax
+    for (int it = 0; it < 12; ++it) {             // 2^12 >= kSpanMax
         const int mid = (lo + hi) >> 1;
         const bool open = lo < hi;
         const bool less = open && (seg[mid] < u);

@@ -42,6 +42,20 @@ struct StepArgs {
 #ifndef GSE_STAGGER
 #define GSE_STAGGER 1            // gather variants: half of the workgroups draw their noise before the memory phases
 #endif
+// Where a workgroup of a gather launch draws its noise (tuning knob, see the kernel comment): 0 = before anything,
+// 1 = after the tile prefix, 2 = while the span is being staged, 3 = behind the state loads.
+// GSE_STAGGER = 0: everybody at 3; 1: two groups (0 and 3); 2: four groups.
+__device__ __forceinline__ int draw_position(unsigned bx) {
+#if GSE_STAGGER == 0
+    return 3;
+#elif GSE_STAGGER == 2
+    return (int)(((bx >> 8) ^ bx) & 3u);
+#elif GSE_STAGGER == 3
+    return (int)((((bx >> 8) ^ bx) & 3u) % 3u == 0 ? 0 : ((((bx >> 8) ^ bx) & 3u) % 3u == 1 ? 2 : 3));
+#else
+    return (((bx >> 8) ^ bx) & 1u) ? 0 : 3;
+#endif
+}
 #ifndef GSE_GATHER_STRIDED
 #define GSE_GATHER_STRIDED 1     // gather variants: a thread's 4 outputs are 256 apart (1) or consecutive (0)
 #endif
@@ -117,12 +131,13 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         }
     };
     constexpr bool kDraw = kPredict && !kInjected;
-    const bool draw_early = kDraw && kGather && GSE_STAGGER && ((((blockIdx.x >> 8) ^ blockIdx.x) & 1) != 0);
+    const int draw_at = (kDraw && kGather) ? draw_position(blockIdx.x) : 3;      // workgroup-uniform
     if (kDraw) __syncthreads();                          // dp staged
-    if (draw_early) draw_all();
+    if (kDraw && draw_at == 0) draw_all();
 
     // ---- gather: ancestors of this thread's 4 outputs -------------------------------------------------
     int32_t anc[kPerThread] = {0, 0, 0, 0};
+    bool drawn2 = false;
     if (kGather) {
         double W;
         if (kScanIn) {
@@ -148,6 +163,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         } else {
             W = totals[b];
         }
+        if (kDraw && draw_at == 1) draw_all();
         const double r = a.ra.r[b];
         // Weights that do not sum to a positive finite number: the reference's normalised cumsum is all-NaN and its
         // sweep never advances (filter/particle.py:98), so every offspring copies particle 0 (anc stays 0).
@@ -166,8 +182,13 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                 const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
                 return (k == last) ? pfx_s[t + 1] : fmin(pfx_s[t] + cb[k], pfx_s[t + 1]);
             };
+            // u_j = (j + r) / N as the reference forms it; for N a power of two the division is an exact scaling and
+            // (j + r) * (1 / N) gives the same bits without a division
+            const bool pow2 = (N & (N - 1)) == 0;
+            const double invN = 1.0 / Nd;
             auto threshold = [&](uint32_t j) -> double {
-                const double u = ((double)j + r) / Nd;
+                const double jr = (double)j + r;
+                const double u = pow2 ? jr * invN : jr / Nd;
                 return kScanIn ? smallest_with_quotient_ge(u, W) : u;
             };
             const int64_t j0 = tile0;
@@ -183,6 +204,10 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             double thr[kPerThread];
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p) thr[p] = threshold(jp[p]);
+            if (kDraw && draw_at == 2) {
+                draw_all();
+                drawn2 = true;
+            }
             if (len <= (int64_t)kSpanPasses * kSpanMax) {
                 // Stage the span in LDS, kSpanMax keys at a time (one pass in the common case; the ancestors of a tile
                 // of 1024 outputs span ~1000 particles at the median and < 8192 in the tail even when the effective
@@ -227,6 +252,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             }
         }
     }
+    if (kDraw && draw_at == 2 && !drawn2) draw_all();      // (weights that do not sum to a positive number: no search)
     // a thread is live if it owns at least one particle (its first one)
     const bool live = jp[0] < Nu;
     float wnew[kPerThread] = {w_uniform, w_uniform, w_uniform, w_uniform};
@@ -280,7 +306,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 0) {
-                if (kDraw && !draw_early) draw_all();
+                if (kDraw && draw_at == 3) draw_all();
                 if (kPredict && kInjected) {
 #pragma unroll
                     for (int p = 0; p < kPerThread; ++p)
