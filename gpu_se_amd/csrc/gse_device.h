@@ -346,7 +346,7 @@ __device__ __forceinline__ double smallest_with_quotient_ge(double u, double W) 
 #endif
 constexpr int kSpanMax = GSE_SPAN_MAX;    // cumulative weights staged in LDS per pass (8 B each)
 static_assert(kSpanMax <= 4096, "span_search bisects 12 times");
-constexpr int kSpanPasses = 8;            // spans up to kSpanPasses * kSpanMax ancestors are bisected in LDS
+
 
 // Ancestor of one output with threshold u among the staged span seg[0..len): first q with seg[q] >= u.
 __device__ __forceinline__ int span_search(const double* seg, int len, double u) {

@@ -208,41 +208,26 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                 draw_all();
                 drawn2 = true;
             }
-            if (len <= (int64_t)kSpanPasses * kSpanMax) {
-                // Stage the span in LDS, kSpanMax keys at a time (one pass in the common case; the ancestors of a tile
-                // of 1024 outputs span ~1000 particles at the median and < 8192 in the tail even when the effective
-                // sample size is 0.01 % of N), and bisect there.  An output is resolved in the pass whose last key
-                // reaches its threshold.
-                bool open[kPerThread] = {true, true, true, true};
-                for (int64_t base = klo; base <= khi; base += kSpanMax) {            // workgroup-uniform
-                    const int cnt = (int)min((int64_t)kSpanMax, khi - base + 1);
-                    if (base != klo) __syncthreads();                                // previous pass fully read
-                    for (int q = tid; q < cnt; q += kBlock) seg[q] = key(base + q);
-                    __syncthreads();
-                    const double top = seg[cnt - 1];
-                    const bool final_pass = base + cnt > khi;
+            if (len <= kSpanMax) {
+                // the span fits LDS (the common case: ~1000 ancestors at the median): stage it, bisect there
+                for (int q = tid; q < (int)len; q += kBlock) seg[q] = key(klo + q);
+                __syncthreads();
 #pragma unroll
-                    for (int p = 0; p < kPerThread; ++p)
-                        if (open[p] && (thr[p] <= top || final_pass)) {
-                            anc[p] = (int32_t)base + span_search(seg, cnt, thr[p]);
-                            open[p] = false;
-                        }
-                }
+                for (int p = 0; p < kPerThread; ++p) anc[p] = (int32_t)klo + span_search(seg, (int)len, thr[p]);
             } else {
-                // A longer stretch of (nearly) weightless particles: search the keys in memory.  With SCAN_IN the tile
-                // is found first in the LDS prefix (no memory access), then 10 probes inside the tile.
+                // A long span: the tile's ancestors are spread over a stretch of (nearly) weightless particles.  Two
+                // levels: LDS gets every s-th key (the last of each group of s, so seg[g] = max of group g); an output
+                // bisects the groups in LDS, then the <= s keys of its group in memory (log2 s probes inside a few
+                // cache lines).  One staging pass and one short dependent chain whatever the length of the span.
+                const int64_t s_ = (len + kSpanMax - 1) / kSpanMax;              // group size, >= 2
+                const int groups = (int)((len + s_ - 1) / s_);                    // <= kSpanMax
+                for (int q = tid; q < groups; q += kBlock) seg[q] = key(min(klo + (int64_t)(q + 1) * s_, khi + 1) - 1);
+                __syncthreads();
 #pragma unroll
                 for (int p = 0; p < kPerThread; ++p) {
-                    int64_t lo = klo, hi = khi;
-                    if (kScanIn) {
-                        int tl = (int)(klo / kTile), th = (int)(khi / kTile);     // first tile whose end value >= thr
-                        while (tl < th) {
-                            const int mid = (tl + th) >> 1;
-                            if (pfx_s[mid + 1] < thr[p]) tl = mid + 1; else th = mid;
-                        }
-                        lo = max(lo, (int64_t)tl * kTile);
-                        hi = min(hi, min((int64_t)(tl + 1) * kTile, N) - 1);
-                    }
+                    const int g_ = span_search(seg, groups, thr[p]);
+                    int64_t lo = klo + (int64_t)g_ * s_;
+                    int64_t hi = min(lo + s_, khi + 1) - 1;
                     while (lo < hi) {
                         const int64_t mid = (lo + hi) >> 1;
                         if (key(mid) < thr[p]) lo = mid + 1; else hi = mid;
