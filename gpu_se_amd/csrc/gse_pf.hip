@@ -56,6 +56,15 @@ __device__ __forceinline__ int draw_position(unsigned bx) {
     return (((bx >> 8) ^ bx) & 1u) ? 0 : 3;
 #endif
 }
+#ifndef GSE_XCD_REMAP
+#define GSE_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int xcd_contiguous_tile(unsigned bx, int T) {
+#if GSE_XCD_REMAP
+    if ((T & 7) == 0) return (int)((bx & 7u) * (unsigned)(T >> 3) + (bx >> 3));
+#endif
+    return (int)bx;
+}
 #ifndef GSE_GATHER_STRIDED
 #define GSE_GATHER_STRIDED 1     // gather variants: a thread's 4 outputs are 256 apart (1) or consecutive (0)
 #endif
@@ -96,7 +105,12 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     extern __shared__ double pfx_s[];         // [T + 1] with SCAN_IN (dynamic; statics above total a multiple of 16 B)
 
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t tile0 = (int64_t)blockIdx.x * kTile;
+    // Tile of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD); an output
+    // tile reads ancestors from its own and the neighbouring tiles, which the previous launch wrote.  Giving each XCD a
+    // CONTIGUOUS range of tiles keeps those neighbours -- and the lines they left in that XCD's L2 -- on one XCD
+    // (speed only: nothing depends on the placement).
+    const int tile_id = xcd_contiguous_tile(blockIdx.x, T);
+    const int64_t tile0 = (int64_t)tile_id * kTile;
     const int64_t i0 = tile0 + (int64_t)tid * kPerThread;       // consecutive mapping: first of this thread's 4
     const double Nd = (double)N;
     const float w_uniform = (float)(1.0 / Nd);
@@ -156,7 +170,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             if (tid == 0) pfx_s[T] = total;
             __syncthreads();
             W = pfx_s[T];
-            if (island && blockIdx.x == 0 && tid == 0) {   // shard bookkeeping (see gse_pf_resample)
+            if (island && tile_id == 0 && tid == 0) {      // shard bookkeeping (see gse_pf_resample)
                 island[b] += log(W);
                 island[gridDim.y + b] = W;
             }
@@ -399,10 +413,10 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         sc[3] = sc[2] + ((i0 + 3 < N) ? (double)wnew[3] : 0.0);
         double total;
         const double excl = block_exclusive_scan(sc[3], red, total);
-        if (tid == 0) tile_sums[(int64_t)b * T + blockIdx.x] = total;
+        if (tid == 0) tile_sums[(int64_t)b * T + tile_id] = total;
         if (kScanOut) {
             // tile-local inclusive scan of the new weights, the expression cumsum_kernel uses: L = excl + s_p
-            if (tid == 0) scan_out_sums[(int64_t)b * T + blockIdx.x] = total;
+            if (tid == 0) scan_out_sums[(int64_t)b * T + tile_id] = total;
             double* lb = scan_out + (int64_t)b * N;
             if (i0 + 3 < N && (N & 1) == 0) {
                 *reinterpret_cast<double2*>(lb + i0) = make_double2(excl + sc[0], excl + sc[1]);
