@@ -15,6 +15,7 @@ GSE_RESAMPLE_SEPARATE_SCAN = 2
 GSE_OP_GATHER, GSE_OP_PREDICT, GSE_OP_UPDATE = 1, 2, 4
 GSE_OP_SCAN_IN, GSE_OP_SCAN_OUT, GSE_OP_SCAN_IN_SLOT1, GSE_OP_SCAN_OUT_SLOT1 = 8, 16, 32, 64
 GSE_SCAN_MAX_TILES = 4096
+GSE_GSUKF_CYCLE_MAX = 64
 
 c_f = ctypes.c_float
 c_d = ctypes.c_double
@@ -62,6 +63,8 @@ PROTOTYPES = {
     "gse_gsukf_sigma_points": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
     "gse_gsukf_predict": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_F, P_MIX, P_RNG, c_vp, c_vp, c_vp]),
     "gse_gsukf_update": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, P_D, P_F, P_MIX, c_vp, c_vp, c_vp]),
+    "gse_gsukf_cycle": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_D, P_D, P_F, P_MIX, P_RNG,
+                                       c_vp, P_MIX, c_vp, c_vp]),
     "gse_gsukf_resample": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_u32, c_vp, c_vp]),
     "gse_gsukf_moments": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
     "gse_model_f": (ctypes.c_int, [c_vp, c_vp, c_i64, P_D, c_d, c_vp]),

@@ -115,6 +115,69 @@ struct GsukfPredictArgs {
     double dt;
 };
 
+// Predict of ONE Gaussian by its 16 lanes.  mu_g / P_g: where this Gaussian is read, mu_o / P_o: where it is written
+// (may be the same memory: every read precedes the workgroup barrier inside, every write follows it).  tile_g: this
+// Gaussian's 56 floats of LDS.  g: its index in the filter (RNG element), nz: its injected noise row [11][5] or null.
+// Must be called by every thread of the workgroup.
+template <bool kInjected>
+__device__ __forceinline__ void gsukf_predict_phase(const float* mu_g, const float* P_g, float* mu_o, float* P_o,
+                                                    float* tile_g, bool live, int j, int b, int64_t g, const float* nz,
+                                                    const DrawParams& dp, int32_t* status, const GsukfPredictArgs& a) {
+    if (live && j < GSE_NSIGMA) {
+        float m[5], L[15], s[5];
+        bool ok;
+        load_and_factor(mu_g, P_g, m, L, ok);
+        if (!ok && j == 0 && status) atomicAdd(status, 1);
+        sigma_point(m, L, j, s);
+        bioreactor_step(s, a.io.f[b].u0, a.io.f[b].u1, a.dt);
+        float e[5];
+        if (kInjected) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) e[k] = nz[j * 5 + k];
+        } else {
+            uint32_t wd[8];
+            rng_words8(a.rng, (uint64_t)(g * GSE_NSIGMA + j), (uint32_t)b, wd);
+            mixture_draw5(dp, wd, e);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) tile_g[j * 5 + k] = s[k] + e[k];
+    }
+    __syncthreads();
+    if (!live || j >= 15) return;
+
+    // mean = (sum_j sigma_j * w_j) / sum(w)  -- fp32, j in order, no FMA contraction  (numpy.average)
+    float mean[5];
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float acc = tile_g[k] * a.sw.w[0];
+#pragma unroll
+            for (int q = 1; q < GSE_NSIGMA; ++q) acc = acc + tile_g[q * 5 + k] * a.sw.w[q];
+            mean[k] = acc / a.sw.scl32;
+        }
+    }
+    // lane l owns symmetric entry (r, c) of P = sum_j d_j (d_j w_j)^T
+    int r, c;
+    sym_entry(j, r, c);
+    float mr = 0.f, mc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        mr = (k == r) ? mean[k] : mr;
+        mc = (k == c) ? mean[k] : mc;
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < GSE_NSIGMA; ++q) {
+        const float dr = tile_g[q * 5 + r] - mr;
+        const float dc = tile_g[q * 5 + c] - mc;
+        acc = fmaf(dr, dc * a.sw.w[q], acc);
+    }
+    P_o[r * 5 + c] = acc;
+    P_o[c * 5 + r] = acc;
+    if (j < 5) mu_o[j] = mean[j];
+}
+
 template <bool kInjected>
 __global__ __launch_bounds__(kBlock) void gsukf_predict_kernel(float* __restrict__ mu, float* __restrict__ P,
                                                                const float* __restrict__ noise, int64_t N,
@@ -133,62 +196,8 @@ __global__ __launch_bounds__(kBlock) void gsukf_predict_kernel(float* __restrict
     const int64_t g = (int64_t)blockIdx.x * kGaussPerBlock + gl;
     const bool live = g < N;
     const int64_t gi = (int64_t)b * N + (live ? g : 0);
-
-    if (live && j < GSE_NSIGMA) {
-        float m[5], L[15], s[5];
-        bool ok;
-        load_and_factor(mu + gi * 5, P + gi * 25, m, L, ok);
-        if (!ok && j == 0 && status) atomicAdd(status, 1);
-        sigma_point(m, L, j, s);
-        bioreactor_step(s, a.io.f[b].u0, a.io.f[b].u1, a.dt);
-        float e[5];
-        if (kInjected) {
-            const float* nz = noise + (gi * GSE_NSIGMA + j) * 5;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) e[k] = nz[k];
-        } else {
-            uint32_t wd[8];
-            rng_words8(a.rng, (uint64_t)(g * GSE_NSIGMA + j), (uint32_t)b, wd);
-            mixture_draw5(dp, wd, e);
-        }
-#pragma unroll
-        for (int k = 0; k < 5; ++k) tile[gl][j * 5 + k] = s[k] + e[k];
-    }
-    __syncthreads();
-    if (!live || j >= 15) return;
-
-    // mean = (sum_j sigma_j * w_j) / sum(w)  -- fp32, j in order, no FMA contraction  (numpy.average)
-    float mean[5];
-    {
-#pragma clang fp contract(off)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            float acc = tile[gl][k] * a.sw.w[0];
-#pragma unroll
-            for (int q = 1; q < GSE_NSIGMA; ++q) acc = acc + tile[gl][q * 5 + k] * a.sw.w[q];
-            mean[k] = acc / a.sw.scl32;
-        }
-    }
-    // lane l owns symmetric entry (r, c) of P = sum_j d_j (d_j w_j)^T
-    int r, c;
-    sym_entry(j, r, c);
-    float mr = 0.f, mc = 0.f;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        mr = (k == r) ? mean[k] : mr;
-        mc = (k == c) ? mean[k] : mc;
-    }
-    float acc = 0.0f;
-#pragma unroll
-    for (int q = 0; q < GSE_NSIGMA; ++q) {
-        const float dr = tile[gl][q * 5 + r] - mr;
-        const float dc = tile[gl][q * 5 + c] - mc;
-        acc = fmaf(dr, dc * a.sw.w[q], acc);
-    }
-    float* Pg = P + gi * 25;
-    Pg[r * 5 + c] = acc;
-    Pg[c * 5 + r] = acc;
-    if (j < 5) mu[gi * 5 + j] = mean[j];
+    gsukf_predict_phase<kInjected>(mu + gi * 5, P + gi * 25, mu + gi * 5, P + gi * 25, tile[gl], live, j, b, g,
+                                   kInjected ? noise + gi * GSE_NSIGMA * 5 : nullptr, dp, status, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -222,32 +231,26 @@ __device__ __forceinline__ void pinv_sym2(double a, double s, double d, double (
     }
 }
 
-__global__ __launch_bounds__(kBlock) void gsukf_update_kernel(float* __restrict__ mu, float* __restrict__ P,
-                                                              float* __restrict__ w, int64_t N,
-                                                              int32_t* __restrict__ status, const GsukfUpdateArgs a) {
-    __shared__ float dev[kGaussPerBlock][GSE_NSIGMA * 5 + 1];     // sigma_j - mu
-    __shared__ double eta[kGaussPerBlock][GSE_NSIGMA * 2];        // g(sigma_j)
-    const int b = blockIdx.y;
-    const int j = threadIdx.x & (kGroup - 1);
-    const int gl = threadIdx.x / kGroup;
-    const int64_t g = (int64_t)blockIdx.x * kGaussPerBlock + gl;
-    const bool live = g < N;
-    const int64_t gi = (int64_t)b * N + (live ? g : 0);
-
+// Update of ONE Gaussian by its 16 lanes, in place in mu_g / P_g (global memory or LDS); the weight is read from w_i
+// and written to w_o.  dev_g / eta_g: this Gaussian's LDS scratch (56 floats, 22 doubles).  Must be called by every
+// thread of the workgroup.
+__device__ __forceinline__ void gsukf_update_phase(float* mu_g, float* P_g, const float* w_i, float* w_o, float* dev_g,
+                                                   double* eta_g, bool live, int j, int b, int32_t* status,
+                                                   const FilterIOs& io, const Pdf2& pdf, const SigmaWeights& sw) {
     float m[5];
     if (live) {
         float L[15], s[5];
         bool ok;
-        load_and_factor(mu + gi * 5, P + gi * 25, m, L, ok);
+        load_and_factor(mu_g, P_g, m, L, ok);
         if (j < GSE_NSIGMA) {
             if (!ok && j == 0 && status) atomicAdd(status, 1);
             sigma_point(m, L, j, s);
             float y0, y1;
             bioreactor_output(s[0], s[2], y0, y1);
-            eta[gl][j * 2 + 0] = (double)y0;
-            eta[gl][j * 2 + 1] = (double)y1;
+            eta_g[j * 2 + 0] = (double)y0;
+            eta_g[j * 2 + 1] = (double)y1;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) dev[gl][j * 5 + k] = s[k] - m[k];
+            for (int k = 0; k < 5; ++k) dev_g[j * 5 + k] = s[k] - m[k];
         }
     }
     __syncthreads();
@@ -258,10 +261,10 @@ __global__ __launch_bounds__(kBlock) void gsukf_update_kernel(float* __restrict_
 #pragma unroll
     for (int q2 = 0; q2 < 2; ++q2) {
 #pragma clang fp contract(off)
-        double acc = eta[gl][q2] * (double)a.sw.w[0];
+        double acc = eta_g[q2] * (double)sw.w[0];
 #pragma unroll
-        for (int q = 1; q < GSE_NSIGMA; ++q) acc = acc + eta[gl][q * 2 + q2] * (double)a.sw.w[q];
-        em[q2] = acc / a.sw.scl64;
+        for (int q = 1; q < GSE_NSIGMA; ++q) acc = acc + eta_g[q * 2 + q2] * (double)sw.w[q];
+        em[q2] = acc / sw.scl64;
     }
     double pyy[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
     double pxy[5][2];
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(kBlock) void gsukf_update_kernel(float* __restrict_
     for (int k = 0; k < 5; ++k) pxy[k][0] = pxy[k][1] = 0.0;
 #pragma unroll
     for (int q = 0; q < GSE_NSIGMA; ++q) {
-        const double wq = (double)a.sw.w[q];
-        const double e0 = eta[gl][q * 2 + 0] - em[0], e1 = eta[gl][q * 2 + 1] - em[1];
+        const double wq = (double)sw.w[q];
+        const double e0 = eta_g[q * 2 + 0] - em[0], e1 = eta_g[q * 2 + 1] - em[1];
         const double ew0 = e0 * wq, ew1 = e1 * wq;
         pyy[0][0] = fma(e0, ew0, pyy[0][0]);
         pyy[0][1] = fma(e0, ew1, pyy[0][1]);
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void gsukf_update_kernel(float* __restrict_
         pyy[1][1] = fma(e1, ew1, pyy[1][1]);
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            const double dk = (double)dev[gl][q * 5 + k];
+            const double dk = (double)dev_g[q * 5 + k];
             pxy[k][0] = fma(dk, ew0, pxy[k][0]);
             pxy[k][1] = fma(dk, ew1, pxy[k][1]);
         }
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void gsukf_update_kernel(float* __restrict_
         K[k][0] = pxy[k][0] * X[0][0] + pxy[k][1] * X[1][0];
         K[k][1] = pxy[k][0] * X[0][1] + pxy[k][1] * X[1][1];
     }
-    const double z0 = a.io.f[b].z0, z1 = a.io.f[b].z1;
+    const double z0 = io.f[b].z0, z1 = io.f[b].z1;
     const double i0 = z0 - em[0], i1 = z1 - em[1];
     float mnew[5];
 #pragma unroll
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void gsukf_update_kernel(float* __restrict_
     const double t0 = kr0 * pyy[0][0] + kr1 * pyy[1][0];
     const double t1 = kr0 * pyy[0][1] + kr1 * pyy[1][1];
     const double corr = t0 * kc0 + t1 * kc1;
-    float* Pg = P + gi * 25;
+    float* Pg = P_g;
     const float prc = (float)((double)Pg[r * 5 + c] - corr);
     float pcr = prc;
     if (r != c) {
@@ -322,13 +325,119 @@ __global__ __launch_bounds__(kBlock) void gsukf_update_kernel(float* __restrict_
     // barrier above, and entries (r, c) / (c, r) are read and written by this lane only.
     Pg[r * 5 + c] = prc;
     if (r != c) Pg[c * 5 + r] = pcr;
-    if (j < 5) mu[gi * 5 + j] = mnew[j];
+    if (j < 5) mu_g[j] = mnew[j];
     if (j == 0) {
         // global update: w *= pdf(z - g(mu_new))
         float y0, y1;
         bioreactor_output(mnew[0], mnew[2], y0, y1);
-        const double lik = mixture_pdf2<0>(a.pdf, z0 - (double)y0, z1 - (double)y1);
-        w[gi] = (float)((double)w[gi] * lik);
+        const double lik = mixture_pdf2<0>(pdf, z0 - (double)y0, z1 - (double)y1);
+        *w_o = (float)((double)(*w_i) * lik);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gsukf_update_kernel(float* __restrict__ mu, float* __restrict__ P,
+                                                              float* __restrict__ w, int64_t N,
+                                                              int32_t* __restrict__ status, const GsukfUpdateArgs a) {
+    __shared__ float dev[kGaussPerBlock][GSE_NSIGMA * 5 + 1];     // sigma_j - mu
+    __shared__ double eta[kGaussPerBlock][GSE_NSIGMA * 2];        // g(sigma_j)
+    const int b = blockIdx.y;
+    const int j = threadIdx.x & (kGroup - 1);
+    const int gl = threadIdx.x / kGroup;
+    const int64_t g = (int64_t)blockIdx.x * kGaussPerBlock + gl;
+    const bool live = g < N;
+    const int64_t gi = (int64_t)b * N + (live ? g : 0);
+    gsukf_update_phase(mu + gi * 5, P + gi * 25, w + gi, w + gi, dev[gl], eta[gl], live, j, b, status, a.io, a.pdf, a.sw);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole cycle predict -> update -> resample of a bank of at most 64 Gaussians in ONE workgroup of 1024 threads
+// (64 groups of 16 lanes): BASELINE config 3 is launch-latency-bound, so one launch instead of five is the lever.
+// mu, P live in LDS between the phases; the resample is the arithmetic of cumsum_kernel + the gather for a single
+// tile (all per-thread sums sit in wavefront 0), so the result is bit-identical to the separate launches.
+constexpr int kSmallBank = 64;
+constexpr int kSmallBlock = kSmallBank * kGroup;      // 1024
+
+struct GsukfCycleArgs {
+    GsukfPredictArgs pred;
+    Pdf2 pdf;
+    double r[GSE_MAX_B];
+};
+
+template <bool kInjected>
+__global__ __launch_bounds__(kSmallBlock) void gsukf_cycle_kernel(float* __restrict__ mu, float* __restrict__ P,
+                                                                  float* __restrict__ w, const float* __restrict__ noise,
+                                                                  int32_t* __restrict__ idx_out, int N,
+                                                                  int32_t* __restrict__ status, const GsukfCycleArgs a) {
+    __shared__ DrawParams dp;
+    __shared__ float tile[kSmallBank][GSE_NSIGMA * 5 + 1];       // predict: sigma points; update: deviations
+    __shared__ double eta[kSmallBank][GSE_NSIGMA * 2];
+    __shared__ float mu_s[kSmallBank][5];
+    __shared__ float P_s[kSmallBank][25];
+    __shared__ float w_s[kSmallBank];
+    __shared__ double c_s[kSmallBank];
+    __shared__ int anc_s[kSmallBank];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int j = tid & (kGroup - 1), gl = tid / kGroup;
+    const bool live = gl < N;
+    const int64_t gi = (int64_t)b * N + (live ? gl : 0);
+    if (!kInjected) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.pred.draw);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
+        for (int i = tid; i < (int)(sizeof(DrawParams) / 4); i += kSmallBlock) dst[i] = src[i];
+        __syncthreads();
+    }
+    // 1. predict: global -> LDS
+    gsukf_predict_phase<kInjected>(mu + gi * 5, P + gi * 25, mu_s[gl], P_s[gl], tile[gl], live, j, b, gl,
+                                   kInjected ? noise + gi * GSE_NSIGMA * 5 : nullptr, dp, status, a.pred);
+    __syncthreads();
+    // 2. update in LDS; the weight goes global -> LDS
+    gsukf_update_phase(mu_s[gl], P_s[gl], w + gi, &w_s[gl], tile[gl], eta[gl], live, j, b, status, a.pred.io, a.pdf,
+                       a.pred.sw);
+    __syncthreads();
+    // 3. resample, one tile: thread t < 16 of wavefront 0 owns weights 4t..4t+3, exactly as cumsum_kernel does
+    __shared__ double total_s;
+    if (tid < 64) {
+        const int i0 = tid * 4;
+        double sc[4];
+        sc[0] = (i0 + 0 < N) ? (double)w_s[min(i0 + 0, kSmallBank - 1)] : 0.0;
+        sc[1] = sc[0] + ((i0 + 1 < N) ? (double)w_s[min(i0 + 1, kSmallBank - 1)] : 0.0);
+        sc[2] = sc[1] + ((i0 + 2 < N) ? (double)w_s[min(i0 + 2, kSmallBank - 1)] : 0.0);
+        sc[3] = sc[2] + ((i0 + 3 < N) ? (double)w_s[min(i0 + 3, kSmallBank - 1)] : 0.0);
+        const double inc = wave_inclusive_scan(sc[3], tid);
+        const double W = __shfl(inc, 63, 64);                       // workgroup total: wavefronts 1.. hold zeros
+        double excl = __shfl_up(inc, 1, 64);
+        if (tid == 0) excl = 0.0;
+        const double top = W / W;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (i0 + p < N) c_s[i0 + p] = (i0 + p == N - 1) ? top : fmin((0.0 + (excl + sc[p])) / W, top);
+        if (tid == 0) total_s = W;
+    }
+    __syncthreads();
+    if (tid < N) {                                                   // ancestor of output tid
+        const double W = total_s;
+        int k = 0;
+        if ((W > 0.0) && (W < INFINITY)) {
+            const double u = ((double)tid + a.r[b]) / (double)N;
+            int lo = 0, hi = N - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (c_s[mid] < u) lo = mid + 1; else hi = mid;
+            }
+            k = lo;
+        }
+        anc_s[tid] = k;
+        if (idx_out) idx_out[(int64_t)b * N + tid] = k;
+        w[(int64_t)b * N + tid] = (float)(1.0 / (double)N);
+    }
+    __syncthreads();
+    // 4. gather LDS -> global (in place: the source is LDS)
+    if (live) {
+        const int src = anc_s[gl];
+        for (int e = j; e < 30; e += kGroup) {
+            if (e < 5) mu[gi * 5 + e] = mu_s[src][e];
+            else P[gi * 25 + (e - 5)] = P_s[src][e - 5];
+        }
     }
 }
 
@@ -464,6 +573,40 @@ int gse_gsukf_update(float* mu, float* P, float* w, int B, int64_t N, const doub
     const unsigned gx = (unsigned)((N + kGaussPerBlock - 1) / kGaussPerBlock);
     hipLaunchKernelGGL(gsukf_update_kernel, dim3(gx, B), dim3(kBlock), 0, (hipStream_t)stream, mu, P, w, N, status, a);
     GSE_LAUNCH_CHECK("gsukf_update_kernel");
+    return GSE_OK;
+}
+
+int gse_gsukf_cycle(float* mu, float* P, float* w, int32_t* idx, int B, int64_t N, const double* u, double dt, const double* z,
+                    const double* r, const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng,
+                    const float* noise, const gse_mixture* measurement_pdf, int32_t* status, void* stream) {
+    if (int rc = check_gsukf("gse_gsukf_cycle", B, N)) return rc;
+    GSE_REQUIRE(N <= kSmallBank, "gse_gsukf_cycle: at most %d Gaussians (got %lld); use the separate calls", kSmallBank,
+                (long long)N);
+    GSE_REQUIRE(mu && P && w && u && z && r && w_sigma && measurement_pdf, "gse_gsukf_cycle: null argument");
+    GSE_REQUIRE(noise || (state_pdf && rng), "gse_gsukf_cycle: need either noise or (state_pdf, rng)");
+    if (int rc = check_mixture("gse_gsukf_cycle", measurement_pdf, GSE_NY)) return rc;
+    GsukfCycleArgs a;
+    pack_io(a.pred.io, B, u, z);
+    pack_sigma_weights(a.pred.sw, w_sigma);
+    a.pred.dt = dt;
+    pack_pdf2(a.pdf, *measurement_pdf);
+    for (int b = 0; b < B; ++b) {
+        GSE_REQUIRE(r[b] >= 0.0 && r[b] < 1.0, "gse_gsukf_cycle: r[%d] = %g is outside [0, 1)", b, r[b]);
+        a.r[b] = r[b];
+    }
+    if (noise) {
+        a.pred.draw = DrawParams{};
+        a.pred.rng = RngKey{};
+        hipLaunchKernelGGL(gsukf_cycle_kernel<true>, dim3(1, B), dim3(kSmallBlock), 0, (hipStream_t)stream, mu, P, w, noise,
+                           idx, (int)N, status, a);
+    } else {
+        if (int rc = check_mixture("gse_gsukf_cycle", state_pdf, GSE_NX)) return rc;
+        pack_draw(a.pred.draw, *state_pdf);
+        a.pred.rng = make_rng_key(*rng, kPurposeGsukf);
+        hipLaunchKernelGGL(gsukf_cycle_kernel<false>, dim3(1, B), dim3(kSmallBlock), 0, (hipStream_t)stream, mu, P, w,
+                           (const float*)nullptr, idx, (int)N, status, a);
+    }
+    GSE_LAUNCH_CHECK("gsukf_cycle_kernel");
     return GSE_OK;
 }
 

@@ -62,33 +62,59 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._step = 0
         self._host_rng = numpy.random.default_rng(self._seed & 0xFFFFFFFF)
 
+        # deferred stages (small banks): predict() and update() are recorded and resample() runs all three in ONE launch
+        self.lazy = True
+        self._pend_predict = None
+        self._pend_update = None
+        self._fusable = n <= _lib.GSE_GSUKF_CYCLE_MAX
+        self._c_u = (_lib.c_d * _lib.GSE_NU)()
+        self._c_z = (_lib.c_d * _lib.GSE_NY)()
+        self._c_r = (_lib.c_d * 1)()
+
         self._threads_per_block = self._tpb = 1024
         self._blocks_per_grid = self._bpg = (n - 1) // 1024 + 1
         self._y_dummy = DevArray.wrap(torch.zeros(self._Ny, dtype=torch.float32, device=dev))
 
     # ------------------------------------------------------------------ attributes
+    def _flush(self):
+        """Run whatever predict / update is pending with the one-kernel-per-method calls."""
+        if self._pend_predict is not None:
+            u, dt = self._pend_predict
+            self._pend_predict = None
+            self._predict_now(u, dt)
+        if self._pend_update is not None:
+            u, z = self._pend_update
+            self._pend_update = None
+            self._update_now(u, z)
+
     @property
     def means(self):
+        self._flush()
         return DevArray.wrap(self._means)
 
     @means.setter
     def means(self, value):
+        self._flush()
         self._means.copy_(as_device(value, torch.float32).reshape(self.N_particles, self._Nx))
 
     @property
     def covariances(self):
+        self._flush()
         return DevArray.wrap(self._covs)
 
     @covariances.setter
     def covariances(self, value):
+        self._flush()
         self._covs.copy_(as_device(value, torch.float32).reshape(self.N_particles, self._Nx, self._Nx))
 
     @property
     def weights(self):
+        self._flush()
         return DevArray.wrap(self._w)
 
     @weights.setter
     def weights(self, value):
+        self._flush()
         self._w.copy_(as_device(value, torch.float32).reshape(self.N_particles))
 
     def _check_status(self):
@@ -102,6 +128,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     # ------------------------------------------------------------------ the cycle
     def _get_sigma_points(self):
         """Return the sigma points for the current Gaussians, device array (N x 11 x Nx) (gs_ukf.py:332-346)."""
+        self._flush()
         n = self.N_particles
         out = torch.empty((n, self._N_sigmas, self._Nx), dtype=torch.float32, device=self._means.device)
         _lib.call("gse_gsukf_sigma_points", self._means.data_ptr(), self._covs.data_ptr(), out.data_ptr(), 1, n,
@@ -109,7 +136,15 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         return DevArray.wrap(out)
 
     def predict(self, u, dt):
-        """Prediction step (gs_ukf.py:348-367)."""
+        """Prediction step (gs_ukf.py:348-367).  With at most 64 Gaussians the step is deferred so that resample() can
+        run predict + update + resample as one launch (the bank is launch-latency-bound)."""
+        if self.lazy and self._fusable and self._pend_predict is None and self._pend_update is None:
+            self._pend_predict = ([float(v) for v in u], float(dt))
+            return
+        self._flush()
+        self._predict_now(u, dt)
+
+    def _predict_now(self, u, dt):
         uu = _lib.doubles(u, _lib.GSE_NU)
         n = self.N_particles
         if isinstance(self.state_pdf, DeterministicGaussianSum):
@@ -126,6 +161,13 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     def update(self, u, z):
         """Update step: local UKF update of every Gaussian, then the global weight update (gs_ukf.py:369-407)."""
+        if self.lazy and self._fusable and self._pend_predict is not None and self._pend_update is None:
+            self._pend_update = ([float(v) for v in u], [float(v) for v in z])
+            return
+        self._flush()
+        self._update_now(u, z)
+
+    def _update_now(self, u, z):
         uu = _lib.doubles(u, _lib.GSE_NU)
         zz = _lib.doubles(z, _lib.GSE_NY)
         pod = self.measurement_pdf._pod()
@@ -138,6 +180,29 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         rr = _lib.doubles([self._host_rng.random() if r is None else r], 1)
         n = self.N_particles
         idx = torch.empty(n, dtype=torch.int32, device=self._w.device) if return_index else None
+        if self._pend_predict is not None and self._pend_update is not None:
+            # the whole cycle in one launch of one workgroup (gse_gsukf_cycle); in place
+            (u, dt), (_, z) = self._pend_predict, self._pend_update
+            self._pend_predict = self._pend_update = None
+            uu, zz = _lib.doubles(u, _lib.GSE_NU), _lib.doubles(z, _lib.GSE_NY)
+            pod_m = self.measurement_pdf._pod()
+            if isinstance(self.state_pdf, DeterministicGaussianSum):
+                noise = self.state_pdf.draw((n, self._N_sigmas)).as_subclass(torch.Tensor).contiguous()
+                _lib.call("gse_gsukf_cycle", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
+                          idx.data_ptr() if return_index else None, 1, n, uu, dt, zz, rr, self._w_sigma_c, None, None,
+                          noise.data_ptr(), ctypes.byref(pod_m), self._status.data_ptr(), stream_ptr())
+            else:
+                pod_s = self.state_pdf._pod()
+                rng = _lib.Rng(seed=self._seed, step=self._step)
+                self._step += 1
+                _lib.call("gse_gsukf_cycle", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
+                          idx.data_ptr() if return_index else None, 1, n, uu, dt, zz, rr, self._w_sigma_c,
+                          ctypes.byref(pod_s), ctypes.byref(rng), None, ctypes.byref(pod_m), self._status.data_ptr(),
+                          stream_ptr())
+            if return_index:
+                return DevArray.wrap(idx)
+            return
+        self._flush()
         _lib.call("gse_gsukf_resample", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
                   self._means_alt.data_ptr(), self._covs_alt.data_ptr(), self._w_alt.data_ptr(),
                   idx.data_ptr() if return_index else None, 1, n, rr, 0, self._ws.data_ptr(), stream_ptr())
@@ -149,6 +214,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     # ------------------------------------------------------------------ estimates
     def _moment_sums(self):
+        self._flush()
         _lib.call("gse_gsukf_moments", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), 1,
                   self.N_particles, self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
         m = self._moments.cpu().numpy()

@@ -184,6 +184,15 @@ int gse_gsukf_update(float *mu, float *P, float *w, int B, int64_t N, const doub
                      const float *w_sigma, const gse_mixture *measurement_pdf, int32_t *status,
                      void *workspace, void *stream);
 
+/* The whole cycle predict -> update -> resample (filter/gs_ukf.py:348-436) of a bank of at most 64 Gaussians in ONE
+ * launch of one workgroup per filter (mu, P stay in LDS between the phases): the 64-Gaussian configuration is
+ * launch-latency-bound, five launches become one.  Same arithmetic and bits as the three separate calls, in place.
+ * r: host [B]; idx (optional): device int32 [B][N] ancestors; other arguments as in the separate calls. */
+int gse_gsukf_cycle(float *mu, float *P, float *w, int32_t *idx, int B, int64_t N, const double *u, double dt,
+                    const double *z, const double *r, const float *w_sigma, const gse_mixture *state_pdf,
+                    const gse_rng *rng, const float *noise, const gse_mixture *measurement_pdf, int32_t *status,
+                    void *stream);
+
 /* ...resample (filter/gs_ukf.py:409-436): as gse_pf_resample, gathering (mu, P) rows. */
 int gse_gsukf_resample(const float *mu_in, const float *P_in, const float *w, float *mu_out, float *P_out,
                        float *w_out, int32_t *idx, int B, int64_t N, const double *r, uint32_t flags,

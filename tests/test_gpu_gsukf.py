@@ -152,3 +152,34 @@ def test_gsukf_philox_cycle_and_errors():
     gf.predict([0.06, 0.2], 0.1)
     with pytest.raises(np.linalg.LinAlgError):
         gf.point_estimate()
+
+
+@pytest.mark.parametrize("n", [1, 7, 33, 64])
+def test_fused_cycle_equals_separate_launches(n):
+    """predict + update + resample of a small bank in ONE launch (gse_gsukf_cycle) vs the three methods run one kernel
+    each: bit-identical means, covariances, weights and ancestors; with Philox noise and with injected noise."""
+    xss = orc.steady_state()
+    z = np.array(orc.bioreactor_g(xss)) + [0.2, -0.1]
+    for deterministic in (False, True):
+        banks = []
+        for lazy in (True, False):
+            gf = make(n, deterministic=deterministic)
+            gf.lazy = lazy
+            banks.append(gf)
+        rng = np.random.default_rng(n)
+        for c in range(4):
+            u = [0.05 + 0.005 * c, 0.2]
+            r = float(rng.random())
+            noise = (rng.standard_normal((n, 11, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+            idx = []
+            for gf in banks:
+                if deterministic:
+                    DeterministicGaussianSum.preload(noise)
+                gf.predict(u, 0.1)
+                gf.update(u, z)
+                idx.append(gf.resample(r=r, return_index=True).get())
+            np.testing.assert_array_equal(idx[0], idx[1])
+            np.testing.assert_array_equal(banks[0].means.get(), banks[1].means.get())
+            np.testing.assert_array_equal(banks[0].covariances.get(), banks[1].covariances.get())
+            np.testing.assert_array_equal(banks[0].weights.get(), banks[1].weights.get())
+        np.testing.assert_array_equal(banks[0].point_estimate(), banks[1].point_estimate())
