@@ -348,6 +348,31 @@ constexpr int kSpanMax = GSE_SPAN_MAX;    // cumulative weights staged in LDS pe
 static_assert(kSpanMax <= 4096, "span_search bisects 12 times");
 
 
+// Four bisections of the staged span advanced together (the four outputs of a thread): the dependent LDS reads of
+// one search are the latency the other three fill.  out[p] = first q with seg[q] >= thr[p].
+__device__ __forceinline__ void span_search4(const double* seg, int len, const double (&thr)[4], int (&out)[4]) {
+    int lo[4] = {0, 0, 0, 0}, hi[4] = {len - 1, len - 1, len - 1, len - 1};
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {             // 2^12 >= kSpanMax
+        double v[4];
+        int mid[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            mid[p] = (lo[p] + hi[p]) >> 1;
+            v[p] = seg[mid[p]];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool open = lo[p] < hi[p];
+            const bool less = open && (v[p] < thr[p]);
+            lo[p] = less ? mid[p] + 1 : lo[p];
+            hi[p] = (open && !less) ? mid[p] : hi[p];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) out[p] = lo[p];
+}
+
 // Ancestor of one output with threshold u among the staged span seg[0..len): first q with seg[q] >= u.
 __device__ __forceinline__ int span_search(const double* seg, int len, double u) {
     int lo = 0, hi = len - 1;

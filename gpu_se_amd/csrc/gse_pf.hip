@@ -56,6 +56,21 @@ __device__ __forceinline__ int draw_position(unsigned bx) {
     return (((bx >> 8) ^ bx) & 1u) ? 0 : 3;
 #endif
 }
+// In-kernel phase stamps (diagnostic build only, -DGSE_STAMPS): workgroup 0's thread 0 records s_memtime at the phase
+// boundaries into a buffer of its own; read back with gse_debug_stamps().  No stamp executes in the normal build.
+#ifdef GSE_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define GSE_STAMP(i)                                                              \
+    do {                                                                          \
+        if (blockIdx.x == GSE_STAMPS && blockIdx.y == 0 && threadIdx.x == 0) {    \
+            unsigned long long t_;                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            g_stamps[i] = t_;                                                     \
+        }                                                                         \
+    } while (0)
+#else
+#define GSE_STAMP(i)
+#endif
 #ifndef GSE_XCD_REMAP
 #define GSE_XCD_REMAP 1
 #endif
@@ -146,8 +161,10 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     };
     constexpr bool kDraw = kPredict && !kInjected;
     const int draw_at = (kDraw && kGather) ? draw_position(blockIdx.x) : 3;      // workgroup-uniform
+    GSE_STAMP(0);
     if (kDraw) __syncthreads();                          // dp staged
     if (kDraw && draw_at == 0) draw_all();
+    GSE_STAMP(1);
 
     // ---- gather: ancestors of this thread's 4 outputs -------------------------------------------------
     int32_t anc[kPerThread] = {0, 0, 0, 0};
@@ -170,6 +187,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             if (tid == 0) pfx_s[T] = total;
             __syncthreads();
             W = pfx_s[T];
+    GSE_STAMP(2);
             if (island && tile_id == 0 && tid == 0) {      // shard bookkeeping (see gse_pf_resample)
                 island[b] += log(W);
                 island[gridDim.y + b] = W;
@@ -207,27 +225,44 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             };
             const int64_t j0 = tile0;
             const int64_t j1 = min(j0 + kTile, N);
-            if (wv < 2) {       // bracket the tile's ancestors: wavefront 0 takes the first output, wavefront 1 the last
+            // thresholds of this thread's four outputs: registers only, ahead of the memory phases
+            double thr[kPerThread];
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) thr[p] = threshold(jp[p]);
+            if (wv < 2) {       // bracket the ancestors: wavefront 0 takes the first output, wavefront 1 the last
                 const int64_t j = (wv == 0) ? j0 : j1 - 1;
                 const int64_t k = wave_search_ge(key, N, threshold((uint32_t)j), lane);
                 if (lane == 0) span[wv] = k;
             }
             __syncthreads();
             const int64_t klo = span[0], khi = span[1];
+    GSE_STAMP(3);
             const int64_t len = khi - klo + 1;
-            double thr[kPerThread];
-#pragma unroll
-            for (int p = 0; p < kPerThread; ++p) thr[p] = threshold(jp[p]);
             if (kDraw && draw_at == 2) {
                 draw_all();
                 drawn2 = true;
             }
             if (len <= kSpanMax) {
                 // the span fits LDS (the common case: ~1000 ancestors at the median): stage it, bisect there
-                for (int q = tid; q < (int)len; q += kBlock) seg[q] = key(klo + q);
-                __syncthreads();
+                {
+                    constexpr int kPer = kSpanMax / kBlock;                      // keys per thread, all loads in flight
+                    double kv[kPer];
 #pragma unroll
-                for (int p = 0; p < kPerThread; ++p) anc[p] = (int32_t)klo + span_search(seg, (int)len, thr[p]);
+                    for (int m = 0; m < kPer; ++m) {
+                        const int q = tid + m * kBlock;
+                        kv[m] = key(klo + min((int64_t)q, len - 1));
+                    }
+#pragma unroll
+                    for (int m = 0; m < kPer; ++m) {
+                        const int q = tid + m * kBlock;
+                        if (q < (int)len) seg[q] = kv[m];
+                    }
+                }
+                __syncthreads();
+                int found[kPerThread];
+                span_search4(seg, (int)len, thr, found);
+#pragma unroll
+                for (int p = 0; p < kPerThread; ++p) anc[p] = (int32_t)klo + found[p];
             } else {
                 // A long span: the tile's ancestors are spread over a stretch of (nearly) weightless particles.  Two
                 // levels: LDS gets every s-th key (the last of each group of s, so seg[g] = max of group g); an output
@@ -252,6 +287,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         }
     }
     if (kDraw && draw_at == 2 && !drawn2) draw_all();      // (weights that do not sum to a positive number: no search)
+    GSE_STAMP(4);
     // a thread is live if it owns at least one particle (its first one)
     const bool live = jp[0] < Nu;
     float wnew[kPerThread] = {w_uniform, w_uniform, w_uniform, w_uniform};
@@ -305,7 +341,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 0) {
+                GSE_STAMP(5);
                 if (kDraw && draw_at == 3) draw_all();
+                GSE_STAMP(6);
                 if (kPredict && kInjected) {
 #pragma unroll
                     for (int p = 0; p < kPerThread; ++p)
@@ -319,6 +357,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                 asm volatile("s_waitcnt vmcnt(0)"
                              : "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[0][2]), "+v"(g[0][3]), "+v"(g[0][4]),
                                "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[1][2]), "+v"(g[1][3]), "+v"(g[1][4])::"memory");
+                if (h == 0) GSE_STAMP(7);
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -370,6 +409,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         // update as a phase of its own: the ODE and the likelihood each need ~20 fp64 constants; interleaving them per
         // particle keeps both sets live, overflows the scalar registers and spills ~100 VGPRs
         __builtin_amdgcn_sched_barrier(0);
+        GSE_STAMP(8);
         if (kUpdate) {
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p) {
@@ -394,6 +434,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             *reinterpret_cast<float4*>(w_out + (int64_t)b * ld + i0) = make_float4(wnew[0], wnew[1], wnew[2], wnew[3]);
         }
     }
+    GSE_STAMP(9);
     if (kUpdate) {
         // tile sum of the new weights, always formed in the same order (4 consecutive per thread, then the workgroup
         // tree) so that fused and separate launches leave bit-identical sums; the strided mapping goes through LDS.
@@ -428,6 +469,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             }
         }
     }
+    GSE_STAMP(10);
 }
 
 // Tile sums for a resample that does not directly follow an update (weights assigned by the caller).
@@ -928,6 +970,15 @@ int gse_pf_resample(const float* x_in, const float* w, float* x_out, float* w_ou
     return pf_step(GSE_OP_GATHER, x_in, x_out, nullptr, w_out, idx, ld, B, N, nullptr, 0.0, nullptr, r, nullptr, nullptr,
                    nullptr, nullptr, nullptr, workspace, stream, "gse_pf_resample");
 }
+
+#ifdef GSE_STAMPS
+// diagnostic build only: copy the phase stamps of the last fused launches to the host (synchronises)
+int gse_debug_stamps(unsigned long long* out32) {
+    GSE_HIP_CHECK(hipDeviceSynchronize());
+    GSE_HIP_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32));
+    return GSE_OK;
+}
+#endif
 
 int gse_pf_moments(const float* x, const float* w, int64_t ld, int B, int64_t N, double* out, void* workspace,
                    void* stream) {
