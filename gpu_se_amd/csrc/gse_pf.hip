@@ -201,14 +201,15 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         // sweep never advances (filter/particle.py:98), so every offspring copies particle 0 (anc stays 0).
         if ((W > 0.0) && (W < INFINITY)) {
             const double* cb = kScanIn ? scan_in + (int64_t)b * N : c + (int64_t)b * N;
-            // The search key of ancestor k and the threshold of an output.
-            //   materialised c[] : key = c[k] (normalised),                 threshold = u = (j + r) / N
-            //   SCAN_IN          : key = min(Pfx[t] + L[k], Pfx[t+1]) (NOT divided by W; the tile's last element is
-            //                      Pfx[t+1]),                               threshold = tau(u)
-            // where tau(u) is the smallest fp64 x with fl(x / W) >= u.  Because x -> fl(x / W) is monotone,
-            // fl(key / W) >= u  <=>  key >= tau(u): the ancestor found is EXACTLY the one the normalised comparison
-            // gives, and no probe of the search needs a division.
-            auto key = [&](int64_t k) -> double {
+            // The search key of ancestor k.
+            //   materialised c[] : ckey(k) = c[k]                                   (normalised by cumsum_kernel)
+            //   SCAN_IN          : xkey(k) = min(Pfx[t] + L[k], Pfx[t+1])           (un-normalised; tile's last: Pfx[t+1])
+            //                      ckey(k) = fl(xkey(k) / W)                         -- the bits cumsum_kernel would store
+            // Outputs compare ckey with u = (j + r) / N, the reference's comparison verbatim.  Where a division per probe
+            // would sit on a dependent chain (the bracket search, the long-span fallback) the un-normalised key is
+            // compared with tau(u) = the smallest fp64 x with fl(x / W) >= u instead: x -> fl(x / W) is monotone, so
+            // fl(xkey / W) >= u  <=>  xkey >= tau(u) -- exactly the same decision, no division in the loop.
+            auto xkey = [&](int64_t k) -> double {
                 if (!kScanIn) return cb[k];
                 const int t = (int)(k / kTile);
                 const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
@@ -218,20 +219,31 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             // (j + r) * (1 / N) gives the same bits without a division
             const bool pow2 = (N & (N - 1)) == 0;
             const double invN = 1.0 / Nd;
-            auto threshold = [&](uint32_t j) -> double {
+            auto u_of = [&](uint32_t j) -> double {
                 const double jr = (double)j + r;
-                const double u = pow2 ? jr * invN : jr / Nd;
-                return kScanIn ? smallest_with_quotient_ge(u, W) : u;
+                return pow2 ? jr * invN : jr / Nd;
             };
+            auto tau_of = [&](double u) -> double { return kScanIn ? smallest_with_quotient_ge(u, W) : u; };
             const int64_t j0 = tile0;
             const int64_t j1 = min(j0 + kTile, N);
-            // thresholds of this thread's four outputs: registers only, ahead of the memory phases
-            double thr[kPerThread];
+            double thr[kPerThread];                       // thresholds of this thread's four outputs
 #pragma unroll
-            for (int p = 0; p < kPerThread; ++p) thr[p] = threshold(jp[p]);
+            for (int p = 0; p < kPerThread; ++p) thr[p] = u_of(jp[p]);
             if (wv < 2) {       // bracket the ancestors: wavefront 0 takes the first output, wavefront 1 the last
                 const int64_t j = (wv == 0) ? j0 : j1 - 1;
-                const int64_t k = wave_search_ge(key, N, threshold((uint32_t)j), lane);
+                const double t_e = tau_of(u_of((uint32_t)j));
+                int64_t lo_k = 0, hi_k = N - 1;
+                if (kScanIn) {
+                    // narrow to one tile in the LDS prefix first (no memory access), then a 64-ary search inside it
+                    int tl = 0, th = T - 1;                                    // first tile whose end key >= t_e
+                    while (tl < th) {
+                        const int mid = (tl + th) >> 1;
+                        if (pfx_s[mid + 1] < t_e) tl = mid + 1; else th = mid;
+                    }
+                    lo_k = (int64_t)tl * kTile;
+                    hi_k = min((int64_t)(tl + 1) * kTile, N) - 1;
+                }
+                const int64_t k = lo_k + wave_search_ge([&](int64_t q) { return xkey(lo_k + q); }, hi_k - lo_k + 1, t_e, lane);
                 if (lane == 0) span[wv] = k;
             }
             __syncthreads();
@@ -243,19 +255,20 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                 drawn2 = true;
             }
             if (len <= kSpanMax) {
-                // the span fits LDS (the common case: ~1000 ancestors at the median): stage it, bisect there
+                // the span fits LDS (the common case: ~1000 ancestors at the median): stage the normalised keys (all
+                // loads, then all divisions, in flight together) and bisect there against u
                 {
-                    constexpr int kPer = kSpanMax / kBlock;                      // keys per thread, all loads in flight
+                    constexpr int kPer = kSpanMax / kBlock;
                     double kv[kPer];
 #pragma unroll
                     for (int m = 0; m < kPer; ++m) {
                         const int q = tid + m * kBlock;
-                        kv[m] = key(klo + min((int64_t)q, len - 1));
+                        kv[m] = xkey(klo + min((int64_t)q, len - 1));
                     }
 #pragma unroll
                     for (int m = 0; m < kPer; ++m) {
                         const int q = tid + m * kBlock;
-                        if (q < (int)len) seg[q] = kv[m];
+                        if (q < (int)len) seg[q] = kScanIn ? kv[m] / W : kv[m];
                     }
                 }
                 __syncthreads();
@@ -270,16 +283,17 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                 // cache lines).  One staging pass and one short dependent chain whatever the length of the span.
                 const int64_t s_ = (len + kSpanMax - 1) / kSpanMax;              // group size, >= 2
                 const int groups = (int)((len + s_ - 1) / s_);                    // <= kSpanMax
-                for (int q = tid; q < groups; q += kBlock) seg[q] = key(min(klo + (int64_t)(q + 1) * s_, khi + 1) - 1);
+                for (int q = tid; q < groups; q += kBlock) seg[q] = xkey(min(klo + (int64_t)(q + 1) * s_, khi + 1) - 1);
                 __syncthreads();
 #pragma unroll
                 for (int p = 0; p < kPerThread; ++p) {
-                    const int g_ = span_search(seg, groups, thr[p]);
+                    const double t_p = tau_of(thr[p]);                            // un-normalised keys here
+                    const int g_ = span_search(seg, groups, t_p);
                     int64_t lo = klo + (int64_t)g_ * s_;
                     int64_t hi = min(lo + s_, khi + 1) - 1;
                     while (lo < hi) {
                         const int64_t mid = (lo + hi) >> 1;
-                        if (key(mid) < thr[p]) lo = mid + 1; else hi = mid;
+                        if (xkey(mid) < t_p) lo = mid + 1; else hi = mid;
                     }
                     anc[p] = (int32_t)lo;
                 }
