@@ -69,7 +69,7 @@ class ShardedParticleFilter:
     """
 
     def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, group=None, merge_device=None,
-                 reduce_every=8):
+                 reduce_every=32):
         self.group = group
         self.world = dist.get_world_size(group) if group is not None else 1
         self.rank = dist.get_rank(group) if group is not None else 0
