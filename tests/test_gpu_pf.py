@@ -414,7 +414,7 @@ def _two_filters(n, seed):
     return out
 
 
-@pytest.mark.parametrize("n", [7, 1024, 5003, 1 << 17])
+@pytest.mark.parametrize("n", [7, 1024, 5003, 1 << 17, 1 << 20])
 def test_fused_cycle_equals_eager_calls(n):
     """resample / predict / update deferred into ONE fused pass must give bit-identical particles and weights to the
     same calls executed one kernel each (lazy=False), for any interleaving of calls and accessors."""
