@@ -1,4 +1,6 @@
-from gpu_se_amd.filter.particle import BatchedParticleFilter, ParallelParticleFilter
-from gpu_se_amd.filter.gs_ukf import ParallelGaussianSumUnscentedKalmanFilter
+"""State estimators whose predict / update / resample cycle runs as HIP kernels on the MI355X: the device halves of the
+reference's ``filter`` package plus the batched form used for Monte-Carlo rollouts."""
+from .gs_ukf import ParallelGaussianSumUnscentedKalmanFilter
+from .particle import BatchedParticleFilter, ParallelParticleFilter
 
-__all__ = ['ParallelParticleFilter', 'BatchedParticleFilter', 'ParallelGaussianSumUnscentedKalmanFilter']
+__all__ = ("ParallelParticleFilter", "BatchedParticleFilter", "ParallelGaussianSumUnscentedKalmanFilter")

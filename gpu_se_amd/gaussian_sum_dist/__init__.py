@@ -1,4 +1,9 @@
-from gpu_se_amd.gaussian_sum_dist.MultivariateGaussianSum import MultivariateGaussianSum
-from gpu_se_amd.gaussian_sum_dist.DeterministicGaussianSum import DeterministicGaussianSum
+"""Gaussian-sum noise models evaluated and sampled on the MI355X (device counterparts of the reference's
+``gaussian_sum_dist`` package; the C ABI behind them is ``gse_mixture_pdf_*`` / ``gse_mixture_draw``)."""
+from . import DeterministicGaussianSum as _deterministic
+from . import MultivariateGaussianSum as _multivariate
 
-__all__ = ['MultivariateGaussianSum', 'DeterministicGaussianSum']
+MultivariateGaussianSum = _multivariate.MultivariateGaussianSum
+DeterministicGaussianSum = _deterministic.DeterministicGaussianSum
+
+__all__ = ("MultivariateGaussianSum", "DeterministicGaussianSum")
