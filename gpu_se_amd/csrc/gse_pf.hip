@@ -59,6 +59,16 @@ __device__ __forceinline__ int draw_position(unsigned bx) {
 // In-kernel phase stamps (diagnostic build only, -DGSE_STAMPS): workgroup 0's thread 0 records s_memtime at the phase
 // boundaries into a buffer of its own; read back with gse_debug_stamps().  No stamp executes in the normal build.
 #ifdef GSE_STAMPS
+__device__ unsigned long long g_block_times[2 * 4096];     // s_memrealtime (100 MHz) at entry / exit of every workgroup
+#define GSE_BLOCK_TIME(which)                                                                      \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {                            \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            g_block_times[2 * blockIdx.x + which] = t_;                                            \
+        }                                                                                          \
+    } while (0)
+__device__ long long g_block_info[2 * 4096];               // (ancestor span length, draw position) per workgroup
 __device__ unsigned long long g_stamps[32];
 #define GSE_STAMP(i)                                                              \
     do {                                                                          \
@@ -70,6 +80,7 @@ __device__ unsigned long long g_stamps[32];
     } while (0)
 #else
 #define GSE_STAMP(i)
+#define GSE_BLOCK_TIME(which)
 #endif
 #ifndef GSE_XCD_REMAP
 #define GSE_XCD_REMAP 1
@@ -162,6 +173,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     constexpr bool kDraw = kPredict && !kInjected;
     const int draw_at = (kDraw && kGather) ? draw_position(blockIdx.x) : 3;      // workgroup-uniform
     GSE_STAMP(0);
+    GSE_BLOCK_TIME(0);
     if (kDraw) __syncthreads();                          // dp staged
     if (kDraw && draw_at == 0) draw_all();
     GSE_STAMP(1);
@@ -250,6 +262,12 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             const int64_t klo = span[0], khi = span[1];
     GSE_STAMP(3);
             const int64_t len = khi - klo + 1;
+#ifdef GSE_STAMPS
+            if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+                g_block_info[2 * blockIdx.x] = len;
+                g_block_info[2 * blockIdx.x + 1] = draw_at;
+            }
+#endif
             if (kDraw && draw_at == 2) {
                 draw_all();
                 drawn2 = true;
@@ -484,6 +502,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         }
     }
     GSE_STAMP(10);
+    GSE_BLOCK_TIME(1);
 }
 
 // Tile sums for a resample that does not directly follow an update (weights assigned by the caller).
@@ -990,6 +1009,12 @@ int gse_pf_resample(const float* x_in, const float* w, float* x_out, float* w_ou
 int gse_debug_stamps(unsigned long long* out32) {
     GSE_HIP_CHECK(hipDeviceSynchronize());
     GSE_HIP_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32));
+    return GSE_OK;
+}
+int gse_debug_block_times(unsigned long long* out8192, long long* info8192) {
+    GSE_HIP_CHECK(hipDeviceSynchronize());
+    GSE_HIP_CHECK(hipMemcpyFromSymbol(out8192, HIP_SYMBOL(g_block_times), sizeof(unsigned long long) * 8192));
+    GSE_HIP_CHECK(hipMemcpyFromSymbol(info8192, HIP_SYMBOL(g_block_info), sizeof(long long) * 8192));
     return GSE_OK;
 }
 #endif
