@@ -525,3 +525,41 @@ def test_batch_of_filters_equals_single_filters():
         np.testing.assert_array_equal(xb[f], x1[0])
         np.testing.assert_array_equal(wb[f], w1[0])
     assert not np.array_equal(xb[0], xb[1])
+
+
+def test_random_call_sequences_lazy_equals_eager():
+    """State-machine soak: 150 random calls (predict / update / resample / reading particles, weights, estimates /
+    assigning weights) on a deferred-execution filter and on an eager one must leave bit-identical state at every
+    point where it is observed."""
+    n = 3000
+    fused, eager = _two_filters(n, 123)
+    rng = np.random.default_rng(99)
+    xss = orc.steady_state()
+    for step in range(150):
+        op = rng.choice(["predict", "update", "resample", "particles", "weights", "estimate", "set_weights"],
+                        p=[0.3, 0.25, 0.2, 0.07, 0.07, 0.07, 0.04])
+        u = [rng.uniform(0.03, 0.09), rng.uniform(0.1, 0.3)]
+        if op == "predict":
+            dt = float(rng.choice([0.05, 0.1]))
+            for pf in (fused, eager):
+                pf.predict(u, dt)
+        elif op == "update":
+            z = np.array(orc.bioreactor_g(xss)) + rng.normal(0, 0.5, 2)
+            for pf in (fused, eager):
+                pf.update(u, z)
+        elif op == "resample":
+            r = float(rng.random())
+            for pf in (fused, eager):
+                pf.resample(r=r)
+        elif op == "particles":
+            np.testing.assert_array_equal(fused.particles.get(), eager.particles.get(), err_msg="step %d" % step)
+        elif op == "weights":
+            np.testing.assert_array_equal(fused.weights.get(), eager.weights.get(), err_msg="step %d" % step)
+        elif op == "estimate":
+            np.testing.assert_array_equal(fused.point_estimate(), eager.point_estimate(), err_msg="step %d" % step)
+        else:
+            w = rng.random(n)
+            for pf in (fused, eager):
+                pf.weights = w / w.sum()
+    np.testing.assert_array_equal(fused.particles.get(), eager.particles.get())
+    np.testing.assert_array_equal(fused.weights.get(), eager.weights.get())
