@@ -280,13 +280,17 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                     double kv[kPer];
 #pragma unroll
                     for (int m = 0; m < kPer; ++m) {
-                        const int q = tid + m * kBlock;
-                        kv[m] = xkey(klo + min((int64_t)q, len - 1));
+                        if ((int64_t)m * kBlock < len) {                       // workgroup-uniform: whole rounds are skipped
+                            const int q = tid + m * kBlock;
+                            kv[m] = xkey(klo + min((int64_t)q, len - 1));
+                        }
                     }
 #pragma unroll
                     for (int m = 0; m < kPer; ++m) {
-                        const int q = tid + m * kBlock;
-                        if (q < (int)len) seg[q] = kScanIn ? kv[m] / W : kv[m];
+                        if ((int64_t)m * kBlock < len) {
+                            const int q = tid + m * kBlock;
+                            if (q < (int)len) seg[q] = kScanIn ? kv[m] / W : kv[m];
+                        }
                     }
                 }
                 __syncthreads();
