@@ -345,46 +345,43 @@ __device__ __forceinline__ double smallest_with_quotient_ge(double u, double W) 
 #define GSE_SPAN_MAX 2048
 #endif
 constexpr int kSpanMax = GSE_SPAN_MAX;    // cumulative weights staged in LDS per pass (8 B each)
-static_assert(kSpanMax <= 4096, "span_search bisects 12 times");
+static_assert(kSpanMax <= 4096 && kSpanMax % 1024 == 0, "the staged span holds whole tiles of 1024 keys");
 
 
-// Four bisections of the staged span advanced together (the four outputs of a thread): the dependent LDS reads of
-// one search are the latency the other three fill.  out[p] = first q with seg[q] >= thr[p].
+// Lower bound in the staged span: out = number of keys below thr = first q with seg[q] >= thr.  The caller guarantees
+// seg[len - 1] >= thr (the span ends at the ancestor of the tile's last output).  Branch-free bit-by-bit descent:
+// the trip count ceil(log2 len) is uniform over the workgroup (a scalar loop), a probe beyond the span is clamped to
+// its last key -- which is not below thr, so the step is (correctly) not taken -- and each probe costs five vector
+// instructions.  Positions are kept as byte offsets.
+__device__ __forceinline__ int span_steps(int len) { return len > 1 ? 32 - __clz(len - 1) : 0; }
+
+// Four searches advanced together (the four outputs of a thread): the dependent LDS reads of one search are the
+// latency the other three fill.
 __device__ __forceinline__ void span_search4(const double* seg, int len, const double (&thr)[4], int (&out)[4]) {
-    int lo[4] = {0, 0, 0, 0}, hi[4] = {len - 1, len - 1, len - 1, len - 1};
-#pragma unroll
-    for (int it = 0; it < 12; ++it) {             // 2^12 >= kSpanMax
+    const char* base = reinterpret_cast<const char*>(seg);
+    const uint32_t last = (uint32_t)(len - 1) * 8u;
+    uint32_t pos[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t step = (4u << span_steps(len)); step >= 8u; step >>= 1) {      // bytes: 8 * 2^(bits-1) ... 8
         double v[4];
-        int mid[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            mid[p] = (lo[p] + hi[p]) >> 1;
-            v[p] = seg[mid[p]];
-        }
+        for (int p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const double*>(base + min(pos[p] + step - 8u, last));
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const bool open = lo[p] < hi[p];
-            const bool less = open && (v[p] < thr[p]);
-            lo[p] = less ? mid[p] + 1 : lo[p];
-            hi[p] = (open && !less) ? mid[p] : hi[p];
-        }
+        for (int p = 0; p < 4; ++p) pos[p] = (v[p] < thr[p]) ? pos[p] + step : pos[p];
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) out[p] = lo[p];
+    for (int p = 0; p < 4; ++p) out[p] = (int)(min(pos[p], last) >> 3);
 }
 
-// Ancestor of one output with threshold u among the staged span seg[0..len): first q with seg[q] >= u.
+// One search (same algorithm).
 __device__ __forceinline__ int span_search(const double* seg, int len, double u) {
-    int lo = 0, hi = len - 1;
-#pragma unroll
-    for (int it = 0; it < 12; ++it) {             // 2^12 >= kSpanMax
-        const int mid = (lo + hi) >> 1;
-        const bool open = lo < hi;
-        const bool less = open && (seg[mid] < u);
-        lo = less ? mid + 1 : lo;
-        hi = (open && !less) ? mid : hi;
+    const char* base = reinterpret_cast<const char*>(seg);
+    const uint32_t last = (uint32_t)(len - 1) * 8u;
+    uint32_t pos = 0u;
+    for (uint32_t step = (4u << span_steps(len)); step >= 8u; step >>= 1) {
+        const double v = *reinterpret_cast<const double*>(base + min(pos + step - 8u, last));
+        pos = (v < u) ? pos + step : pos;
     }
-    return lo;
+    return (int)(min(pos, last) >> 3);
 }
 
 }  // namespace gse

@@ -82,6 +82,19 @@ __device__ unsigned long long g_stamps[32];
 #define GSE_STAMP(i)
 #define GSE_BLOCK_TIME(which)
 #endif
+#ifndef GSE_PRIO
+#define GSE_PRIO 1               // gather variants: issue priority by phase (0: none; 1: memory phases high; 2: arithmetic phases high)
+#endif
+#if GSE_PRIO == 1
+#define GSE_PRIO_MEM() __builtin_amdgcn_s_setprio(3)
+#define GSE_PRIO_ALU() __builtin_amdgcn_s_setprio(0)
+#elif GSE_PRIO == 2
+#define GSE_PRIO_MEM() __builtin_amdgcn_s_setprio(0)
+#define GSE_PRIO_ALU() __builtin_amdgcn_s_setprio(3)
+#else
+#define GSE_PRIO_MEM()
+#define GSE_PRIO_ALU()
+#endif
 #ifndef GSE_XCD_REMAP
 #define GSE_XCD_REMAP 1
 #endif
@@ -95,10 +108,50 @@ __device__ __forceinline__ int xcd_contiguous_tile(unsigned bx, int T) {
 #define GSE_GATHER_STRIDED 1     // gather variants: a thread's 4 outputs are 256 apart (1) or consecutive (0)
 #endif
 
+#ifndef GSE_WT_STORES
+#define GSE_WT_STORES 2          // bit mask of step-kernel outputs stored write-through (sc1): 1 states, 2 weights, 4 scans
+#endif
+// Output stores of the step kernel.  A launch at N = 2^20 writes 33 MB; what stays dirty in the eight L2s is written back
+// by the release at the END of the kernel, a serial tail (tools/micro/store_tail.hip: 32 MB of plain stores trail a
+// launch by +2.9 us, write-through ones by +0.7).  But the next launch re-reads the states and the scans from the L2
+// of the XCD that wrote them (XCD-contiguous tiles), and write-through stores drop their lines: measured, the lost hits
+// cost more than the tail (all outputs write-through: 29.2 us against 27.7; scans alone +2.5 us).  Only the weights,
+// which no later launch of the cycle reads, go out write-through by default.  Relaxed agent-scope
+// atomic stores are plain `global_store ... sc1` instructions, counted and padded by the compiler.
+template <int kBit>
+__device__ __forceinline__ void store_out(float* p, float v) {
+    if constexpr ((GSE_WT_STORES & kBit) != 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <int kBit>
+__device__ __forceinline__ void store_out2(double* p, double a_, double b_) {      // p 16-byte aligned
+    if constexpr ((GSE_WT_STORES & kBit) != 0) {
+        __hip_atomic_store(p, a_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 1, b_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *reinterpret_cast<double2*>(p) = make_double2(a_, b_);
+    }
+}
+using v4f_t = float __attribute__((ext_vector_type(4)));
+template <int kBit>
+__device__ __forceinline__ void store_out4(float* p, v4f_t v) {                     // p 16-byte aligned
+    if constexpr ((GSE_WT_STORES & kBit) != 0) {
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+        const unsigned long long lo = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+        const unsigned long long hi = ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
+        __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *reinterpret_cast<v4f_t*>(p) = v;
+    }
+}
+
 #define GSE_LOAD_DWORD(dst, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 // scalar base (uniform row pointer) + 32-bit byte offset per lane
+// (hipcc pads nothing inside an asm statement: an SGPR written by the scalar unit just before needs 5 wait states
+// before a vector-memory instruction may read it as its base -- the s_nop opens the string)
 #define GSE_LOAD_DWORD_S(dst, voff, sbase) \
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
 #define GSE_LOAD_DWORDX4(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 
 // Particle <-> thread mapping.  Without gather a thread owns 4 CONSECUTIVE particles (one dwordx4 per state row).
@@ -163,17 +216,20 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     //      using them, so that on every CU one group computes while the other waits.
     float e[kPerThread][GSE_NX];
     auto draw_all = [&]() {
+        if (kGather) GSE_PRIO_ALU();
 #pragma unroll
         for (int p = 0; p < kPerThread; ++p) {
             uint32_t wd[8];
             rng_words8(a.rng, (uint64_t)jp[p], (uint32_t)b, wd);
             mixture_draw5(dp, wd, e[p]);
         }
+        if (kGather) GSE_PRIO_MEM();
     };
     constexpr bool kDraw = kPredict && !kInjected;
     const int draw_at = (kDraw && kGather) ? draw_position(blockIdx.x) : 3;      // workgroup-uniform
     GSE_STAMP(0);
     GSE_BLOCK_TIME(0);
+    if (kGather) GSE_PRIO_MEM();
     if (kDraw) __syncthreads();                          // dp staged
     if (kDraw && draw_at == 0) draw_all();
     GSE_STAMP(1);
@@ -241,25 +297,51 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             double thr[kPerThread];                       // thresholds of this thread's four outputs
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p) thr[p] = u_of(jp[p]);
-            if (wv < 2) {       // bracket the ancestors: wavefront 0 takes the first output, wavefront 1 the last
-                const int64_t j = (wv == 0) ? j0 : j1 - 1;
-                const double t_e = tau_of(u_of((uint32_t)j));
-                int64_t lo_k = 0, hi_k = N - 1;
-                if (kScanIn) {
-                    // narrow to one tile in the LDS prefix first (no memory access), then a 64-ary search inside it
-                    int tl = 0, th = T - 1;                                    // first tile whose end key >= t_e
-                    while (tl < th) {
-                        const int mid = (tl + th) >> 1;
-                        if (pfx_s[mid + 1] < t_e) tl = mid + 1; else th = mid;
-                    }
-                    lo_k = (int64_t)tl * kTile;
-                    hi_k = min((int64_t)(tl + 1) * kTile, N) - 1;
+            // Where the ancestors of this tile's outputs live.  SCAN_IN, the common case: the span lies inside one or
+            // two ancestor TILES, found in the LDS prefix alone (every wavefront for itself: two 64-ary rounds per end,
+            // no memory access, no barrier) -- the whole tiles are staged and bisected, a superset of the exact span,
+            // which changes nothing in the result.  The tile range is conservative by construction: a tile is excluded
+            // at the low end only if its last key is below u_first W (1 - 2^-50), at the high end the first tile whose
+            // last key reaches u_last W (1 + 2^-50) closes the range; the margins dwarf the roundings (2^-52) of the
+            // products and of the quotient the exact comparison uses.
+            int64_t klo = 0, khi = -1;
+            bool whole_tiles = false;
+            int tl0 = 0;
+            if (kScanIn) {
+                const double p_lo = (u_of((uint32_t)j0) * W) * (1.0 - 0x1p-50);
+                const double p_hi = (u_of((uint32_t)(j1 - 1)) * W) * (1.0 + 0x1p-50);
+                tl0 = (int)wave_search_ge([&](int64_t q) { return pfx_s[q + 1]; }, T, p_lo, lane);
+                const int tl1 = (int)wave_search_ge([&](int64_t q) { return pfx_s[q + 1]; }, T, p_hi, lane);
+                if (tl1 - tl0 < kSpanMax / kTile) {                            // workgroup-uniform
+                    whole_tiles = true;
+                    klo = (int64_t)tl0 * kTile;
+                    khi = min((int64_t)(tl1 + 1) * kTile, N) - 1;
                 }
-                const int64_t k = lo_k + wave_search_ge([&](int64_t q) { return xkey(lo_k + q); }, hi_k - lo_k + 1, t_e, lane);
-                if (lane == 0) span[wv] = k;
             }
-            __syncthreads();
-            const int64_t klo = span[0], khi = span[1];
+            if (!whole_tiles) {
+                // exact bracket: wavefront 0 searches the ancestor of the first output, wavefront 1 that of the last
+                if (wv < 2) {
+                    const int64_t j = (wv == 0) ? j0 : j1 - 1;
+                    const double t_e = tau_of(u_of((uint32_t)j));
+                    int64_t lo_k = 0, hi_k = N - 1;
+                    if (kScanIn) {
+                        // narrow to one tile in the LDS prefix first (no memory access), then a 64-ary search inside it
+                        int tl = 0, th = T - 1;                                    // first tile whose end key >= t_e
+                        while (tl < th) {
+                            const int mid = (tl + th) >> 1;
+                            if (pfx_s[mid + 1] < t_e) tl = mid + 1; else th = mid;
+                        }
+                        lo_k = (int64_t)tl * kTile;
+                        hi_k = min((int64_t)(tl + 1) * kTile, N) - 1;
+                    }
+                    const int64_t k =
+                        lo_k + wave_search_ge([&](int64_t q) { return xkey(lo_k + q); }, hi_k - lo_k + 1, t_e, lane);
+                    if (lane == 0) span[wv] = k;
+                }
+                __syncthreads();
+                klo = span[0];
+                khi = span[1];
+            }
     GSE_STAMP(3);
             const int64_t len = khi - klo + 1;
 #ifdef GSE_STAMPS
@@ -278,11 +360,26 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                 {
                     constexpr int kPer = kSpanMax / kBlock;
                     double kv[kPer];
+                    if (kScanIn && whole_tiles) {
+                        // whole tiles: the tile of a round is uniform, so are its two prefix entries
 #pragma unroll
-                    for (int m = 0; m < kPer; ++m) {
-                        if ((int64_t)m * kBlock < len) {                       // workgroup-uniform: whole rounds are skipped
-                            const int q = tid + m * kBlock;
-                            kv[m] = xkey(klo + min((int64_t)q, len - 1));
+                        for (int m = 0; m < kPer; ++m) {
+                            if ((int64_t)m * kBlock < len) {                   // workgroup-uniform: whole rounds are skipped
+                                const int tm = tl0 + (m * kBlock) / kTile;
+                                const int64_t k = klo + m * kBlock + tid;
+                                const int64_t tile_last = min((int64_t)(tm + 1) * kTile, N) - 1;
+                                const double below = pfx_s[tm], top = pfx_s[tm + 1];
+                                const double l = cb[min(k, tile_last)];
+                                kv[m] = (k >= tile_last) ? top : fmin(below + l, top);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < kPer; ++m) {
+                            if ((int64_t)m * kBlock < len) {
+                                const int q = tid + m * kBlock;
+                                kv[m] = xkey(klo + min((int64_t)q, len - 1));
+                            }
                         }
                     }
 #pragma unroll
@@ -404,6 +501,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
                         for (int k = 0; k < GSE_NX; ++k)
                             GSE_LOAD_DWORD_S(g[q][k], (uint32_t)anc[2 + q] * 4u, xin_b + k * ld);
+                    GSE_PRIO_ALU();
                 }
             } else if (h == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4)::"memory");
@@ -426,7 +524,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                     if (jp[p] < Nu) {
                         float* xb = x_out + (int64_t)b * GSE_NX * ld;
 #pragma unroll
-                        for (int k = 0; k < GSE_NX; ++k) (xb + k * ld)[jp[p]] = s[k];
+                        for (int k = 0; k < GSE_NX; ++k) store_out<1>(xb + k * ld + jp[p], s[k]);
                     }
                 } else {
 #pragma unroll
@@ -440,7 +538,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         if (!kGather && kPredict) {
             float* xb = x_out + (int64_t)b * GSE_NX * ld + i0;
 #pragma unroll
-            for (int k = 0; k < GSE_NX; ++k) *reinterpret_cast<v4f*>(xb + k * ld) = row[k];
+            for (int k = 0; k < GSE_NX; ++k) store_out4<1>(xb + k * ld, row[k]);
         }
         // update as a phase of its own: the ODE and the likelihood each need ~20 fp64 constants; interleaving them per
         // particle keeps both sets live, overflows the scalar registers and spills ~100 VGPRs
@@ -463,11 +561,12 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p)
                 if (jp[p] < Nu) {
-                    wb[jp[p]] = wnew[p];
+                    store_out<2>(wb + jp[p], wnew[p]);
                     if (ib) ib[jp[p]] = anc[p];
                 }
         } else if (kUpdate) {
-            *reinterpret_cast<float4*>(w_out + (int64_t)b * ld + i0) = make_float4(wnew[0], wnew[1], wnew[2], wnew[3]);
+            const v4f w4o = {wnew[0], wnew[1], wnew[2], wnew[3]};
+            store_out4<2>(w_out + (int64_t)b * ld + i0, w4o);
         }
     }
     GSE_STAMP(9);
@@ -496,8 +595,8 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             if (tid == 0) scan_out_sums[(int64_t)b * T + tile_id] = total;
             double* lb = scan_out + (int64_t)b * N;
             if (i0 + 3 < N && (N & 1) == 0) {
-                *reinterpret_cast<double2*>(lb + i0) = make_double2(excl + sc[0], excl + sc[1]);
-                *reinterpret_cast<double2*>(lb + i0 + 2) = make_double2(excl + sc[2], excl + sc[3]);
+                store_out2<4>(lb + i0, excl + sc[0], excl + sc[1]);
+                store_out2<4>(lb + i0 + 2, excl + sc[2], excl + sc[3]);
             } else {
 #pragma unroll
                 for (int p = 0; p < kPerThread; ++p)
@@ -898,6 +997,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     GSE_REQUIRE((workspace && aligned16(workspace)) || !(ops & (GSE_OP_GATHER | GSE_OP_UPDATE)),
                 "%s: gather / update need a 16-byte aligned device workspace", fn);
     GSE_REQUIRE(N < ((int64_t)1 << 31), "%s: N must be below 2^31", fn);
+    GSE_REQUIRE(!(ops & GSE_OP_GATHER) || N <= ((int64_t)1 << 30), "%s: gather uses 32-bit byte offsets: N must not exceed 2^30", fn);
     StepArgs a;
     pack_io(a.io, B, (P ? u : nullptr), (U ? z : nullptr));
     if (G) {

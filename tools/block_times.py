@@ -39,3 +39,7 @@ for x in range(8):
     sel = (bx % 8) == x
     print("blockIdx %% 8 == %d (one XCD): duration median %.2f" % (x, np.median(dur[sel])), end=";  ")
 print()
+print("end-time histogram (us):", list(zip(np.round(np.histogram(end, bins=14)[1][:-1], 1), np.histogram(end, bins=14)[0])))
+# groups of 4 consecutive-in-XCD workgroups: bx, bx+8, bx+16, bx+24 share an XCD; a CU hosts 4 workgroups
+order = np.argsort(end)
+print("last 12 to finish: bx", order[-12:], "end", np.round(end[order[-12:]], 1), "dur", np.round(dur[order[-12:]], 1), "span", inf[order[-12:], 0])

@@ -1,6 +1,7 @@
 #!/bin/bash
-# A/B matrix on the GPU box: compile-time knobs of the fused step kernel, timed with the realistic cycle of kbench
+# A/B matrix on the GPU box (several flags of one configuration are joined with commas): compile-time knobs of the fused step kernel, timed with the realistic cycle of kbench
 for FLAGS in ${GSE_EXP_LIST:-"-DGSE_STAGGER=1"}; do
+  FLAGS=${FLAGS//,/ }
   GSE_CXXFLAGS="$FLAGS" python gpu_se_amd/build.py --force > /dev/null 2>&1 || { echo "build failed: $FLAGS"; continue; }
   tag=$(echo "$FLAGS" | tr -cd 'A-Za-z0-9_=' )
   tools/prof.sh exp_$tag tools/kbench.py 20 200 > /dev/null
