@@ -75,6 +75,7 @@ PROTOTYPES = {
     "gse_cumsum_normalised": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "gse_systematic_index": (ctypes.c_int, [c_vp, c_vp, c_i64, c_d, c_vp]),
     "gse_rng_raw": (ctypes.c_int, [c_vp, c_i64, P_RNG, c_u32, c_vp]),
+    "gse_mpc_step": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
 }
 
 _lib = None

@@ -1,0 +1,229 @@
+"""Model-predictive controller of the closed loop (reference controller.py:9-279), evaluated on the device.
+
+The reference states the controller as a sparse QP over (state deltas, outputs, u_{-1}, input moves) and calls OSQP on
+every control tick.  Between ticks only theta = (x0, u_{-1}, bias) changes (controller.py:236-262), so here the QP is
+condensed ONCE, on the host, in fp64:
+
+    * the equality rows (controller.py:119-178: u_{-1} pinned, the delta-state recursion, the accumulated outputs)
+      define every state and output as a linear function of the moves d = (du_0 .. du_M) and of theta:
+      y = Phi d + Psi theta;
+    * the cost (controller.py:99-110) becomes  1/2 d' Hc d + (F theta + f0)' d  with the dense, constant,
+      positive-definite  Hc = Phi' (I x Q) Phi + I x R;
+    * of the inequality rows (controller.py:180-219) only those with a finite bound are kept:
+      lo <= Cin d + Pin theta <= hi.
+
+What is left per tick is the explicit law documented at ``gse_mpc_step`` (include/gse.h): a handful of small
+matrix-vector products and Hildreth's dual sweeps over the bounded rows, evaluated for B rollouts by one kernel
+launch.  There is no host fall-back: without libgse_hip the controller does not step.
+
+Parity: the QP this class condenses is checked against the reference's own matrices (tests/golden/mpc_qp.npz) --
+every (d, theta) is mapped to the full variable vector, which must satisfy the reference's equality rows exactly and
+reproduce its objective; OSQP itself is not available offline, so the SOLUTION is verified through optimality
+(feasible, and no worse than an independent solver's optimum), see tests/test_oracle_mpc.py, tests/test_gpu_mpc.py.
+"""
+import ctypes
+
+import numpy
+
+from gpu_se_amd import _lib
+
+MAX_ROWS = 64            # GSE_MPC_MAX_ROWS
+
+
+class _Law(ctypes.Structure):
+    _fields_ = [("n_theta", ctypes.c_int32), ("n_u", ctypes.c_int32), ("n_y", ctypes.c_int32), ("n_rows", ctypes.c_int32),
+                ("max_sweeps", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double)] + \
+               [(name, ctypes.c_void_p) for name in ("Gc", "gc0", "S", "lo", "hi", "Gu", "gu0", "Tu", "Gy", "gy0", "Ty")]
+
+
+def _bounds(pairs, n):
+    if pairs is None:
+        return numpy.full(n, -numpy.inf), numpy.full(n, numpy.inf)
+    lo, hi = (numpy.asarray(v, dtype=float) for v in zip(*pairs))
+    return lo, hi
+
+
+class MPC:
+    """Deterministic reformulation of a linear chance-constrained MPC on a discrete linear model
+    (controller.py:9-62).  Same constructor, attributes (``P``, ``M``, ``Q``, ``R``, ``model``, ``ysp``,
+    ``y_predicted``) and ``step`` contract as the reference; ``step_batch`` advances B rollouts at once."""
+
+    def __init__(self, P, M, Q, R, lin_model, ysp, y_bounds=None, u_bounds=None, u_step_bounds=None,
+                 max_sweeps=4000, eps_abs=1e-13, eps_rel=1e-10):
+        if M > P or M < 1:
+            raise ValueError("MPC needs 1 <= M <= P")
+        self.P, self.M = int(P), int(M)
+        self.Q, self.R = numpy.asarray(Q, dtype=float), numpy.asarray(R, dtype=float)
+        self.model = lin_model
+        self.ysp = numpy.asarray(ysp, dtype=float)
+        self.y_predicted = None
+        self._known = None
+        Nx, Ni = lin_model.B.shape
+        No = lin_model.C.shape[0]
+        self.Nx, self.Ni, self.No = Nx, Ni, No
+        self._y_lim = _bounds(y_bounds, No)
+        self._u_lim = _bounds(u_bounds, Ni)
+        self._du_lim = _bounds(u_step_bounds, Ni)
+        self._solver = (int(max_sweeps), float(eps_abs), float(eps_rel))
+        self._built = None          # condensed problem + explicit law: built on first use (a P = 2999 horizon takes
+        self._dev = None            # ~10 s of dense algebra; callers that only want the estimator never pay it)
+
+    @property
+    def _law(self):
+        if self._built is None:
+            self._condense()
+        return self._built[0]
+
+    @property
+    def _condensed(self):
+        if self._built is None:
+            self._condense()
+        return self._built[1]
+
+    # ------------------------------------------------------------------------------------------------------------
+    # host set-up
+    # ------------------------------------------------------------------------------------------------------------
+    def response(self, d, theta):
+        """Outputs y_1 .. y_P (stacked, [P*No, cols]) and state deltas for move columns ``d`` [(M+1)*Ni, cols] and
+        parameter columns ``theta`` [Nx+Ni+No, cols] -- the reference's equality rows solved forwards
+        (controller.py:119-178):  dmu_1 = (A - I) x0 + B (u_-1 + du_0),  dmu_k = A dmu_{k-1} + B du_{k-1} (k <= M),
+        y_1 = C (x0 + dmu_1) + D (u_-1 + du_0 + du_1) + bias,  y_k = y_{k-1} + C dmu_k + D du_k + bias."""
+        A, B, C, D = self.model.A, self.model.B, self.model.C, self.model.D
+        Nx, Ni, P, M = self.Nx, self.Ni, self.P, self.M
+        x0, um1, bias = theta[:Nx], theta[Nx:Nx + Ni], theta[Nx + Ni:]
+        move = lambda j: d[j * Ni:(j + 1) * Ni]
+        dmu = (A - numpy.eye(Nx)) @ x0 + B @ (um1 + move(0))
+        y = C @ (x0 + dmu) + D @ (um1 + move(0) + move(1)) + bias
+        ys, dmus = [y], [dmu]
+        for k in range(2, P + 1):
+            dmu = A @ dmu
+            if k <= M:
+                dmu = dmu + B @ move(k - 1)
+                y = y + C @ dmu + D @ move(k) + bias
+            else:
+                y = y + C @ dmu + bias
+            ys.append(y)
+            dmus.append(dmu)
+        return numpy.vstack(ys), numpy.vstack(dmus)
+
+    def _condense(self):
+        Nx, Ni, No, P, M = self.Nx, self.Ni, self.No, self.P, self.M
+        nd, nt = (M + 1) * Ni, Nx + Ni + No
+        Phi, _ = self.response(numpy.eye(nd), numpy.zeros((nt, nd)))
+        Psi, _ = self.response(numpy.zeros((nd, nt)), numpy.eye(nt))
+        QPhi = numpy.einsum("ij,pjk->pik", self.Q, Phi.reshape(P, No, nd)).reshape(P * No, nd)      # (I x Q) Phi
+        Hc = QPhi.T @ Phi
+        for j in range(M + 1):
+            Hc[j * Ni:(j + 1) * Ni, j * Ni:(j + 1) * Ni] += self.R
+        F = QPhi.T @ Psi
+        f0 = -QPhi.T @ numpy.tile(self.ysp, P)
+        # bounded rows, in the order of the reference's inequality blocks: outputs, input moves, first input
+        rows_d, rows_t, lo, hi = [], [], [], []
+
+        def unit(i):
+            e = numpy.zeros(nd)
+            e[i] = 1.0
+            return e
+
+        def add(row_d, row_t, lo_i, hi_i):
+            if numpy.isfinite(lo_i) or numpy.isfinite(hi_i):
+                rows_d.append(row_d); rows_t.append(row_t); lo.append(lo_i); hi.append(hi_i)
+
+        for k in range(P):
+            for o in range(No):
+                add(Phi[k * No + o], Psi[k * No + o], self._y_lim[0][o], self._y_lim[1][o])
+        for j in range(M + 1):
+            for i in range(Ni):
+                add(unit(j * Ni + i), numpy.zeros(nt), self._du_lim[0][i], self._du_lim[1][i])
+        for i in range(Ni):          # u_-1 + du_0 (controller.py:209-219 keeps the bound on the first input only)
+            add(unit(i), numpy.eye(nt)[Nx + i], self._u_lim[0][i], self._u_lim[1][i])
+        m = len(lo)
+        if m > MAX_ROWS:
+            raise NotImplementedError("this MPC has %d bounded rows; the device solver takes at most %d "
+                                      "(bound fewer outputs / moves, or shorten the horizons)" % (m, MAX_ROWS))
+        Cin = numpy.array(rows_d).reshape(m, nd)
+        Pin = numpy.array(rows_t).reshape(m, nt)
+        chol = numpy.linalg.cholesky(Hc)
+        solve = lambda rhs: numpy.linalg.solve(chol.T, numpy.linalg.solve(chol, rhs))
+        HiF, Hif0, HiCt = solve(F), solve(f0), solve(Cin.T)
+        law = dict(
+            Gc=-Cin @ HiF + Pin, gc0=-Cin @ Hif0, S=Cin @ HiCt, lo=numpy.array(lo, dtype=float), hi=numpy.array(hi, dtype=float),
+            Gu=-HiF[:Ni], gu0=-Hif0[:Ni], Tu=HiCt[:Ni].reshape(Ni, m),
+            Gy=-Phi[:No] @ HiF + Psi[:No], gy0=-Phi[:No] @ Hif0, Ty=(Phi[:No] @ HiCt).reshape(No, m))
+        self._built = (law, dict(Hc=Hc, F=F, f0=f0, Cin=Cin, Pin=Pin, Phi=Phi, Psi=Psi, HiF=HiF, Hif0=Hif0, HiCt=HiCt))
+
+    def moves(self, theta, nu):
+        """All input moves d* for parameter rows ``theta`` [B, n_theta] and multipliers ``nu`` [B, n_rows] (host;
+        for inspection and tests -- the loop itself needs only du_0 and y_1)."""
+        c = self._condensed
+        return (-(c["HiF"] @ theta.T) - c["Hif0"][:, None] - c["HiCt"] @ nu.T).T
+
+    # ------------------------------------------------------------------------------------------------------------
+    # device evaluation
+    # ------------------------------------------------------------------------------------------------------------
+    def _device_law(self):
+        import torch
+        if self._dev is None:
+            lib = _lib.load()
+            dev = torch.device("cuda", torch.cuda.current_device())
+            keep = {k: torch.as_tensor(numpy.ascontiguousarray(v, dtype=numpy.float64), device=dev) for k, v in self._law.items()}
+            law = _Law()
+            law.n_theta, law.n_u, law.n_y = self.Nx + self.Ni + self.No, self.Ni, self.No
+            law.n_rows = len(self._law["lo"])
+            law.max_sweeps, law.eps_abs, law.eps_rel = self._solver
+            for k, t in keep.items():
+                setattr(law, k, t.data_ptr() if t.numel() else None)
+            self._dev = (lib, law, keep)
+        return self._dev
+
+    def step_device(self, theta, du0=None, y1=None, status=None):
+        """theta: device tensor [B, Nx+Ni+No] fp64 -> (du0 [B, Ni], y1 [B, No], status [B] int32), all on the device,
+        enqueued on the current stream without synchronising."""
+        import torch
+        lib, law, _ = self._device_law()
+        B = theta.shape[0]
+        assert theta.dtype == torch.float64 and theta.is_contiguous() and theta.shape[1] == law.n_theta
+        du0 = torch.empty((B, self.Ni), dtype=torch.float64, device=theta.device) if du0 is None else du0
+        y1 = torch.empty((B, self.No), dtype=torch.float64, device=theta.device) if y1 is None else y1
+        status = torch.empty((B,), dtype=torch.int32, device=theta.device) if status is None else status
+        _lib.check(lib.gse_mpc_step(ctypes.byref(law), theta.data_ptr(), B, du0.data_ptr(), y1.data_ptr(),
+                                    status.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return du0, y1, status
+
+    def step_batch(self, x0, um1, y0):
+        """B rollouts at once.  x0 [B, Nx], um1 [B, Ni], y0 [B, No] in deviation variables (host arrays).  Returns
+        (ctrl [B, Ni], ok [B] bool); ``y_predicted`` ([B, No]) advances for the rollouts that solved, as the
+        reference's does when ``step`` returns normally (controller.py:270-279)."""
+        import torch
+        clip = lambda v: numpy.maximum(numpy.minimum(numpy.asarray(v, dtype=float), 1e10), -1e10)   # controller.py:238-241
+        x0, um1, y0 = clip(x0), clip(um1), clip(y0)
+        if self.y_predicted is None:
+            predicted, known = numpy.zeros_like(y0), numpy.zeros(len(y0), dtype=bool)
+        else:
+            predicted, known = self.y_predicted, self._known
+        bias = numpy.where(known[:, None], y0 - predicted, 0.0)      # no bias before the first solved step (:248-251)
+        theta = torch.as_tensor(numpy.ascontiguousarray(numpy.hstack([x0, um1, bias])), device="cuda")
+        du0, y1, status = self.step_device(theta)
+        ok = status.cpu().numpy() == 0
+        ctrl = du0.cpu().numpy() + um1
+        self.y_predicted = numpy.where(ok[:, None], y1.cpu().numpy() - bias, predicted)
+        self._known = known | ok
+        return ctrl, ok
+
+    def step(self, x0, um1, y0):
+        """The MPC control input for one system (controller.py:236-279): raises ValueError when the QP has no
+        solution the solver can reach, exactly where the reference raises on a non-solved OSQP status."""
+        keep = self.y_predicted
+        if keep is not None:
+            self.y_predicted, self._known = numpy.atleast_2d(keep), numpy.ones(1, dtype=bool)
+        try:
+            ctrl, ok = self.step_batch(numpy.atleast_2d(x0), numpy.atleast_2d(um1), numpy.atleast_2d(y0))
+        except Exception:
+            self.y_predicted = keep
+            raise
+        if not ok[0]:
+            self.y_predicted = keep
+            raise ValueError("the MPC's QP was not solved (bounds infeasible or sweeps exhausted)")
+        self.y_predicted = self.y_predicted[0]
+        return ctrl[0]

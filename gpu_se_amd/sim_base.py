@@ -1,11 +1,9 @@
-"""Entry points of the reference's sim_base.py for the estimator path: get_parts, get_noise, get_random_io.
-
-What is NOT here (out of scope): the linear model and the OSQP-based MPC that the
-reference's get_parts also builds -- they are returned as None.  The closed-loop Simulation driver is a later
-row of the coverage table.
+"""Entry points of the reference's sim_base.py: get_parts, get_noise, get_random_io, performance and the closed-loop
+drivers: plant + estimator + MPC, one rollout (Simulation) or B rollouts (BatchedSimulation).
 """
 import numpy
 
+from gpu_se_amd import controller
 from gpu_se_amd import filter as _filter
 from gpu_se_amd import gaussian_sum_dist, model
 
@@ -16,20 +14,16 @@ def get_parts(dt_control=1, N_particles=2 * 15, gpu=True, pf=True):
     Returns
     -------
     bioreactor : model.Bioreactor   the nonlinear plant at its steady state
-    lin_model : None                (linearisation for the MPC: out of scope here)
-    K : None                        (MPC controller: out of scope here)
+    lin_model : model.LinearModel   linearisation about u = [0.04, 0.1], states / outputs (Cg, Cfa), both inputs
+    K : controller.MPC              P = 300 // dt_control, M = 200 // dt_control, Q = diag(0.1, 1), R = I, u >= 0
     pf : filter.ParallelParticleFilter or filter.ParallelGaussianSumUnscentedKalmanFilter
     """
     if not gpu:
         raise NotImplementedError("gpu_se_amd provides the device classes only (gpu=True); the NumPy classes of "
                                   "the reference are restated under oracle/ as test infrastructure")
-    _ = dt_control
-    bioreactor = model.Bioreactor(
-        X0=model.Bioreactor.find_SS(
-            numpy.array([0.06, 0.2]),
-            #            Ng,         Nx,      Nfa, Ne, Nh
-            numpy.array([260 / 180, 640 / 24.6, 1000 / 116, 0, 0])),
-        high_N=False)
+    shape = numpy.array([260 / 180, 640 / 24.6, 1000 / 116, 0, 0])        # Ng, Nx, Nfa, Ne, Nh
+    bioreactor = model.Bioreactor(X0=model.Bioreactor.find_SS(numpy.array([0.06, 0.2]), shape), high_N=False)
+    lin_model, K = get_controller(bioreactor, dt_control)
 
     my_filter = _filter.ParallelParticleFilter if pf else _filter.ParallelGaussianSumUnscentedKalmanFilter
     state_pdf, measurement_pdf = get_noise()
@@ -42,7 +36,21 @@ def get_parts(dt_control=1, N_particles=2 * 15, gpu=True, pf=True):
         x0=x0,
         state_pdf=state_pdf,
         measurement_pdf=measurement_pdf)
-    return bioreactor, None, None, estimator
+    return bioreactor, lin_model, K, estimator
+
+
+def get_controller(bioreactor, dt_control=1):
+    """The linear model and the MPC of get_parts (sim_base.py:55-86)."""
+    shape = numpy.array([260 / 180, 640 / 24.6, 1000 / 116, 0, 0])
+    lin_model = model.LinearModel.create_LinearModel(
+        bioreactor, x_bar=model.Bioreactor.find_SS(numpy.array([0.04, 0.1]), shape), u_bar=numpy.array([0.04, 0.1]),
+        T=dt_control)
+    lin_model.select_subset(states=[0, 2], inputs=[0, 1], outputs=[0, 2])           # Cg, Cfa; Fg_in, Fm_in
+    K = controller.MPC(
+        P=int(300 // dt_control), M=max(int(200 // dt_control), 1), Q=numpy.diag([0.1, 1]), R=numpy.diag([1, 1]),
+        lin_model=lin_model, ysp=lin_model.yn2d(numpy.array([280, 850]), subselect=False),
+        u_bounds=[numpy.array([0, numpy.inf]) - lin_model.u_bar[0], numpy.array([0, numpy.inf]) - lin_model.u_bar[1]])
+    return lin_model, K
 
 
 def get_noise(lib=None, deterministic=False):
@@ -87,10 +95,9 @@ def get_realistic_io(rng, x_ref):
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# Closed loop (sim_base.py:164-309).  The estimator runs on the device; the plant, its noise and the bookkeeping are
-# scalar host work exactly as in the reference.  The MPC of the reference (controller.py, OSQP) is out of scope: the
-# controller is a pluggable callable, and the default is what the reference's loop applies whenever its QP solve
-# raises (sim_base.py:264-273): hold u = [0.06, 0.2].
+# Closed loop (sim_base.py:164-309).  The estimator and the controller run on the device; the plant, its noise and the
+# bookkeeping are scalar host work exactly as in the reference.  ``controller=`` replaces the MPC by any callable
+# (x_estimate, u_previous, y_measured) -> u, e.g. hold_controller.
 # ----------------------------------------------------------------------------------------------------------------
 _OUTPUTS = [0, 2]            # lin_model.outputs after select_subset (sim_base.py:69-73): Cg, Cfa
 _INPUTS = [0, 1]
@@ -127,10 +134,10 @@ def hold_controller(x_estimate, u_previous, y_measured):
 
 
 class Simulation:
-    """Holds details of a closed-loop simulation (sim_base.py:207-309): plant + estimator (+ controller).
+    """Holds details of a closed-loop simulation (sim_base.py:207-309): plant + estimator + MPC.
 
-    Parameters as in the reference; ``controller`` is a callable (x_estimate, u_previous, y_measured) -> u replacing
-    the reference's MPC object, ``seed`` seeds the plant's noise."""
+    Parameters as in the reference; ``controller`` optionally replaces the MPC by a callable
+    (x_estimate, u_previous, y_measured) -> u, ``seed`` seeds the plant's noise."""
 
     def __init__(self, N_particles, dt_control, dt_predict, end_time=50, pf=True, controller=None, seed=0):
         self.ts = numpy.linspace(0, end_time, int(end_time * 10))
@@ -138,7 +145,7 @@ class Simulation:
         self.dt_control = dt_control
         self.dt_predict = dt_predict
         self.bioreactor, self.lin_model, self.K, self.f = get_parts(dt_control=dt_control, N_particles=N_particles, pf=pf)
-        self.controller = controller or hold_controller
+        self.controller = controller
         self._rng = numpy.random.default_rng(seed)
 
         self.us = [_U_FALLBACK.copy()]
@@ -148,23 +155,44 @@ class Simulation:
         self.xs_f = [self.f.point_estimate()]
         self.ys_f = [numpy.array(model.Bioreactor.static_outputs(self.xs_f[-1], self.us[-1]))]
         self.covariance_point_size = [self.f.point_covariance()]
+        self.biass = []
         self.performance = None
+        self.mpc_frac = None
         self.predict_count, self.update_count = 0, 0
+
+    def _control(self):
+        """One controller call (sim_base.py:262-274): the MPC in deviation variables; when its QP is not solved the
+        reference substitutes [0.06, 0.2] for the DEVIATION input (the operating point is then added on top)."""
+        lm = self.lin_model
+        u_next = self.us[-1].copy()
+        if self.controller is not None:
+            return numpy.asarray(self.controller(self.xs_f[-1], self.us[-1], self.ys_meas[-1]), dtype=numpy.float64), True
+        try:
+            u = self.K.step(lm.xn2d(self.xs_f[-1]), lm.un2d(self.us[-1]), lm.yn2d(self.ys_meas[-1]))
+            solved = True
+        except ValueError:
+            u, solved = _U_FALLBACK.copy(), False
+        u_next[lm.inputs] = lm.ud2n(u)
+        return u_next, solved
 
     def simulate(self):
         """Performs a simulation using the simulation parameters (sim_base.py:243-309)."""
         t_next_control, t_next_predict = 0, 0
+        solved_count = failed_count = 0
         for t in self.ts[1:]:
             if t > t_next_predict:
                 self.f.predict(self.us[-1], self.dt)
                 self.predict_count += 1
                 t_next_predict += self.dt_predict
             if t > t_next_control:
+                if self.controller is None and self.K.y_predicted is not None:
+                    self.biass.append(self.lin_model.yn2d(self.ys_meas[-1]) - self.K.y_predicted)
                 self.f.update(self.us[-1], self.ys_meas[-1][_OUTPUTS])
                 self.f.resample()
                 self.update_count += 1
                 self.xs_f.append(self.f.point_estimate())
-                u = numpy.asarray(self.controller(self.xs_f[-1], self.us[-1], self.ys_meas[-1]), dtype=numpy.float64)
+                u, solved = self._control()
+                solved_count, failed_count = solved_count + solved, failed_count + (not solved)
                 self.us.append(u.copy())
                 t_next_control += self.dt_control
             else:
@@ -184,6 +212,7 @@ class Simulation:
         for name in ("us", "xs", "ys", "ys_meas", "xs_f", "ys_f", "covariance_point_size"):
             setattr(self, name, numpy.array(getattr(self, name)))
         self.performance = performance(self.ys[:, _OUTPUTS], self.ys_f, self.ts)
+        self.mpc_frac = solved_count / max(solved_count + failed_count, 1)
 
 
 class BatchedSimulation:
@@ -198,12 +227,13 @@ class BatchedSimulation:
         self.dt = self.ts[1]
         self.dt_control, self.dt_predict = dt_control, dt_predict
         xss = model.Bioreactor.find_SS(numpy.array([0.06, 0.2]), numpy.array([260 / 180, 640 / 24.6, 1000 / 116, 0, 0]))
+        self.lin_model, self.K = get_controller(model.Bioreactor(X0=xss.copy(), high_N=False), dt_control)
         state_pdf, measurement_pdf = get_noise()
         x0, _ = get_noise()
         x0.means += numpy.asarray(xss[numpy.newaxis, :], dtype=numpy.float32)
         self.f = _filter.BatchedParticleFilter(model.Bioreactor.homeostatic_DEs, model.Bioreactor.static_outputs,
                                                N_particles, x0, state_pdf, measurement_pdf, batch=self.B)
-        self.controller = controller or hold_controller
+        self.controller = controller
         self._rng = numpy.random.default_rng(seed)
         self.X = numpy.repeat(xss[None, :], self.B, axis=0)
         self.us = [numpy.repeat(_U_FALLBACK[None, :], self.B, axis=0)]
@@ -215,6 +245,19 @@ class BatchedSimulation:
         self.ys_f.append(numpy.stack([est[:, 0] * 180, est[:, 2] * 116], axis=1))
         self.covariance_point_size.append(cov)
         self.performance = None
+        self.mpc_frac = None
+
+    def _control(self, est):
+        """All rollouts' controller calls at once (one kernel launch); see Simulation._control."""
+        if self.controller is not None:
+            u = numpy.array([self.controller(est[b], self.us[-1][b], self.ys_meas[-1][b]) for b in range(self.B)])
+            return u, numpy.ones(self.B, dtype=bool)
+        lm = self.lin_model
+        u_dev, ok = self.K.step_batch(lm.xn2d(est), lm.un2d(self.us[-1]), lm.yn2d(self.ys_meas[-1]))
+        u_dev = numpy.where(ok[:, None], u_dev, _U_FALLBACK[None, :])
+        u_next = self.us[-1].copy()
+        u_next[:, lm.inputs] = lm.ud2n(u_dev)
+        return u_next, ok
 
     def _outputs(self):
         return self.X * numpy.array([180, 24.6, 116, 46, 1])
@@ -226,6 +269,7 @@ class BatchedSimulation:
 
     def simulate(self):
         t_next_control, t_next_predict = 0, 0
+        solved = asked = 0
         for t in self.ts[1:]:
             if t > t_next_predict:
                 self.f.predict(self.us[-1], self.dt)
@@ -235,7 +279,9 @@ class BatchedSimulation:
                 self.f.resample()
                 est = self.f.point_estimate()
                 self.xs_f.append(est)
-                u = numpy.array([self.controller(est[b], self.us[-1][b], self.ys_meas[-1][b]) for b in range(self.B)])
+                u, ok = self._control(est)
+                solved += int(ok.sum())
+                asked += self.B
                 self.us.append(u)
                 t_next_control += self.dt_control
             else:
@@ -254,3 +300,4 @@ class BatchedSimulation:
             setattr(self, name, numpy.array(getattr(self, name)))
         self.performance = numpy.array([performance(self.ys[:, b][:, _OUTPUTS], self.ys_f[:, b], self.ts)
                                         for b in range(self.B)])
+        self.mpc_frac = solved / max(asked, 1)

@@ -226,6 +226,38 @@ int gse_systematic_index(const double *c, int64_t *idx, int64_t N, double r, voi
  * the published Philox4x32-10 algorithm). */
 int gse_rng_raw(uint32_t *out, int64_t M, const gse_rng *rng, uint32_t purpose, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Model-predictive controller (controller.py:9-279): the step that follows point_estimate() in the closed loop
+ * (sim_base.py:262-270).  The reference hands a sparse QP in (states, outputs, inputs, input moves) to OSQP on
+ * every control tick; only three small vectors of that QP change from tick to tick -- theta = (x0, u_{-1}, bias),
+ * controller.py:236-262 -- so the QP is condensed ONCE on the host (gpu_se_amd/controller.py) into an explicit law
+ *
+ *     c0    = Gc theta + gc0                      the bounded rows at the unconstrained optimum   [n_rows]
+ *     nu    = argmax of the dual:  lo <= c0 - S nu <= hi,  nu_i (c_i - bound_i) = 0             (Hildreth sweeps)
+ *     du0   = Gu theta + gu0 - Tu nu              first input move                               [n_u]
+ *     y1    = Gy theta + gy0 - Ty nu              first predicted output                         [n_y]
+ *
+ * and this entry point evaluates the law for B rollouts, one wavefront each.  All matrices are row-major fp64 in
+ * DEVICE memory, read-only; theta, du0, y1, status are device arrays, so the controller sits between the moments
+ * kernel and the next predict without a host round trip.  status[b] = 0 converged, 1 not converged within
+ * max_sweeps (infeasible or ill-conditioned bounds: the caller falls back as sim_base.py:271-273 does).
+ */
+#define GSE_MPC_MAX_ROWS 64      /* bounded rows (finite y / u / du limits) the device solver takes */
+#define GSE_MPC_MAX_THETA 16     /* Nx + Ni + No of the controller's (sub-selected) linear model     */
+#define GSE_MPC_MAX_OUT 8        /* Ni, No                                                            */
+typedef struct gse_mpc_law {
+    int32_t n_theta, n_u, n_y, n_rows;
+    int32_t max_sweeps, reserved;
+    double  eps_abs, eps_rel;    /* row residual <= eps_abs + eps_rel * (|c0_i| + |bound_i|) ends the sweeps */
+    const double *Gc, *gc0;      /* [n_rows][n_theta], [n_rows]  */
+    const double *S;             /* [n_rows][n_rows] symmetric positive semi-definite */
+    const double *lo, *hi;       /* [n_rows], -inf / +inf allowed */
+    const double *Gu, *gu0, *Tu; /* [n_u][n_theta], [n_u], [n_u][n_rows] */
+    const double *Gy, *gy0, *Ty; /* [n_y][n_theta], [n_y], [n_y][n_rows] */
+} gse_mpc_law;
+int gse_mpc_step(const gse_mpc_law *law, const double *theta /* [B][n_theta] */, int64_t B, double *du0 /* [B][n_u] */,
+                 double *y1 /* [B][n_y] */, int32_t *status /* [B] */, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,10 @@ Fixture list:
   G5 gsukf_trace.npz    GS-UKF N in {1,7,64}: sigma points, predict, update, resample, estimates
   G6 pf_stat.npz        posterior-mean envelope over independent seeds (statistical parity)
   G7 constants.npz      mixture constants, inverse covariances, sigma weights, X_ss
+  G8 linear_model.npz   LinearModel.create_LinearModel of the bioreactor (get_parts wiring), dt_control in {1, 0.1}
+  G9 mpc_qp.npz         controller.MPC: the QP it hands to OSQP (H, q, A, l, u) for several horizons / bounds, and the
+                        l, u vectors after step() has written x0, u_{-1} and the bias into them.  (osqp is not
+                        installed: the SOLUTION of these QPs is not a reference output and is not stored.)
 """
 import os
 import sys
@@ -397,8 +401,79 @@ def gen_pf_stat(X, seed=606):
     save("pf_stat.npz", **out)
 
 
+def _ref_linear_model(dt_control):
+    import model.LinearModel  # noqa: F401  (reference)
+    ss = ref_model.Bioreactor.find_SS
+    shape = numpy.array([260 / 180, 640 / 24.6, 1000 / 116, 0, 0])
+    bioreactor = ref_model.Bioreactor(X0=ss(numpy.array([0.06, 0.2]), shape), high_N=False)
+    lin = ref_model.LinearModel.create_LinearModel(bioreactor, x_bar=ss(numpy.array([0.04, 0.1]), shape),
+                                                   u_bar=numpy.array([0.04, 0.1]), T=dt_control)
+    return bioreactor, lin
+
+
+def gen_linear_model():
+    out = {}
+    for tag, dt_control in (("dt1", 1.0), ("dt01", 0.1)):
+        _, lin = _ref_linear_model(dt_control)
+        for name in ("A", "B", "C", "D", "x_bar", "u_bar", "f_bar", "y_bar"):
+            out["%s_full_%s" % (tag, name)] = numpy.array(getattr(lin, name), dtype=numpy.float64)
+        lin.select_subset(states=[0, 2], inputs=[0, 1], outputs=[0, 2])
+        for name in ("A", "B", "C", "D", "x_bar", "u_bar", "f_bar", "y_bar"):
+            out["%s_sub_%s" % (tag, name)] = numpy.array(getattr(lin, name), dtype=numpy.float64)
+        out["%s_ysp" % tag] = lin.yn2d(numpy.array([280, 850]), subselect=False)
+    save("linear_model.npz", **out)
+
+
+def gen_mpc_qp():
+    import controller  # noqa: E402  (reference; osqp is the inert placeholder above)
+    _, lin = _ref_linear_model(1.0)
+    lin.select_subset(states=[0, 2], inputs=[0, 1], outputs=[0, 2])
+    ysp = lin.yn2d(numpy.array([280, 850]), subselect=False)
+    ub_default = [numpy.array([0, numpy.inf]) - lin.u_bar[0], numpy.array([0, numpy.inf]) - lin.u_bar[1]]
+    cases = {
+        "small": dict(P=6, M=3, u_bounds=ub_default),
+        "square": dict(P=5, M=5, u_bounds=ub_default),
+        "free": dict(P=8, M=4),
+        "boxed": dict(P=8, M=4, u_bounds=[(-0.03, 0.05), (-0.08, 0.1)], u_step_bounds=[(-0.01, 0.01), (-0.02, 0.02)],
+                      y_bounds=[(-3.0, 3.0), (-400.0, 400.0)]),
+        "parts": dict(P=300, M=200, u_bounds=ub_default),          # get_parts(dt_control=1), sim_base.py:75-86
+    }
+    rng = numpy.random.default_rng(909)
+    out = {"names": numpy.array(sorted(cases))}
+    for name, kw in cases.items():
+        K = controller.MPC(Q=numpy.diag([0.1, 1]), R=numpy.diag([1, 1]), lin_model=lin, ysp=ysp, **kw)
+        A = K.A_matrix.tocoo()
+        H = K.H.tocoo()
+        out[name + "_PM"] = numpy.array([kw["P"], kw["M"]])
+        out[name + "_shape"] = numpy.array(A.shape)
+        for tag, mat in (("A", A), ("H", H)):
+            out["%s_%s_row" % (name, tag)] = mat.row.astype(numpy.int32)
+            out["%s_%s_col" % (name, tag)] = mat.col.astype(numpy.int32)
+            out["%s_%s_val" % (name, tag)] = mat.data.astype(numpy.float64)
+        out[name + "_q"] = numpy.array(K.q)
+        out[name + "_l0"] = K.l_matrix.copy()
+        out[name + "_u0"] = K.u_matrix.copy()
+        # two consecutive step() calls: the placeholder's solve() raises after l, u have been written
+        x0 = rng.normal(size=2) * numpy.array([0.05, 0.5])
+        um1 = rng.normal(size=2) * 0.01
+        y0 = rng.normal(size=2) * numpy.array([5.0, 50.0])
+        for k, y_pred in enumerate((None, numpy.array([1.5, -20.0]))):
+            K.y_predicted = y_pred
+            try:
+                K.step(x0, um1, y0)
+            except RuntimeError:
+                pass
+            out["%s_step%d_l" % (name, k)] = K.l_matrix.copy()
+            out["%s_step%d_u" % (name, k)] = K.u_matrix.copy()
+        out[name + "_x0"] = x0
+        out[name + "_um1"] = um1
+        out[name + "_y0"] = y0
+        out[name + "_ypred"] = numpy.array([1.5, -20.0])
+    save("mpc_qp.npz", **out)
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"constants", "model", "pdf", "resample", "pf", "gsukf", "stat"}
+    which = set(sys.argv[1:]) or {"constants", "model", "pdf", "resample", "pf", "gsukf", "stat", "linear", "mpc"}
     Xss = x_ss()
     print("X_ss =", Xss)
     if "constants" in which:
@@ -415,3 +490,7 @@ if __name__ == "__main__":
         gen_gsukf(Xss)
     if "stat" in which:
         gen_pf_stat(Xss)
+    if "linear" in which:
+        gen_linear_model()
+    if "mpc" in which:
+        gen_mpc_qp()

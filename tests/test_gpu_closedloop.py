@@ -58,7 +58,8 @@ def test_batched_filter_tracks_per_filter_measurements():
 
 def test_closed_loop_simulation_tracks_the_plant():
     gpu_se_amd.seed(1)
-    sim = sim_base.Simulation(N_particles=1 << 14, dt_control=0.1, dt_predict=0.1, end_time=6, seed=3)
+    sim = sim_base.Simulation(N_particles=1 << 14, dt_control=0.1, dt_predict=0.1, end_time=6, seed=3,
+                              controller=sim_base.hold_controller)
     sim.simulate()
     steps = len(sim.ts)
     assert sim.xs.shape == (steps, 5) and sim.ys_f.shape == (steps, 2) and sim.us.shape == (steps, 2)
@@ -72,7 +73,8 @@ def test_closed_loop_simulation_tracks_the_plant():
 
 def test_batched_closed_loops():
     gpu_se_amd.seed(2)
-    sim = sim_base.BatchedSimulation(batch=4, N_particles=1 << 13, dt_control=0.1, dt_predict=0.1, end_time=4, seed=7)
+    sim = sim_base.BatchedSimulation(batch=4, N_particles=1 << 13, dt_control=0.1, dt_predict=0.1, end_time=4, seed=7,
+                                     controller=sim_base.hold_controller)
     sim.simulate()
     steps = len(sim.ts)
     assert sim.xs.shape == (steps, 4, 5) and sim.ys_f.shape == (steps, 4, 2)

@@ -8,7 +8,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 18
 end_time = float(sys.argv[3]) if len(sys.argv) > 3 else 5
 gpu_se_amd.seed(1)
-sim = sim_base.BatchedSimulation(batch=B, N_particles=1 << log2n, dt_control=0.1, dt_predict=0.1, end_time=end_time, seed=1)
+sim = sim_base.BatchedSimulation(batch=B, N_particles=1 << log2n, dt_control=0.1, dt_predict=0.1, end_time=end_time, seed=1,
+                                 controller=sim_base.hold_controller if os.environ.get("GSE_HOLD") else None)
 torch.cuda.synchronize()
 t = time.perf_counter()
 sim.simulate()
