@@ -14,6 +14,7 @@ GSE_RESAMPLE_TILES_VALID = 1
 GSE_RESAMPLE_SEPARATE_SCAN = 2
 GSE_OP_GATHER, GSE_OP_PREDICT, GSE_OP_UPDATE = 1, 2, 4
 GSE_OP_SCAN_IN, GSE_OP_SCAN_OUT, GSE_OP_SCAN_IN_SLOT1, GSE_OP_SCAN_OUT_SLOT1 = 8, 16, 32, 64
+GSE_OP_U_DEVICE, GSE_OP_Z_DEVICE = 128, 256
 GSE_SCAN_MAX_TILES = 2048      # policy: beyond 2^21 particles the two-kernel resample is faster (measured)
 GSE_GSUKF_CYCLE_MAX = 64
 
@@ -76,6 +77,8 @@ PROTOTYPES = {
     "gse_systematic_index": (ctypes.c_int, [c_vp, c_vp, c_i64, c_d, c_vp]),
     "gse_rng_raw": (ctypes.c_int, [c_vp, c_i64, P_RNG, c_u32, c_vp]),
     "gse_mpc_step": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "gse_loop_control": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "gse_plant_step": (ctypes.c_int, [c_vp, c_vp, c_d, P_MIX, P_MIX, P_RNG, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
 }
 
 _lib = None

@@ -37,6 +37,15 @@ class _Law(ctypes.Structure):
                [(name, ctypes.c_void_p) for name in ("Gc", "gc0", "S", "lo", "hi", "Gu", "gu0", "Tu", "Gy", "gy0", "Ty")]
 
 
+class _Glue(ctypes.Structure):
+    """struct gse_loop_glue (include/gse.h)."""
+    _fields_ = [("n_state_full", ctypes.c_int32), ("n_input_full", ctypes.c_int32), ("n_output_full", ctypes.c_int32),
+                ("reserved", ctypes.c_int32),
+                ("states", ctypes.c_int32 * 8), ("inputs", ctypes.c_int32 * 8), ("outputs", ctypes.c_int32 * 8),
+                ("x_bar", ctypes.c_double * 8), ("u_bar", ctypes.c_double * 8), ("y_bar", ctypes.c_double * 8),
+                ("u_fallback", ctypes.c_double * 8)]
+
+
 def _bounds(pairs, n):
     if pairs is None:
         return numpy.full(n, -numpy.inf), numpy.full(n, numpy.inf)
@@ -190,6 +199,37 @@ class MPC:
         _lib.check(lib.gse_mpc_step(ctypes.byref(law), theta.data_ptr(), B, du0.data_ptr(), y1.data_ptr(),
                                     status.data_ptr(), torch.cuda.current_stream().cuda_stream))
         return du0, y1, status
+
+    def loop_state(self, B, device):
+        """Device-side bookkeeping of ``loop_control`` for B rollouts: (y_predicted [B, No], known [B], status [B])."""
+        import torch
+        return (torch.zeros((B, self.No), dtype=torch.float64, device=device),
+                torch.zeros((B,), dtype=torch.int32, device=device), torch.zeros((B,), dtype=torch.int32, device=device))
+
+    def loop_control(self, moments, y_meas, u, state, u_fallback, full_dims=(5, 2, 5), theta_out=None):
+        """The controller call of the closed loop on the device (``gse_loop_control``): estimator moments [B, 26],
+        measured outputs [B, n_out] and the current inputs ``u`` [B, n_in] (updated in place) are device tensors;
+        ``state`` comes from ``loop_state``.  Nothing is synchronised."""
+        import torch
+        lib, law, _ = self._device_law()
+        lm = self.model
+        key = (tuple(full_dims), tuple(float(v) for v in u_fallback))
+        if getattr(self, "_glue_key", None) != key:             # the glue only depends on the model: build it once
+            glue = _Glue()
+            glue.n_state_full, glue.n_input_full, glue.n_output_full = full_dims
+            for name, idx in (("states", lm.states), ("inputs", lm.inputs), ("outputs", lm.outputs)):
+                for k, v in enumerate(idx):
+                    getattr(glue, name)[k] = int(v)
+            for name, vec in (("x_bar", lm.x_bar), ("u_bar", lm.u_bar), ("y_bar", lm.y_bar), ("u_fallback", u_fallback)):
+                for k, v in enumerate(vec):
+                    getattr(glue, name)[k] = float(v)
+            self._glue_key, self._glue = key, glue
+        glue = self._glue
+        y_pred, known, status = state
+        _lib.check(lib.gse_loop_control(ctypes.byref(law), ctypes.byref(glue), moments.data_ptr(), y_meas.data_ptr(),
+                                        u.data_ptr(), y_pred.data_ptr(), known.data_ptr(), status.data_ptr(),
+                                        theta_out.data_ptr() if theta_out is not None else None, u.shape[0],
+                                        torch.cuda.current_stream().cuda_stream))
 
     def step_batch(self, x0, um1, y0):
         """B rollouts at once.  x0 [B, Nx], um1 [B, Ni], y0 [B, No] in deviation variables (host arrays).  Returns

@@ -42,7 +42,8 @@ struct RngKey {
     uint64_t elem0;             // global index of element 0
 };
 
-enum : uint32_t { kPurposePrior = 0, kPurposePredict = 1, kPurposeDraw = 2, kPurposeGsukf = 3 };
+enum : uint32_t { kPurposePrior = 0, kPurposePredict = 1, kPurposeDraw = 2, kPurposeGsukf = 3, kPurposePlantState = 4,
+                  kPurposePlantMeas = 5 };
 
 __host__ __device__ inline RngKey make_rng_key(const gse_rng& r, uint32_t purpose) {
     RngKey k;
@@ -141,7 +142,8 @@ __device__ __forceinline__ double div_by_constant(double x, double c, double y) 
     return fma(r, y, q);
 }
 
-__device__ __forceinline__ void bioreactor_increment(const float (&x)[5], double fg, double fm, double dt,
+template <class T>       // T = float (particles, sigma points: stored fp32) or double (the plant of the closed loop)
+__device__ __forceinline__ void bioreactor_increment(const T (&x)[5], double fg, double fm, double dt,
                                                      double (&dx)[5]) {
 #pragma clang fp contract(off)
     const double cg_in = 5000.0 / 180.0;
@@ -248,6 +250,27 @@ __device__ __forceinline__ double block_sum(double v, double* lds) {
     if (lane == 0) lds[wv] = v;
     __syncthreads();
     return (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// kCount sums over the 256-thread workgroup at once: wavefront reductions in registers, ONE barrier, then thread c
+// adds the four wavefront totals of value c in block_sum's order ((w0 + w1) + (w2 + w3)) and hands it to emit(c, total).
+// (block_sum per value costs two barriers each: 42 for the 21 moments of a particle filter.)  lds: >= 4 * kCount doubles.
+template <int kCount, class Emit>
+__device__ __forceinline__ void block_sums(double (&v)[kCount], double* lds, Emit emit) {
+    static_assert(kCount <= 64, "one thread per value adds the wavefront totals");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < kCount; ++c) v[c] = wave_sum(v[c]);
+    __syncthreads();                      // protect lds against a previous use
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < kCount; ++c) lds[wv * kCount + c] = v[c];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < kCount) {
+        const int c = threadIdx.x;
+        emit(c, (lds[c] + lds[kCount + c]) + (lds[2 * kCount + c] + lds[3 * kCount + c]));
+    }
 }
 
 // Exclusive scan over the workgroup of one value per thread; also returns the workgroup total.

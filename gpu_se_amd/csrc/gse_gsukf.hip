@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_cycle_kernel(float* __restr
 __global__ __launch_bounds__(kBlock) void gsukf_moments_kernel(const float* __restrict__ mu, const float* __restrict__ P,
                                                                const float* __restrict__ w,
                                                                double* __restrict__ partials, int64_t N) {
-    __shared__ double red[4];
+    __shared__ double red[4 * 36];
     const int b = blockIdx.y;
     const float* mb = mu + (int64_t)b * N * 5;
     const float* Pb = P + (int64_t)b * N * 25;
@@ -477,11 +477,7 @@ __global__ __launch_bounds__(kBlock) void gsukf_moments_kernel(const float* __re
             for (int l = k; l < 5; ++l) acc[c++] += wp * (double)Pb[g * 25 + k * 5 + l];
     }
     double* out = partials + ((int64_t)b * kMomentBlocks + blockIdx.x) * kMomentWidth;
-#pragma unroll
-    for (int c = 0; c < 36; ++c) {
-        const double tot = block_sum(acc[c], red);
-        if (threadIdx.x == 0) out[c] = tot;
-    }
+    block_sums<36>(acc, red, [&](int c, double total) { out[c] = total; });
 }
 
 static int pack_sigma_weights(SigmaWeights& sw, const float* w_sigma) {

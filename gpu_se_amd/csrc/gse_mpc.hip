@@ -40,26 +40,22 @@ struct MpcLawDev {
 
 constexpr int kMpcWavesPerBlock = 4;
 
-__global__ __launch_bounds__(64 * kMpcWavesPerBlock) void mpc_step_kernel(const MpcLawDev law,
-                                                                           const double* __restrict__ theta, int64_t B,
-                                                                           double* __restrict__ du0,
-                                                                           double* __restrict__ y1,
-                                                                           int32_t* __restrict__ status) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * kMpcWavesPerBlock + (threadIdx.x >> 6);
-    if (b >= B) return;                                   // whole wavefronts leave; no barrier below
+// The law for one rollout, by one wavefront.  theta_lane: lane k < n_theta holds theta[k].  On return lane k < n_u holds
+// du0[k] in out, lane 32 + k (k < n_y) holds y1[k]; the return value (uniform) is 1 if the sweeps converged.
+__device__ __forceinline__ int mpc_solve(const MpcLawDev& law, double theta_lane, int lane, double& out) {
     const int m = law.n_rows, nt = law.n_theta;
-    const double* th = theta + b * nt;
-
     // this lane's row at the unconstrained optimum
     const bool row = lane < m;
     double c = 0.0, lo = -INFINITY, hi = INFINITY, sii = 1.0;
     if (row) {
         c = law.gc0[lane];
-        for (int k = 0; k < nt; ++k) c += law.Gc[lane * nt + k] * th[k];
         lo = law.lo[lane];
         hi = law.hi[lane];
         sii = law.S[lane * m + lane];
+    }
+    for (int k = 0; k < nt; ++k) {
+        const double tk = __shfl(theta_lane, k, 64);
+        if (row) c += law.Gc[lane * nt + k] * tk;
     }
     const double c0 = c;
     double nu = 0.0;
@@ -91,48 +87,245 @@ __global__ __launch_bounds__(64 * kMpcWavesPerBlock) void mpc_step_kernel(const 
         const bool ok = !row || (res <= law.eps_abs + law.eps_rel * scale);
         converged = __all(ok) ? 1 : 0;
     }
-    // outputs: lane k < n_u forms du0[k], lane 32 + k forms y1[k]; the multipliers come round by shuffles
+    // outputs: lane k < n_u forms du0[k], lane 32 + k forms y1[k]; theta and the multipliers come round by shuffles
     const bool for_u = lane < law.n_u, for_y = lane >= 32 && lane - 32 < law.n_y;
+    const bool mine = for_u || for_y;
     const int k = for_u ? lane : lane - 32;
+    const double* G = for_u ? law.Gu : law.Gy;
     double acc = 0.0;
-    if (for_u || for_y) {
-        const double* G = for_u ? law.Gu : law.Gy;
-        acc = for_u ? law.gu0[k] : law.gy0[k];
-        for (int q = 0; q < nt; ++q) acc += G[k * nt + q] * th[q];
+    if (mine) acc = for_u ? law.gu0[k] : law.gy0[k];
+    for (int q = 0; q < nt; ++q) {
+        const double tq = __shfl(theta_lane, q, 64);
+        if (mine) acc += G[k * nt + q] * tq;
     }
     for (int i = 0; i < m; ++i) {
         const double nui = __shfl(nu, i, 64);
-        if ((for_u || for_y) && nui != 0.0) acc -= (for_u ? law.Tu : law.Ty)[k * m + i] * nui;
+        if (mine && nui != 0.0) acc -= (for_u ? law.Tu : law.Ty)[k * m + i] * nui;
     }
-    if (for_u) du0[b * law.n_u + k] = acc;
-    if (for_y) y1[b * law.n_y + k] = acc;
+    out = acc;
+    return converged;
+}
+
+__global__ __launch_bounds__(64 * kMpcWavesPerBlock) void mpc_step_kernel(const MpcLawDev law,
+                                                                           const double* __restrict__ theta, int64_t B,
+                                                                           double* __restrict__ du0,
+                                                                           double* __restrict__ y1,
+                                                                           int32_t* __restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * kMpcWavesPerBlock + (threadIdx.x >> 6);
+    if (b >= B) return;                                   // whole wavefronts leave; no barrier below
+    const double th = lane < law.n_theta ? theta[b * law.n_theta + lane] : 0.0;
+    double out;
+    const int converged = mpc_solve(law, th, lane, out);
+    if (lane < law.n_u) du0[b * law.n_u + lane] = out;
+    if (lane >= 32 && lane - 32 < law.n_y) y1[b * law.n_y + lane - 32] = out;
     if (lane == 0) status[b] = converged ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The controller call of the closed loop (sim_base.py:253-274) for B rollouts without leaving the device:
+// the filter's moments -> point estimate -> deviation variables -> MPC -> next input, bias bookkeeping included.
+// ------------------------------------------------------------------------------------------------
+struct LoopGlue {
+    int32_t n_state_full, n_input_full, n_output_full, pad;
+    int32_t states[GSE_MPC_MAX_OUT], inputs[GSE_MPC_MAX_OUT], outputs[GSE_MPC_MAX_OUT];
+    double x_bar[GSE_MPC_MAX_OUT], u_bar[GSE_MPC_MAX_OUT], y_bar[GSE_MPC_MAX_OUT], u_fallback[GSE_MPC_MAX_OUT];
+};
+
+__global__ __launch_bounds__(64 * kMpcWavesPerBlock) void loop_control_kernel(
+    const MpcLawDev law, const LoopGlue g, const double* __restrict__ moments, const double* __restrict__ y_meas,
+    double* __restrict__ u, double* __restrict__ y_pred, int32_t* __restrict__ known, int32_t* __restrict__ status,
+    double* __restrict__ theta_out, int64_t B) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * kMpcWavesPerBlock + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int nx = law.n_theta - law.n_u - law.n_y, ni = law.n_u, no = law.n_y;
+    // theta = (x0, u_-1, bias) in deviation variables, clipped as controller.py:238-241
+    double th = 0.0, bias = 0.0, um1 = 0.0;
+    if (lane < nx) {
+        // point estimate = weights @ particles, NOT normalised (particle.py:318-320): S1 + pivot * S0
+        const double* m = moments + b * 26;
+        const int sidx = g.states[lane];
+        th = (m[1 + sidx] + m[21 + sidx] * m[0]) - g.x_bar[lane];
+    } else if (lane < nx + ni) {
+        const int i = lane - nx;
+        um1 = u[b * g.n_input_full + g.inputs[i]] - g.u_bar[i];
+        th = um1;
+    } else if (lane < nx + ni + no) {
+        const int o = lane - nx - ni;
+        const double ydev = y_meas[b * g.n_output_full + g.outputs[o]] - g.y_bar[o];
+        const double yd = fmax(fmin(ydev, 1e10), -1e10);
+        bias = known[b] ? yd - y_pred[b * no + o] : 0.0;          // no bias before the first solved step (:248-251)
+        th = bias;
+    }
+    if (lane < nx + ni) th = fmax(fmin(th, 1e10), -1e10);
+    if (theta_out && lane < law.n_theta) theta_out[b * law.n_theta + lane] = th;
+    double out;
+    const int converged = mpc_solve(law, th, lane, out);
+    // next input: the first move on top of u_-1 (controller.py:272-275); when the QP is not solved the reference puts
+    // [0.06, 0.2] where the DEVIATION input goes (sim_base.py:271-274), the operating point is added either way
+    const double um1_i = __shfl(um1, nx + (lane < ni ? lane : 0), 64);
+    if (lane < ni) u[b * g.n_input_full + g.inputs[lane]] = (converged ? out + um1_i : g.u_fallback[lane]) + g.u_bar[lane];
+    const double bias_o = __shfl(bias, nx + ni + (lane >= 32 && lane - 32 < no ? lane - 32 : 0), 64);
+    if (converged && lane >= 32 && lane - 32 < no) y_pred[b * no + lane - 32] = out - bias_o;
+    if (lane == 0) {
+        if (converged) known[b] = 1;
+        status[b] = converged ? 0 : 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The plant of the closed loop (sim_base.py:278-287, BioreactorModel.py:95-122): Euler step of the fp64 model, clamp,
+// state noise, outputs, measurement noise -- one thread per rollout.
+// ------------------------------------------------------------------------------------------------
+struct PlantArgs {
+    DrawParams state_noise, meas_noise;
+    RngKey rng_state, rng_meas;
+    double dt;
+};
+
+__global__ __launch_bounds__(256) void plant_step_kernel(double* __restrict__ X, const double* __restrict__ u, int64_t B,
+                                                         const PlantArgs a, double* __restrict__ y,
+                                                         double* __restrict__ y_meas, double* __restrict__ z,
+                                                         double* __restrict__ log_x, double* __restrict__ log_u) {
+    __shared__ DrawParams dp[2];
+    {
+        const uint32_t* s0 = reinterpret_cast<const uint32_t*>(&a.state_noise);
+        const uint32_t* s1 = reinterpret_cast<const uint32_t*>(&a.meas_noise);
+        uint32_t* d0 = reinterpret_cast<uint32_t*>(&dp[0]);
+        uint32_t* d1 = reinterpret_cast<uint32_t*>(&dp[1]);
+        for (int i = threadIdx.x; i < (int)(sizeof(DrawParams) / 4); i += 256) { d0[i] = s0[i]; d1[i] = s1[i]; }
+        __syncthreads();
+    }
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    double x[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) x[k] = X[b * 5 + k];
+    const double fg = u[b * 2], fm = u[b * 2 + 1];
+    double dx[5];
+    bioreactor_increment(x, fg, fm, 1.0, dx);              // DEs(): the derivative (homeostatic_DEs with dt = 1)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) x[k] = x[k] + dx[k] * a.dt;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = fmax(x[k], 0.0);    // BioreactorModel.py:108
+    uint32_t wd[8];
+    float e[5];
+    rng_words8(a.rng_state, (uint64_t)b, 0u, wd);
+    mixture_draw5(dp[0], wd, e);                           // state_pdf.draw(): fp32 values added to the fp64 state
+#pragma unroll
+    for (int k = 0; k < 5; ++k) x[k] += (double)e[k];
+    const double mm[5] = {180.0, 24.6, 116.0, 46.0, 1.0};   // BioreactorModel.py:118-120
+    double out[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) out[k] = x[k] * mm[k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        X[b * 5 + k] = x[k];
+        if (log_x) log_x[b * 5 + k] = x[k];
+        y[b * 5 + k] = out[k];
+    }
+    rng_words8(a.rng_meas, (uint64_t)b, 0u, wd);
+    mixture_draw5(dp[1], wd, e);                           // measurement noise on the controlled outputs (Cg, Cfa)
+    out[0] += (double)e[0];
+    out[2] += (double)e[1];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) y_meas[b * 5 + k] = out[k];
+    z[b * 2] = out[0];
+    z[b * 2 + 1] = out[2];
+    if (log_u) { log_u[b * 2] = fg; log_u[b * 2 + 1] = fm; }
 }
 
 }  // namespace gse
 
 using namespace gse;
 
-extern "C" int gse_mpc_step(const gse_mpc_law* law, const double* theta, int64_t B, double* du0, double* y1,
-                            int32_t* status, void* stream) {
-    GSE_REQUIRE(law && theta && du0 && y1 && status && B >= 1, "gse_mpc_step: bad argument");
+namespace {
+
+int pack_law(const char* fn, const gse_mpc_law* law, MpcLawDev& d) {
+    GSE_REQUIRE(law, "%s: null law", fn);
     GSE_REQUIRE(law->n_rows >= 0 && law->n_rows <= GSE_MPC_MAX_ROWS,
-                "gse_mpc_step: %d bounded rows; the device solver takes at most %d", law->n_rows, GSE_MPC_MAX_ROWS);
+                "%s: %d bounded rows; the device solver takes at most %d", fn, law->n_rows, GSE_MPC_MAX_ROWS);
     GSE_REQUIRE(law->n_theta >= 1 && law->n_theta <= GSE_MPC_MAX_THETA && law->n_u >= 1 && law->n_u <= GSE_MPC_MAX_OUT &&
                     law->n_y >= 1 && law->n_y <= GSE_MPC_MAX_OUT,
-                "gse_mpc_step: law dimensions (n_theta %d, n_u %d, n_y %d) out of range", law->n_theta, law->n_u, law->n_y);
-    GSE_REQUIRE(law->max_sweeps >= 1 && law->eps_abs >= 0.0 && law->eps_rel >= 0.0, "gse_mpc_step: bad stopping rule");
-    GSE_REQUIRE(law->Gu && law->gu0 && law->Gy && law->gy0, "gse_mpc_step: null law matrix");
+                "%s: law dimensions (n_theta %d, n_u %d, n_y %d) out of range", fn, law->n_theta, law->n_u, law->n_y);
+    GSE_REQUIRE(law->max_sweeps >= 1 && law->eps_abs >= 0.0 && law->eps_rel >= 0.0, "%s: bad stopping rule", fn);
+    GSE_REQUIRE(law->Gu && law->gu0 && law->Gy && law->gy0, "%s: null law matrix", fn);
     GSE_REQUIRE(law->n_rows == 0 || (law->Gc && law->gc0 && law->S && law->lo && law->hi && law->Tu && law->Ty),
-                "gse_mpc_step: null law matrix");
-    MpcLawDev d;
+                "%s: null law matrix", fn);
     d.n_theta = law->n_theta; d.n_u = law->n_u; d.n_y = law->n_y; d.n_rows = law->n_rows; d.max_sweeps = law->max_sweeps;
     d.eps_abs = law->eps_abs; d.eps_rel = law->eps_rel;
     d.Gc = law->Gc; d.gc0 = law->gc0; d.S = law->S; d.lo = law->lo; d.hi = law->hi;
     d.Gu = law->Gu; d.gu0 = law->gu0; d.Tu = law->Tu; d.Gy = law->Gy; d.gy0 = law->gy0; d.Ty = law->Ty;
+    return GSE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gse_mpc_step(const gse_mpc_law* law, const double* theta, int64_t B, double* du0, double* y1, int32_t* status,
+                 void* stream) {
+    GSE_REQUIRE(theta && du0 && y1 && status && B >= 1, "gse_mpc_step: bad argument");
+    MpcLawDev d;
+    if (int rc = pack_law("gse_mpc_step", law, d)) return rc;
     const unsigned blocks = (unsigned)((B + kMpcWavesPerBlock - 1) / kMpcWavesPerBlock);
     hipLaunchKernelGGL(mpc_step_kernel, dim3(blocks), dim3(64 * kMpcWavesPerBlock), 0, (hipStream_t)stream, d, theta, B, du0,
                        y1, status);
     GSE_LAUNCH_CHECK("mpc_step_kernel");
     return GSE_OK;
 }
+
+int gse_loop_control(const gse_mpc_law* law, const gse_loop_glue* glue, const double* moments, const double* y_meas,
+                     double* u, double* y_pred, int32_t* known, int32_t* status, double* theta_out, int64_t B,
+                     void* stream) {
+    GSE_REQUIRE(glue && moments && y_meas && u && y_pred && known && status && B >= 1, "gse_loop_control: bad argument");
+    MpcLawDev d;
+    if (int rc = pack_law("gse_loop_control", law, d)) return rc;
+    const int nx = d.n_theta - d.n_u - d.n_y;
+    GSE_REQUIRE(nx >= 1 && nx <= GSE_MPC_MAX_OUT, "gse_loop_control: n_theta must be Nx + Ni + No with 1 <= Nx <= %d",
+                GSE_MPC_MAX_OUT);
+    GSE_REQUIRE(glue->n_state_full == GSE_NX, "gse_loop_control: the estimator's moments are those of a %d-state filter",
+                GSE_NX);
+    GSE_REQUIRE(glue->n_input_full >= d.n_u && glue->n_output_full >= d.n_y && glue->n_input_full <= 64 &&
+                    glue->n_output_full <= 64, "gse_loop_control: bad plant dimensions");
+    LoopGlue g;
+    g.n_state_full = glue->n_state_full; g.n_input_full = glue->n_input_full; g.n_output_full = glue->n_output_full;
+    g.pad = 0;
+    for (int k = 0; k < GSE_MPC_MAX_OUT; ++k) {
+        g.states[k] = glue->states[k]; g.inputs[k] = glue->inputs[k]; g.outputs[k] = glue->outputs[k];
+        g.x_bar[k] = glue->x_bar[k]; g.u_bar[k] = glue->u_bar[k]; g.y_bar[k] = glue->y_bar[k];
+        g.u_fallback[k] = glue->u_fallback[k];
+    }
+    for (int k = 0; k < nx; ++k)
+        GSE_REQUIRE(g.states[k] >= 0 && g.states[k] < g.n_state_full, "gse_loop_control: states[%d] out of range", k);
+    for (int k = 0; k < d.n_u; ++k)
+        GSE_REQUIRE(g.inputs[k] >= 0 && g.inputs[k] < g.n_input_full, "gse_loop_control: inputs[%d] out of range", k);
+    for (int k = 0; k < d.n_y; ++k)
+        GSE_REQUIRE(g.outputs[k] >= 0 && g.outputs[k] < g.n_output_full, "gse_loop_control: outputs[%d] out of range", k);
+    const unsigned blocks = (unsigned)((B + kMpcWavesPerBlock - 1) / kMpcWavesPerBlock);
+    hipLaunchKernelGGL(loop_control_kernel, dim3(blocks), dim3(64 * kMpcWavesPerBlock), 0, (hipStream_t)stream, d, g, moments,
+                       y_meas, u, y_pred, known, status, theta_out, B);
+    GSE_LAUNCH_CHECK("loop_control_kernel");
+    return GSE_OK;
+}
+
+int gse_plant_step(double* X, const double* u, double dt, const gse_mixture* state_noise, const gse_mixture* meas_noise,
+                   const gse_rng* rng, double* y, double* y_meas, double* z, double* log_x, double* log_u, int64_t B,
+                   void* stream) {
+    GSE_REQUIRE(X && u && state_noise && meas_noise && rng && y && y_meas && z && B >= 1, "gse_plant_step: bad argument");
+    if (int rc = check_mixture("gse_plant_step", state_noise, GSE_NX)) return rc;
+    if (int rc = check_mixture("gse_plant_step", meas_noise, GSE_NY)) return rc;
+    PlantArgs a;
+    pack_draw(a.state_noise, *state_noise);
+    pack_draw(a.meas_noise, *meas_noise);
+    a.rng_state = make_rng_key(*rng, kPurposePlantState);
+    a.rng_meas = make_rng_key(*rng, kPurposePlantMeas);
+    a.dt = dt;
+    hipLaunchKernelGGL(plant_step_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, u, B, a, y,
+                       y_meas, z, log_x, log_u);
+    GSE_LAUNCH_CHECK("plant_step_kernel");
+    return GSE_OK;
+}
+
+}  // extern "C"

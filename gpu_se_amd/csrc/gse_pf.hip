@@ -33,6 +33,8 @@ struct StepArgs {
     Pdf2 pdf;              // measurement noise (update)
     RngKey rng;
     double dt;
+    const double* u_dev;   // GSE_OP_U_DEVICE / GSE_OP_Z_DEVICE: [B][2] in device memory instead of io (a closed loop
+    const double* z_dev;   // whose controller and plant run on the device never brings them to the host)
 };
 
 #ifndef GSE_STEP_MIN_WAVES
@@ -469,8 +471,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         v4f row[GSE_NX];
         float gq[2][GSE_NX];
         float obs0[kPerThread], obs2[kPerThread];     // Cg, Cfa of the (new) state: all the update needs
-        const double fg = a.io.f[b].u0, fm = a.io.f[b].u1;
-        const double z0 = a.io.f[b].z0, z1 = a.io.f[b].z1;
+        // per-filter inputs: kernel arguments, or two uniform (scalar) loads each when they live on the device
+        const double fg = a.u_dev ? a.u_dev[2 * b] : a.io.f[b].u0, fm = a.u_dev ? a.u_dev[2 * b + 1] : a.io.f[b].u1;
+        const double z0 = a.z_dev ? a.z_dev[2 * b] : a.io.f[b].z0, z1 = a.z_dev ? a.z_dev[2 * b + 1] : a.io.f[b].z1;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 0) {
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const Payload pl, const 
 // Per-workgroup partial sums of {w, w d, w d d^T} with d = x - pivot, fp64; blocks stride over the tiles.
 __global__ __launch_bounds__(kBlock) void pf_moments_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             double* __restrict__ partials, int64_t N, int64_t ld) {
-    __shared__ double red[4];
+    __shared__ double red[4 * 21];
     const int b = blockIdx.y;
     const float* xb = x + (int64_t)b * GSE_NX * ld;
     const float* wb = w + (int64_t)b * ld;
@@ -854,11 +857,7 @@ __global__ __launch_bounds__(kBlock) void pf_moments_kernel(const float* __restr
         }
     }
     double* out = partials + ((int64_t)b * kMomentBlocks + blockIdx.x) * kMomentWidth;
-#pragma unroll
-    for (int c = 0; c < 21; ++c) {
-        const double tot = block_sum(acc[c], red);
-        if (threadIdx.x == 0) out[c] = tot;
-    }
+    block_sums<21>(acc, red, [&](int c, double total) { out[c] = total; });
 }
 
 // Fixed-order reduction of the per-workgroup partials -> out[b][0..width); appends `tail` pivot values.
@@ -867,15 +866,17 @@ __global__ __launch_bounds__(kBlock) void moments_finish_kernel(const double* __
                                                                 const float* __restrict__ pivot_src,
                                                                 int64_t pivot_filter_stride, int64_t pivot_elem_stride,
                                                                 int pivot_at) {
-    __shared__ double red[4];
-    const int b = blockIdx.x;
+    // thread (g, c) = (tid / 64, tid % 64) adds the partials q = g, g + 4, ... of column c in that fixed order; the four
+    // group totals are added as (g0 + g1) + (g2 + g3): one barrier whatever the width (<= 64 columns)
+    __shared__ double part[4][64];
+    const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const double* pb = partials + (int64_t)b * kMomentBlocks * kMomentWidth;
-    for (int c = 0; c < width; ++c) {
-        double v = 0.0;
-        for (int q = threadIdx.x; q < nblk; q += kBlock) v += pb[(int64_t)q * kMomentWidth + c];
-        const double tot = block_sum(v, red);
-        if (threadIdx.x == 0) out[(int64_t)b * out_stride + c] = tot;
-    }
+    double v = 0.0;
+    if (c < width)
+        for (int q = g; q < nblk; q += 4) v += pb[(int64_t)q * kMomentWidth + c];
+    part[g][c] = v;
+    __syncthreads();
+    if (g == 0 && c < width) out[(int64_t)b * out_stride + c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
     if (threadIdx.x < GSE_NX)
         out[(int64_t)b * out_stride + pivot_at + threadIdx.x] =
             (double)pivot_src[(int64_t)b * pivot_filter_stride + threadIdx.x * pivot_elem_stride];
@@ -985,7 +986,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     if (int rc = check_pf_geometry(fn, B, N, ld)) return rc;
     const bool G = ops & GSE_OP_GATHER, P = ops & GSE_OP_PREDICT, U = ops & GSE_OP_UPDATE;
     const uint32_t known = GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE | GSE_OP_SCAN_IN | GSE_OP_SCAN_OUT |
-                           GSE_OP_SCAN_IN_SLOT1 | GSE_OP_SCAN_OUT_SLOT1;
+                           GSE_OP_SCAN_IN_SLOT1 | GSE_OP_SCAN_OUT_SLOT1 | GSE_OP_U_DEVICE | GSE_OP_Z_DEVICE;
     GSE_REQUIRE((ops & (GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE)) != 0 && (ops & ~known) == 0,
                 "%s: bad ops mask 0x%x", fn, ops);
     const int scan = ((ops & GSE_OP_SCAN_IN) ? 1 : 0) | ((ops & GSE_OP_SCAN_OUT) ? 2 : 0);
@@ -999,7 +1000,12 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     GSE_REQUIRE(N < ((int64_t)1 << 31), "%s: N must be below 2^31", fn);
     GSE_REQUIRE(!(ops & GSE_OP_GATHER) || N <= ((int64_t)1 << 30), "%s: gather uses 32-bit byte offsets: N must not exceed 2^30", fn);
     StepArgs a;
-    pack_io(a.io, B, (P ? u : nullptr), (U ? z : nullptr));
+    const bool u_on_device = (ops & GSE_OP_U_DEVICE) != 0, z_on_device = (ops & GSE_OP_Z_DEVICE) != 0;
+    GSE_REQUIRE(!u_on_device || (P && u), "%s: GSE_OP_U_DEVICE needs GSE_OP_PREDICT and a device pointer u", fn);
+    GSE_REQUIRE(!z_on_device || (U && z), "%s: GSE_OP_Z_DEVICE needs GSE_OP_UPDATE and a device pointer z", fn);
+    pack_io(a.io, B, (P && !u_on_device ? u : nullptr), (U && !z_on_device ? z : nullptr));
+    a.u_dev = u_on_device ? u : nullptr;
+    a.z_dev = z_on_device ? z : nullptr;
     if (G) {
         GSE_REQUIRE(x_out && w_out && r, "%s: gather needs x_out, w_out and r", fn);
         GSE_REQUIRE(x_out != x_in && aligned16(x_out) && aligned16(w_out), "%s: x_out must be a separate aligned buffer", fn);
@@ -1129,7 +1135,9 @@ int gse_pf_moments(const float* x, const float* w, int64_t ld, int B, int64_t N,
     GSE_REQUIRE(x && w && out && workspace, "gse_pf_moments: null argument");
     GSE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(workspace), "gse_pf_moments: pointers must be 16-byte aligned");
     Workspace ws = carve_workspace(workspace, B, N);
-    const int nblk = (int)std::min<int64_t>(kMomentBlocks, tiles_of(N));
+    // workgroups per filter: enough to fill the chip in total (~4096), so that with many filters each workgroup sweeps
+    // several tiles and the reduction at its end is paid less often
+    const int nblk = (int)std::min<int64_t>(std::min<int64_t>(kMomentBlocks, tiles_of(N)), std::max<int64_t>(4096 / B, 32));
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pf_moments_kernel, dim3(nblk, B), dim3(kBlock), 0, st, x, w, ws.partials, N, ld);
     GSE_LAUNCH_CHECK("pf_moments_kernel");

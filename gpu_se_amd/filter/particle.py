@@ -138,6 +138,12 @@ class ParallelParticleFilter:
         for i in range(B * width):
             buf[i] = flat[i]
 
+    def _device_io(self, t, width):
+        """A per-filter input given as a device tensor ([B][width] fp64, contiguous): passed by pointer."""
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == self._B * width):
+            raise ValueError("device inputs must be contiguous float64 CUDA tensors of shape (%d, %d)" % (self._B, width))
+        return t
+
     # ------------------------------------------------------------------ deferred stages
     # resample() and predict() do not launch their particle pass at once: resample() computes the cumulative
     # weights (one small kernel) and leaves the gather pending, predict() leaves the model step pending; the next
@@ -177,7 +183,11 @@ class ParallelParticleFilter:
         if self._pend_predict is not None:
             ops |= _lib.GSE_OP_PREDICT
             u, dt = self._pend_predict
-            self._fill(cu, u, _lib.GSE_NU)
+            if torch.is_tensor(u):                          # inputs that live on the device (closed loop on the device)
+                ops |= _lib.GSE_OP_U_DEVICE
+                cu = ctypes.cast(ctypes.c_void_p(u.data_ptr()), _lib.P_D)
+            else:
+                self._fill(cu, u, _lib.GSE_NU)
             if injected:
                 noise = self.state_pdf.draw((self._B, n)).as_subclass(torch.Tensor)  # (B, n, Nx) replayed values
                 buf = torch.zeros_like(self._x)
@@ -194,7 +204,11 @@ class ParallelParticleFilter:
         scan_out = None
         if update is not None:
             ops |= _lib.GSE_OP_UPDATE
-            self._fill(cz, update[1], _lib.GSE_NY)
+            if torch.is_tensor(update[1]):
+                ops |= _lib.GSE_OP_Z_DEVICE
+                cz = ctypes.cast(ctypes.c_void_p(self._device_io(update[1], _lib.GSE_NY).data_ptr()), _lib.P_D)
+            else:
+                self._fill(cz, update[1], _lib.GSE_NY)
             pod_meas = ctypes.byref(self.measurement_pdf._pod())
             if self._scan_capable and not injected and self.measurement_pdf._Nd == 2:
                 # leave the tile-local scans of the new weights behind: the next resample then needs no kernel
@@ -253,7 +267,9 @@ class ParallelParticleFilter:
         (particle.py:265-277).  u: (N_inputs) host array-like; dt: float.  Deferred -- see above."""
         if self._pend_predict is not None:
             self._flush()                                   # two predicts in a row: run the first one now
-        if self._B == 1:
+        if torch.is_tensor(u):
+            u = self._device_io(u, _lib.GSE_NU)             # read by the kernel when it runs: do not overwrite before
+        elif self._B == 1:
             u0, u1 = numpy.asarray(u, dtype=numpy.float64).reshape(-1)
             u = (float(u0), float(u1))
         else:

