@@ -85,9 +85,15 @@ __device__ unsigned long long g_stamps[32];
 #define GSE_BLOCK_TIME(which)
 #endif
 #ifndef GSE_PRIO
-#define GSE_PRIO 1               // gather variants: issue priority by phase (0: none; 1: memory phases high; 2: arithmetic phases high)
+#define GSE_PRIO 4               // gather variants: issue priority by phase.  0: none; 1: memory phases high, the noise draw
+                                 // and the arithmetic tail low; 2: the reverse; 3: as 1 without touching the draw; 4 / 5: as
+                                 // 1 / 3 with s_setprio as an asm statement (the builtin is a scheduling barrier for hipcc
+                                 // and costs 11 VGPRs -> 28 B of scratch per lane, 11 MB of spill writes per launch)
 #endif
-#if GSE_PRIO == 1
+#if GSE_PRIO == 4 || GSE_PRIO == 5
+#define GSE_PRIO_MEM() asm volatile("s_setprio 3")
+#define GSE_PRIO_ALU() asm volatile("s_setprio 0")
+#elif GSE_PRIO == 1 || GSE_PRIO == 3
 #define GSE_PRIO_MEM() __builtin_amdgcn_s_setprio(3)
 #define GSE_PRIO_ALU() __builtin_amdgcn_s_setprio(0)
 #elif GSE_PRIO == 2
@@ -96,6 +102,13 @@ __device__ unsigned long long g_stamps[32];
 #else
 #define GSE_PRIO_MEM()
 #define GSE_PRIO_ALU()
+#endif
+#if GSE_PRIO == 1 || GSE_PRIO == 2 || GSE_PRIO == 4       // (3, 5: the draw keeps the priority of the phase it sits in)
+#define GSE_PRIO_DRAW_BEGIN() GSE_PRIO_ALU()
+#define GSE_PRIO_DRAW_END() GSE_PRIO_MEM()
+#else
+#define GSE_PRIO_DRAW_BEGIN()
+#define GSE_PRIO_DRAW_END()
 #endif
 #ifndef GSE_XCD_REMAP
 #define GSE_XCD_REMAP 1
@@ -111,14 +124,15 @@ __device__ __forceinline__ int xcd_contiguous_tile(unsigned bx, int T) {
 #endif
 
 #ifndef GSE_WT_STORES
-#define GSE_WT_STORES 2          // bit mask of step-kernel outputs stored write-through (sc1): 1 states, 2 weights, 4 scans
+#define GSE_WT_STORES 0          // bit mask of step-kernel outputs stored write-through (sc1): 1 states, 2 weights, 4 scans
 #endif
 // Output stores of the step kernel.  A launch at N = 2^20 writes 33 MB; what stays dirty in the eight L2s is written back
 // by the release at the END of the kernel, a serial tail (tools/micro/store_tail.hip: 32 MB of plain stores trail a
 // launch by +2.9 us, write-through ones by +0.7).  But the next launch re-reads the states and the scans from the L2
 // of the XCD that wrote them (XCD-contiguous tiles), and write-through stores drop their lines: measured, the lost hits
-// cost more than the tail (all outputs write-through: 29.2 us against 27.7; scans alone +2.5 us).  Only the weights,
-// which no later launch of the cycle reads, go out write-through by default.  Relaxed agent-scope
+// cost more than the tail (all outputs write-through: 29.2 us against 27.7; scans alone +2.5 us), and dword-wide
+// write-through stores inflate the bytes written to HBM (weights only: WRITE_SIZE 45 MB per launch instead of 33.5 for a
+// gain inside the noise).  Off by default; kept as a knob.  Relaxed agent-scope
 // atomic stores are plain `global_store ... sc1` instructions, counted and padded by the compiler.
 template <int kBit>
 __device__ __forceinline__ void store_out(float* p, float v) {
@@ -176,6 +190,8 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     const double* __restrict__ scan_in, double* __restrict__ scan_out_sums, double* __restrict__ scan_out,
     double* __restrict__ island, int64_t N, int64_t ld, int T, const StepArgs a) {
     constexpr bool kScanIn = (kScan & 1) != 0, kScanOut = (kScan & 2) != 0;
+    constexpr bool kDevIO = (kScan & 4) != 0;      // u / z may come from device memory (variants without gather only:
+    static_assert(!kDevIO || !kGather, "");         //  the fused gather kernel has no registers to spare for them)
     static_assert(!kScanIn || kGather, "SCAN_IN belongs to the gather stage");
     static_assert(!kScanOut || kUpdate, "SCAN_OUT belongs to the update stage");
     __shared__ DrawParams dp;
@@ -218,14 +234,14 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     //      using them, so that on every CU one group computes while the other waits.
     float e[kPerThread][GSE_NX];
     auto draw_all = [&]() {
-        if (kGather) GSE_PRIO_ALU();
+        if (kGather) GSE_PRIO_DRAW_BEGIN();
 #pragma unroll
         for (int p = 0; p < kPerThread; ++p) {
             uint32_t wd[8];
             rng_words8(a.rng, (uint64_t)jp[p], (uint32_t)b, wd);
             mixture_draw5(dp, wd, e[p]);
         }
-        if (kGather) GSE_PRIO_MEM();
+        if (kGather) GSE_PRIO_DRAW_END();
     };
     constexpr bool kDraw = kPredict && !kInjected;
     const int draw_at = (kDraw && kGather) ? draw_position(blockIdx.x) : 3;      // workgroup-uniform
@@ -472,8 +488,11 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         float gq[2][GSE_NX];
         float obs0[kPerThread], obs2[kPerThread];     // Cg, Cfa of the (new) state: all the update needs
         // per-filter inputs: kernel arguments, or two uniform (scalar) loads each when they live on the device
-        const double fg = a.u_dev ? a.u_dev[2 * b] : a.io.f[b].u0, fm = a.u_dev ? a.u_dev[2 * b + 1] : a.io.f[b].u1;
-        const double z0 = a.z_dev ? a.z_dev[2 * b] : a.io.f[b].z0, z1 = a.z_dev ? a.z_dev[2 * b + 1] : a.io.f[b].z1;
+        double fg = a.io.f[b].u0, fm = a.io.f[b].u1, z0 = a.io.f[b].z0, z1 = a.io.f[b].z1;
+        if constexpr (kDevIO) {
+            if (a.u_dev) { fg = a.u_dev[2 * b]; fm = a.u_dev[2 * b + 1]; }
+            if (a.z_dev) { z0 = a.z_dev[2 * b]; z1 = a.z_dev[2 * b + 1]; }
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 0) {
@@ -956,6 +975,10 @@ bool step_pick_scan(int scan, const StepLaunch& L) {
     if constexpr (kScanOk && G) if (scan == 1) { step_go<G, P, I, U, ND, 1>(L); return true; }
     if constexpr (kScanOk && U) if (scan == 2) { step_go<G, P, I, U, ND, 2>(L); return true; }
     if constexpr (kScanOk && G && U) if (scan == 3) { step_go<G, P, I, U, ND, 3>(L); return true; }
+    if constexpr (!G && !I) {                                    // + 4: inputs from device memory
+        if (scan == 4) { step_go<G, P, I, U, ND, 4>(L); return true; }
+        if constexpr (kScanOk && U) if (scan == 6) { step_go<G, P, I, U, ND, 6>(L); return true; }
+    }
     return false;
 }
 template <bool G, bool P, bool I, bool U>
@@ -1003,6 +1026,8 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const bool u_on_device = (ops & GSE_OP_U_DEVICE) != 0, z_on_device = (ops & GSE_OP_Z_DEVICE) != 0;
     GSE_REQUIRE(!u_on_device || (P && u), "%s: GSE_OP_U_DEVICE needs GSE_OP_PREDICT and a device pointer u", fn);
     GSE_REQUIRE(!z_on_device || (U && z), "%s: GSE_OP_Z_DEVICE needs GSE_OP_UPDATE and a device pointer z", fn);
+    GSE_REQUIRE(!(u_on_device || z_on_device) || (!G && !noise),
+                "%s: device-resident u / z are not available in a launch that gathers or injects noise", fn);
     pack_io(a.io, B, (P && !u_on_device ? u : nullptr), (U && !z_on_device ? z : nullptr));
     a.u_dev = u_on_device ? u : nullptr;
     a.z_dev = z_on_device ? z : nullptr;
@@ -1053,7 +1078,8 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     L.a = &a;
     GSE_REQUIRE(!(scan == 3) || L.slot_in != L.slot_out, "%s: SCAN_IN and SCAN_OUT must use different slots", fn);
     const bool nd2 = U && a.pdf.nd == 2;
-    const bool ok = G ? step_pick_p<true>(P, I, U, nd2, scan, L) : step_pick_p<false>(P, I, U, nd2, scan, L);
+    const int variant = scan | ((u_on_device || z_on_device) ? 4 : 0);
+    const bool ok = G ? step_pick_p<true>(P, I, U, nd2, variant, L) : step_pick_p<false>(P, I, U, nd2, variant, L);
     if (!ok) return fail(GSE_ERR_UNSUPPORTED, "%s: stage combination 0x%x is not available (scan modes need the Philox "
                          "draw and a 2-component measurement mixture)", fn, ops);
     GSE_LAUNCH_CHECK("pf_step_kernel");

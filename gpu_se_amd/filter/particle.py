@@ -162,6 +162,13 @@ class ParallelParticleFilter:
             pend, self._pend_predict = self._pend_predict, None
             self._launch_step(update=None)
             self._pend_predict = pend
+        device_io = (self._pend_predict is not None and torch.is_tensor(self._pend_predict[0])) or \
+            (update is not None and torch.is_tensor(update[1]))
+        if device_io and self._pend_gather:
+            # inputs that live on the device are read by the variants without gather: copy the ancestors first
+            pend, self._pend_predict = self._pend_predict, None
+            self._launch_step(update=None)
+            self._pend_predict = pend
         ops = 0
         n = self.N_particles
         gather = self._pend_gather

@@ -150,6 +150,7 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
 #define GSE_OP_SCAN_OUT_SLOT1 64u
 #define GSE_OP_U_DEVICE 128u     /* (with PREDICT) u is a DEVICE pointer [B][2] fp64, read when the kernel runs */
 #define GSE_OP_Z_DEVICE 256u     /* (with UPDATE)  z is a DEVICE pointer [B][2] fp64                            */
+                                 /* (both: launches without GSE_OP_GATHER and without injected noise only)      */
 int gse_pf_step(uint32_t ops, const float *x_in, float *x_out, const float *w_in, float *w_out, int32_t *idx,
                 int64_t ld, int B, int64_t N, const double *u, double dt, const double *z, const double *r,
                 const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,
