@@ -880,22 +880,41 @@ __global__ __launch_bounds__(kBlock) void pf_moments_kernel(const float* __restr
 }
 
 // Fixed-order reduction of the per-workgroup partials -> out[b][0..width); appends `tail` pivot values.
-__global__ __launch_bounds__(kBlock) void moments_finish_kernel(const double* __restrict__ partials, int nblk, int width,
-                                                                double* __restrict__ out, int out_stride,
-                                                                const float* __restrict__ pivot_src,
-                                                                int64_t pivot_filter_stride, int64_t pivot_elem_stride,
-                                                                int pivot_at) {
-    // thread (g, c) = (tid / 64, tid % 64) adds the partials q = g, g + 4, ... of column c in that fixed order; the four
-    // group totals are added as (g0 + g1) + (g2 + g3): one barrier whatever the width (<= 64 columns)
-    __shared__ double part[4][64];
+constexpr int kFinishGroups = 16;        // 1024 threads: (group, column) = (tid / 64, tid % 64)
+__global__ __launch_bounds__(64 * kFinishGroups) void moments_finish_kernel(const double* __restrict__ partials, int nblk,
+                                                                           int width, double* __restrict__ out,
+                                                                           int out_stride,
+                                                                           const float* __restrict__ pivot_src,
+                                                                           int64_t pivot_filter_stride,
+                                                                           int64_t pivot_elem_stride, int pivot_at) {
+    // Thread (g, c) adds the partials q = g, g + 16, ... of column c into 8 interleaved accumulators (8 loads in flight),
+    // folds them pairwise, and the 16 group totals are folded pairwise after one barrier: a fixed order, so the result
+    // does not depend on timing; <= 4 dependent load rounds for 512 partials.
+    __shared__ double part[kFinishGroups][64];
     const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const double* pb = partials + (int64_t)b * kMomentBlocks * kMomentWidth;
-    double v = 0.0;
-    if (c < width)
-        for (int q = g; q < nblk; q += 4) v += pb[(int64_t)q * kMomentWidth + c];
-    part[g][c] = v;
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (c < width) {
+        for (int q0 = g; q0 < nblk; q0 += 8 * kFinishGroups) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = q0 + j * kFinishGroups;
+                if (q < nblk) a[j] += pb[(int64_t)q * kMomentWidth + c];
+            }
+        }
+    }
+    part[g][c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
-    if (g == 0 && c < width) out[(int64_t)b * out_stride + c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    if (g == 0 && c < width) {
+        double t[kFinishGroups];
+#pragma unroll
+        for (int k = 0; k < kFinishGroups; ++k) t[k] = part[k][c];
+#pragma unroll
+        for (int span = 1; span < kFinishGroups; span *= 2)
+#pragma unroll
+            for (int k = 0; k < kFinishGroups; k += 2 * span) t[k] += t[k + span];
+        out[(int64_t)b * out_stride + c] = t[0];
+    }
     if (threadIdx.x < GSE_NX)
         out[(int64_t)b * out_stride + pivot_at + threadIdx.x] =
             (double)pivot_src[(int64_t)b * pivot_filter_stride + threadIdx.x * pivot_elem_stride];
@@ -933,8 +952,8 @@ int launch_gsukf_gather(const GsukfPayload& pl, float* w_out, int32_t* idx, int 
 
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
                            const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, hipStream_t st) {
-    hipLaunchKernelGGL(moments_finish_kernel, dim3(B), dim3(kBlock), 0, st, partials, nblk, width, out, out_stride,
-                       pivot_src, pfs, pes, pivot_at);
+    hipLaunchKernelGGL(moments_finish_kernel, dim3(B), dim3(64 * kFinishGroups), 0, st, partials, nblk, width, out,
+                       out_stride, pivot_src, pfs, pes, pivot_at);
 }
 
 }  // namespace gse
