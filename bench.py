@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log2-particles", type=float, default=20.0, help="particles per GPU = 2^this")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-resample", action="store_true",
+                    help="N > 1: one systematic resample of the whole ensemble per cycle (all-gather of tile sums + "
+                         "all-to-all of particles over xGMI) instead of the default island resampling")
     ap.add_argument("--cpu-log2-particles", type=float, default=17.0)
     return ap.parse_args()
 
@@ -152,7 +155,7 @@ def main():
         u, z = io[i]
         pf.predict(u, dt)
         pf.update(u, z)
-        pf.resample()
+        pf.resample(exact=args.exact_resample)
 
     for i in range(warmup):
         cycle(i)
@@ -209,10 +212,12 @@ def main():
             "config": {"workload": "ParallelParticleFilter HIP, N=2^%g particles per GPU, systematic resample "
                                    "(BASELINE config 2)" % args.log2_particles,
                        "particles_per_gpu": n, "total_particles": n * world, "dt": dt,
-                       "parallelism": "particle shards x%d, island resampling, async RCCL all-reduce of the weight sum every "
-                                      "%d cycles, posterior merge (all-reduce of 22 doubles per rank) at estimates"
-                                      % (world, pf.reduce_every)
-                       if world > 1 else "single GPU"},
+                       "parallelism": ("particle shards x%d, EXACT global resampling (all-gather of tile sums + all-to-all "
+                                       "of particles per cycle), posterior merge at estimates" % world)
+                       if (world > 1 and args.exact_resample) else
+                       ("particle shards x%d, island resampling, async RCCL all-reduce of the weight sum every "
+                        "%d cycles, posterior merge (all-reduce of 22 doubles per rank) at estimates"
+                        % (world, pf.reduce_every)) if world > 1 else "single GPU"},
             "particles_per_s": round(value * n, 1),
             "roofline": roofline,
         }

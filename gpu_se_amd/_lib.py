@@ -78,6 +78,10 @@ PROTOTYPES = {
     "gse_rng_raw": (ctypes.c_int, [c_vp, c_i64, P_RNG, c_u32, c_vp]),
     "gse_mpc_step": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "gse_loop_control": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "gse_pf_tile_sums": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp]),
+    "gse_tile_prefix": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "gse_pf_shard_cumsum": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "gse_pf_shard_gather": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_d, c_vp, c_vp, c_vp]),
     "gse_plant_step": (ctypes.c_int, [c_vp, c_vp, c_d, P_MIX, P_MIX, P_RNG, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
 }
 

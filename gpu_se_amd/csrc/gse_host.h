@@ -83,6 +83,20 @@ struct PfPayload {                    // state-major particle rows
     }
 };
 
+struct RowsPayload {                  // state-major particles in, row-major offspring out (the send buffer of a shard)
+    const float* __restrict__ in;
+    float* __restrict__ out;
+    int64_t ld;
+    __device__ __forceinline__ void copy(int b, int64_t anc, int64_t j) const {
+        (void)b;
+        float v[GSE_NX];
+#pragma unroll
+        for (int k = 0; k < GSE_NX; ++k) v[k] = in[k * ld + anc];
+#pragma unroll
+        for (int k = 0; k < GSE_NX; ++k) out[j * GSE_NX + k] = v[k];
+    }
+};
+
 struct GsukfPayload {                 // row-major (mu[5], P[25]) per Gaussian
     const float* __restrict__ mu_in;
     const float* __restrict__ P_in;

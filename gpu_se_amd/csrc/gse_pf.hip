@@ -716,11 +716,14 @@ __device__ __forceinline__ void inline_tile_prefix(const double* __restrict__ s,
 
 // tile_src: kInlinePrefix ? tile sums [B][T] : exclusive tile prefix [B][T + 1] (from tile_scan_kernel).
 // c: [B][N] fp64.  totals: [B] fp64 (sum of the weights).  island: optional [2][B] shard bookkeeping.
+// Shards of a sharded ensemble (exact global resampling, gse_pf_shard_cumsum): tile_src is the prefix over the tiles of
+// ALL shards, this shard's tiles start at tile_offset and the total sits at total_at.
 template <bool kInlinePrefix>
 __global__ __launch_bounds__(kBlock) void cumsum_kernel(const float* __restrict__ w, double* __restrict__ c,
                                                         const double* __restrict__ tile_src,
                                                         double* __restrict__ totals, double* __restrict__ island,
-                                                        int64_t N, int64_t ldw, int T) {
+                                                        int64_t N, int64_t ldw, int T, int64_t prefix_stride,
+                                                        int64_t tile_offset, int64_t total_at) {
     __shared__ double red[4];
     __shared__ double pfx[3];
     const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
@@ -729,10 +732,10 @@ __global__ __launch_bounds__(kBlock) void cumsum_kernel(const float* __restrict_
         inline_tile_prefix(tile_src + (int64_t)b * T, T, t, red, pfx);
         P0 = pfx[0]; P1 = pfx[1]; W = pfx[2];
     } else {
-        const double* pf = tile_src + (int64_t)b * (T + 1);
-        P0 = pf[t]; P1 = pf[t + 1]; W = pf[T];
+        const double* pf = tile_src + (int64_t)b * prefix_stride;
+        P0 = pf[tile_offset + t]; P1 = pf[tile_offset + t + 1]; W = pf[total_at];
     }
-    if (t == 0 && tid == 0) {
+    if (t == 0 && tid == 0 && totals) {
         totals[b] = W;
         if (island) {                          // shard bookkeeping: accumulated log-weight and this cycle's sum
             island[b] += log(W);
@@ -766,30 +769,34 @@ __global__ __launch_bounds__(kBlock) void cumsum_kernel(const float* __restrict_
     }
 }
 
+// Outputs j_base .. j_base + count - 1 of an ensemble of n_total particles, whose ancestors all lie among the N keys
+// of c (the whole ensemble: j_base = 0, count = n_total = N; one shard of a sharded ensemble: its own keys, the outputs
+// that descend from it, and everything written relative to j_base).  w_out may be null.
 template <class Payload>
 __global__ __launch_bounds__(kBlock) void gather_kernel(const Payload pl, const double* __restrict__ c,
                                                         const double* __restrict__ totals, float* __restrict__ w_out,
                                                         int32_t* __restrict__ idx_out, int64_t N, int64_t ldw,
-                                                        const ResampleArgs ra) {
+                                                        const ResampleArgs ra, int64_t j_base, int64_t count,
+                                                        int64_t n_total) {
     __shared__ double seg[kSpanMax];
     __shared__ int64_t span[2];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t j0 = (int64_t)blockIdx.x * kTile;
-    const int64_t j1 = min(j0 + kTile, N);
+    const int64_t j0 = j_base + (int64_t)blockIdx.x * kTile;
+    const int64_t j1 = min(j0 + kTile, j_base + count);
     const double r = ra.r[b];
-    const double Nd = (double)N;
-    const double W = totals[b];
+    const double Nd = (double)n_total;
+    const double W = totals ? totals[b] : 1.0;
     const double* cb = c + (int64_t)b * N;
     const float w_uniform = (float)(1.0 / Nd);
-    float* wo = w_out + (int64_t)b * ldw;
-    int32_t* io = idx_out ? idx_out + (int64_t)b * ldw : nullptr;
+    float* wo = w_out ? w_out + (int64_t)b * ldw - j_base : nullptr;      // indexed by j below
+    int32_t* io = idx_out ? idx_out + (int64_t)b * ldw - j_base : nullptr;
 
     // Weights that do not sum to a positive finite number: the reference's normalised cumsum is all-NaN and its
     // sweep never advances (filter/particle.py:98), so every offspring copies particle 0.
     if (!(W > 0.0) || !(W < INFINITY)) {
         for (int64_t j = j0 + tid; j < j1; j += kBlock) {
-            pl.copy(b, 0, j);
-            wo[j] = w_uniform;
+            pl.copy(b, 0, j - j_base);
+            if (wo) wo[j] = w_uniform;
             if (io) io[j] = 0;
         }
         return;
@@ -813,8 +820,8 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const Payload pl, const 
             const double u = ((double)j + r) / Nd;
             const int lo = span_search(seg, (int)len, u);
             const int64_t anc = klo + lo;
-            pl.copy(b, anc, j);
-            wo[j] = w_uniform;
+            pl.copy(b, anc, j - j_base);
+            if (wo) wo[j] = w_uniform;
             if (io) io[j] = (int32_t)anc;
         }
     } else {
@@ -826,8 +833,8 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const Payload pl, const 
                 const int64_t mid = (lo + hi) >> 1;
                 if (cb[mid] < u) lo = mid + 1; else hi = mid;
             }
-            pl.copy(b, lo, j);
-            wo[j] = w_uniform;
+            pl.copy(b, lo, j - j_base);
+            if (wo) wo[j] = w_uniform;
             if (io) io[j] = (int32_t)lo;
         }
     }
@@ -931,12 +938,12 @@ int launch_cumsum(const float* w, int64_t ldw, int B, int64_t N, uint32_t flags,
     }
     if (T <= kInlinePrefixMaxT && !(flags & GSE_RESAMPLE_SEPARATE_SCAN)) {
         hipLaunchKernelGGL(cumsum_kernel<true>, dim3(T, B), dim3(kBlock), 0, st, w, c_out, ws.tile_sums, ws.totals, island,
-                           N, ldw, T);
+                           N, ldw, T, (int64_t)0, (int64_t)0, (int64_t)0);
     } else {
         hipLaunchKernelGGL(tile_scan_kernel, dim3(B), dim3(kBlock), 0, st, ws.tile_sums, ws.tile_prefix, T);
         GSE_LAUNCH_CHECK("tile_scan_kernel");
         hipLaunchKernelGGL(cumsum_kernel<false>, dim3(T, B), dim3(kBlock), 0, st, w, c_out, ws.tile_prefix, ws.totals,
-                           island, N, ldw, T);
+                           island, N, ldw, T, (int64_t)(T + 1), (int64_t)0, (int64_t)T);
     }
     GSE_LAUNCH_CHECK("cumsum_kernel");
     return GSE_OK;
@@ -945,7 +952,7 @@ int launch_cumsum(const float* w, int64_t ldw, int B, int64_t N, uint32_t flags,
 int launch_gsukf_gather(const GsukfPayload& pl, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra,
                         const Workspace& ws, hipStream_t st) {
     hipLaunchKernelGGL(gather_kernel<GsukfPayload>, dim3((unsigned)tiles_of(N), B), dim3(kBlock), 0, st, pl, ws.cumsum,
-                       ws.totals, w_out, idx, N, N, ra);
+                       ws.totals, w_out, idx, N, N, ra, (int64_t)0, N, N);
     GSE_LAUNCH_CHECK("gather_kernel<gsukf>");
     return GSE_OK;
 }
@@ -1157,6 +1164,56 @@ int gse_pf_resample(const float* x_in, const float* w, float* x_out, float* w_ou
     if (int rc = gse_pf_resample_begin(w, ld, B, N, flags, island, workspace, stream)) return rc;
     return pf_step(GSE_OP_GATHER, x_in, x_out, nullptr, w_out, idx, ld, B, N, nullptr, 0.0, nullptr, r, nullptr, nullptr,
                    nullptr, nullptr, nullptr, workspace, stream, "gse_pf_resample");
+}
+
+// ---- exact resampling of an ensemble sharded over several GPUs (gpu_se_amd/distributed.py) ----------
+int gse_pf_tile_sums(const float* w, int64_t ld, int B, int64_t N, double* sums, void* stream) {
+    if (int rc = check_pf_geometry("gse_pf_tile_sums", B, N, ld)) return rc;
+    GSE_REQUIRE(w && sums && aligned16(w), "gse_pf_tile_sums: bad pointer");
+    const int T = (int)tiles_of(N);
+    hipLaunchKernelGGL(tile_sum_kernel, dim3(T, B), dim3(kBlock), 0, (hipStream_t)stream, w, sums, N, ld, T);
+    GSE_LAUNCH_CHECK("tile_sum_kernel");
+    return GSE_OK;
+}
+
+int gse_tile_prefix(const double* sums, int64_t T, double* prefix, void* stream) {
+    GSE_REQUIRE(sums && prefix && T >= 1 && T < ((int64_t)1 << 30), "gse_tile_prefix: bad argument");
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, sums, prefix, (int)T);
+    GSE_LAUNCH_CHECK("tile_scan_kernel");
+    return GSE_OK;
+}
+
+int gse_pf_shard_cumsum(const float* w, int64_t N_local, const double* prefix_all, int64_t tile_offset, int64_t T_total,
+                        double* c, void* stream) {
+    GSE_REQUIRE(w && prefix_all && c && aligned16(w) && aligned16(c) && N_local >= 1, "gse_pf_shard_cumsum: bad argument");
+    const int T = (int)tiles_of(N_local);
+    GSE_REQUIRE(tile_offset >= 0 && tile_offset + T <= T_total, "gse_pf_shard_cumsum: this shard's tiles [%lld, %lld) lie "
+                "outside the %lld tiles of the ensemble", (long long)tile_offset, (long long)(tile_offset + T), (long long)T_total);
+    GSE_REQUIRE(N_local % kTile == 0 || tile_offset + T == T_total,
+                "gse_pf_shard_cumsum: every shard but the last must hold a multiple of %d particles", kTile);
+    const int64_t ldw = (N_local + 3) / 4 * 4;
+    hipLaunchKernelGGL(cumsum_kernel<false>, dim3(T, 1), dim3(kBlock), 0, (hipStream_t)stream, w, c, prefix_all,
+                       (double*)nullptr, (double*)nullptr, N_local, ldw, T, (int64_t)0, tile_offset, T_total);
+    GSE_LAUNCH_CHECK("cumsum_kernel<shard>");
+    return GSE_OK;
+}
+
+int gse_pf_shard_gather(const float* x_in, int64_t ld, int64_t N_local, const double* c, int64_t j_base, int64_t count,
+                        int64_t n_total, double r, float* rows_out, int32_t* idx_out, void* stream) {
+    if (int rc = check_pf_geometry("gse_pf_shard_gather", 1, N_local, ld)) return rc;
+    GSE_REQUIRE(x_in && c && rows_out && aligned16(x_in), "gse_pf_shard_gather: bad pointer");
+    GSE_REQUIRE(j_base >= 0 && count >= 0 && j_base + count <= n_total && n_total >= N_local,
+                "gse_pf_shard_gather: outputs [%lld, %lld) of %lld", (long long)j_base, (long long)(j_base + count),
+                (long long)n_total);
+    GSE_REQUIRE(r >= 0.0 && r < 1.0, "gse_pf_shard_gather: r = %g is outside [0, 1)", r);
+    if (count == 0) return GSE_OK;
+    RowsPayload pl{x_in, rows_out, ld};
+    ResampleArgs ra;
+    ra.r[0] = r;
+    hipLaunchKernelGGL(gather_kernel<RowsPayload>, dim3((unsigned)tiles_of(count), 1), dim3(kBlock), 0, (hipStream_t)stream, pl,
+                       c, (const double*)nullptr, (float*)nullptr, idx_out, N_local, count, ra, j_base, count, n_total);
+    GSE_LAUNCH_CHECK("gather_kernel<rows>");
+    return GSE_OK;
 }
 
 #ifdef GSE_STAMPS

@@ -11,6 +11,11 @@ and carries its accumulated log-weight; the only exchange is the posterior merge
 
 The collective payload is 22 P doubles (1.4 KB at P = 8): latency-bound, xGMI bandwidth is irrelevant; it is
 issued asynchronously so that it overlaps the next predict.
+
+``resample(exact=True)`` removes the island approximation: one systematic resample of the WHOLE
+ensemble, bit-identical to a single GPU holding the concatenation of the shards.  It costs an all-gather of the tile sums
+(8 B per 1024 particles) and one all-to-all of the offspring whose ancestor lives on another rank (20 B each, at most
+n per rank, over xGMI); see ``exact_resample_plan`` for the bookkeeping every rank derives on its own.
 """
 import numpy
 import torch
@@ -60,6 +65,38 @@ def merge_rows(rows, pivot):
     return mean, cov
 
 
+def output_boundaries(end_keys, n_total, r):
+    """J[q] = number of outputs j in [0, n_total) whose threshold u_j = (j + r) / n_total does not exceed the normalised
+    cumulative weight at the end of shard q - 1; J[0] = 0.  Outputs [J[q], J[q + 1]) are the offspring of shard q's
+    particles (ancestor of j = first k with c[k] >= u_j, particle.py:96-100, and c ends shard q at end_keys[q]).
+    The comparison uses the very expression the kernels use for u_j, so the split is exact, not approximate."""
+    end_keys = numpy.asarray(end_keys, dtype=numpy.float64)
+    n = int(n_total)
+    nd = float(n)
+    u = lambda j: (numpy.asarray(j, dtype=numpy.float64) + r) / nd
+    out = [0]
+    for e in end_keys:
+        j = int(min(max(numpy.floor(e * nd - r), -1), n - 1))         # candidate for the last output with u_j <= e
+        while j >= 0 and u(j) > e:
+            j -= 1
+        while j + 1 < n and u(j + 1) <= e:
+            j += 1
+        out.append(max(j + 1, out[-1]))
+    out[-1] = n                                                       # c ends at 1 >= every u_j
+    return out
+
+
+def exact_resample_plan(J, spans, rank):
+    """Split sizes of the all-to-all for ``rank``: what it sends to every rank (offspring of ITS particles, outputs
+    [J[rank], J[rank + 1]), cut by the ranks' output ranges ``spans`` = [(lo, count)]), and what it receives from every
+    rank (the pieces of its own output range)."""
+    overlap = lambda a0, a1, b0, b1: max(0, min(a1, b1) - max(a0, b0))
+    send = [overlap(J[rank], J[rank + 1], lo, lo + cnt) for lo, cnt in spans]
+    lo, cnt = spans[rank]
+    recv = [overlap(J[q], J[q + 1], lo, lo + cnt) for q in range(len(spans))]
+    return send, recv
+
+
 class ShardedParticleFilter:
     """One big particle filter whose particles live on all ranks of ``group``.
 
@@ -92,6 +129,10 @@ class ShardedParticleFilter:
         # ~25 us of host time, more than a whole cycle of device work at N = 2^20.
         self.reduce_every = max(1, int(reduce_every))
         self._resamples = 0
+        import gpu_se_amd
+        # host generator that is the SAME on every rank (exact resampling draws one r for the whole ensemble)
+        self._common_rng = numpy.random.default_rng(gpu_se_amd._seed_state["seed"] ^ 0xE4AC7)
+        self.last_exact = None
 
     @classmethod
     def from_get_parts(cls, n_local, group=None):
@@ -122,9 +163,70 @@ class ShardedParticleFilter:
             if self._resamples % self.reduce_every == 0:
                 self._reduce_weight_sum()
 
-    def resample(self, r=None):
-        """Local systematic resample (island filter); see update() for the bookkeeping."""
+    def resample(self, r=None, exact=False):
+        """Local systematic resample (island filter); see update() for the bookkeeping.  ``exact=True``: one systematic
+        resample of the whole ensemble across the ranks (every rank must call it, with the same ``r`` if one is given)."""
+        if exact and self.group is not None and self.world > 1:
+            return self._exact_resample(r)
         self.local.resample(r=r)
+
+    def _exact_resample(self, r):
+        import ctypes
+        f = self.local
+        lib = _lib.load()
+        f._flush()
+        dev = f._x.device
+        n, P = f.N_particles, self.world
+        spans = [shard_bounds(self.N_particles, P, q) for q in range(P)]
+        if any(cnt % _lib.GSE_TILE for _, cnt in spans[:-1]):
+            raise ValueError("exact resampling needs every shard but the last to hold a multiple of %d particles" % _lib.GSE_TILE)
+        tiles = [-(-cnt // _lib.GSE_TILE) for _, cnt in spans]
+        T_total, tile_offset = sum(tiles), sum(tiles[:self.rank])
+        stream = torch.cuda.current_stream().cuda_stream
+        if r is None:                                       # one number for the whole ensemble, the same on every rank
+            r = float(self._common_rng.random())
+        # 1. tile sums of every shard
+        mine = torch.empty((tiles[self.rank],), dtype=torch.float64, device=dev)
+        _lib.check(lib.gse_pf_tile_sums(f._w.data_ptr(), f._ld, 1, n, mine.data_ptr(), stream))
+        sums = self._all_gather_uneven(mine, tiles).to(dev)
+        # 2. + 3. the prefix over ALL tiles, then this shard's normalised cumulative weights
+        prefix = torch.empty((T_total + 1,), dtype=torch.float64, device=dev)
+        _lib.check(lib.gse_tile_prefix(sums.data_ptr(), T_total, prefix.data_ptr(), stream))
+        c = torch.empty((n,), dtype=torch.float64, device=dev)
+        _lib.check(lib.gse_pf_shard_cumsum(f._w.data_ptr(), n, prefix.data_ptr(), tile_offset, T_total, c.data_ptr(), stream))
+        ends = numpy.cumsum(tiles)
+        host = prefix[torch.as_tensor(numpy.concatenate([ends, [T_total]]), device=dev)].cpu().numpy()
+        total = host[-1]
+        if not (total > 0 and numpy.isfinite(total)):
+            raise FloatingPointError("the ensemble's weights do not sum to a positive finite number")
+        J = output_boundaries(host[:-1] / total, self.N_particles, r)
+        send, recv = exact_resample_plan(J, spans, self.rank)
+        # 4. the offspring of this shard's particles, rows [count][5], then the exchange
+        count = J[self.rank + 1] - J[self.rank]
+        rows = torch.empty((max(count, 1), _lib.GSE_NX), dtype=torch.float32, device=dev)
+        _lib.check(lib.gse_pf_shard_gather(f._x.data_ptr(), f._ld, n, c.data_ptr(), J[self.rank], count, self.N_particles,
+                                           ctypes.c_double(r), rows.data_ptr(), None, stream))
+        got = self._all_to_all_rows(rows[:count], send, recv)
+        f._x[0, :, :n] = got.to(dev).t()
+        f._w[0, :n] = 1.0 / n                               # every particle of the ensemble weighs 1 / N again:
+        f._island[0, 0] = float(numpy.log(n / self.N_particles))     # the shard's share is its share of the particles
+        f._tiles_valid, f._scan_slot, f._moments_host = False, None, None
+        self.last_exact = dict(r=r, J=J, send=send, recv=recv)
+
+    def _all_gather_uneven(self, mine, counts):
+        """All ranks' 1-d tensors (lengths ``counts``) concatenated; on the collective's device."""
+        width = max(counts)
+        padded = torch.zeros((width,), dtype=mine.dtype, device=self._merge_device)
+        padded[:mine.numel()] = mine.to(self._merge_device)
+        parts = [torch.empty_like(padded) for _ in counts]
+        dist.all_gather(parts, padded, group=self.group)
+        return torch.cat([p[:k] for p, k in zip(parts, counts)])
+
+    def _all_to_all_rows(self, rows, send, recv):
+        src = rows.to(self._merge_device).contiguous()
+        dst = torch.empty((sum(recv), rows.shape[1]), dtype=rows.dtype, device=self._merge_device)
+        dist.all_to_all_single(dst, src, output_split_sizes=recv, input_split_sizes=send, group=self.group)
+        return dst
 
     def _reduce_weight_sum(self):
         if self.group is not None:

@@ -291,6 +291,26 @@ int gse_plant_step(double *X /* [B][5], in/out */, const double *u /* [B][2] */,
                    double *z /* [B][2] */, double *log_x /* [B][5] or NULL */, double *log_u /* [B][2] or NULL */,
                    int64_t B, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Exact systematic resampling of an ensemble SHARDED over several GPUs: the result is, bit for
+ * bit, what gse_pf_resample gives on one GPU holding the concatenation of the shards (particle.py:296-316 semantics).
+ * Every rank (gpu_se_amd/distributed.py):
+ *   1. gse_pf_tile_sums on its weights -> all-gather of the tile sums (8 B per 1024 particles);
+ *   2. gse_tile_prefix over the tile sums of ALL shards (same summation order as the single-GPU prefix);
+ *   3. gse_pf_shard_cumsum: the normalised cumulative weights of its own particles, c [N_local] fp64;
+ *   4. the outputs [J_q, J_q+1) that descend from shard q follow from the prefix at the shard boundaries alone, so
+ *      every rank knows all send / receive counts; gse_pf_shard_gather writes those offspring as rows [count][5]
+ *      (idx_out: their LOCAL ancestor indices), and one all-to-all over xGMI delivers each rank its n outputs.
+ * Every shard but the last must hold a multiple of GSE_TILE particles (tile boundaries of the concatenation).
+ */
+int gse_pf_tile_sums(const float *w, int64_t ld, int B, int64_t N, double *sums /* [B][T] */, void *stream);
+int gse_tile_prefix(const double *sums /* [T] */, int64_t T, double *prefix /* [T + 1], [T] = total */, void *stream);
+int gse_pf_shard_cumsum(const float *w, int64_t N_local, const double *prefix_all /* [T_total + 1] */, int64_t tile_offset,
+                        int64_t T_total, double *c /* [N_local] */, void *stream);
+int gse_pf_shard_gather(const float *x_in /* [5][ld] */, int64_t ld, int64_t N_local, const double *c, int64_t j_base,
+                        int64_t count, int64_t n_total, double r, float *rows_out /* [count][5] */,
+                        int32_t *idx_out /* [count] or NULL */, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,3 +98,91 @@ def test_two_rank_merge_over_gloo():
         np.testing.assert_allclose(mean, want, rtol=1e-12)
         np.testing.assert_allclose(wsum, w.sum(), rtol=1e-12)
     np.testing.assert_array_equal(out[0][0], out[1][0])
+
+
+# ------------------------------------------------------------------------------ exact resampling across ranks
+def test_output_boundaries_split_the_outputs_exactly():
+    """The outputs that descend from a shard, derived from the cumulative weight at the shard ends alone, against a
+    brute-force search over the whole ensemble (incl. weightless shards, r at the ends of [0, 1), tiny ensembles)."""
+    rng = np.random.default_rng(1)
+    for n in (8, 1000, 4096, 12345):
+        for trial in range(40):
+            w = rng.random(n) ** 4
+            cuts = sorted(rng.choice(np.arange(1, n), size=3, replace=False))
+            bounds = [0] + list(cuts) + [n]
+            if trial % 5 == 0:
+                w[bounds[1]:bounds[2]] = 0.0                       # a shard without weight gets no offspring
+            c = np.cumsum(w) / w.sum()
+            c[-1] = 1.0
+            r = (0.0, 1.0 - 2.0 ** -53, rng.random())[trial % 3]
+            anc = np.searchsorted(c, (np.arange(n) + r) / n, side="left")
+            J = gd.output_boundaries([c[k - 1] for k in bounds[1:]], n, r)
+            assert J[0] == 0 and J[-1] == n
+            for q in range(4):
+                mine = np.flatnonzero((anc >= bounds[q]) & (anc < bounds[q + 1]))
+                assert len(mine) == J[q + 1] - J[q]
+                if len(mine):
+                    assert mine[0] == J[q] and mine[-1] == J[q + 1] - 1
+    send, recv = gd.exact_resample_plan([0, 5, 5, 30, 40], [(0, 10), (10, 10), (20, 10), (30, 10)], 2)
+    assert send == [5, 10, 10, 0] and recv == [0, 0, 10, 0]
+
+
+def _exact_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, w, _ = _problem_big()
+    n_total = len(w)
+    spans = [gd.shard_bounds(n_total, world, q) for q in range(world)]
+    lo, cnt = spans[rank]
+    xs, ws = x[lo:lo + cnt], w[lo:lo + cnt].astype(np.float64)
+    # the host logic of ShardedParticleFilter._exact_resample, with NumPy standing in for the four kernels
+    shard = object.__new__(gd.ShardedParticleFilter)
+    shard.group, shard.world, shard.rank, shard._merge_device = dist.group.WORLD, world, rank, torch.device("cpu")
+    tiles = [-(-c // 1024) for _, c in spans]
+    mine = np.add.reduceat(ws, np.arange(0, cnt, 1024))
+    sums = shard._all_gather_uneven(torch.as_tensor(mine), tiles).numpy()
+    prefix = np.concatenate([[0.0], np.cumsum(sums)])
+    t0 = sum(tiles[:rank])
+    c_local = (prefix[t0] + np.cumsum(ws)) / prefix[-1]
+    ends = prefix[np.cumsum(tiles)] / prefix[-1]
+    c_local[-1] = ends[rank]
+    r = 0.6180339887
+    J = gd.output_boundaries(ends, n_total, r)
+    send, recv = gd.exact_resample_plan(J, spans, rank)
+    j = np.arange(J[rank], J[rank + 1])
+    anc = np.searchsorted(c_local, (j + r) / n_total, side="left")
+    got = shard._all_to_all_rows(torch.as_tensor(xs[anc]), send, recv).numpy()
+    out[rank] = (got, lo, cnt, J)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _problem_big():
+    rng = np.random.default_rng(9)
+    n = 3 * 4096
+    x = rng.standard_normal((n, 5)).astype(np.float32)
+    w = rng.random(n) ** 6
+    w[4096:6000] = 0.0
+    return x, w, None
+
+
+def test_exact_resample_exchange_over_gloo():
+    """Three ranks: every rank ends up with exactly its slice of the systematic resample of the whole ensemble."""
+    world = 3
+    manager = mp.Manager()
+    out = manager.dict()
+    mp.spawn(_exact_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    x, w, _ = _problem_big()
+    n = len(w)
+    c = np.cumsum(w.astype(np.float64)) / w.sum()
+    anc = np.minimum(np.searchsorted(c, (np.arange(n) + 0.6180339887) / n, side="left"), n - 1)
+    moved = 0
+    for rank in range(world):
+        got, lo, cnt, J = out[rank]
+        assert got.shape == (cnt, 5)
+        # cumulative sums associate differently here (tile prefix + in-tile sums): allow the neighbour on exact ties
+        same = np.all(got == x[anc[lo:lo + cnt]], axis=1)
+        assert same.mean() > 0.999
+        moved += int(np.sum((anc[lo:lo + cnt] < lo) | (anc[lo:lo + cnt] >= lo + cnt)))
+    assert moved > 0                                                # particles did cross ranks

@@ -128,3 +128,64 @@ def test_sharded_filter_two_ranks_share_one_posterior():
     assert c0 == c1 and lo0 == 0 and lo1 == 1 << 15 and l0 != l1
     xss = orc.steady_state()
     assert abs(e0[0] * 180 - (xss[0] * 180 + 0.3)) < 0.4          # follows the measurement (sigma 0.245)
+
+
+# ------------------------------------------------------------------------------ exact resampling across two ranks
+def _exact_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # collectives on the host; both ranks on one GPU
+    torch.cuda.set_device(0)
+    import gpu_se_amd as g
+    from gpu_se_amd.distributed import ShardedParticleFilter
+    g.seed(31)
+    n_local = 12 * 1024
+    spf = ShardedParticleFilter.from_get_parts(n_local=n_local, group=dist.group.WORLD)
+    xss = orc.steady_state()
+    z = np.array(orc.bioreactor_g(xss)) + [0.3 + 0.2 * rank, -0.2]   # the ranks see different likelihood mass
+    records = []
+    for c in range(3):
+        spf.predict([0.06, 0.2], 0.1)
+        spf.update([0.06, 0.2], z)
+        before = (spf.local.particles.get().copy(), spf.local.weights.get().copy())
+        spf.resample(r=0.25 + 0.2 * c, exact=True)
+        records.append((before, spf.local.particles.get().copy(), spf.local.weights.get().copy(), dict(spf.last_exact)))
+    est = spf.point_estimate()
+    out[rank] = (records, est)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exact_resample_two_ranks_equals_one_filter_on_the_concatenation():
+    """two shards resampled as ONE ensemble give, bit for bit, the particles a single filter holding
+    the concatenation produces with the same r."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    manager = mp.Manager()
+    out = manager.dict()
+    mp.spawn(_exact_worker, args=(2, port, out), nprocs=2, join=True)
+    n_local = 12 * 1024
+    state_pdf, meas_pdf = sim_base.get_noise()
+    x0, _ = sim_base.get_noise()
+    one = ParallelParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, 2 * n_local, x0, state_pdf, meas_pdf)
+    crossed = 0
+    for c in range(3):
+        (x_a, w_a), new_a, wn_a, info_a = out[0][0][c]
+        (x_b, w_b), new_b, wn_b, info_b = out[1][0][c]
+        assert info_a["J"] == info_b["J"] and info_a["r"] == info_b["r"]
+        # island weights enter the concatenation un-normalised exactly as the shards held them
+        one.particles = np.concatenate([x_a, x_b])
+        one.weights = np.concatenate([w_a, w_b])
+        idx = one.resample(r=0.25 + 0.2 * c, return_index=True).get()
+        want = one.particles.get()
+        np.testing.assert_array_equal(np.concatenate([new_a, new_b]), want)
+        np.testing.assert_array_equal(wn_a, np.full(n_local, np.float32(1.0 / n_local)))
+        crossed += int(np.sum(idx[:n_local] >= n_local) + np.sum(idx[n_local:] < n_local))
+        assert info_a["send"][1] == int(np.sum(idx[n_local:] < n_local))
+    assert crossed > 0
+    np.testing.assert_array_equal(out[0][1], out[1][1])               # and the merged estimate is shared
