@@ -70,6 +70,8 @@ PROTOTYPES = {
     "gse_gsukf_moments": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
     "gse_model_f": (ctypes.c_int, [c_vp, c_vp, c_i64, P_D, c_d, c_vp]),
     "gse_model_g": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "gse_model_g_u": (ctypes.c_int, [c_vp, c_vp, c_i64, P_D, c_vp]),
+    "gse_model_tag": (c_u64, []),
     "gse_mixture_pdf_f32": (ctypes.c_int, [c_vp, c_i64, P_MIX, c_vp, c_vp]),
     "gse_mixture_pdf_f64": (ctypes.c_int, [c_vp, c_i64, P_MIX, c_vp, c_vp]),
     "gse_mixture_draw": (ctypes.c_int, [c_vp, c_i64, c_i64, P_MIX, P_RNG, c_vp]),

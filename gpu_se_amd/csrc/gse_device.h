@@ -195,6 +195,62 @@ __device__ __forceinline__ void bioreactor_output(float cg, float cfa, float& y0
 }
 
 // ------------------------------------------------------------------------------------------------
+// The model the particle-filter kernels are compiled for.  Default: the bioreactor above.  With
+// -DGSE_USER_MODEL='"<header>"' (gpu_se_amd/usermodel.py: a restricted Python f / g translated to HIP and the library
+// rebuilt at run time -- what Numba's JIT does for the reference, particle.py:176-208) the header provides
+//     template <class T> void user_increment(const T (&x)[5], double u0, double u1, double dt, double (&dx)[5]);
+//     void user_output(const float (&x)[5], double u0, double u1, float& y0, float& y1);
+// with unused states / inputs left at zero.  What the update stage must keep of a particle's new state differs: the
+// bioreactor's g reads states 0 and 2 only (two registers per particle), a user's g may read all five.
+// ------------------------------------------------------------------------------------------------
+#ifdef GSE_USER_MODEL
+}  // namespace gse
+#include GSE_USER_MODEL
+namespace gse {
+constexpr int kModelNx = GSE_USER_NX;      // states the model uses (the storage keeps GSE_NX rows, the rest stay zero)
+constexpr int kObsKept = GSE_NX;
+template <class T>
+__device__ __forceinline__ void model_increment(const T (&x)[5], double u0, double u1, double dt, double (&dx)[5]) {
+    user_increment(x, u0, u1, dt, dx);
+}
+__device__ __forceinline__ void model_keep(const float (&s)[5], float (&obs)[kObsKept]) {
+#pragma unroll
+    for (int k = 0; k < GSE_NX; ++k) obs[k] = s[k];
+}
+__device__ __forceinline__ void model_output_kept(const float (&obs)[kObsKept], double u0, double u1, float& y0, float& y1) {
+    user_output(obs, u0, u1, y0, y1);
+}
+__device__ __forceinline__ void model_output(const float (&x)[5], double u0, double u1, float& y0, float& y1) {
+    user_output(x, u0, u1, y0, y1);
+}
+#else
+constexpr int kModelNx = GSE_NX;
+constexpr int kObsKept = 2;
+template <class T>
+__device__ __forceinline__ void model_increment(const T (&x)[5], double u0, double u1, double dt, double (&dx)[5]) {
+    bioreactor_increment(x, u0, u1, dt, dx);
+}
+__device__ __forceinline__ void model_keep(const float (&s)[5], float (&obs)[kObsKept]) {
+    obs[0] = s[0];
+    obs[1] = s[2];
+}
+__device__ __forceinline__ void model_output_kept(const float (&obs)[kObsKept], double, double, float& y0, float& y1) {
+    bioreactor_output(obs[0], obs[1], y0, y1);
+}
+__device__ __forceinline__ void model_output(const float (&x)[5], double, double, float& y0, float& y1) {
+    bioreactor_output(x[0], x[2], y0, y1);
+}
+#endif
+
+// x += f(x): one rounding of the fp64 sum to fp32 (what "row_f32 += tuple_f64" does in NumPy).
+__device__ __forceinline__ void model_step(float (&x)[5], double u0, double u1, double dt) {
+    double dx[5];
+    model_increment(x, u0, u1, dt, dx);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) x[k] = (float)((double)x[k] + dx[k]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Measurement mixture density (Ny = 2), fp64.
 // ------------------------------------------------------------------------------------------------
 struct Pdf2 {

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         //      first -- registers only -- and the first half's draw is what hides the latency of the loads above.
         v4f row[GSE_NX];
         float gq[2][GSE_NX];
-        float obs0[kPerThread], obs2[kPerThread];     // Cg, Cfa of the (new) state: all the update needs
+        float obs[kPerThread][kObsKept];              // what g reads of the (new) state (bioreactor: Cg, Cfa)
         // per-filter inputs: kernel arguments, or two uniform (scalar) loads each when they live on the device
         double fg = a.io.f[b].u0, fm = a.io.f[b].u1, z0 = a.io.f[b].z0, z1 = a.io.f[b].z1;
         if constexpr (kDevIO) {
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
                 for (int k = 0; k < GSE_NX; ++k) s[k] = kGather ? gq[q][k] : row[k][p];
                 if (kPredict) {
-                    bioreactor_step(s, fg, fm, a.dt);
+                    model_step(s, fg, fm, a.dt);
 #pragma unroll
                     for (int k = 0; k < GSE_NX; ++k) s[k] += e[p][k];
                 }
@@ -552,8 +552,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
                     for (int k = 0; k < GSE_NX; ++k) row[k][p] = s[k];
                 }
-                obs0[p] = s[0];
-                obs2[p] = s[2];
+                model_keep(s, obs[p]);
             }
         }
         // the new state goes out now, ahead of the update phase (consecutive mapping: one dwordx4 per row)
@@ -570,7 +569,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p) {
                 float y0, y1;
-                bioreactor_output(obs0[p], obs2[p], y0, y1);
+                model_output_kept(obs[p], fg, fm, y0, y1);
                 const double lik = mixture_pdf2<kNd>(a.pdf, z0 - (double)y0, z1 - (double)y1);
                 wnew[p] = (float)((double)wnew[p] * lik);
             }
@@ -1054,7 +1053,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     GSE_REQUIRE(!z_on_device || (U && z), "%s: GSE_OP_Z_DEVICE needs GSE_OP_UPDATE and a device pointer z", fn);
     GSE_REQUIRE(!(u_on_device || z_on_device) || (!G && !noise),
                 "%s: device-resident u / z are not available in a launch that gathers or injects noise", fn);
-    pack_io(a.io, B, (P && !u_on_device ? u : nullptr), (U && !z_on_device ? z : nullptr));
+    pack_io(a.io, B, ((P || U) && !u_on_device ? u : nullptr), (U && !z_on_device ? z : nullptr));   // (g may read u)
     a.u_dev = u_on_device ? u : nullptr;
     a.z_dev = z_on_device ? z : nullptr;
     if (G) {
@@ -1076,7 +1075,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
             a.rng = RngKey{};
         } else {
             GSE_REQUIRE(state_pdf && rng, "%s: predict needs state_pdf and rng (or injected noise)", fn);
-            if (int rc = check_mixture(fn, state_pdf, GSE_NX)) return rc;
+            if (int rc = check_mixture(fn, state_pdf, kModelNx)) return rc;
             GSE_REQUIRE((rng->element_offset & 3u) == 0, "%s: rng element_offset must be a multiple of 4", fn);
             pack_draw(a.draw, *state_pdf);
             a.rng = make_rng_key(*rng, kPurposePredict);
@@ -1140,9 +1139,8 @@ int gse_pf_predict_injected(float* x, int64_t ld, int B, int64_t N, const double
 
 int gse_pf_update(const float* x, float* w, int64_t ld, int B, int64_t N, const double* u, const double* z,
                   const gse_mixture* measurement_pdf, void* workspace, void* stream) {
-    (void)u;                                         // g does not depend on the inputs (static_outputs ignores u)
-    GSE_REQUIRE(w, "gse_pf_update: null argument");
-    return pf_step(GSE_OP_UPDATE, x, nullptr, w, w, nullptr, ld, B, N, nullptr, 0.0, z, nullptr, nullptr, nullptr, nullptr,
+    GSE_REQUIRE(w, "gse_pf_update: null argument");      // (the bioreactor's g ignores u; a user model's may not)
+    return pf_step(GSE_OP_UPDATE, x, nullptr, w, w, nullptr, ld, B, N, u, 0.0, z, nullptr, nullptr, nullptr, nullptr,
                    measurement_pdf, nullptr, workspace, stream, "gse_pf_update");
 }
 

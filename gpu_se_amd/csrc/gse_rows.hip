@@ -17,16 +17,20 @@ __global__ __launch_bounds__(kBlock) void model_f_kernel(const float* __restrict
 #pragma unroll
     for (int k = 0; k < 5; ++k) s[k] = x[i * 5 + k];
     double dx[5];
-    bioreactor_increment(s, fg, fm, dt, dx);
+    model_increment(s, fg, fm, dt, dx);
 #pragma unroll
     for (int k = 0; k < 5; ++k) out[i * 5 + k] = (float)dx[k];
 }
 
-__global__ __launch_bounds__(kBlock) void model_g_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t M) {
+__global__ __launch_bounds__(kBlock) void model_g_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t M,
+                                                         double u0, double u1) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= M) return;
+    float s[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[k] = x[i * 5 + k];
     float y0, y1;
-    bioreactor_output(x[i * 5 + 0], x[i * 5 + 2], y0, y1);
+    model_output(s, u0, u1, y0, y1);
     out[i * 2 + 0] = y0;
     out[i * 2 + 1] = y1;
 }
@@ -145,11 +149,24 @@ int gse_model_f(const float* x, float* out, int64_t M, const double* u, double d
     return GSE_OK;
 }
 
-int gse_model_g(const float* x, float* out, int64_t M, void* stream) {
+int gse_model_g_u(const float* x, float* out, int64_t M, const double* u, void* stream) {
     GSE_REQUIRE(x && out && M >= 1, "gse_model_g: bad argument");
-    hipLaunchKernelGGL(model_g_kernel, dim3(blocks_for(M)), dim3(kBlock), 0, (hipStream_t)stream, x, out, M);
+    hipLaunchKernelGGL(model_g_kernel, dim3(blocks_for(M)), dim3(kBlock), 0, (hipStream_t)stream, x, out, M,
+                       u ? u[0] : 0.0, u ? u[1] : 0.0);
     GSE_LAUNCH_CHECK("model_g_kernel");
     return GSE_OK;
+}
+
+int gse_model_g(const float* x, float* out, int64_t M, void* stream) { return gse_model_g_u(x, out, M, nullptr, stream); }
+
+// 0: the built-in bioreactor model; otherwise the tag of the user model this library was compiled for
+// (-DGSE_USER_MODEL_TAG, gpu_se_amd/usermodel.py)
+uint64_t gse_model_tag(void) {
+#ifdef GSE_USER_MODEL_TAG
+    return GSE_USER_MODEL_TAG;
+#else
+    return 0;
+#endif
 }
 
 static int mixture_pdf_common(const void* e, bool f64, int64_t M, const gse_mixture* m, double* out, void* stream) {

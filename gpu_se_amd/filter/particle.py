@@ -13,14 +13,24 @@ from gpu_se_amd.gaussian_sum_dist import DeterministicGaussianSum
 from gpu_se_amd.model import Bioreactor
 
 
+def _model_library(f, g):
+    """The library whose kernels carry the model (f, g): the shipped one for the bioreactor functions, otherwise the
+    one gpu_se_amd.usermodel translates and compiles for the pair (the reference lets Numba JIT arbitrary Python,
+    particle.py:176-208).  Returns (ctypes library, compiled model or None)."""
+    if f is Bioreactor.homeostatic_DEs and g is Bioreactor.static_outputs:
+        return _lib.load(), None
+    from gpu_se_amd import usermodel
+    model = usermodel.compile_model(f, g)
+    return model.lib, model
+
+
 def _require_builtin_model(f, g):
-    """The reference JIT-compiles arbitrary Python f/g with Numba (particle.py:176-208).  Here the model is
-    compiled ahead of time: only the bioreactor functions have kernels, anything else is an error."""
+    """For the classes without run-time compiled kernels (the GS-UKF): bioreactor functions only."""
     if f is not Bioreactor.homeostatic_DEs or g is not Bioreactor.static_outputs:
         raise NotImplementedError(
-            "gpu_se_amd filters run the built-in bioreactor model only: pass "
+            "this filter runs the built-in bioreactor model only: pass "
             "f=gpu_se_amd.model.Bioreactor.homeostatic_DEs and g=gpu_se_amd.model.Bioreactor.static_outputs "
-            "(there is no CPU fallback for other callables)")
+            "(user models are compiled for the particle filter; there is no CPU fallback)")
 
 
 class _KernelLauncher:
@@ -69,8 +79,13 @@ class ParallelParticleFilter:
     _parallel_resample = _KernelLauncher(_parallel_resample)
 
     def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, element_offset=0, _batch=1):
-        _require_builtin_model(f, g)
-        lib = _lib.load()
+        lib, self._model = _model_library(f, g)
+        self._lib = lib
+        self._nx = self._model.nx if self._model else _lib.GSE_NX      # states of the model (storage always has 5 rows)
+        for name, pdf, want in (("x0", x0, self._nx), ("state_pdf", state_pdf, self._nx),
+                                ("measurement_pdf", measurement_pdf, _lib.GSE_NY)):
+            if pdf._Nx != want:
+                raise ValueError("%s is %d-dimensional, the model needs %d" % (name, pdf._Nx, want))
         self.f = f
         self.g = g
         self.N_particles = int(N_particles)
@@ -124,6 +139,14 @@ class ParallelParticleFilter:
             self._tpb, self._bpg = 32 * ((n - 1) // 32 + 1), 1
         self._y_dummy = DevArray.wrap(torch.zeros(_lib.GSE_NY, dtype=torch.float32, device=dev))
 
+    def _call(self, name, *args):
+        rc = getattr(self._lib, name)(*args)
+        if rc:
+            self._check(rc)
+
+    def _check(self, rc):
+        (self._model.check if self._model else _lib.check)(rc)
+
     # -- per-filter host inputs -> the persistent ctypes buffers ([B][2]; one row is broadcast to all filters)
     def _fill(self, buf, values, width):
         B = self._B
@@ -137,6 +160,17 @@ class ParallelParticleFilter:
         flat = a.ravel()
         for i in range(B * width):
             buf[i] = flat[i]
+
+    def _host_u(self, u):
+        """Inputs as the kernels take them: two per filter (a user model with one input gets a zero for the other)."""
+        a = numpy.asarray(u, dtype=numpy.float64)
+        if self._model is not None and self._model.nu < _lib.GSE_NU:
+            a = a.reshape(-1, self._model.nu) if self._B > 1 else a.reshape(1, -1)
+            a = numpy.concatenate([a, numpy.zeros((a.shape[0], _lib.GSE_NU - a.shape[1]))], axis=1)
+        if self._B == 1:
+            u0, u1 = a.reshape(-1)
+            return (float(u0), float(u1))
+        return numpy.array(a, dtype=numpy.float64)
 
     def _device_io(self, t, width):
         """A per-filter input given as a device tensor ([B][width] fp64, contiguous): passed by pointer."""
@@ -162,6 +196,11 @@ class ParallelParticleFilter:
             pend, self._pend_predict = self._pend_predict, None
             self._launch_step(update=None)
             self._pend_predict = pend
+        if self._model is not None and update is not None and self._pend_predict is not None and \
+                not torch.is_tensor(self._pend_predict[0]) and not torch.is_tensor(update[0]) and \
+                not numpy.array_equal(numpy.asarray(self._pend_predict[0], dtype=numpy.float64).reshape(-1),
+                                      numpy.asarray(self._host_u(update[0]), dtype=numpy.float64).reshape(-1)):
+            self._launch_step(update=None)                      # one launch carries one u: predict with its own first
         device_io = (self._pend_predict is not None and torch.is_tensor(self._pend_predict[0])) or \
             (update is not None and torch.is_tensor(update[1]))
         if device_io and self._pend_gather:
@@ -198,7 +237,7 @@ class ParallelParticleFilter:
             if injected:
                 noise = self.state_pdf.draw((self._B, n)).as_subclass(torch.Tensor)  # (B, n, Nx) replayed values
                 buf = torch.zeros_like(self._x)
-                buf[:, :, :n] = noise.reshape(self._B, n, _lib.GSE_NX).transpose(1, 2)
+                buf[:, :self._nx, :n] = noise.reshape(self._B, n, self._nx).transpose(1, 2)
                 self._noise_buf = buf
                 noise_ptr = buf.data_ptr()
             else:
@@ -211,6 +250,8 @@ class ParallelParticleFilter:
         scan_out = None
         if update is not None:
             ops |= _lib.GSE_OP_UPDATE
+            if self._model is not None and not torch.is_tensor(update[0]) and not (ops & _lib.GSE_OP_U_DEVICE):
+                self._fill(cu, self._host_u(update[0]), _lib.GSE_NU)       # a user model's g may read u
             if torch.is_tensor(update[1]):
                 ops |= _lib.GSE_OP_Z_DEVICE
                 cz = ctypes.cast(ctypes.c_void_p(self._device_io(update[1], _lib.GSE_NY).data_ptr()), _lib.P_D)
@@ -226,7 +267,7 @@ class ParallelParticleFilter:
                            self._island.data_ptr() if self._island is not None else None, self._ws.data_ptr(),
                            stream_ptr(self._dev_index))
         if rc:
-            _lib.check(rc)
+            self._check(rc)
         if gather:
             self._x, self._x_alt = self._x_alt, self._x
             self._w, self._w_alt = self._w_alt, self._w
@@ -242,14 +283,14 @@ class ParallelParticleFilter:
     @property
     def particles(self):
         self._flush()
-        v = self._x[:, :, :self.N_particles].transpose(1, 2)            # (B, N, Nx) strided view
+        v = self._x[:, :self._nx, :self.N_particles].transpose(1, 2)   # (B, N, Nx) strided view
         return DevArray.wrap(v[0] if self._B == 1 else v)
 
     @particles.setter
     def particles(self, value):
-        v = as_device(value, torch.float32).reshape(self._B, self.N_particles, _lib.GSE_NX)
+        v = as_device(value, torch.float32).reshape(self._B, self.N_particles, self._nx)
         self._flush()
-        self._x[:, :, :self.N_particles] = v.transpose(1, 2)
+        self._x[:, :self._nx, :self.N_particles] = v.transpose(1, 2)
         self._moments_host = None
 
     @property
@@ -276,11 +317,8 @@ class ParallelParticleFilter:
             self._flush()                                   # two predicts in a row: run the first one now
         if torch.is_tensor(u):
             u = self._device_io(u, _lib.GSE_NU)             # read by the kernel when it runs: do not overwrite before
-        elif self._B == 1:
-            u0, u1 = numpy.asarray(u, dtype=numpy.float64).reshape(-1)
-            u = (float(u0), float(u1))
         else:
-            u = numpy.array(u, dtype=numpy.float64)
+            u = self._host_u(u)
         self._pend_predict = (u, float(dt))
         if not self.lazy:
             self._flush()
@@ -309,7 +347,7 @@ class ParallelParticleFilter:
                                          self._island.data_ptr() if self._island is not None else None,
                                          self._ws.data_ptr(), stream_ptr(self._dev_index))
             if rc:
-                _lib.check(rc)
+                self._check(rc)
             self._gather_slot = None
         self._tiles_valid = False
         self._scan_slot = None
@@ -326,8 +364,8 @@ class ParallelParticleFilter:
         """(S0 (B,), S1 (B, 5), S2 (B, 5, 5), pivot (B, 5)) with d = x - pivot, from the device (synchronises)."""
         self._flush()
         if self._moments_host is None:                      # nothing changed since the last estimate: reuse it
-            _lib.call("gse_pf_moments", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
-                      self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
+            self._call("gse_pf_moments", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
+                       self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
             self._moments_host = self._moments.cpu().numpy()
         m = self._moments_host
         iu = numpy.triu_indices(_lib.GSE_NX)
@@ -345,7 +383,8 @@ class ParallelParticleFilter:
 
     def _moment_sums_all(self):
         """Per filter (S0, w@x, sum w (x - w@x)(x - w@x)^T) -- the reference's un-normalised quantities."""
-        return [moments_to_mean_cov(s0, s1, s2[numpy.triu_indices(_lib.GSE_NX)], pivot)
+        k = self._nx
+        return [moments_to_mean_cov(s0, s1[:k], s2[:k, :k][numpy.triu_indices(k)], pivot[:k])
                 for s0, s1, s2, pivot in self._raw_moments_all()]
 
     def _moment_sums(self):
@@ -361,23 +400,29 @@ class ParallelParticleFilter:
         return numpy.linalg.svd(cov, compute_uv=False)[0]
 
     # ------------------------------------------------------------------ pieces the benchmark scripts call
-    def f_vectorize(self, particles, u, dt):
-        """out[i] = f(particles[i], u, dt) as a device array (M x Nx) fp32 (particle.py:176-191)."""
+    def _rows5(self, particles):
         p = as_device(particles, torch.float32)
         lead = p.shape[:-1]
-        p2 = p.reshape(-1, _lib.GSE_NX).contiguous()
+        p2 = p.reshape(-1, self._nx)
+        if self._nx < _lib.GSE_NX:
+            p2 = torch.cat([p2, torch.zeros((p2.shape[0], _lib.GSE_NX - self._nx), dtype=torch.float32, device=p2.device)], dim=1)
+        return p2.contiguous(), lead
+
+    def f_vectorize(self, particles, u, dt):
+        """out[i] = f(particles[i], u, dt) as a device array (M x Nx) fp32 (particle.py:176-191)."""
+        p2, lead = self._rows5(particles)
         out = torch.empty_like(p2)
-        _lib.call("gse_model_f", p2.data_ptr(), out.data_ptr(), p2.shape[0], _lib.doubles(u, _lib.GSE_NU), float(dt),
-                  stream_ptr())
-        return DevArray.wrap(out.reshape(lead + (_lib.GSE_NX,)))
+        uu = self._host_u(u) if self._B == 1 else numpy.asarray(u, dtype=numpy.float64).reshape(-1)[:2]
+        self._call("gse_model_f", p2.data_ptr(), out.data_ptr(), p2.shape[0], _lib.doubles(uu, _lib.GSE_NU), float(dt),
+                   stream_ptr())
+        return DevArray.wrap(out[:, :self._nx].reshape(lead + (self._nx,)))
 
     def g_vectorize(self, particles, u, _y_dummy=None):
         """out[i] = g(particles[i], u) as a device array (M x Ny) fp32 (particle.py:193-208)."""
-        p = as_device(particles, torch.float32)
-        lead = p.shape[:-1]
-        p2 = p.reshape(-1, _lib.GSE_NX)
+        p2, lead = self._rows5(particles)
         out = torch.empty((p2.shape[0], _lib.GSE_NY), dtype=torch.float32, device=p2.device)
-        _lib.call("gse_model_g", p2.data_ptr(), out.data_ptr(), p2.shape[0], stream_ptr())
+        uu = self._host_u(u) if self._B == 1 else numpy.asarray(u, dtype=numpy.float64).reshape(-1)[:2]
+        self._call("gse_model_g_u", p2.data_ptr(), out.data_ptr(), p2.shape[0], _lib.doubles(uu, _lib.GSE_NU), stream_ptr())
         return DevArray.wrap(out.reshape(lead + (_lib.GSE_NY,)))
 
 

@@ -214,6 +214,12 @@ int gse_gsukf_moments(const float *mu, const float *P, const float *w, int B, in
 int gse_model_f(const float *x, float *out, int64_t M, const double *u, double dt, void *stream);
 /* g_vectorize (filter/particle.py:193-208): out[i] = g(x[i], u); x: [M][5], out: [M][2] fp32. */
 int gse_model_g(const float *x, float *out, int64_t M, void *stream);
+/* The same with the inputs g may depend on (u host [2] or NULL = zeros); the bioreactor's g ignores them. */
+int gse_model_g_u(const float *x, float *out, int64_t M, const double *u, void *stream);
+/* Which model this library's particle-filter kernels were compiled for: 0 = the bioreactor (the shipped library);
+ * otherwise the tag of a user model translated and compiled at run time (gpu_se_amd/usermodel.py -- the counterpart of
+ * the reference's Numba JIT of arbitrary f / g, filter/particle.py:176-208). */
+uint64_t gse_model_tag(void);
 /* MultivariateGaussianSum.pdf (MultivariateGaussianSum.py:39-63): e [M][nx] fp32 or fp64 -> out [M] fp64. */
 int gse_mixture_pdf_f32(const float *e, int64_t M, const gse_mixture *m, double *out, void *stream);
 int gse_mixture_pdf_f64(const double *e, int64_t M, const gse_mixture *m, double *out, void *stream);

@@ -1,0 +1,126 @@
+"""Particle filter with user-supplied models on the device: the kernels compiled for a translated
+Python f / g against the same Python functions evaluated in NumPy."""
+import numpy as np
+import pytest
+import torch
+
+import gpu_se_amd
+from gpu_se_amd import gaussian_sum_dist as gsd
+from gpu_se_amd.filter import ParallelParticleFilter, ParallelGaussianSumUnscentedKalmanFilter
+from gpu_se_amd.model import Bioreactor
+from oracle import gse_oracle as orc
+import usermodels as um
+
+pytestmark = pytest.mark.gpu
+
+
+def _two_state_parts(deterministic=False):
+    cls = gsd.DeterministicGaussianSum if deterministic else gsd.MultivariateGaussianSum
+    x0 = gsd.MultivariateGaussianSum(means=np.array([[10.0, 0.0], [-10.0, -10.0]]),
+                                     covariances=np.array([[[1, 0], [0, 1]], [[2, 0.5], [0.5, 0.5]]]), weights=np.array([0.3, 0.7]))
+    state = cls(means=np.array([[1e-3, 0], [0, -1e-3]]),
+                covariances=np.array([[[1e-4, 0], [0, 1e-5]], [[2e-4, 1e-5], [1e-5, 5e-6]]]), weights=np.array([0.5, 0.5]))
+    meas = gsd.MultivariateGaussianSum(means=np.array([[1.0, 0], [0, -1.0]]),
+                                       covariances=np.array([[[0.1, 0], [0, 0.1]], [[0.2, 0.01], [0.01, 0.005]]]),
+                                       weights=np.array([0.7, 0.9]))          # tests/ParticleFilter_test.py:23-52
+    return x0, state, meas
+
+
+def _python_rows(fn, x32, *args):
+    """fn on every row of an fp32 array, evaluated in float64 as the device does."""
+    return np.array([fn([float(v) for v in row], *args) for row in x32], dtype=np.float64)
+
+
+def test_predict_and_update_with_a_two_state_model_bit_exact():
+    gpu_se_amd.seed(3)
+    n = 5000
+    x0, state, meas = _two_state_parts(deterministic=True)
+    rng = np.random.default_rng(0)
+    noise = (rng.standard_normal((n, 2)) * [1e-2, 3e-3]).astype(np.float32)
+    gsd.DeterministicGaussianSum.preload(noise)
+    pf = ParallelParticleFilter(um.two_state_f, um.two_state_g, n, x0, state, meas)
+    assert tuple(pf.particles.shape) == (n, 2)
+    before = pf.particles.get().copy()
+    pf.predict([1.3], 0.05)
+    after = pf.particles.get()
+    inc = _python_rows(um.two_state_f, before, [1.3], 0.05)
+    want = (before.astype(np.float64) + inc).astype(np.float32) + noise
+    np.testing.assert_array_equal(after, want)
+    # update: w *= pdf(z - g(x, u)) with g reading u
+    z = np.array([0.7, -8.0])
+    w0 = pf.weights.get().astype(np.float64)
+    pf.update([0.4], z)
+    y = _python_rows(um.two_state_g, after, [0.4]).astype(np.float32)
+    lik = orc.MixtureOracle(meas.means, meas.covariances, meas.weights).pdf(z[None, :] - y.astype(np.float64))
+    np.testing.assert_allclose(pf.weights.get(), (w0 * lik).astype(np.float32), rtol=2e-6, atol=1e-37)
+    # the pieces the reference's scripts call
+    np.testing.assert_array_equal(pf.f_vectorize(before[:100], [1.3], 0.05).get(), inc[:100].astype(np.float32))
+    np.testing.assert_array_equal(pf.g_vectorize(after[:100], [0.4]).get(), y[:100])
+    est = pf.point_estimate()
+    assert est.shape == (2,) and np.isfinite(pf.point_covariance())
+    wn = pf.weights.get().astype(np.float64)
+    np.testing.assert_allclose(est, wn @ after.astype(np.float64), rtol=1e-9, atol=1e-12)
+
+
+def test_three_state_model_full_cycle_matches_a_numpy_filter():
+    """Cycles with injected noise and given r: particles, weights and ancestors against a NumPy filter that calls the
+    same Python functions (every supported construct: subscripts, conditionals, min / max / exp / sqrt)."""
+    gpu_se_amd.seed(4)
+    n = 3000
+    x0 = gsd.MultivariateGaussianSum(means=np.array([[2.0, 1.0, 3.0]]), covariances=np.array([np.diag([0.5, 0.1, 0.8])]),
+                                     weights=np.array([1.0]))
+    state = gsd.DeterministicGaussianSum(means=np.zeros((1, 3)), covariances=np.array([np.diag([1e-3, 1e-3, 1e-3])]),
+                                         weights=np.array([1.0]))
+    meas = gsd.MultivariateGaussianSum(means=np.zeros((2, 2)), covariances=np.array([np.diag([4.0, 1.0]), np.diag([40.0, 9.0])]),
+                                       weights=np.array([0.8, 0.2]))
+    rng = np.random.default_rng(1)
+    cycles = 4
+    noise = (rng.standard_normal((n, 3)) * 0.03).astype(np.float32)     # the replay buffer serves the same rows every draw
+    gsd.DeterministicGaussianSum.preload(noise)
+    pf = ParallelParticleFilter(um.three_state_f, um.three_state_g, n, x0, state, meas)
+    pf.lazy = False
+    x = pf.particles.get().copy()
+    w = pf.weights.get().astype(np.float64)
+    mix = orc.MixtureOracle(meas.means, meas.covariances, meas.weights)
+    for c in range(cycles):
+        u, z, r = [0.3 + 0.1 * c, 0.5], np.array([21.0 + c, 2.5]), 0.15 + 0.2 * c
+        pf.predict(u, 0.2)
+        pf.update(u, z)
+        idx = pf.resample(r=r, return_index=True).get()
+        x = (x.astype(np.float64) + _python_rows(um.three_state_f, x, u, 0.2)).astype(np.float32) + noise
+        y = _python_rows(um.three_state_g, x, u).astype(np.float32)
+        w = (w * mix.pdf(z[None, :] - y.astype(np.float64))).astype(np.float32).astype(np.float64)
+        cum = np.cumsum(w) / w.sum()
+        want_idx = np.minimum(np.searchsorted(cum, (np.arange(n) + r) / n, side="left"), n - 1)
+        assert np.mean(idx != want_idx) < 2e-3                      # (cumulative sums associate differently: ties)
+        x = x[idx]
+        w = np.full(n, np.float64(np.float32(1.0 / n)))
+        np.testing.assert_array_equal(pf.particles.get(), x)
+
+
+def test_user_model_with_philox_noise_and_fused_cycle():
+    """The production path (lazy fused launches, Philox noise): the estimate follows the measurements."""
+    gpu_se_amd.seed(5)
+    n = 1 << 15
+    x0, state, meas = _two_state_parts()
+    pf = ParallelParticleFilter(um.two_state_f, um.two_state_g, n, x0, state, meas)
+    truth = np.array([9.0, 0.5])
+    for c in range(12):
+        pf.predict([1.0], 0.01)
+        truth = truth + np.array(um.two_state_f(truth, [1.0], 0.01))
+        pf.update([1.0], np.array(um.two_state_g(truth, [1.0])) + [0.7, -0.3])
+        pf.resample()
+    est = pf.point_estimate()
+    assert np.all(np.isfinite(est)) and abs(est[1] - truth[1]) < 0.6 and abs(est[0] * est[1] - truth[0] * truth[1]) < 2.5
+
+
+def test_other_classes_refuse_user_models_loudly():
+    x0, state, meas = _two_state_parts()
+    with pytest.raises(NotImplementedError):
+        ParallelGaussianSumUnscentedKalmanFilter(um.two_state_f, um.two_state_g, 8, x0, state, meas)
+    with pytest.raises(ValueError, match="dimensional"):
+        ParallelParticleFilter(um.three_state_f, um.three_state_g, 16, x0, state, meas)
+    # and the shipped library still serves the bioreactor
+    from gpu_se_amd import sim_base
+    _, _, _, pf = sim_base.get_parts(N_particles=256)
+    assert pf._model is None and tuple(pf.particles.shape) == (256, 5)

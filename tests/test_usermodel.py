@@ -1,0 +1,48 @@
+"""User models, CPU side: translation of restricted Python to HIP, and that the particle-filter
+library builds for a translated model (hipcc cross-compiles without a GPU) and carries the model's tag."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from gpu_se_amd import usermodel
+import usermodels as um
+
+
+def test_translation_of_the_reference_style_pair():
+    nx, nu, text = usermodel.translate(um.two_state_f, um.two_state_g)
+    assert (nx, nu) == (2, 1)
+    assert "user_increment" in text and "user_output" in text and "fp contract(off)" in text
+    assert "dx_[2] = 0.0;" in text and "dx_[4] = 0.0;" in text              # unused states stay where they are
+    nx, nu, text = usermodel.translate(um.three_state_f, um.three_state_g)
+    assert (nx, nu) == (3, 2)
+    for piece in ("fmax(", "fabs(", "exp(", "sqrt(", "fmin(", "?"):
+        assert piece in text
+
+
+def test_unsupported_python_is_refused():
+    with pytest.raises(usermodel.ModelError, match="outside the supported form"):
+        usermodel.translate(um.loop_f, um.two_state_g)
+    with pytest.raises(usermodel.ModelError, match="exactly 2 outputs"):
+        usermodel.translate(um.two_state_f, _one_output)
+    with pytest.raises(usermodel.ModelError):
+        usermodel.translate(lambda x, u, dt: (x[0] * dt,), um.two_state_g)   # not a plain function definition
+
+
+def _one_output(x, u):
+    return x[0] + u[0],
+
+
+def test_library_builds_for_a_user_model():
+    model = usermodel.compile_model(um.two_state_f, um.two_state_g)
+    assert os.path.exists(model.path) and (model.nx, model.nu) == (2, 1)
+    assert int(model.lib.gse_model_tag()) == model.tag != 0
+    for name in ("gse_pf_step", "gse_pf_resample_begin", "gse_pf_moments", "gse_model_f", "gse_model_g_u", "gse_last_error"):
+        assert hasattr(model.lib, name), name
+    # argument checking works in the model's library too, without a GPU
+    assert model.lib.gse_pf_step(512, 16, 16, None, None, None, 8, 1, 8, None, 0.0, None, None, None, None, None, None,
+                                 None, None, None) < 0
+    assert b"bad ops mask" in model.lib.gse_last_error()
+    assert usermodel.compile_model(um.two_state_f, um.two_state_g) is model          # cached
+    usermodel.compile_model(um.three_state_f, um.three_state_g)
