@@ -53,9 +53,15 @@ __device__ __forceinline__ int mpc_solve(const MpcLawDev& law, double theta_lane
         hi = law.hi[lane];
         sii = law.S[lane * m + lane];
     }
-    for (int k = 0; k < nt; ++k) {
-        const double tk = __shfl(theta_lane, k, 64);
-        if (row) c += law.Gc[lane * nt + k] * tk;
+    {   // (all coefficient loads first, in flight together: this kernel is nothing but dependent latencies)
+        double gk[GSE_MPC_MAX_THETA];
+#pragma unroll
+        for (int k = 0; k < GSE_MPC_MAX_THETA; ++k) gk[k] = (row && k < nt) ? law.Gc[lane * nt + k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < GSE_MPC_MAX_THETA; ++k) {
+            const double tk = __shfl(theta_lane, k, 64);
+            if (k < nt) c += gk[k] * tk;
+        }
     }
     const double c0 = c;
     double nu = 0.0;
@@ -94,9 +100,15 @@ __device__ __forceinline__ int mpc_solve(const MpcLawDev& law, double theta_lane
     const double* G = for_u ? law.Gu : law.Gy;
     double acc = 0.0;
     if (mine) acc = for_u ? law.gu0[k] : law.gy0[k];
-    for (int q = 0; q < nt; ++q) {
-        const double tq = __shfl(theta_lane, q, 64);
-        if (mine) acc += G[k * nt + q] * tq;
+    {
+        double gq[GSE_MPC_MAX_THETA];
+#pragma unroll
+        for (int q = 0; q < GSE_MPC_MAX_THETA; ++q) gq[q] = (mine && q < nt) ? G[k * nt + q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < GSE_MPC_MAX_THETA; ++q) {
+            const double tq = __shfl(theta_lane, q, 64);
+            if (q < nt) acc += gq[q] * tq;
+        }
     }
     for (int i = 0; i < m; ++i) {
         const double nui = __shfl(nu, i, 64);
