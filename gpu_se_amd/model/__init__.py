@@ -1,4 +1,9 @@
-from gpu_se_amd.model.BioreactorModel import Bioreactor
-from gpu_se_amd.model.LinearModel import LinearModel
+"""Host-side models: the bioreactor plant (its f / g are the functions the device kernels implement) and the
+discrete linear model the MPC is built on.  Nothing here touches the GPU."""
+from . import BioreactorModel as _plant
+from . import LinearModel as _linear
 
-__all__ = ['Bioreactor', 'LinearModel']
+Bioreactor = _plant.Bioreactor
+LinearModel = _linear.LinearModel
+
+__all__ = ("Bioreactor", "LinearModel")
