@@ -75,6 +75,22 @@ def test_closed_loop_with_mpc_drives_the_outputs_to_the_setpoint():
     assert cfa[0] < 620 and cfa[-1] > cfa[0] + 60                # moving towards 850 mg/L
     assert abs(sim.ys[-1, 0] - 280) < 25                         # glucose held near its set point
     assert np.isfinite(sim.performance)
+    # every decision of the loop, recomputed from the loop's own records by the independent exact solver on the
+    # reference's QP (get_parts' horizons: tests/golden/mpc_qp.npz "parts" holds the matrices for this very model)
+    lm = sim.lin_model
+    H, q, A = golden_dense("parts", "H"), GOLD["parts_q"], golden_dense("parts", "A")
+    lay = orc.layout(300, 200, 2, 2, 2)
+    control_ticks = [t for t in range(1, len(sim.ts)) if not np.array_equal(sim.us[t], sim.us[t - 1])]
+    y_pred, checked = None, 0
+    for k, t in enumerate(control_ticks[:4]):
+        x0, um1, y0 = lm.xn2d(sim.xs_f[k + 1]), lm.un2d(sim.us[t - 1]), lm.yn2d(sim.ys_meas[t - 1])
+        bias = np.zeros(2) if y_pred is None else y0 - y_pred
+        l, u = orc.write_step(GOLD["parts_l0"], GOLD["parts_u0"], 300, 2, 2, 2, x0, um1, bias)
+        z, _, _ = orc.solve_qp(H, q, A, l, u)
+        np.testing.assert_allclose(lm.un2d(sim.us[t]), z[lay["du"]:lay["du"] + 2] + um1, rtol=1e-5, atol=1e-7)
+        y_pred = z[lay["y"]:lay["y"] + 2] - bias
+        checked += 1
+    assert checked >= 3
 
 
 def test_batched_closed_loops_with_mpc():
