@@ -1,20 +1,35 @@
 // gse_gsukf.hip -- Gaussian-sum unscented Kalman filter on gfx950.
 //
-// A bank of N Gaussians (mu_i, P_i, w_i); each is a UKF with 2*5+1 = 11 unscaled sigma points
-// (filter/gs_ukf.py).  Mapping: 16 lanes per Gaussian (a quarter wavefront), lane j < 11 owns sigma point j, so
-// the 64-Gaussian configuration runs as 16 wavefronts side by side instead of 64 serial sigma loops -- that
-// configuration is launch-latency-bound and wants the shortest critical path per launch.
-// Per Gaussian: the 5x5 Cholesky is done redundantly in every lane's registers (35 flops); sigma points go
-// through the model in registers; the 11-term contractions (mean, P, P_xy, P_yy) are staged through an LDS tile
-// and summed in the reference's order (j = 0..10) so that results track the NumPy class closely; lane l < 15
-// owns entry l of the symmetric 5x5 output.  These contractions are 5x11x5 at most: far too small to feed
-// the matrix cores (a 16x16x4 fp32 MFMA tile would be >90 % padding) and nowhere near a bound.
+// A bank of N Gaussians (mu_i, P_i, w_i); each is a UKF with 2*5+1 = 11 unscaled sigma points (filter/gs_ukf.py).
+// A workgroup of 1024 threads takes 64 Gaussians and every phase alternates between two mappings:
+//   * per SIGMA POINT, 16 lanes per Gaussian (lane j < 11 owns sigma point j): the model step with its noise draw
+//     (predict) and the output function (update) -- the part with 11-fold parallelism per Gaussian;
+//   * per GAUSSIAN, one lane each (the 64 lanes of wavefront 0): the 5x5 Cholesky, the 11-term contractions (mean, P,
+//     P_xy, P_yy), the 2x2 pseudo-inverse, the gain and the covariance update.  A wavefront issues an instruction once
+//     whatever the number of lanes that need it, so doing this per-Gaussian algebra in all 16 lanes of every Gaussian
+//     (the first version) cost 16 wavefronts' worth of issue slots per 64 Gaussians instead of one: at 2^18 Gaussians
+//     update 138 -> 72 us (predict, whose sigma-point part dominates, 76 -> 84 us: the single-wavefront parts are not
+//     overlapped, one workgroup fills a CU), the cycle 236 -> 180 us.  The 64-Gaussian configuration (BASELINE config 3)
+//     is launch-latency-bound and gains most: 19.2 -> 11.7 us per cycle -- the per-Gaussian algebra is the same
+//     instruction stream but its loads and LDS traffic are no longer multiplied by 16.
+// Hand-offs go through LDS (rows padded to odd strides: a lane per Gaussian walks rows).  Sums run in the reference's
+// order (j = 0..10) so that results track the NumPy class closely.  These contractions are 5x11x5 at most: far too small
+// to feed the matrix cores (a 16x16x4 fp32 MFMA tile would be >90 % padding) and nowhere near a bound.
 #include "gse_host.h"
 
 namespace gse {
 
-constexpr int kGroup = 16;                       // lanes per Gaussian
-constexpr int kGaussPerBlock = kBlock / kGroup;  // 16
+constexpr int kGroup = 16;                       // lanes per Gaussian in the per-sigma-point parts
+constexpr int kGaussPerBlock = kBlock / kGroup;  // 16 (gsukf_sigma_kernel only)
+#ifndef GSE_GSUKF_WIDE_BANK
+#define GSE_GSUKF_WIDE_BANK 64   // (16 / 32 / 64 measured at 2^18 Gaussians: 212 / 218 / 180 us per cycle)
+#endif
+constexpr int kWideBank = GSE_GSUKF_WIDE_BANK;   // Gaussians per workgroup of the separate predict / update kernels
+constexpr int kBank = 64;                        // Gaussians per workgroup of the one-launch cycle kernel
+constexpr int kBankBlock = kBank * kGroup;       // 1024 threads
+constexpr int kFacStride = 21;                   // LDS row: m[5], L[15] (+1: odd stride)
+constexpr int kTileStride = GSE_NSIGMA * 5 + 2;  // 57 floats
+constexpr int kEtaStride = GSE_NSIGMA * 2 + 1;   // 23 doubles
 
 // Packed lower-triangular index helpers: entry (i, j), j <= i, lives at i*(i+1)/2 + j.
 __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
@@ -115,89 +130,126 @@ struct GsukfPredictArgs {
     double dt;
 };
 
-// Predict of ONE Gaussian by its 16 lanes.  mu_g / P_g: where this Gaussian is read, mu_o / P_o: where it is written
-// (may be the same memory: every read precedes the workgroup barrier inside, every write follows it).  tile_g: this
-// Gaussian's 56 floats of LDS.  g: its index in the filter (RNG element), nz: its injected noise row [11][5] or null.
-// Must be called by every thread of the workgroup.
-template <bool kInjected>
-__device__ __forceinline__ void gsukf_predict_phase(const float* mu_g, const float* P_g, float* mu_o, float* P_o,
-                                                    float* tile_g, bool live, int j, int b, int64_t g, const float* nz,
-                                                    const DrawParams& dp, int32_t* status, const GsukfPredictArgs& a) {
-    if (live && j < GSE_NSIGMA) {
-        float m[5], L[15], s[5];
+// Phase A of predict and update: lane t < nloc of the workgroup factorises local Gaussian t and leaves (m, L) in fac[t].
+// Src: t -> (mu pointer, P pointer); global memory or LDS.  Ends with a workgroup barrier.
+template <class Src>
+__device__ __forceinline__ void gsukf_factor_block(Src src, float (*fac)[kFacStride], int nloc, int32_t* status) {
+    const int t = threadIdx.x;
+    if (t < nloc) {
+        float m[5], L[15];
         bool ok;
+        const float *mu_g, *P_g;
+        src(t, mu_g, P_g);
         load_and_factor(mu_g, P_g, m, L, ok);
-        if (!ok && j == 0 && status) atomicAdd(status, 1);
+        if (!ok && status) atomicAdd(status, 1);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) fac[t][k] = m[k];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) fac[t][5 + k] = L[k];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void read_factor(const float* fac_g, float (&m)[5], float (&L)[15]) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) m[k] = fac_g[k];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) L[k] = fac_g[5 + k];
+}
+
+// Predict of the workgroup's nloc Gaussians (local index gl = tid / 16, lane j = tid % 16).  src / dst: local index ->
+// where (mu, P) are read / written (may be the same memory: every read precedes a barrier that every write follows).
+// g0: filter index of local Gaussian 0 (RNG element), noise: injected rows [N][11][5] of this filter or null.
+// Must be called by every thread of the workgroup.
+template <bool kInjected, class Src, class Dst>
+__device__ __forceinline__ void gsukf_predict_block(Src src, Dst dst, float (*fac)[kFacStride], float (*tile)[kTileStride],
+                                                    int nloc, int b, int64_t g0, const float* noise, const DrawParams& dp,
+                                                    int32_t* status, const GsukfPredictArgs& a) {
+    gsukf_factor_block(src, fac, nloc, status);
+    // B. one sigma point per lane: model step + noise
+    const int j = threadIdx.x & (kGroup - 1), gl = threadIdx.x / kGroup;
+    if (gl < nloc && j < GSE_NSIGMA) {
+        float m[5], L[15], s[5];
+        read_factor(fac[gl], m, L);
         sigma_point(m, L, j, s);
         bioreactor_step(s, a.io.f[b].u0, a.io.f[b].u1, a.dt);
         float e[5];
         if (kInjected) {
+            const float* nz = noise + (g0 + gl) * GSE_NSIGMA * 5;
 #pragma unroll
             for (int k = 0; k < 5; ++k) e[k] = nz[j * 5 + k];
         } else {
             uint32_t wd[8];
-            rng_words8(a.rng, (uint64_t)(g * GSE_NSIGMA + j), (uint32_t)b, wd);
+            rng_words8(a.rng, (uint64_t)((g0 + gl) * GSE_NSIGMA + j), (uint32_t)b, wd);
             mixture_draw5(dp, wd, e);
         }
 #pragma unroll
-        for (int k = 0; k < 5; ++k) tile_g[j * 5 + k] = s[k] + e[k];
+        for (int k = 0; k < 5; ++k) tile[gl][j * 5 + k] = s[k] + e[k];
     }
     __syncthreads();
-    if (!live || j >= 15) return;
-
-    // mean = (sum_j sigma_j * w_j) / sum(w)  -- fp32, j in order, no FMA contraction  (numpy.average)
-    float mean[5];
-    {
+    // C. one Gaussian per lane: mean and covariance of its 11 points
+    const int t = threadIdx.x;
+    if (t < nloc) {
+        float sg[GSE_NSIGMA * 5];
+#pragma unroll
+        for (int i = 0; i < GSE_NSIGMA * 5; ++i) sg[i] = tile[t][i];
+        // mean = (sum_j sigma_j * w_j) / sum(w)  -- fp32, j in order, no FMA contraction  (numpy.average)
+        float mean[5];
+        {
 #pragma clang fp contract(off)
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            float acc = tile_g[k] * a.sw.w[0];
+            for (int k = 0; k < 5; ++k) {
+                float acc = sg[k] * a.sw.w[0];
 #pragma unroll
-            for (int q = 1; q < GSE_NSIGMA; ++q) acc = acc + tile_g[q * 5 + k] * a.sw.w[q];
-            mean[k] = acc / a.sw.scl32;
+                for (int q = 1; q < GSE_NSIGMA; ++q) acc = acc + sg[q * 5 + k] * a.sw.w[q];
+                mean[k] = acc / a.sw.scl32;
+            }
         }
-    }
-    // lane l owns symmetric entry (r, c) of P = sum_j d_j (d_j w_j)^T
-    int r, c;
-    sym_entry(j, r, c);
-    float mr = 0.f, mc = 0.f;
+        float *mu_o, *P_o;
+        dst(t, mu_o, P_o);
+        // P = sum_j d_j (d_j w_j)^T, entry by entry of the upper triangle, mirrored
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        mr = (k == r) ? mean[k] : mr;
-        mc = (k == c) ? mean[k] : mc;
-    }
-    float acc = 0.0f;
+        for (int r = 0; r < 5; ++r)
 #pragma unroll
-    for (int q = 0; q < GSE_NSIGMA; ++q) {
-        const float dr = tile_g[q * 5 + r] - mr;
-        const float dc = tile_g[q * 5 + c] - mc;
-        acc = fmaf(dr, dc * a.sw.w[q], acc);
+            for (int c = r; c < 5; ++c) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int q = 0; q < GSE_NSIGMA; ++q) {
+                    const float dr = sg[q * 5 + r] - mean[r];
+                    const float dc = sg[q * 5 + c] - mean[c];
+                    acc = fmaf(dr, dc * a.sw.w[q], acc);
+                }
+                P_o[r * 5 + c] = acc;
+                P_o[c * 5 + r] = acc;
+            }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) mu_o[k] = mean[k];
     }
-    P_o[r * 5 + c] = acc;
-    P_o[c * 5 + r] = acc;
-    if (j < 5) mu_o[j] = mean[j];
 }
 
-template <bool kInjected>
-__global__ __launch_bounds__(kBlock) void gsukf_predict_kernel(float* __restrict__ mu, float* __restrict__ P,
-                                                               const float* __restrict__ noise, int64_t N,
-                                                               int32_t* __restrict__ status, const GsukfPredictArgs a) {
+template <bool kInjected, int kBankT>
+__global__ __launch_bounds__(kBankT * kGroup) void gsukf_predict_kernel(float* __restrict__ mu, float* __restrict__ P,
+                                                                        const float* __restrict__ noise, int64_t N,
+                                                                        int32_t* __restrict__ status,
+                                                                        const GsukfPredictArgs a) {
     __shared__ DrawParams dp;
-    __shared__ float tile[kGaussPerBlock][GSE_NSIGMA * 5 + 1];
+    __shared__ float fac[kBankT][kFacStride];
+    __shared__ float tile[kBankT][kTileStride];
     if (!kInjected) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.draw);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
-        for (int i = threadIdx.x; i < (int)(sizeof(DrawParams) / 4); i += kBlock) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(DrawParams) / 4); i += kBankT * kGroup) dst[i] = src[i];
         __syncthreads();
     }
     const int b = blockIdx.y;
-    const int j = threadIdx.x & (kGroup - 1);
-    const int gl = threadIdx.x / kGroup;
-    const int64_t g = (int64_t)blockIdx.x * kGaussPerBlock + gl;
-    const bool live = g < N;
-    const int64_t gi = (int64_t)b * N + (live ? g : 0);
-    gsukf_predict_phase<kInjected>(mu + gi * 5, P + gi * 25, mu + gi * 5, P + gi * 25, tile[gl], live, j, b, g,
-                                   kInjected ? noise + gi * GSE_NSIGMA * 5 : nullptr, dp, status, a);
+    const int64_t g0 = (int64_t)blockIdx.x * kBankT;
+    const int nloc = (int)min((int64_t)kBankT, N - g0);
+    float* mu_b = mu + ((int64_t)b * N + g0) * 5;
+    float* P_b = P + ((int64_t)b * N + g0) * 25;
+    auto src = [&](int t, const float*& m_, const float*& p_) { m_ = mu_b + t * 5; p_ = P_b + t * 25; };
+    auto dst = [&](int t, float*& m_, float*& p_) { m_ = mu_b + t * 5; p_ = P_b + t * 25; };
+    gsukf_predict_block<kInjected>(src, dst, fac, tile, nloc, b, g0, kInjected ? noise + (int64_t)b * N * GSE_NSIGMA * 5 : nullptr,
+                                   dp, status, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -231,31 +283,33 @@ __device__ __forceinline__ void pinv_sym2(double a, double s, double d, double (
     }
 }
 
-// Update of ONE Gaussian by its 16 lanes, in place in mu_g / P_g (global memory or LDS); the weight is read from w_i
-// and written to w_o.  dev_g / eta_g: this Gaussian's LDS scratch (56 floats, 22 doubles).  Must be called by every
-// thread of the workgroup.
-__device__ __forceinline__ void gsukf_update_phase(float* mu_g, float* P_g, const float* w_i, float* w_o, float* dev_g,
-                                                   double* eta_g, bool live, int j, int b, int32_t* status,
-                                                   const FilterIOs& io, const Pdf2& pdf, const SigmaWeights& sw) {
-    float m[5];
-    if (live) {
-        float L[15], s[5];
-        bool ok;
-        load_and_factor(mu_g, P_g, m, L, ok);
-        if (j < GSE_NSIGMA) {
-            if (!ok && j == 0 && status) atomicAdd(status, 1);
-            sigma_point(m, L, j, s);
-            float y0, y1;
-            bioreactor_output(s[0], s[2], y0, y1);
-            eta_g[j * 2 + 0] = (double)y0;
-            eta_g[j * 2 + 1] = (double)y1;
+// Update of the workgroup's nloc Gaussians, in place where src / dst point (global memory or LDS); weights are read
+// through w_in(t) and written through w_out(t).  Must be called by every thread of the workgroup.
+template <class Src, class Dst, class Win, class Wout>
+__device__ __forceinline__ void gsukf_update_block(Src src, Dst dst, Win w_in, Wout w_out, float (*fac)[kFacStride],
+                                                   float (*dev)[kTileStride], double (*eta)[kEtaStride], int nloc, int b,
+                                                   int32_t* status, const FilterIOs& io, const Pdf2& pdf,
+                                                   const SigmaWeights& sw) {
+    gsukf_factor_block(src, fac, nloc, status);
+    // B. one sigma point per lane: outputs and deviations
+    const int j = threadIdx.x & (kGroup - 1), gl = threadIdx.x / kGroup;
+    if (gl < nloc && j < GSE_NSIGMA) {
+        float m[5], L[15], s[5];
+        read_factor(fac[gl], m, L);
+        sigma_point(m, L, j, s);
+        float y0, y1;
+        bioreactor_output(s[0], s[2], y0, y1);
+        eta[gl][j * 2 + 0] = (double)y0;
+        eta[gl][j * 2 + 1] = (double)y1;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) dev_g[j * 5 + k] = s[k] - m[k];
-        }
+        for (int k = 0; k < 5; ++k) dev[gl][j * 5 + k] = s[k] - m[k];
     }
     __syncthreads();
-    if (!live || j >= 15) return;
-
+    // C. one Gaussian per lane
+    const int t = threadIdx.x;
+    if (t >= nloc) return;
+    const double* eta_g = eta[t];
+    const float* dev_g = dev[t];
     // eta_mean, P_yy, P_xy in fp64, j in order (the CPU class keeps etas in fp64: filter/gs_ukf.py:116-131)
     double em[2];
 #pragma unroll
@@ -296,57 +350,60 @@ __device__ __forceinline__ void gsukf_update_phase(float* mu_g, float* P_g, cons
     }
     const double z0 = io.f[b].z0, z1 = io.f[b].z1;
     const double i0 = z0 - em[0], i1 = z1 - em[1];
+    const float* m = fac[t];
     float mnew[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) mnew[k] = (float)((double)m[k] + (K[k][0] * i0 + K[k][1] * i1));
 
-    // P -= (K P_yy) K^T : lane l owns entry (r, c)
-    int r, c;
-    sym_entry(j, r, c);
-    double kr0 = 0, kr1 = 0, kc0 = 0, kc1 = 0;
+    // P -= (K P_yy) K^T, entry (r, c) and its mirror (which uses (K P_yy)[c] . K[r]; identical when P_yy is symmetric to
+    // rounding).  Every entry is read before it is written, and by this lane only.
+    const float *mu_g, *P_g;
+    src(t, mu_g, P_g);
+    float *mu_o, *P_o;
+    dst(t, mu_o, P_o);
+    double kp[5][2];                                  // rows of K P_yy
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        kr0 = (k == r) ? K[k][0] : kr0; kr1 = (k == r) ? K[k][1] : kr1;
-        kc0 = (k == c) ? K[k][0] : kc0; kc1 = (k == c) ? K[k][1] : kc1;
+        kp[k][0] = K[k][0] * pyy[0][0] + K[k][1] * pyy[1][0];
+        kp[k][1] = K[k][0] * pyy[0][1] + K[k][1] * pyy[1][1];
     }
-    const double t0 = kr0 * pyy[0][0] + kr1 * pyy[1][0];
-    const double t1 = kr0 * pyy[0][1] + kr1 * pyy[1][1];
-    const double corr = t0 * kc0 + t1 * kc1;
-    float* Pg = P_g;
-    const float prc = (float)((double)Pg[r * 5 + c] - corr);
-    float pcr = prc;
-    if (r != c) {
-        // the mirrored entry uses (K P_yy)[c] . K[r]; identical when P_yy is symmetric to rounding
-        const double u0 = kc0 * pyy[0][0] + kc1 * pyy[1][0];
-        const double u1 = kc0 * pyy[0][1] + kc1 * pyy[1][1];
-        pcr = (float)((double)Pg[c * 5 + r] - (u0 * kr0 + u1 * kr1));
-    }
-    // Hazard-free without another barrier: every read of P by OTHER lanes (load_and_factor) precedes the
-    // barrier above, and entries (r, c) / (c, r) are read and written by this lane only.
-    Pg[r * 5 + c] = prc;
-    if (r != c) Pg[c * 5 + r] = pcr;
-    if (j < 5) mu_g[j] = mnew[j];
-    if (j == 0) {
-        // global update: w *= pdf(z - g(mu_new))
-        float y0, y1;
-        bioreactor_output(mnew[0], mnew[2], y0, y1);
-        const double lik = mixture_pdf2<0>(pdf, z0 - (double)y0, z1 - (double)y1);
-        *w_o = (float)((double)(*w_i) * lik);
-    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int c = r; c < 5; ++c) {
+            const float prc = (float)((double)P_g[r * 5 + c] - (kp[r][0] * K[c][0] + kp[r][1] * K[c][1]));
+            float pcr = prc;
+            if (r != c) pcr = (float)((double)P_g[c * 5 + r] - (kp[c][0] * K[r][0] + kp[c][1] * K[r][1]));
+            P_o[r * 5 + c] = prc;
+            if (r != c) P_o[c * 5 + r] = pcr;
+        }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) mu_o[k] = mnew[k];
+    // global update: w *= pdf(z - g(mu_new))
+    float y0, y1;
+    bioreactor_output(mnew[0], mnew[2], y0, y1);
+    const double lik = mixture_pdf2<0>(pdf, z0 - (double)y0, z1 - (double)y1);
+    *w_out(t) = (float)((double)(*w_in(t)) * lik);
 }
 
-__global__ __launch_bounds__(kBlock) void gsukf_update_kernel(float* __restrict__ mu, float* __restrict__ P,
-                                                              float* __restrict__ w, int64_t N,
-                                                              int32_t* __restrict__ status, const GsukfUpdateArgs a) {
-    __shared__ float dev[kGaussPerBlock][GSE_NSIGMA * 5 + 1];     // sigma_j - mu
-    __shared__ double eta[kGaussPerBlock][GSE_NSIGMA * 2];        // g(sigma_j)
+template <int kBankT>
+__global__ __launch_bounds__(kBankT * kGroup) void gsukf_update_kernel(float* __restrict__ mu, float* __restrict__ P,
+                                                                       float* __restrict__ w, int64_t N,
+                                                                       int32_t* __restrict__ status,
+                                                                       const GsukfUpdateArgs a) {
+    __shared__ float fac[kBankT][kFacStride];
+    __shared__ float dev[kBankT][kTileStride];       // sigma_j - mu
+    __shared__ double eta[kBankT][kEtaStride];       // g(sigma_j)
     const int b = blockIdx.y;
-    const int j = threadIdx.x & (kGroup - 1);
-    const int gl = threadIdx.x / kGroup;
-    const int64_t g = (int64_t)blockIdx.x * kGaussPerBlock + gl;
-    const bool live = g < N;
-    const int64_t gi = (int64_t)b * N + (live ? g : 0);
-    gsukf_update_phase(mu + gi * 5, P + gi * 25, w + gi, w + gi, dev[gl], eta[gl], live, j, b, status, a.io, a.pdf, a.sw);
+    const int64_t g0 = (int64_t)blockIdx.x * kBankT;
+    const int nloc = (int)min((int64_t)kBankT, N - g0);
+    float* mu_b = mu + ((int64_t)b * N + g0) * 5;
+    float* P_b = P + ((int64_t)b * N + g0) * 25;
+    float* w_b = w + (int64_t)b * N + g0;
+    auto src = [&](int t, const float*& m_, const float*& p_) { m_ = mu_b + t * 5; p_ = P_b + t * 25; };
+    auto dst = [&](int t, float*& m_, float*& p_) { m_ = mu_b + t * 5; p_ = P_b + t * 25; };
+    gsukf_update_block(src, dst, [&](int t) { return (const float*)(w_b + t); }, [&](int t) { return w_b + t; }, fac, dev, eta,
+                       nloc, b, status, a.io, a.pdf, a.sw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -369,13 +426,15 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_cycle_kernel(float* __restr
                                                                   int32_t* __restrict__ idx_out, int N,
                                                                   int32_t* __restrict__ status, const GsukfCycleArgs a) {
     __shared__ DrawParams dp;
-    __shared__ float tile[kSmallBank][GSE_NSIGMA * 5 + 1];       // predict: sigma points; update: deviations
-    __shared__ double eta[kSmallBank][GSE_NSIGMA * 2];
+    __shared__ float fac[kBank][kFacStride];
+    __shared__ float tile[kBank][kTileStride];                   // predict: sigma points; update: deviations
+    __shared__ double eta[kBank][kEtaStride];
     __shared__ float mu_s[kSmallBank][5];
     __shared__ float P_s[kSmallBank][25];
     __shared__ float w_s[kSmallBank];
     __shared__ double c_s[kSmallBank];
     __shared__ int anc_s[kSmallBank];
+    static_assert(kSmallBank == kBank, "the cycle kernel is one bank");
     const int tid = threadIdx.x, b = blockIdx.y;
     const int j = tid & (kGroup - 1), gl = tid / kGroup;
     const bool live = gl < N;
@@ -386,13 +445,19 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_cycle_kernel(float* __restr
         for (int i = tid; i < (int)(sizeof(DrawParams) / 4); i += kSmallBlock) dst[i] = src[i];
         __syncthreads();
     }
+    float* mu_b = mu + (int64_t)b * N * 5;
+    float* P_b = P + (int64_t)b * N * 25;
+    float* w_b = w + (int64_t)b * N;
+    auto from_global = [&](int t, const float*& m_, const float*& p_) { m_ = mu_b + t * 5; p_ = P_b + t * 25; };
+    auto from_lds = [&](int t, const float*& m_, const float*& p_) { m_ = mu_s[t]; p_ = P_s[t]; };
+    auto to_lds = [&](int t, float*& m_, float*& p_) { m_ = mu_s[t]; p_ = P_s[t]; };
     // 1. predict: global -> LDS
-    gsukf_predict_phase<kInjected>(mu + gi * 5, P + gi * 25, mu_s[gl], P_s[gl], tile[gl], live, j, b, gl,
-                                   kInjected ? noise + gi * GSE_NSIGMA * 5 : nullptr, dp, status, a.pred);
+    gsukf_predict_block<kInjected>(from_global, to_lds, fac, tile, N, b, 0,
+                                   kInjected ? noise + (int64_t)b * N * GSE_NSIGMA * 5 : nullptr, dp, status, a.pred);
     __syncthreads();
     // 2. update in LDS; the weight goes global -> LDS
-    gsukf_update_phase(mu_s[gl], P_s[gl], w + gi, &w_s[gl], tile[gl], eta[gl], live, j, b, status, a.pred.io, a.pdf,
-                       a.pred.sw);
+    gsukf_update_block(from_lds, to_lds, [&](int t) { return (const float*)(w_b + t); }, [&](int t) { return &w_s[t]; }, fac,
+                       tile, eta, N, b, status, a.pred.io, a.pdf, a.pred.sw);
     __syncthreads();
     // 3. resample, one tile: thread t < 16 of wavefront 0 owns weights 4t..4t+3, exactly as cumsum_kernel does
     __shared__ double total_s;
@@ -538,18 +603,18 @@ int gse_gsukf_predict(float* mu, float* P, int B, int64_t N, const double* u, do
     pack_io(a.io, B, u, nullptr);
     pack_sigma_weights(a.sw, w_sigma);
     a.dt = dt;
-    const unsigned gx = (unsigned)((N + kGaussPerBlock - 1) / kGaussPerBlock);
+    const unsigned gx = (unsigned)((N + kWideBank - 1) / kWideBank);
     if (noise) {
         a.draw = DrawParams{};
         a.rng = RngKey{};
-        hipLaunchKernelGGL(gsukf_predict_kernel<true>, dim3(gx, B), dim3(kBlock), 0, (hipStream_t)stream, mu, P, noise, N,
-                           status, a);
+        hipLaunchKernelGGL((gsukf_predict_kernel<true, kWideBank>), dim3(gx, B), dim3(kWideBank * kGroup), 0,
+                           (hipStream_t)stream, mu, P, noise, N, status, a);
     } else {
         if (int rc = check_mixture("gse_gsukf_predict", state_pdf, GSE_NX)) return rc;
         pack_draw(a.draw, *state_pdf);
         a.rng = make_rng_key(*rng, kPurposeGsukf);
-        hipLaunchKernelGGL(gsukf_predict_kernel<false>, dim3(gx, B), dim3(kBlock), 0, (hipStream_t)stream, mu, P,
-                           (const float*)nullptr, N, status, a);
+        hipLaunchKernelGGL((gsukf_predict_kernel<false, kWideBank>), dim3(gx, B), dim3(kWideBank * kGroup), 0,
+                           (hipStream_t)stream, mu, P, (const float*)nullptr, N, status, a);
     }
     GSE_LAUNCH_CHECK("gsukf_predict_kernel");
     return GSE_OK;
@@ -566,8 +631,9 @@ int gse_gsukf_update(float* mu, float* P, float* w, int B, int64_t N, const doub
     pack_io(a.io, B, u, z);
     pack_pdf2(a.pdf, *measurement_pdf);
     pack_sigma_weights(a.sw, w_sigma);
-    const unsigned gx = (unsigned)((N + kGaussPerBlock - 1) / kGaussPerBlock);
-    hipLaunchKernelGGL(gsukf_update_kernel, dim3(gx, B), dim3(kBlock), 0, (hipStream_t)stream, mu, P, w, N, status, a);
+    const unsigned gx = (unsigned)((N + kWideBank - 1) / kWideBank);
+    hipLaunchKernelGGL(gsukf_update_kernel<kWideBank>, dim3(gx, B), dim3(kWideBank * kGroup), 0, (hipStream_t)stream, mu, P, w,
+                       N, status, a);
     GSE_LAUNCH_CHECK("gsukf_update_kernel");
     return GSE_OK;
 }
