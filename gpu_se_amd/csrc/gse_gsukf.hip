@@ -8,10 +8,10 @@
 //     P_xy, P_yy), the 2x2 pseudo-inverse, the gain and the covariance update.  A wavefront issues an instruction once
 //     whatever the number of lanes that need it, so doing this per-Gaussian algebra in all 16 lanes of every Gaussian
 //     (the first version) cost 16 wavefronts' worth of issue slots per 64 Gaussians instead of one: at 2^18 Gaussians
-//     update 138 -> 72 us (predict, whose sigma-point part dominates, 76 -> 84 us: the single-wavefront parts are not
-//     overlapped, one workgroup fills a CU), the cycle 236 -> 180 us.  The 64-Gaussian configuration (BASELINE config 3)
-//     is launch-latency-bound and gains most: 19.2 -> 11.7 us per cycle -- the per-Gaussian algebra is the same
-//     instruction stream but its loads and LDS traffic are no longer multiplied by 16.
+//     update 138 -> 55 us (predict, whose sigma-point part dominates, stays at ~75 us: its single-wavefront parts are
+//     not overlapped, one workgroup fills a CU), the cycle 236 -> 143 us.  The 64-Gaussian configuration (BASELINE
+//     config 3) is launch-latency-bound and gains most: 19.2 -> 11.2 us per cycle -- the per-Gaussian algebra is the
+//     same instruction stream but its loads and LDS traffic are no longer multiplied by 16.
 // Hand-offs go through LDS (rows padded to odd strides: a lane per Gaussian walks rows).  Sums run in the reference's
 // order (j = 0..10) so that results track the NumPy class closely.  These contractions are 5x11x5 at most: far too small
 // to feed the matrix cores (a 16x16x4 fp32 MFMA tile would be >90 % padding) and nowhere near a bound.
@@ -22,7 +22,7 @@ namespace gse {
 constexpr int kGroup = 16;                       // lanes per Gaussian in the per-sigma-point parts
 constexpr int kGaussPerBlock = kBlock / kGroup;  // 16 (gsukf_sigma_kernel only)
 #ifndef GSE_GSUKF_WIDE_BANK
-#define GSE_GSUKF_WIDE_BANK 64   // (16 / 32 / 64 measured at 2^18 Gaussians: 212 / 218 / 180 us per cycle)
+#define GSE_GSUKF_WIDE_BANK 64   // (16 / 32 / 64 Gaussians per workgroup, 2^18 Gaussians: 64 is 15 % faster than 16 or 32)
 #endif
 constexpr int kWideBank = GSE_GSUKF_WIDE_BANK;   // Gaussians per workgroup of the separate predict / update kernels
 constexpr int kBank = 64;                        // Gaussians per workgroup of the one-launch cycle kernel
@@ -166,9 +166,10 @@ __device__ __forceinline__ void gsukf_predict_block(Src src, Dst dst, float (*fa
                                                     int nloc, int b, int64_t g0, const float* noise, const DrawParams& dp,
                                                     int32_t* status, const GsukfPredictArgs& a) {
     gsukf_factor_block(src, fac, nloc, status);
-    // B. one sigma point per lane: model step + noise
-    const int j = threadIdx.x & (kGroup - 1), gl = threadIdx.x / kGroup;
-    if (gl < nloc && j < GSE_NSIGMA) {
+    // B. one sigma point per lane, packed densely (11 per Gaussian: 704 points keep 11 of the 16 wavefronts busy, the
+    //    other five skip the model step and the noise draw altogether)
+    const int gl = (int)threadIdx.x / GSE_NSIGMA, j = (int)threadIdx.x - gl * GSE_NSIGMA;
+    if (gl < nloc) {
         float m[5], L[15], s[5];
         read_factor(fac[gl], m, L);
         sigma_point(m, L, j, s);
@@ -324,7 +325,7 @@ __device__ __forceinline__ void gsukf_update_block(Src src, Dst dst, Win w_in, W
     double pxy[5][2];
 #pragma unroll
     for (int k = 0; k < 5; ++k) pxy[k][0] = pxy[k][1] = 0.0;
-#pragma unroll
+#pragma unroll 1          // (fully unrolled, the compiler hoists all 77 LDS reads of this loop and spills)
     for (int q = 0; q < GSE_NSIGMA; ++q) {
         const double wq = (double)sw.w[q];
         const double e0 = eta_g[q * 2 + 0] - em[0], e1 = eta_g[q * 2 + 1] - em[1];
@@ -361,22 +362,23 @@ __device__ __forceinline__ void gsukf_update_block(Src src, Dst dst, Win w_in, W
     src(t, mu_g, P_g);
     float *mu_o, *P_o;
     dst(t, mu_o, P_o);
-    double kp[5][2];                                  // rows of K P_yy
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        kp[k][0] = K[k][0] * pyy[0][0] + K[k][1] * pyy[1][0];
-        kp[k][1] = K[k][0] * pyy[0][1] + K[k][1] * pyy[1][1];
-    }
-#pragma unroll
-    for (int r = 0; r < 5; ++r)
+    for (int r = 0; r < 5; ++r) {
+        const double t0 = K[r][0] * pyy[0][0] + K[r][1] * pyy[1][0];     // row r of K P_yy
+        const double t1 = K[r][0] * pyy[0][1] + K[r][1] * pyy[1][1];
 #pragma unroll
         for (int c = r; c < 5; ++c) {
-            const float prc = (float)((double)P_g[r * 5 + c] - (kp[r][0] * K[c][0] + kp[r][1] * K[c][1]));
+            const float prc = (float)((double)P_g[r * 5 + c] - (t0 * K[c][0] + t1 * K[c][1]));
             float pcr = prc;
-            if (r != c) pcr = (float)((double)P_g[c * 5 + r] - (kp[c][0] * K[r][0] + kp[c][1] * K[r][1]));
+            if (r != c) {
+                const double u0 = K[c][0] * pyy[0][0] + K[c][1] * pyy[1][0];
+                const double u1 = K[c][0] * pyy[0][1] + K[c][1] * pyy[1][1];
+                pcr = (float)((double)P_g[c * 5 + r] - (u0 * K[r][0] + u1 * K[r][1]));
+            }
             P_o[r * 5 + c] = prc;
             if (r != c) P_o[c * 5 + r] = pcr;
         }
+    }
 #pragma unroll
     for (int k = 0; k < 5; ++k) mu_o[k] = mnew[k];
     // global update: w *= pdf(z - g(mu_new))
