@@ -1235,9 +1235,13 @@ int gse_pf_moments(const float* x, const float* w, int64_t ld, int B, int64_t N,
     GSE_REQUIRE(x && w && out && workspace, "gse_pf_moments: null argument");
     GSE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(workspace), "gse_pf_moments: pointers must be 16-byte aligned");
     Workspace ws = carve_workspace(workspace, B, N);
-    // workgroups per filter: enough to fill the chip in total (~4096), so that with many filters each workgroup sweeps
-    // several tiles and the reduction at its end is paid less often
-    const int nblk = (int)std::min<int64_t>(std::min<int64_t>(kMomentBlocks, tiles_of(N)), std::max<int64_t>(4096 / B, 32));
+#ifndef GSE_MOMENT_TOTAL_BLOCKS
+#define GSE_MOMENT_TOTAL_BLOCKS 1024
+#endif
+    // workgroups per filter: four per CU in total, so that with many filters each workgroup sweeps several tiles and the
+    // reduction at its end is paid less often (32 filters x 2^18 particles: 60 / 42 / 38 us with 4096 / 2048 / 1024
+    // workgroups in total -- 5.3 TB/s at 1024)
+    const int nblk = (int)std::min<int64_t>(std::min<int64_t>(kMomentBlocks, tiles_of(N)), std::max<int64_t>(GSE_MOMENT_TOTAL_BLOCKS / B, 32));
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pf_moments_kernel, dim3(nblk, B), dim3(kBlock), 0, st, x, w, ws.partials, N, ld);
     GSE_LAUNCH_CHECK("pf_moments_kernel");
