@@ -312,7 +312,8 @@ class BatchedSimulation:
         device memory (GSE_OP_U_DEVICE / GSE_OP_Z_DEVICE), the plant (gse_plant_step) and the controller
         (gse_loop_control) are kernels, and every per-tick record goes into device arrays that are read once, at the
         end.  The host only enqueues -- per tick: plant + moments, and on control ticks update / resample / controller --
-        and never waits.  The plant's noise comes from Philox streams of its own here (the host loop uses NumPy's)."""
+        and never waits.  The plant's noise comes from Philox streams of its own here (the host loop uses NumPy's); the
+        bias log ``biass`` of the single-rollout class is not kept."""
         import ctypes
         import torch
         from gpu_se_amd import _lib
@@ -362,7 +363,7 @@ class BatchedSimulation:
             if now > t_next_control:
                 f.update(u, z)
                 f.resample()
-                record_moments(t)                         # the estimate the controller acts on (moments[t] is rewritten below)
+                record_moments(t)                         # the estimate the controller acts on, and this tick's record
                 K.loop_control(moments[t], ys_meas[t - 1], u, (y_pred, known, status[t]), _U_FALLBACK)
                 n_control += 1
                 last_control = t
