@@ -66,18 +66,31 @@ __device__ __forceinline__ int mpc_solve(const MpcLawDev& law, double theta_lane
     const double c0 = c;
     double nu = 0.0;
     int converged = (m == 0) ? 1 : 0;
+    // a few bounded rows (the usual case: two): this lane's row of S stays in registers, no load inside the sweeps
+    constexpr int kFewRows = 8;
+    const bool few = m <= kFewRows;
+    double srow[kFewRows];
+#pragma unroll
+    for (int i = 0; i < kFewRows; ++i) srow[i] = (few && row && i < m) ? law.S[lane * m + i] : 0.0;
+    auto coordinate = [&](int i, double s_li) {
+        // lane i decides its multiplier; everybody applies the change
+        double delta = 0.0;
+        if (lane == i && sii > 0.0) {
+            const double r = c + sii * nu;
+            const double want = (r > hi) ? (r - hi) / sii : ((r < lo) ? (r - lo) / sii : 0.0);
+            delta = want - nu;
+            nu = want;
+        }
+        delta = __shfl(delta, i, 64);
+        if (row && delta != 0.0) c -= s_li * delta;                           // S symmetric: column i = row i
+    };
     for (int sweep = 0; sweep < law.max_sweeps && !converged; ++sweep) {
-        for (int i = 0; i < m; ++i) {
-            // lane i decides its multiplier; everybody applies the change
-            double delta = 0.0;
-            if (lane == i && sii > 0.0) {
-                const double r = c + sii * nu;
-                const double want = (r > hi) ? (r - hi) / sii : ((r < lo) ? (r - lo) / sii : 0.0);
-                delta = want - nu;
-                nu = want;
-            }
-            delta = __shfl(delta, i, 64);
-            if (row && delta != 0.0) c -= law.S[lane * m + i] * delta;        // S symmetric: column i = row i
+        if (few) {
+#pragma unroll
+            for (int i = 0; i < kFewRows; ++i)
+                if (i < m) coordinate(i, srow[i]);
+        } else {
+            for (int i = 0; i < m; ++i) coordinate(i, row ? law.S[lane * m + i] : 0.0);
         }
         // residual of this lane's row: distance to the bound it is supposed to sit on, or its violation
         double res = 0.0, scale = fabs(c0);
