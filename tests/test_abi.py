@@ -27,6 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(handle, name), name
     assert declared == set(lib.PROTOTYPES), declared ^ set(lib.PROTOTYPES)
     assert handle.gse_version() == 100
+    assert handle.gse_model_tag() == 0                 # the shipped library carries the bioreactor model
 
 
 def test_struct_layout_matches_header(lib):
