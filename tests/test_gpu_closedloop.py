@@ -189,3 +189,36 @@ def test_exact_resample_two_ranks_equals_one_filter_on_the_concatenation():
         assert info_a["send"][1] == int(np.sum(idx[n_local:] < n_local))
     assert crossed > 0
     np.testing.assert_array_equal(out[0][1], out[1][1])               # and the merged estimate is shared
+
+
+def test_config5_size_cycle_properties():
+    """BASELINE config 5 per GPU (32 filters x 2^18 particles, 8.4 M particles in one launch): size-independent
+    properties of one fused cycle -- ancestors sorted and in range per filter, offspring counts within one of N w,
+    offspring equal to their ancestors, weights reset, every filter following ITS measurement."""
+    gpu_se_amd.seed(8)
+    n, B = 1 << 18, 32
+    f = BatchedParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, *_parts(9), batch=B)
+    xss = orc.steady_state()
+    shift = np.linspace(-0.004, 0.004, B)
+    z = np.stack([(xss[0] + shift) * 180, np.full(B, xss[2] * 116)], axis=1)
+    u = np.repeat([[0.06, 0.2]], B, axis=0)
+    for c in range(3):
+        f.predict(u, 0.1)
+        f.update(u, z)
+        f.resample()
+    f.predict(u, 0.1)
+    f.update(u, z)
+    x = f.particles.get().copy()                                   # (B, N, 5) before the resample
+    w = f.weights.get().astype(np.float64)
+    r = np.linspace(0.05, 0.95, B)
+    idx = f.resample(r=r, return_index=True).get()
+    xn = f.particles.get()
+    for b in range(0, B, 5):
+        assert np.all(np.diff(idx[b]) >= 0) and idx[b].min() >= 0 and idx[b].max() < n
+        counts = np.bincount(idx[b], minlength=n)
+        assert np.all(np.abs(counts - w[b] / w[b].sum() * n) < 1.0 + 1e-6)
+        np.testing.assert_array_equal(xn[b], x[b][idx[b]])
+    np.testing.assert_array_equal(f.weights.get(), np.full((B, n), np.float32(1.0 / n)))
+    est = f.point_estimate()
+    assert np.all(np.diff(est[:, 0]) > 0)                          # ordered like the measurements
+    np.testing.assert_allclose(est[:, 0], xss[0] + shift, atol=1.5e-3)
