@@ -4,16 +4,25 @@ the bioreactor model at N = 2^20 particles per MI355X (BASELINE.json config 2), 
 API -> ctypes C ABI -> HIP kernels.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N ...          starts its own N rank processes (before anything touches a GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W          (the driver's form: RANK / WORLD_SIZE come from the env)
 
-N > 1: one process per GPU, each rank owns a contiguous shard of 2^20 particles of one big ensemble (weak
-scaling, independent Philox sub-streams, island resampling); the only collective is an RCCL all-reduce of
-the global weight sum per cycle, issued asynchronously.  Rank 0 prints ONE JSON line.
+N > 1: one process per GPU, each rank owns a contiguous shard of ONE big ensemble (weak scaling: 2^20 particles per
+rank; at N = 8 the default is 2^21 per rank = 2^24 in total, BASELINE config 4), independent Philox sub-streams, island
+resampling; the only collective is a small asynchronous RCCL all-reduce of the shards' log-weights every 32nd cycle and
+the posterior merge at estimates.  Rank 0 prints ONE JSON line.
+
+`value` is the whole job's throughput in the metric's unit: particle-cycles per second over all ranks divided by 2^20,
+i.e. "cycles per second of 2^20-particle filters" -- at N = 1 with 2^20 particles exactly the cycles per second of
+BASELINE config 2; `ensemble_cycles_per_s` and `particles_per_s` are reported beside it.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,7 +32,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALG_BYTES = {"predict": 40, "update": 28, "resample": 72}     # SURVEY 8d, per particle
+GSUKF_ALG_BYTES = 760                                          # SURVEY 8d, per Gaussian per cycle
 HBM_PEAK_GBS = 8000.0
+UNIT_PARTICLES = 1 << 20
 
 
 def parse():
@@ -31,13 +42,53 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--log2-particles", type=float, default=20.0, help="particles per GPU = 2^this")
+    ap.add_argument("--log2-particles", type=float, default=None,
+                    help="particles per GPU = 2^this (default 20; 21 with --gpus 8: BASELINE config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements (per-method protocol, GS-UKF, closed loop)")
     ap.add_argument("--exact-resample", action="store_true",
                     help="N > 1: one systematic resample of the whole ensemble per cycle (all-gather of tile sums + "
                          "all-to-all of particles over xGMI) instead of the default island resampling")
-    ap.add_argument("--cpu-log2-particles", type=float, default=17.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.log2_particles is None:
+        args.log2_particles = 21.0 if args.gpus == 8 else 20.0
+    return args
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: this process starts the ranks itself.  It has not imported torch and never touches a GPU;
+# the ranks are fresh child processes (no exec of a process that initialised the GPU).
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:           # a rank died: the others would wait at a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def make_inputs(steps, dt, seed=0):
@@ -60,14 +111,27 @@ def make_inputs(steps, dt, seed=0):
     return out
 
 
+def csrc_hash():
+    """sha256 over the kernel sources and the ABI header: ties a committed profile to the build it was taken on."""
+    h = hashlib.sha256()
+    files = sorted(os.listdir(os.path.join(ROOT, "gpu_se_amd", "csrc")))
+    for name in files:
+        with open(os.path.join(ROOT, "gpu_se_amd", "csrc", name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    with open(os.path.join(ROOT, "include", "gse.h"), "rb") as fh:
+        h.update(b"gse.h\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(n):
     """HBM bytes per launch of the cycle kernel from the committed PMC profile (rocprofv3 cannot run inside this
-    process): profiles/pmc_traffic.json, valid for N = 2^20; None otherwise."""
+    process): profiles/pmc_traffic.json, valid for N = 2^20 and for the sources whose hash it records."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if n != 1 << 20 or not os.path.exists(path):
-        return None
+        return None, None
     with open(path) as fh:
-        return json.load(fh).get("traffic_bytes_per_launch")
+        d = json.load(fh)
+    return d.get("traffic_bytes_per_launch"), d.get("csrc_sha256_16")
 
 
 def time_method_events(torch, fn, reps):
@@ -82,11 +146,22 @@ def time_method_events(torch, fn, reps):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-def cpu_baseline(log2n, dt=1.0):
-    """The loop-faithful oracle (one Python call per particle, like filter/particle.py:54-103) on one host core,
-    one cycle at 2^log2n particles; plus the vectorised oracle at the same size."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n_full, dt=1.0):
+    """The loop-faithful oracle (one Python call per particle, like filter/particle.py:54-103) on ONE host core:
+    one whole cycle at the benchmark's N (no extrapolation), 100 cycles of BASELINE config 1 (N = 1024), and the
+    vectorised-NumPy oracle at the benchmark's N as the stronger CPU line."""
     from oracle import gse_oracle as orc
-    n = int(round(2 ** log2n))
     rng = np.random.default_rng(0)
     sp, mp = orc.bioreactor_noise(rng)
     x0, _ = orc.bioreactor_noise(rng)
@@ -94,38 +169,144 @@ def cpu_baseline(log2n, dt=1.0):
     x0.means = x0.means + xss[None, :].astype(np.float32)
     u = np.array([0.05, 0.1])
     z = np.array(orc.bioreactor_g(xss)) + [0.1, -0.2]
-    pf = orc.ParticleFilterOracle(n, x0, sp, mp, rng=rng)
-    t0 = time.perf_counter()
-    pf.predict(u, dt)
-    t1 = time.perf_counter()
-    pf.update(u, z)
-    t2 = time.perf_counter()
-    pf.resample()
-    t3 = time.perf_counter()
-    loop = dict(predict=t1 - t0, update=t2 - t1, resample=t3 - t2)
-    pv = orc.ParticleFilterOracle(n, x0, sp, mp, rng=rng)
+
+    def one_cycle(pf):
+        t0 = time.perf_counter()
+        pf.predict(u, dt)
+        t1 = time.perf_counter()
+        pf.update(u, z)
+        t2 = time.perf_counter()
+        pf.resample()
+        t3 = time.perf_counter()
+        return t1 - t0, t2 - t1, t3 - t2
+
+    full = one_cycle(orc.ParticleFilterOracle(n_full, x0, sp, mp, rng=rng))
+    small = orc.ParticleFilterOracle(1024, x0, sp, mp, rng=rng)
+    per = np.array([one_cycle(small) for _ in range(100)])
+    pv = orc.ParticleFilterOracle(n_full, x0, sp, mp, rng=rng)
     t0 = time.perf_counter()
     for _ in range(3):
         pv.predict_vec(u, dt)
         pv.update_vec(u, z)
         pv.resample(loop=False)
     vec = (time.perf_counter() - t0) / 3
-    return n, loop, vec
+    return full, np.median(per, axis=0), vec
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# secondary measurements (rank 0 of a one-GPU run): every number DESIGN.md section 5 quotes comes out of this line
+# ---------------------------------------------------------------------------------------------------------------------
+def protocol_sum(torch, n, io, dt, runs=100):
+    """SURVEY 8d / results/pf_openloop/pf_run_seq.py:15-130: predict, update and resample timed one call at a time, each
+    followed by a device synchronisation (one kernel per method, filter.lazy = False), medians of `runs`, summed."""
+    import gpu_se_amd
+    from gpu_se_amd import sim_base
+    gpu_se_amd.seed(3)
+    _, _, _, f = sim_base.get_parts(N_particles=n)
+    f.lazy = False
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
+    for u, z in io[:5]:
+        f.predict(u, dt); f.update(u, z); f.resample()
+    t = {"predict": [], "update": [], "resample": []}
+    for i in range(runs):
+        u, z = io[(5 + i) % len(io)]
+        t["predict"].append(timed(lambda: f.predict(u, dt)))
+        t["update"].append(timed(lambda: f.update(u, z)))
+        t["resample"].append(timed(lambda: f.resample()))
+    med = {k: round(1e6 * float(np.median(v)), 2) for k, v in t.items()}
+    f.lazy = True
+    cyc = []
+    for i in range(runs):
+        u, z = io[(5 + i) % len(io)]
+        cyc.append(timed(lambda: (f.predict(u, dt), f.update(u, z), f.resample())))
+    return {"predict_us": med["predict"], "update_us": med["update"], "resample_us": med["resample"],
+            "sum_us": round(sum(med.values()), 2), "fused_cycle_synchronised_us": round(1e6 * float(np.median(cyc)), 2),
+            "runs": runs, "note": "each call followed by a device synchronisation, one kernel per method (lazy=False); "
+                                  "`value` instead times back-to-back cycles without synchronisation"}
+
+
+def gsukf_block(torch, sizes=(64, 1 << 18)):
+    """BASELINE config 3 and the large-bank end of results/gsf_openloop/gsf_run_seq.py:483-484: device time per GS-UKF
+    cycle (HIP events), 760 algorithmic bytes per Gaussian."""
+    import gpu_se_amd
+    from gpu_se_amd import sim_base
+    from gpu_se_amd.model import Bioreactor
+    xss = Bioreactor.find_SS([0.06, 0.2], [260 / 180, 640 / 24.6, 1000 / 116, 0, 0])
+    z = np.array(Bioreactor.static_outputs(xss, None))
+    u = [0.06, 0.2]
+    out = {}
+    for n in sizes:
+        gpu_se_amd.seed(3)
+        _, _, _, gf = sim_base.get_parts(N_particles=n, pf=False)
+
+        def cycle(_i):
+            gf.predict(u, 0.1); gf.update(u, z); gf.resample()
+        for i in range(20):
+            cycle(i)
+        reps = 300 if n <= 4096 else 100
+        t0 = time.perf_counter()
+        dev = time_method_events(torch, cycle, reps)
+        wall = (time.perf_counter() - t0) / reps
+        est = gf.point_estimate()
+        assert np.all(np.isfinite(est)), est
+        entry = {"device_us_per_cycle": round(dev * 1e6, 2), "wall_us_per_cycle": round(wall * 1e6, 2)}
+        if n <= 4096:
+            entry["bound"] = "launch latency (one workgroup): no roofline fraction"
+        else:
+            gbs = GSUKF_ALG_BYTES * n / dev / 1e9
+            entry.update({"achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                          "algorithmic_bytes_per_gaussian": GSUKF_ALG_BYTES})
+        out["N=%d" % n] = entry
+    return out
+
+
+def closed_loop_block(torch, B=32, log2n=18, end_time=50):
+    """BASELINE config 5 per GPU: 32 closed-loop rollouts x 2^18 particles, 499 ticks, MPC every tick, everything
+    resident on the device (sim_base.BatchedSimulation(resident=True))."""
+    from gpu_se_amd import sim_base
+    sim = sim_base.BatchedSimulation(batch=B, N_particles=1 << log2n, dt_control=0.1, dt_predict=0.1, end_time=end_time,
+                                     seed=1, resident=True)
+    sim.K._device_law()
+    warm = sim_base.BatchedSimulation(batch=B, N_particles=1 << 10, dt_control=0.1, dt_predict=0.1, end_time=2, seed=2,
+                                      resident=True)
+    warm.K = sim.K
+    warm.simulate()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    sim.simulate()
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ticks = len(sim.ts) - 1
+    dev_s = e0.elapsed_time(e1) * 1e-3
+    return {"rollouts": B, "particles_per_rollout": 1 << log2n, "ticks": ticks, "device_s": round(dev_s, 4),
+            "wall_s": round(wall, 4), "ticks_per_s_device": round(ticks / dev_s, 1),
+            "particle_cycles_per_s_device": round(ticks * B * (1 << log2n) / dev_s, 1),
+            "median_ITSE": float(np.median(sim.performance)), "mpc_solved_fraction": round(float(sim.mpc_frac), 4)}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
     import torch
     import torch.distributed as dist
     import gpu_se_amd
-    from gpu_se_amd import sim_base
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
     # rehearsal on a one-GPU box: GSE_BENCH_REHEARSAL=1 maps every rank to device 0 and uses gloo for the collectives
     rehearsal = os.environ.get("GSE_BENCH_REHEARSAL") == "1"
     backend = "gloo" if rehearsal else "nccl"
@@ -194,43 +375,66 @@ def main():
             lp.resample()
         reps = max(50, min(steps, 400))
         per = {"cycle": time_method_events(torch, local_cycle, reps)}
-        dom = "cycle"
-        achieved = 140.0 * n / per[dom] / 1e9
-        roofline = {"bound": "hbm", "kernel": "pf_step_kernel<gather,predict,update,scan>",
+        achieved = 140.0 * n / per["cycle"] / 1e9
+        traffic, traffic_hash = pmc_traffic(n)
+        sources = csrc_hash()
+        single_launch = lp._scan_capable
+        roofline = {"bound": "hbm",
+                    "kernel": "pf_step_kernel<gather,predict,update,scan>" if single_launch
+                    else "cumsum_kernel + pf_step_kernel<gather,predict,update> (two launches per cycle at this N)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(n),
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic if traffic_hash == sources else None,
+                    "traffic_profiled_on_csrc": traffic_hash, "csrc_sha256_16": sources,
                     "algorithmic_bytes_per_particle": 140,
                     "device_us": {k: round(v * 1e6, 2) for k, v in per.items()},
-                    "note": "one launch per cycle; achieved = 140 B x N / average launch-to-launch device time"}
-        value = world * steps / elapsed
+                    "note": "achieved = 140 B x N / average launch-to-launch device time of one cycle (HIP events on "
+                            "the launch stream); traffic = PMC bytes of the committed profile, null when the kernel "
+                            "sources changed since it was taken"}
+        particle_cycles = float(world) * n * steps / elapsed
+        value = particle_cycles / UNIT_PARTICLES
         result = {
             "metric": "PF steps/sec (predict+update+resample) @ N particles, bioreactor model",
-            "value": round(value, 2), "unit": "cycles/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "value": round(value, 2), "unit": "cycles/s per 2^20 particles (particle-cycles/s / 2^20)",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 model/likelihood/cumsum on f32 state",
             "data": "synthetic",
-            "config": {"workload": "ParallelParticleFilter HIP, N=2^%g particles per GPU, systematic resample "
-                                   "(BASELINE config 2)" % args.log2_particles,
+            "config": {"workload": "ParallelParticleFilter HIP, N=2^%g particles per GPU, systematic resample (%s)"
+                                   % (args.log2_particles,
+                                      "BASELINE config 4: 2^24 particles over 8 GPUs" if (world == 8 and n == 1 << 21)
+                                      else "BASELINE config 2" if (world == 1 and n == 1 << 20)
+                                      else "weak scaling of BASELINE config 2"),
                        "particles_per_gpu": n, "total_particles": n * world, "dt": dt,
                        "parallelism": ("particle shards x%d, EXACT global resampling (all-gather of tile sums + all-to-all "
                                        "of particles per cycle), posterior merge at estimates" % world)
                        if (world > 1 and args.exact_resample) else
-                       ("particle shards x%d, island resampling, async RCCL all-reduce of the weight sum every "
-                        "%d cycles, posterior merge (all-reduce of 22 doubles per rank) at estimates"
-                        % (world, pf.reduce_every)) if world > 1 else "single GPU"},
-            "particles_per_s": round(value * n, 1),
+                       ("particle shards x%d, island resampling, async RCCL all-reduce of the shards' log-weights every "
+                        "%d cycles (exact resample when the effective number of islands drops below %.2g x %d: %d in "
+                        "this run), posterior merge (all-reduce of 22 doubles per rank) at estimates"
+                        % (world, pf.reduce_every, pf.ess_fraction, world, pf.exact_resamples))
+                       if world > 1 else "single GPU"},
+            "ensemble_cycles_per_s": round(steps / elapsed, 2),
+            "particles_per_s": round(particle_cycles, 1),
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
-            cn, loop, vec = cpu_baseline(args.cpu_log2_particles, dt)
-            scale = n / cn
+        if world == 1 and not args.no_extras:
+            result["protocol_sum_us"] = protocol_sum(torch, n, io, dt)
+            result["gsukf"] = gsukf_block(torch)
+            result["closed_loop"] = closed_loop_block(torch)
+        if world == 1 and not args.no_cpu_baseline:
+            full, small, vec = cpu_baseline(n, dt)
             result["cpu_baseline"] = {
-                "value": round(1.0 / (sum(loop.values()) * scale), 5), "unit": "cycles/s", "cores": 1, "kind": "port",
-                "sample": "1 cycle of the loop-faithful oracle (oracle/gse_oracle.py ParticleFilterOracle) at N=2^%g, "
-                          "scaled linearly to N=2^%g" % (args.cpu_log2_particles, args.log2_particles),
-                "seconds_on_sample": {k: round(v, 3) for k, v in loop.items()},
-                "vectorised_numpy_cycles_per_s": round(1.0 / (vec * scale), 4),
-                "host": "%d logical cpus" % (os.cpu_count() or 0)}
+                "value": round(1.0 / sum(full), 5), "unit": "cycles/s", "cores": 1, "kind": "port",
+                "sample": "1 whole cycle of the loop-faithful oracle (oracle/gse_oracle.py ParticleFilterOracle, one "
+                          "Python call per particle as filter/particle.py:54-103) at N=%d, not extrapolated" % n,
+                "seconds_on_sample": {k: round(v, 3) for k, v in zip(("predict", "update", "resample"), full)},
+                "config1_N1024": {"cycles_per_s": round(1.0 / float(np.sum(small)), 2),
+                                  "median_ms": {k: round(1e3 * float(v), 3)
+                                                for k, v in zip(("predict", "update", "resample"), small)},
+                                  "runs": 100},
+                "vectorised_numpy_cycles_per_s": round(1.0 / vec, 4),
+                "host": "%s, %d logical cpus" % (cpu_model_name(), os.cpu_count() or 0)}
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()

@@ -7,7 +7,8 @@ and carries its accumulated log-weight; the only exchange is the posterior merge
 
     merge buffer [P][22] fp64, rank p fills row p with  { log A_p, S0, S1[5], S2[15] } / zeros elsewhere,
     all-reduce(SUM) makes every row visible on every rank (an all-gather expressed as the all-reduce the
-    north-star names), then  estimate = sum_p a_p (S1_p / S0_p) / sum_p a_p,  a_p = exp(log A_p - max_q log A_q).
+    north-star names), then  estimate = sum_p A_p S1_p / sum_p A_p S0_p:  particle i of shard p carries the global
+    weight A_p w_i, where A_p absorbs the weight sums of the shard's past resamples and w_i is its live local weight.
 
 The collective payload is 22 P doubles (1.4 KB at P = 8): latency-bound, xGMI bandwidth is irrelevant; it is
 issued asynchronously so that it overlaps the next predict.
@@ -45,15 +46,11 @@ def pack_merge_row(log_island, s0, s1, s2, kernel_pivot, common_pivot):
 
 
 def merge_rows(rows, pivot):
-    """Combine the shards' rows (numpy [P][22]) into the global (mean, covariance).  Shard p enters with weight
-    a_p = exp(log A_p - max log A); within a shard moments are normalised by its S0."""
+    """Combine the shards' rows (numpy [P][22]) into the global (mean, covariance).  Shard p enters with its total
+    weight A_p S0_p (its accumulated island weight times the sum of its live local weights -- S0_p = 1 right after
+    a local resample, anything between update() and resample()); within a shard moments are normalised by S0_p."""
     rows = numpy.asarray(rows, dtype=numpy.float64)
-    live = (rows[:, 1] > 0) & numpy.isfinite(rows[:, 0])
-    if not live.any():
-        raise FloatingPointError("every shard has zero weight (all likelihoods underflowed)")
-    la = numpy.where(live, rows[:, 0], -numpy.inf)
-    a = numpy.exp(la - la[live].max())
-    a = a / a.sum()
+    a, live = shard_shares(rows[:, 0], rows[:, 1])
     s0 = numpy.where(live, rows[:, 1], 1.0)
     first = (a[:, None] * rows[:, 2:7] / s0[:, None]).sum(axis=0)           # E[x - pivot]
     iu = numpy.triu_indices(5)
@@ -63,6 +60,26 @@ def merge_rows(rows, pivot):
     mean = pivot + first
     cov = second - numpy.outer(first, first)
     return mean, cov
+
+
+def shard_shares(log_island, s0):
+    """Normalised total weight of every shard, a_p = A_p S0_p / sum_q A_q S0_q, formed in the log domain; shards with
+    no weight (S0 = 0 or a log-weight that is not finite) get 0.  Returns (a, live mask)."""
+    log_island = numpy.asarray(log_island, dtype=numpy.float64)
+    s0 = numpy.asarray(s0, dtype=numpy.float64)
+    live = (s0 > 0) & numpy.isfinite(log_island) & numpy.isfinite(s0)
+    if not live.any():
+        raise FloatingPointError("every shard has zero weight (all likelihoods underflowed)")
+    la = numpy.where(live, log_island + numpy.log(numpy.where(live, s0, 1.0)), -numpy.inf)
+    a = numpy.exp(la - la[live].max())
+    return a / a.sum(), live
+
+
+def island_ess(log_island):
+    """Effective number of islands (sum a)^2 / sum a^2 of the shards' accumulated weights: P when the shards weigh the
+    same, 1 when one shard carries the posterior."""
+    a, _ = shard_shares(log_island, numpy.ones(len(log_island)))
+    return 1.0 / float(numpy.sum(a * a))
 
 
 def output_boundaries(end_keys, n_total, r):
@@ -122,13 +139,23 @@ class ShardedParticleFilter:
         # the collective runs where the backend wants its tensors: device for nccl/RCCL, host for gloo (CPU tests)
         backend = dist.get_backend(group) if group is not None else None
         self._merge_device = merge_device or (dev if backend in (None, "nccl") else torch.device("cpu"))
-        self._wsum = torch.zeros(1, dtype=torch.float64, device=self._merge_device)
         self._pending = None
         # The weight-sum all-reduce is bookkeeping (island weights travel as log-weights and are only combined when
         # an estimate is asked for), so it is issued every reduce_every-th resample: a torch.distributed call costs
         # ~25 us of host time, more than a whole cycle of device work at N = 2^20.
         self.reduce_every = max(1, int(reduce_every))
         self._resamples = 0
+        # Island policy: the shards' accumulated log-weights are exchanged with that same all-reduce (P doubles, slot p
+        # written by rank p); when the effective number of islands falls below ess_fraction * P the NEXT resample is an
+        # exact one over the whole ensemble, which levels the shards (every rank sees the same numbers one cycle later,
+        # so every rank takes the same decision).  ess_fraction = 0 switches the policy off.
+        self.ess_fraction = 0.5
+        self._shares = torch.zeros(self.world, dtype=torch.float64, device=self._merge_device)
+        self._shares_cycle = None                           # resample count at which the pending exchange was issued
+        self._force_exact = False
+        self._islands_apart = False                         # an island resample has run since the last exact one
+        self.exact_resamples = 0
+        self.last_island_ess = float(self.world)
         import gpu_se_amd
         # host generator that is the SAME on every rank (exact resampling draws one r for the whole ensemble)
         self._common_rng = numpy.random.default_rng(gpu_se_amd._seed_state["seed"] ^ 0xE4AC7)
@@ -160,15 +187,31 @@ class ShardedParticleFilter:
         self.local.update(u, z)
         if resampled:
             self._resamples += 1
-            if self._resamples % self.reduce_every == 0:
-                self._reduce_weight_sum()
+            self._islands_apart = True
+            if self.group is not None and self.world > 1 and self._resamples % self.reduce_every == 0:
+                self._exchange_shares()
 
     def resample(self, r=None, exact=False):
         """Local systematic resample (island filter); see update() for the bookkeeping.  ``exact=True``: one systematic
         resample of the whole ensemble across the ranks (every rank must call it, with the same ``r`` if one is given)."""
-        if exact and self.group is not None and self.world > 1:
-            return self._exact_resample(r)
+        if self.group is not None and self.world > 1:
+            self._consider_shares()
+            if exact or self._force_exact:
+                self._force_exact = False
+                return self._exact_resample(r)
         self.local.resample(r=r)
+
+    def _consider_shares(self):
+        """One cycle after the shards' log-weights were exchanged: read them (the only synchronisation of the island
+        mode, once per reduce_every cycles) and decide, identically on every rank, whether the islands have drifted
+        apart far enough for an exact resample."""
+        if self._shares_cycle is None or self._resamples <= self._shares_cycle:
+            return
+        self.wait_collectives()
+        self._shares_cycle = None
+        self.last_island_ess = island_ess(self._shares.cpu().numpy())
+        if self.ess_fraction > 0 and self.last_island_ess < self.ess_fraction * self.world:
+            self._force_exact = True
 
     def _exact_resample(self, r):
         import ctypes
@@ -185,15 +228,31 @@ class ShardedParticleFilter:
         stream = torch.cuda.current_stream().cuda_stream
         if r is None:                                       # one number for the whole ensemble, the same on every rank
             r = float(self._common_rng.random())
+        # 0. A particle's weight in the whole ensemble is A_p w_i (A_p = exp(island[0]) of its shard).  After island
+        #    resamples the A_p differ, so the local weights are brought to one scale first: w_i * exp(log A_p - max_q
+        #    log A_q), fp32 like the weights themselves.  (Exact-only sequences on equal shards: every A_p is the same
+        #    and the scale is exactly 1 -- nothing is touched and the result is bit for bit the single-GPU one.)
+        w_src = f._w
+        uneven = any(cnt != spans[0][1] for _, cnt in spans)
+        if self._islands_apart or uneven:
+            mine_log = torch.zeros(P, dtype=torch.float64, device=self._merge_device)
+            mine_log[self.rank] = f._island[0, 0].to(self._merge_device)
+            dist.all_reduce(mine_log, op=dist.ReduceOp.SUM, group=self.group)
+            logs = mine_log.cpu().numpy()
+            if not numpy.all(numpy.isfinite(logs)):
+                raise FloatingPointError("a shard's accumulated log-weight is not finite")
+            scale = float(numpy.exp(logs[self.rank] - logs.max()))
+            if scale != 1.0:
+                w_src = f._w * numpy.float32(scale)
         # 1. tile sums of every shard
         mine = torch.empty((tiles[self.rank],), dtype=torch.float64, device=dev)
-        _lib.check(lib.gse_pf_tile_sums(f._w.data_ptr(), f._ld, 1, n, mine.data_ptr(), stream))
+        _lib.check(lib.gse_pf_tile_sums(w_src.data_ptr(), f._ld, 1, n, mine.data_ptr(), stream))
         sums = self._all_gather_uneven(mine, tiles).to(dev)
         # 2. + 3. the prefix over ALL tiles, then this shard's normalised cumulative weights
         prefix = torch.empty((T_total + 1,), dtype=torch.float64, device=dev)
         _lib.check(lib.gse_tile_prefix(sums.data_ptr(), T_total, prefix.data_ptr(), stream))
         c = torch.empty((n,), dtype=torch.float64, device=dev)
-        _lib.check(lib.gse_pf_shard_cumsum(f._w.data_ptr(), n, prefix.data_ptr(), tile_offset, T_total, c.data_ptr(), stream))
+        _lib.check(lib.gse_pf_shard_cumsum(w_src.data_ptr(), n, prefix.data_ptr(), tile_offset, T_total, c.data_ptr(), stream))
         ends = numpy.cumsum(tiles)
         host = prefix[torch.as_tensor(numpy.concatenate([ends, [T_total]]), device=dev)].cpu().numpy()
         total = host[-1]
@@ -211,6 +270,8 @@ class ShardedParticleFilter:
         f._w[0, :n] = 1.0 / n                               # every particle of the ensemble weighs 1 / N again:
         f._island[0, 0] = float(numpy.log(n / self.N_particles))     # the shard's share is its share of the particles
         f._tiles_valid, f._scan_slot, f._moments_host = False, None, None
+        self._islands_apart = False
+        self.exact_resamples += 1
         self.last_exact = dict(r=r, J=J, send=send, recv=recv)
 
     def _all_gather_uneven(self, mine, counts):
@@ -228,15 +289,18 @@ class ShardedParticleFilter:
         dist.all_to_all_single(dst, src, output_split_sizes=recv, input_split_sizes=send, group=self.group)
         return dst
 
-    def _reduce_weight_sum(self):
-        if self.group is not None:
-            self.wait_collectives()
-            # a buffer of its own: the next launch rewrites island[1] while the collective may still be in flight
-            if self._merge_device.type == "cuda":
-                self._wsum.copy_(self.local._island[1])
-            else:
-                self._wsum = self.local._island[1].cpu()
-            self._pending = dist.all_reduce(self._wsum, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    def _exchange_shares(self):
+        """Asynchronous all-reduce of the shards' accumulated log-weights (slot p = rank p's island[0], zeros elsewhere):
+        the global weight bookkeeping of SURVEY 8e.  Nothing waits for it until the next resample() / an estimate."""
+        self.wait_collectives()
+        # a buffer of its own: later launches keep updating island[0] while the collective may still be in flight
+        self._shares.zero_()
+        if self._merge_device.type == "cuda":
+            self._shares[self.rank:self.rank + 1].copy_(self.local._island[0])
+        else:
+            self._shares[self.rank] = float(self.local._island[0, 0].item())
+        self._pending = dist.all_reduce(self._shares, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._shares_cycle = self._resamples
 
     def wait_collectives(self):
         if self._pending is not None:

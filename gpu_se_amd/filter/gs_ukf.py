@@ -8,7 +8,7 @@ import torch
 import gpu_se_amd
 from gpu_se_amd import _lib
 from gpu_se_amd.devarray import DevArray, as_device, device, stream_ptr
-from gpu_se_amd.filter.particle import _KernelLauncher, _parallel_resample, _require_builtin_model
+from gpu_se_amd.filter.particle import _KernelLauncher, _parallel_resample, _require_builtin_model, rows_f, rows_g
 from gpu_se_amd.gaussian_sum_dist import DeterministicGaussianSum
 
 
@@ -234,14 +234,11 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         """Returns the maximum singular value of the filter's covariance (gs_ukf.py:442-449)."""
         return numpy.linalg.svd(self._moment_sums()[2], compute_uv=False)[0]
 
-    f_vectorize = None   # bound below
-    g_vectorize = None
+    # ------------------------------------------------------------------ pieces the benchmark scripts call
+    def f_vectorize(self, particles, u, dt):
+        """out[..., :] = f(particles[..., :], u, dt), device array fp32 (gs_ukf.py:243-258; gsf_run_seq.py:220)."""
+        return rows_f(_lib.call, self._Nx, particles, [float(v) for v in numpy.asarray(u, dtype=numpy.float64).reshape(-1)], dt)
 
-
-def _bind_row_helpers():
-    from gpu_se_amd.filter.particle import ParallelParticleFilter
-    ParallelGaussianSumUnscentedKalmanFilter.f_vectorize = ParallelParticleFilter.f_vectorize
-    ParallelGaussianSumUnscentedKalmanFilter.g_vectorize = ParallelParticleFilter.g_vectorize
-
-
-_bind_row_helpers()
+    def g_vectorize(self, particles, u, _y_dummy=None):
+        """out[..., :] = g(particles[..., :], u), device array (.. x Ny) fp32 (gs_ukf.py:260-275; gsf_run_seq.py:285)."""
+        return rows_g(_lib.call, self._Nx, particles, [float(v) for v in numpy.asarray(u, dtype=numpy.float64).reshape(-1)])

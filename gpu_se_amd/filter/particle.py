@@ -400,30 +400,16 @@ class ParallelParticleFilter:
         return numpy.linalg.svd(cov, compute_uv=False)[0]
 
     # ------------------------------------------------------------------ pieces the benchmark scripts call
-    def _rows5(self, particles):
-        p = as_device(particles, torch.float32)
-        lead = p.shape[:-1]
-        p2 = p.reshape(-1, self._nx)
-        if self._nx < _lib.GSE_NX:
-            p2 = torch.cat([p2, torch.zeros((p2.shape[0], _lib.GSE_NX - self._nx), dtype=torch.float32, device=p2.device)], dim=1)
-        return p2.contiguous(), lead
+    def _row_u(self, u):
+        return self._host_u(u) if self._B == 1 else numpy.asarray(u, dtype=numpy.float64).reshape(-1)[:2]
 
     def f_vectorize(self, particles, u, dt):
         """out[i] = f(particles[i], u, dt) as a device array (M x Nx) fp32 (particle.py:176-191)."""
-        p2, lead = self._rows5(particles)
-        out = torch.empty_like(p2)
-        uu = self._host_u(u) if self._B == 1 else numpy.asarray(u, dtype=numpy.float64).reshape(-1)[:2]
-        self._call("gse_model_f", p2.data_ptr(), out.data_ptr(), p2.shape[0], _lib.doubles(uu, _lib.GSE_NU), float(dt),
-                   stream_ptr())
-        return DevArray.wrap(out[:, :self._nx].reshape(lead + (self._nx,)))
+        return rows_f(self._call, self._nx, particles, self._row_u(u), dt)
 
     def g_vectorize(self, particles, u, _y_dummy=None):
         """out[i] = g(particles[i], u) as a device array (M x Ny) fp32 (particle.py:193-208)."""
-        p2, lead = self._rows5(particles)
-        out = torch.empty((p2.shape[0], _lib.GSE_NY), dtype=torch.float32, device=p2.device)
-        uu = self._host_u(u) if self._B == 1 else numpy.asarray(u, dtype=numpy.float64).reshape(-1)[:2]
-        self._call("gse_model_g_u", p2.data_ptr(), out.data_ptr(), p2.shape[0], _lib.doubles(uu, _lib.GSE_NU), stream_ptr())
-        return DevArray.wrap(out.reshape(lead + (_lib.GSE_NY,)))
+        return rows_g(self._call, self._nx, particles, self._row_u(u))
 
 
 class BatchedParticleFilter(ParallelParticleFilter):
@@ -455,6 +441,32 @@ class BatchedParticleFilter(ParallelParticleFilter):
 
     def point_covariance(self):
         return self.estimates()[1]
+
+
+def _rows5(particles, nx):
+    """(..., nx) array-like -> contiguous (M, 5) fp32 device rows (unused states zero) and the leading shape."""
+    p = as_device(particles, torch.float32)
+    lead = p.shape[:-1]
+    p2 = p.reshape(-1, nx)
+    if nx < _lib.GSE_NX:
+        p2 = torch.cat([p2, torch.zeros((p2.shape[0], _lib.GSE_NX - nx), dtype=torch.float32, device=p2.device)], dim=1)
+    return p2.contiguous(), lead
+
+
+def rows_f(call, nx, particles, uu, dt):
+    """f applied to every row through gse_model_f of the library behind ``call`` (shared by both filter classes)."""
+    p2, lead = _rows5(particles, nx)
+    out = torch.empty_like(p2)
+    call("gse_model_f", p2.data_ptr(), out.data_ptr(), p2.shape[0], _lib.doubles(uu, _lib.GSE_NU), float(dt), stream_ptr())
+    return DevArray.wrap(out[:, :nx].reshape(lead + (nx,)))
+
+
+def rows_g(call, nx, particles, uu):
+    """g applied to every row through gse_model_g_u."""
+    p2, lead = _rows5(particles, nx)
+    out = torch.empty((p2.shape[0], _lib.GSE_NY), dtype=torch.float32, device=p2.device)
+    call("gse_model_g_u", p2.data_ptr(), out.data_ptr(), p2.shape[0], _lib.doubles(uu, _lib.GSE_NU), stream_ptr())
+    return DevArray.wrap(out.reshape(lead + (_lib.GSE_NY,)))
 
 
 def moments_to_mean_cov(s0, s1, s2_upper, pivot):

@@ -514,3 +514,12 @@ def words_to_draw(words, mixture):
         sel = comp == d
         out[sel] = mixture.means[d].astype(np.float64) + n[sel, :mixture.nx] @ chol.T
     return out, comp
+
+
+def predict_noise(seed, step, elements, mixture, filter_id=0):
+    """The state noise the particle filter's predict stage adds to particle `elements` (global indices) at Philox step
+    `step`: (noise fp64 (M, nx), component (M,)).  Word mapping of pf_step_kernel (gse_device.h rng_words8 +
+    mixture_draw5): two Philox blocks per particle, purpose "predict"."""
+    words = rng_words8(seed, step, RNG_PURPOSE["predict"], np.asarray(elements, dtype=np.uint64), filter_id)
+    return words_to_draw(words, mixture)
+

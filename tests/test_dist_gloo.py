@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -55,6 +56,34 @@ def test_merge_equals_single_filter():
     rows.append(np.zeros(22))
     mean2, _ = gd.merge_rows(np.array(rows), xss)
     np.testing.assert_allclose(mean2, mean, rtol=1e-14)
+
+
+def test_merge_between_update_and_resample_uses_the_live_weight_sums():
+    """Particle i of shard p weighs A_p w_i in the whole ensemble.  Between update() and resample() the local weights
+    are NOT normalised and their sums S0_p differ from shard to shard: the merge must weigh shard p by A_p S0_p."""
+    x, w, xss = _problem()
+    rows = []
+    for (lo, hi), local_scale in (((0, 1200), 0.37), ((1200, 3000), 12.5)):
+        # w_i = A_p * w_local_i with an arbitrary split of the scale between the island weight and the local weights
+        rows.append(_shard_row(x[lo:hi], w[lo:hi] / local_scale, np.log(local_scale), xss))
+    assert abs(rows[0][1] - rows[1][1]) > 1.0                         # the S0 differ
+    mean, cov = gd.merge_rows(np.array(rows), xss)
+    wn = w / w.sum()
+    want_mean = wn @ x.astype(np.float64)
+    dd = x.astype(np.float64) - want_mean
+    np.testing.assert_allclose(mean, want_mean, rtol=1e-12)
+    np.testing.assert_allclose(cov, dd.T @ (dd * wn[:, None]), rtol=1e-8, atol=1e-16)
+
+
+def test_shard_shares_and_island_ess():
+    a, live = gd.shard_shares([np.log(3.0), np.log(1.0), -np.inf, 0.0], [1.0, 1.0, 1.0, 0.0])
+    np.testing.assert_allclose(a, [0.75, 0.25, 0.0, 0.0], rtol=1e-15)
+    assert list(live) == [True, True, False, False]
+    assert gd.island_ess(np.full(8, -700.0)) == pytest.approx(8.0)
+    assert gd.island_ess([0.0, -800.0, -900.0]) == pytest.approx(1.0)
+    assert gd.island_ess([0.0, 0.0, np.log(2.0)]) == pytest.approx(16.0 / 6.0)
+    with pytest.raises(FloatingPointError):
+        gd.shard_shares([-np.inf, np.nan], [1.0, 1.0])
 
 
 def _free_port():

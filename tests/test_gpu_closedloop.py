@@ -85,7 +85,7 @@ def test_batched_closed_loops():
 
 
 # ------------------------------------------------------------------------------ sharded filter across two ranks
-def _sharded_worker(rank, world, port, out):
+def _sharded_worker(rank, world, port, out, n_local=1 << 15):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -95,7 +95,7 @@ def _sharded_worker(rank, world, port, out):
     import gpu_se_amd as g
     from gpu_se_amd.distributed import ShardedParticleFilter
     g.seed(77)
-    spf = ShardedParticleFilter.from_get_parts(n_local=1 << 15, group=dist.group.WORLD)
+    spf = ShardedParticleFilter.from_get_parts(n_local=n_local, group=dist.group.WORLD)
     spf.reduce_every = 2
     xss = orc.steady_state()
     z = np.array(orc.bioreactor_g(xss)) + [0.3, -0.2]
@@ -130,7 +130,148 @@ def test_sharded_filter_two_ranks_share_one_posterior():
     assert abs(e0[0] * 180 - (xss[0] * 180 + 0.3)) < 0.4          # follows the measurement (sigma 0.245)
 
 
+def test_sharded_filter_two_ranks_at_config4_shard_size():
+    """BASELINE config 4 shards the 2^24-particle ensemble into 2^21 particles per rank: two such shards (the test box
+    has one GPU; both ranks share it) run the single-launch cycle and merge to one posterior."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    manager = mp.Manager()
+    out = manager.dict()
+    mp.spawn(_sharded_worker, args=(2, port, out, 1 << 21), nprocs=2, join=True)
+    (e0, c0, lo0, l0), (e1, c1, lo1, l1) = out[0], out[1]
+    np.testing.assert_array_equal(e0, e1)
+    assert c0 == c1 and lo0 == 0 and lo1 == 1 << 21 and l0 != l1
+    xss = orc.steady_state()
+    assert abs(e0[0] * 180 - (xss[0] * 180 + 0.3)) < 0.4
+
+
+# ------------------------------------------------------------------------------ island policy
+def _policy_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import gpu_se_amd as g
+    from gpu_se_amd import distributed as gd
+    g.seed(5)
+    spf = gd.ShardedParticleFilter.from_get_parts(n_local=1 << 14, group=dist.group.WORLD)
+    spf.reduce_every = 4
+    spf.ess_fraction = 0.75                      # two islands: act when their effective number falls below 1.5
+    xss = orc.steady_state()
+    rng = np.random.default_rng(3)                                   # the same inputs on both ranks
+    ess_log, trace = [], []
+    for c in range(500):
+        u = [rng.uniform(0.03, 0.09), rng.uniform(0.1, 0.3)]
+        z = np.array(orc.bioreactor_g(xss)) + rng.normal(0, 0.3, 2)
+        if c < 60:
+            z = z + [0.5 * rank, 0.0]            # the shards are told different things for a while: their weights drift apart
+        spf.predict(u, 0.1)
+        spf.update(u, z)
+        spf.resample()
+        ess_log.append(spf.last_island_ess)
+        trace.append(spf.exact_resamples)
+    spf.wait_collectives()
+    spf.local._flush()
+    logs = torch.zeros(world, dtype=torch.float64)
+    logs[rank] = float(spf.local._island[0, 0].item())
+    dist.all_reduce(logs)
+    shares, _ = gd.shard_shares(logs.numpy(), np.ones(world))
+    est = spf.point_estimate()
+    out[rank] = (shares, spf.exact_resamples, min(ess_log), trace, est)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_island_policy_keeps_the_shards_alive():
+    """500 cycles on two shards whose likelihoods are pushed apart for the first 60: the shards' log-weights are
+    exchanged every 4th cycle, the effective number of islands falls below 0.75 P, an exact resample of the whole
+    ensemble levels them (every rank takes the decision at the same cycle), and at the end no shard is dead weight."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    manager = mp.Manager()
+    out = manager.dict()
+    mp.spawn(_policy_worker, args=(2, port, out), nprocs=2, join=True)
+    (sh0, k0, ess0, tr0, e0), (sh1, k1, ess1, tr1, e1) = out[0], out[1]
+    assert k0 == k1 and k0 >= 1                       # the policy fired, on both ranks alike ...
+    assert tr0 == tr1                                 # ... at the same cycles
+    assert ess0 < 1.5 and ess0 == ess1                # it saw the islands apart
+    np.testing.assert_array_equal(sh0, sh1)
+    assert sh0.min() >= 1e-3, sh0                     # no shard has become dead weight
+    np.testing.assert_array_equal(e0, e1)
+    xss = orc.steady_state()
+    assert abs(e0[0] - xss[0]) < 0.02
+
+
 # ------------------------------------------------------------------------------ exact resampling across two ranks
+def _mixed_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import gpu_se_amd as g
+    from gpu_se_amd.distributed import ShardedParticleFilter
+    g.seed(32)
+    n_local = 8 * 1024
+    spf = ShardedParticleFilter.from_get_parts(n_local=n_local, group=dist.group.WORLD)
+    spf.ess_fraction = 0.0                                           # the exact resample below is asked for explicitly
+    xss = orc.steady_state()
+    z = np.array(orc.bioreactor_g(xss)) + [0.3 + 0.3 * rank, -0.2]   # the ranks see different likelihood mass
+    for c in range(2):                                               # island cycles: the shards' A_p drift apart
+        spf.predict([0.06, 0.2], 0.1)
+        spf.update([0.06, 0.2], z)
+        spf.resample(r=0.37)
+    spf.predict([0.06, 0.2], 0.1)
+    spf.update([0.06, 0.2], z)
+    est_before = spf.point_estimate()                                # between update and resample: live S0 differ
+    x, w = spf.local.particles.get().copy(), spf.local.weights.get().copy()
+    log_a = float(spf.local._island[0, 0].item())
+    spf.resample(r=0.61, exact=True)
+    out[rank] = (x, w, log_a, spf.local.particles.get().copy(), est_before, float(spf.local._island[0, 0].item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exact_resample_after_island_resamples_uses_the_island_weights():
+    """resample() followed by resample(exact=True): particle i of shard p weighs A_p w_i in the whole ensemble, so the
+    exact resample must scale the shards' weights by their island weights (fp32, exp(log A_p - max log A)) -- the
+    offspring are bit for bit those of ONE filter holding the concatenation with the scaled weights; and the estimate
+    taken between update() and resample() is the weighted mean of that same concatenation."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    manager = mp.Manager()
+    out = manager.dict()
+    mp.spawn(_mixed_worker, args=(2, port, out), nprocs=2, join=True)
+    (x_a, w_a, la, new_a, est_a, ia), (x_b, w_b, lb, new_b, est_b, ib) = out[0], out[1]
+    assert la != lb                                                   # the island weights did drift apart
+    n_local = len(w_a)
+    top = max(la, lb)
+    scaled = np.concatenate([w_a * np.float32(np.exp(la - top)), w_b * np.float32(np.exp(lb - top))])
+    state_pdf, meas_pdf = sim_base.get_noise()
+    x0, _ = sim_base.get_noise()
+    one = ParallelParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, 2 * n_local, x0, state_pdf, meas_pdf)
+    one.particles = np.concatenate([x_a, x_b])
+    one.weights = scaled
+    wn = scaled.astype(np.float64) / scaled.astype(np.float64).sum()
+    np.testing.assert_allclose(est_a, wn @ np.concatenate([x_a, x_b]).astype(np.float64), rtol=1e-6)
+    np.testing.assert_array_equal(est_a, est_b)
+    one.resample(r=0.61)
+    np.testing.assert_array_equal(np.concatenate([new_a, new_b]), one.particles.get())
+    assert ia == ib == np.log(0.5)                                    # the shards are level again
+
+
 def _exact_worker(rank, world, port, out):
     import os
     import torch.distributed as dist

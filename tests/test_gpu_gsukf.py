@@ -14,7 +14,7 @@ from gpu_se_amd.filter import ParallelGaussianSumUnscentedKalmanFilter as GSF   
 from gpu_se_amd.gaussian_sum_dist import DeterministicGaussianSum               # noqa: E402
 from gpu_se_amd.model import Bioreactor                      # noqa: E402
 from oracle import gse_oracle as orc                         # noqa: E402
-from tests.test_oracle_golden import assert_cov_close        # noqa: E402
+from tests.test_oracle_golden import assert_cov_close, PRED_COV_TOL        # noqa: E402
 
 
 def assert_mean_close(mu, ref, cov, rel_sigma=5e-5, rtol=3e-7):
@@ -62,13 +62,13 @@ def test_gsukf_trace_per_step(golden, n):
         DeterministicGaussianSum.preload(g[t + "noise"][c])
         gf.predict(g[t + "u"][c], g[t + "dt"][c])
         np.testing.assert_allclose(gf.means.get(), g[t + "m_pred"][c], rtol=1e-6, atol=1e-8)
-        assert_cov_close(gf.covariances.get(), g[t + "P_pred"][c], 3e-2)
+        assert_cov_close(gf.covariances.get(), g[t + "P_pred"][c], PRED_COV_TOL[n])
         gf.means, gf.covariances = g[t + "m_pred"][c], g[t + "P_pred"][c]
         np.testing.assert_allclose(gf._get_sigma_points().get(), g[t + "sig_upd"][c], rtol=1e-6, atol=1e-8)
         gf.update(g[t + "u"][c], g[t + "z"][c])
         assert_mean_close(gf.means.get(), g[t + "m_upd"][c], g[t + "P_pred"][c])
         assert_cov_close(gf.covariances.get(), g[t + "P_upd"][c], 1e-4)
-        np.testing.assert_allclose(gf.weights.get(), g[t + "w_upd"][c], rtol=1e-3)
+        np.testing.assert_allclose(gf.weights.get(), g[t + "w_upd"][c], rtol=2e-4)
         gf.means, gf.covariances, gf.weights = g[t + "m_upd"][c], g[t + "P_upd"][c], g[t + "w_upd"][c]
         idx = gf.resample(r=float(g[t + "r"][c]), return_index=True).get()
         w32 = g[t + "w_upd"][c].astype(np.float32).astype(np.float64)
@@ -129,7 +129,21 @@ def test_gsukf_known_answer(golden):
     gf.means, gf.covariances = g["ka_m_upd"], g["ka_P_upd"]
     gf.predict(g["ka_u"], 0.1)
     np.testing.assert_allclose(gf.means.get(), g["ka_m_pred"], rtol=1e-6, atol=1e-8)
-    assert_cov_close(gf.covariances.get(), g["ka_P_pred"], 3e-2)
+    assert_cov_close(gf.covariances.get(), g["ka_P_pred"], 5e-4)
+
+
+def test_row_helpers_on_the_gsukf():
+    """f_vectorize / g_vectorize of the GS-UKF class (the reference's gsf_run_seq.py:220, :285, :315 call them on the
+    filter object): f on the sigma points, g on the means, against the fp64 oracle."""
+    gf = make(64)
+    u = [0.05, 0.18]
+    sig = gf._get_sigma_points()
+    inc = gf.f_vectorize(sig, u, 0.1).get()
+    assert inc.shape == (64, 11, 5)
+    ref = orc.bioreactor_f_vec(sig.get().reshape(-1, 5), u, 0.1).astype(np.float32).reshape(64, 11, 5)
+    np.testing.assert_array_equal(inc, ref)
+    ys = gf.g_vectorize(gf.means, u, gf._y_dummy).get()
+    np.testing.assert_array_equal(ys, orc.bioreactor_g_vec(gf.means.get()))
 
 
 def test_gsukf_philox_cycle_and_errors():

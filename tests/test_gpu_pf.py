@@ -128,8 +128,7 @@ def test_predict_rng_matches_word_mapping():
     pf.predict(u, dt)
     osp, omp = orc.bioreactor_noise()
     o = orc.ParticleFilterOracle(n, None, osp, omp, particles=x0)
-    words = orc.rng_words8(pf._seed, 0, orc.RNG_PURPOSE["predict"], np.arange(n))
-    noise, comp = orc.words_to_draw(words, osp)
+    noise, comp = orc.predict_noise(pf._seed, 0, np.arange(n), osp)
     o.predict_vec(u, dt, noise=noise.astype(np.float32))
     sd = np.sqrt(np.array([np.diag(osp.covariances[c]) for c in comp]))
     assert np.max(np.abs(pf.particles.get() - o.particles) / sd) < 1e-3   # fp32 add of a 2e-5-sigma-accurate normal
@@ -414,7 +413,9 @@ def _two_filters(n, seed):
     return out
 
 
-@pytest.mark.parametrize("n", [7, 1024, 5003, 1 << 17, 1 << 20])
+# 2^21 = one shard of BASELINE config 4 and the largest N that runs the single-launch cycle (2048 tiles); one more tile
+# and the policy switches to the two-kernel resample (cumsum + fused gather/predict/update): both sides are covered
+@pytest.mark.parametrize("n", [7, 1024, 5003, 1 << 17, 1 << 20, 1 << 21, (1 << 21) + 1024])
 def test_fused_cycle_equals_eager_calls(n):
     """resample / predict / update deferred into ONE fused pass must give bit-identical particles and weights to the
     same calls executed one kernel each (lazy=False), for any interleaving of calls and accessors."""
@@ -440,6 +441,56 @@ def test_fused_cycle_equals_eager_calls(n):
             np.testing.assert_array_equal(fused.particles.get(), eager.particles.get())
             np.testing.assert_array_equal(fused.weights.get(), eager.weights.get())
     np.testing.assert_array_equal(fused.point_estimate(), eager.point_estimate())
+
+
+@pytest.mark.parametrize("n", [5003, 1 << 20, 1 << 21, (1 << 21) + 1024])
+def test_single_launch_philox_cycle_against_oracle(n):
+    """The benchmarked kernel variant itself -- pf_step_kernel<gather, predict (Philox), update, scan in + out>, one
+    launch per cycle -- against the oracle fed the same Philox words (oracle.predict_noise), at BASELINE config 2's size,
+    at config 4's shard size, and one tile beyond it where the class switches to cumsum + fused step.  Per cycle:
+    ancestors vs oracle.systematic_index on the device's fp32 weights (<= 2 last-bit ties of the fp64 cumulative sums),
+    particles within 1e-3 sigma of the oracle's ODE step + mapped draw, weights to 2e-6 of the oracle's update on
+    the device's particles."""
+    gpu_se_amd.seed(2020)
+    _, _, _, pf = sim_base.get_parts(N_particles=n)
+    assert pf.lazy and pf._scan_capable == (n <= (1 << 21))
+    osp, omp = orc.bioreactor_noise()
+    xss = orc.steady_state()
+    rng = np.random.default_rng(n)
+    x = pf.particles.get().copy()
+    w = pf.weights.get().copy()
+    dt = 1.0
+    for c in range(3):
+        u = [rng.uniform(0.03, 0.09), rng.uniform(0.1, 0.3)]
+        z = np.array(orc.bioreactor_g(xss)) + rng.normal(0, 0.3, 2)
+        r = float(rng.random())
+        want_idx = None
+        if c > 0:
+            pf.resample(r=r)                       # deferred: runs inside the launch that carries the update
+            pf._want_index = True                  # (test hook: have that launch write the ancestors out too)
+            want_idx = orc.systematic_index(w.astype(np.float64), r)
+        pf.predict(u, dt)
+        pf.update(u, z)
+        assert pf._scan_slot is not None if pf._scan_capable else pf._scan_slot is None
+        x_new = pf.particles.get().copy()
+        w_new = pf.weights.get().copy()
+        good = np.ones(n, dtype=bool)
+        if c > 0:
+            idx = host(pf._last_index)[0, :n]
+            good = idx == want_idx
+            assert np.sum(~good) <= 2, int(np.sum(~good))
+            x = x[idx]
+            w = np.full(n, np.float32(1.0 / n), dtype=np.float32)
+        o = orc.ParticleFilterOracle(n, None, osp, omp, particles=x)
+        noise, comp = orc.predict_noise(pf._seed, c, np.arange(n), osp)
+        o.predict_vec(u, dt, noise=noise.astype(np.float32))
+        sd = np.sqrt(np.diagonal(osp.covariances, axis1=1, axis2=2))[comp]
+        assert np.max(np.abs(x_new - o.particles) / sd) < 1e-3
+        o.particles = x_new
+        o.weights = w.copy()
+        o.update_vec(u, z)
+        np.testing.assert_allclose(w_new, o.weights, rtol=2e-6, atol=1.2e-38)
+        x, w = x_new, w_new
 
 
 def test_fused_step_against_oracle():

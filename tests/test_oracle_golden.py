@@ -159,6 +159,11 @@ def test_pf_vectorised_equals_loop(golden):
         np.testing.assert_array_equal(ia, ib)
 
 
+# Covariance after predict against the reference's fp32 accumulation (measured: <= 8.6e-4 at N = 64, 1.3e-4 at N = 7,
+# 5e-5 at N = 1 -- the reference sums 11 fp32 outer products whose cancellation grows with the spread of the bank)
+PRED_COV_TOL = {1: 5e-4, 2: 5e-4, 7: 5e-4, 64: 3e-3}
+
+
 @pytest.mark.parametrize("n", [1, 7, 64])
 def test_gsukf_trace(golden, n):
     g = golden("gsukf_trace.npz")
@@ -170,7 +175,7 @@ def test_gsukf_trace(golden, n):
         # per-step: start every step from the reference's own state
         gf.predict(g[t + "u"][c], g[t + "dt"][c], noise=g[t + "noise"][c])
         np.testing.assert_allclose(gf.means, g[t + "m_pred"][c], rtol=1e-6, atol=1e-8)
-        assert_cov_close(gf.covariances, g[t + "P_pred"][c], 3e-2)
+        assert_cov_close(gf.covariances, g[t + "P_pred"][c], PRED_COV_TOL[n])
         gf.means, gf.covariances = g[t + "m_pred"][c].copy(), g[t + "P_pred"][c].copy()
         np.testing.assert_allclose(gf.sigma_points(), g[t + "sig_upd"][c], rtol=1e-6, atol=1e-9)
         gf.update(g[t + "u"][c], g[t + "z"][c])
@@ -198,4 +203,4 @@ def test_gsukf_known_answer(golden):
     np.testing.assert_allclose(gf.means[0], [1.5572222, 26.016260, 5.2668104, 0, 15.188571], rtol=1e-6, atol=1e-9)
     gf.predict(g["ka_u"], 0.1, noise=np.zeros((2, 11, 5), np.float32))
     np.testing.assert_allclose(gf.means, g["ka_m_pred"], rtol=1e-6, atol=1e-8)
-    assert_cov_close(gf.covariances, g["ka_P_pred"], 3e-2)
+    assert_cov_close(gf.covariances, g["ka_P_pred"], 5e-4)
