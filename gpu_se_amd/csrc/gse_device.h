@@ -62,7 +62,10 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
     const uint64_t p1 = (uint64_t)M1 * (uint64_t)c[2];
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    // three-way XOR in ONE instruction: v_bitop3_b32 (new on gfx950) with truth table 0x96 = a ^ b ^ c; hipcc does not form
+    // it from `a ^ b ^ c` by itself (two v_xor_b32).  The round key is uniform and rides the instruction's scalar operand.
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c[1], k0, 0x96);
+    const uint32_t n2 = __builtin_amdgcn_bitop3_b32(hi0, c[3], k1, 0x96);
     c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
 }
 
@@ -86,6 +89,23 @@ __device__ __forceinline__ void rng_words8(const RngKey& key, uint64_t elem, uin
         philox4x32_10(c, key.k0, key.k1);
         out[4 * sub + 0] = c[0]; out[4 * sub + 1] = c[1]; out[4 * sub + 2] = c[2]; out[4 * sub + 3] = c[3];
     }
+}
+
+// The particle filter's predict stage draws the noise of FOUR particles from SIX Philox blocks (24 words: 20 for ten
+// Box-Muller pairs = 20 normals, 4 for the mixture components) instead of two blocks per particle (8 words of which 7
+// are used).  The four particles of a group are the ones a thread owns in the strided mapping of pf_step_kernel:
+// local indices  t + 256 p  (p = 0..3) of one tile of 1024, group id = tile * 256 + t  -- a function of the particle's
+// LOCAL index alone, so every launch geometry that keeps this mapping draws the same numbers.  Counter:
+//   word 0 = group id (28 bits) | bits 32..35 of the shard's element offset << 28,  word 1 = element offset (low 32 bits),
+//   word 2 = step,  word 3 = (step_hi & 0xff) << 24 | purpose << 20 | sub << 16 | filter,   sub = 0..5.
+// (oracle: gse_oracle.predict_noise.)
+__device__ __forceinline__ void rng_block_of_group(const RngKey& key, uint32_t group, uint32_t fb, uint32_t sub,
+                                                   uint32_t (&c)[4]) {
+    c[0] = group | ((uint32_t)(key.elem0 >> 32) << 28);
+    c[1] = (uint32_t)key.elem0;
+    c[2] = key.step_lo;
+    c[3] = (key.hi + fb) | (sub << 16);
+    philox4x32_10(c, key.k0, key.k1);
 }
 
 // Box-Muller on two 32-bit words: u1 = (a + 0.5) / 2^32 in (0, 1], angle = b / 2^32 revolutions.
@@ -128,6 +148,40 @@ __device__ __forceinline__ void mixture_draw5(const DrawParams& dp, const uint32
         for (int j = 0; j <= k; ++j) acc = fmaf(L[at + j], n[j], acc);
         at += k + 1;
         out[k] = acc;
+    }
+}
+
+// The state noise of the four particles of a group (see rng_block_of_group): blocks 0..4 give normals 4b .. 4b+3 (two
+// Box-Muller pairs each), block 5 the four component words; particle p takes normals 5p .. 5p+4 and word p of block 5.
+__device__ __forceinline__ void mixture_draw5x4(const DrawParams& dp, const RngKey& key, uint32_t group, uint32_t fb,
+                                                float (&out)[4][5]) {
+    uint32_t cw[4];
+    rng_block_of_group(key, group, fb, 5u, cw);
+    float n[20];
+#pragma unroll
+    for (uint32_t blk = 0; blk < 5; ++blk) {
+        uint32_t w[4];
+        rng_block_of_group(key, group, fb, blk, w);
+        box_muller(w[0], w[1], n[4 * blk + 0], n[4 * blk + 1]);
+        box_muller(w[2], w[3], n[4 * blk + 2], n[4 * blk + 3]);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float uc = (float)(cw[p] >> 8) * 5.9604644775390625e-08f;   // [0, 1) with 24 bits
+        int comp = 0;
+#pragma unroll
+        for (int d = 0; d < GSE_MAX_ND - 1; ++d) comp += (d < dp.nd - 1 && uc >= dp.cumw[d]) ? 1 : 0;
+        const float* L = dp.chol[comp];
+        const float* m = dp.mean[comp];
+        int at = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float acc = m[k];
+#pragma unroll
+            for (int j = 0; j <= k; ++j) acc = fmaf(L[at + j], n[5 * p + j], acc);
+            at += k + 1;
+            out[p][k] = acc;
+        }
     }
 }
 

@@ -190,13 +190,18 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     const double* __restrict__ scan_in, double* __restrict__ scan_out_sums, double* __restrict__ scan_out,
     double* __restrict__ island, int64_t N, int64_t ld, int T, const StepArgs a) {
     constexpr bool kScanIn = (kScan & 1) != 0, kScanOut = (kScan & 2) != 0;
+    constexpr bool kDraw = kPredict && !kInjected;      // noise from Philox (registers only) rather than from memory
+    // strided particle <-> thread mapping (see below): whenever the launch gathers or draws -- the Philox blocks of the
+    // draw are shared by the four particles a thread owns in THIS mapping (gse_device.h, rng_block_of_group)
+    constexpr bool kStrided = GSE_GATHER_STRIDED && (kGather || kDraw);
+    static_assert(!kDraw || kStrided, "the grouped draw needs the strided mapping");
     constexpr bool kDevIO = (kScan & 4) != 0;      // u / z may come from device memory (variants without gather only:
     static_assert(!kDevIO || !kGather, "");         //  the fused gather kernel has no registers to spare for them)
     static_assert(!kScanIn || kGather, "SCAN_IN belongs to the gather stage");
     static_assert(!kScanOut || kUpdate, "SCAN_OUT belongs to the update stage");
     __shared__ DrawParams dp;
     __shared__ double seg[kGather ? kSpanMax : 2];
-    __shared__ float wtile[((kGather && kUpdate) || kScanOut) ? kTile : 4];
+    __shared__ __attribute__((aligned(16))) float wtile[(kStrided && kUpdate) ? kTile : 4];
     __shared__ int64_t span[2];
     __shared__ double red[4];
     extern __shared__ double pfx_s[];         // [T + 1] with SCAN_IN (dynamic; statics above total a multiple of 16 B)
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     uint32_t jp[kPerThread];
 #pragma unroll
     for (int p = 0; p < kPerThread; ++p)
-        jp[p] = (uint32_t)((kGather && GSE_GATHER_STRIDED) ? tile0 + tid + (int64_t)p * kBlock : i0 + p);
+        jp[p] = (uint32_t)(kStrided ? tile0 + tid + (int64_t)p * kBlock : i0 + p);
     const uint32_t Nu = (uint32_t)N;
 
     if (kPredict && !kInjected) {
@@ -235,15 +240,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     float e[kPerThread][GSE_NX];
     auto draw_all = [&]() {
         if (kGather) GSE_PRIO_DRAW_BEGIN();
-#pragma unroll
-        for (int p = 0; p < kPerThread; ++p) {
-            uint32_t wd[8];
-            rng_words8(a.rng, (uint64_t)jp[p], (uint32_t)b, wd);
-            mixture_draw5(dp, wd, e[p]);
-        }
+        mixture_draw5x4(dp, a.rng, (uint32_t)tile_id * kBlock + (uint32_t)tid, (uint32_t)b, e);
         if (kGather) GSE_PRIO_DRAW_END();
     };
-    constexpr bool kDraw = kPredict && !kInjected;
     const int draw_at = (kDraw && kGather) ? draw_position(blockIdx.x) : 3;      // workgroup-uniform
     GSE_STAMP(0);
     GSE_BLOCK_TIME(0);
@@ -254,6 +253,11 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 
     // ---- gather: ancestors of this thread's 4 outputs -------------------------------------------------
     int32_t anc[kPerThread] = {0, 0, 0, 0};
+    if (kStrided && !kGather) {
+        // no resample in this launch: every particle is its own "ancestor" (clipped: lanes beyond N read a valid row)
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p) anc[p] = (int32_t)min(jp[p], Nu - 1u);
+    }
     bool drawn2 = false;
     if (kGather) {
         double W;
@@ -446,9 +450,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         // ---- issue every load now; the RNG arithmetic below needs no memory and hides their latency.  (Plain loads
         //      get sunk below the RNG by the compiler to save registers, which serialises "RNG, then wait for HBM";
         //      the asm statements pin the issue point and the wait is tied to the registers -- guide 5.7.)
-        float g[2][GSE_NX];                   // gathered rows of the current half (kGather)
-        v4f r0, r1, r2, r3, r4;               // contiguous rows (!kGather)
-        if (kGather) {
+        float g[2][GSE_NX];                   // indexed rows of the current half (strided mapping)
+        v4f r0, r1, r2, r3, r4;               // contiguous rows (consecutive mapping)
+        if (kStrided) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -462,13 +466,19 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             GSE_LOAD_DWORDX4(r4, xb + 4 * ld);
         }
         if (kUpdate && !kGather) {
-            const float4 w4 = *reinterpret_cast<const float4*>(w_in + (int64_t)b * ld + i0);
-            wnew[0] = w4.x; wnew[1] = w4.y; wnew[2] = w4.z; wnew[3] = w4.w;
+            const float* wb = w_in + (int64_t)b * ld;
+            if (kStrided) {
+#pragma unroll
+                for (int p = 0; p < kPerThread; ++p) wnew[p] = (jp[p] < Nu) ? wb[jp[p]] : 0.f;
+            } else {
+                const float4 w4 = *reinterpret_cast<const float4*>(wb + i0);
+                wnew[0] = w4.x; wnew[1] = w4.y; wnew[2] = w4.z; wnew[3] = w4.w;
+            }
         }
         float nz[kPerThread][GSE_NX];
         if (kPredict && kInjected) {
             const float* nb = noise + (int64_t)b * GSE_NX * ld;
-            if (kGather) {
+            if (kStrided) {
 #pragma unroll
                 for (int p = 0; p < kPerThread; ++p)
 #pragma unroll
@@ -506,9 +516,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                         for (int k = 0; k < GSE_NX; ++k) e[p][k] = nz[p][k];
                 }
             }
-            // the state rows of this half must have landed now; with gather, the other half's loads are issued right
-            // behind the wait so that they fly during this half's ODE step and the next draw
-            if (kGather) {
+            // the state rows of this half must have landed now; in the strided mapping the other half's loads are issued
+            // right behind the wait so that they fly during this half's ODE step
+            if (kStrided) {
                 asm volatile("s_waitcnt vmcnt(0)"
                              : "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[0][2]), "+v"(g[0][3]), "+v"(g[0][4]),
                                "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[1][2]), "+v"(g[1][3]), "+v"(g[1][4])::"memory");
@@ -523,27 +533,27 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
                         for (int k = 0; k < GSE_NX; ++k)
                             GSE_LOAD_DWORD_S(g[q][k], (uint32_t)anc[2 + q] * 4u, xin_b + k * ld);
-                    GSE_PRIO_ALU();
+                    if (kGather) GSE_PRIO_ALU();
                 }
             } else if (h == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4)::"memory");
                 row[0] = r0; row[1] = r1; row[2] = r2; row[3] = r3; row[4] = r4;
             }
-            // predict: ODE step + noise.  With gather the particle's new state goes out at once (dword stores,
+            // predict: ODE step + noise.  In the strided mapping the particle's new state goes out at once (dword stores,
             // contiguous across the wavefront) and only the two observed states stay in registers for the update.
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int p = 2 * h + q;
                 float s[GSE_NX];
 #pragma unroll
-                for (int k = 0; k < GSE_NX; ++k) s[k] = kGather ? gq[q][k] : row[k][p];
+                for (int k = 0; k < GSE_NX; ++k) s[k] = kStrided ? gq[q][k] : row[k][p];
                 if (kPredict) {
                     model_step(s, fg, fm, a.dt);
 #pragma unroll
                     for (int k = 0; k < GSE_NX; ++k) s[k] += e[p][k];
                 }
-                if (kGather) {
-                    if (jp[p] < Nu) {
+                if (kStrided) {
+                    if ((kGather || kPredict) && jp[p] < Nu) {
                         float* xb = x_out + (int64_t)b * GSE_NX * ld;
 #pragma unroll
                         for (int k = 0; k < GSE_NX; ++k) store_out<1>(xb + k * ld + jp[p], s[k]);
@@ -556,7 +566,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             }
         }
         // the new state goes out now, ahead of the update phase (consecutive mapping: one dwordx4 per row)
-        if (!kGather && kPredict) {
+        if (!kStrided && kPredict) {
             float* xb = x_out + (int64_t)b * GSE_NX * ld + i0;
 #pragma unroll
             for (int k = 0; k < GSE_NX; ++k) store_out4<1>(xb + k * ld, row[k]);
@@ -575,31 +585,34 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             }
         }
 
-        // ---- weights, ancestor indices
+        // ---- ancestor indices; the uniform weights of a resample without update (an update stores its weights below,
+        //      once they are back in consecutive order)
         if (kGather) {
             float* wb = w_out + (int64_t)b * ld;
             int32_t* ib = idx_out ? idx_out + (int64_t)b * ld : nullptr;
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p)
                 if (jp[p] < Nu) {
-                    store_out<2>(wb + jp[p], wnew[p]);
+                    if (!kUpdate) store_out<2>(wb + jp[p], wnew[p]);
                     if (ib) ib[jp[p]] = anc[p];
                 }
-        } else if (kUpdate) {
-            const v4f w4o = {wnew[0], wnew[1], wnew[2], wnew[3]};
-            store_out4<2>(w_out + (int64_t)b * ld + i0, w4o);
         }
     }
     GSE_STAMP(9);
     if (kUpdate) {
         // tile sum of the new weights, always formed in the same order (4 consecutive per thread, then the workgroup
         // tree) so that fused and separate launches leave bit-identical sums; the strided mapping goes through LDS.
-        if (kGather && GSE_GATHER_STRIDED) {
+        if (kStrided) {
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p) wtile[tid + p * kBlock] = wnew[p];
             __syncthreads();
-#pragma unroll
-            for (int p = 0; p < kPerThread; ++p) wnew[p] = wtile[tid * kPerThread + p];
+            const float4 t4 = *reinterpret_cast<const float4*>(&wtile[tid * kPerThread]);
+            wnew[0] = t4.x; wnew[1] = t4.y; wnew[2] = t4.z; wnew[3] = t4.w;
+        }
+        // the new weights, four consecutive ones per thread: one dwordx4 store (rows are padded to a multiple of 4)
+        if (i0 < N) {
+            const v4f w4o = {wnew[0], wnew[1], wnew[2], wnew[3]};
+            store_out4<2>(w_out + (int64_t)b * ld + i0, w4o);
         }
         // (the tile sum is DEFINED as the total of the workgroup scan of the per-thread sums -- tile_scan_total -- in
         // every kernel that forms one, so one reduction serves both the sum and the tile-local scan)

@@ -516,10 +516,47 @@ def words_to_draw(words, mixture):
     return out, comp
 
 
-def predict_noise(seed, step, elements, mixture, filter_id=0):
-    """The state noise the particle filter's predict stage adds to particle `elements` (global indices) at Philox step
-    `step`: (noise fp64 (M, nx), component (M,)).  Word mapping of pf_step_kernel (gse_device.h rng_words8 +
-    mixture_draw5): two Philox blocks per particle, purpose "predict"."""
-    words = rng_words8(seed, step, RNG_PURPOSE["predict"], np.asarray(elements, dtype=np.uint64), filter_id)
-    return words_to_draw(words, mixture)
+def predict_noise(seed, step, elements, mixture, filter_id=0, element_offset=0):
+    """The state noise the particle filter's predict stage adds to the particles with LOCAL indices `elements` (within
+    their filter / shard, whose first particle has the global index `element_offset`) at Philox step `step`:
+    (noise fp64 (M, nx), component (M,)).
 
+    Mapping of pf_step_kernel (gse_device.h rng_block_of_group + mixture_draw5x4): the four particles  t + 256 p
+    (p = 0..3) of a tile of 1024 form a group, group id = tile * 256 + t, and share SIX Philox blocks with counter
+    (group | offset bits 32..35 << 28, offset low 32 bits, step_lo, (step_hi & 0xff) << 24 | purpose << 20 | sub << 16 |
+    filter), sub = 0..5: blocks 0..4 are ten Box-Muller pairs = normals 0..19, particle p takes normals 5p .. 5p+4 and
+    its component from word p of block 5 (top 24 bits)."""
+    e = np.asarray(elements, dtype=np.uint64)
+    group = (e >> np.uint64(10)) * np.uint64(256) + (e & np.uint64(255))
+    slot = ((e >> np.uint64(8)) & np.uint64(3)).astype(np.int64)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    off = int(element_offset)
+    c0 = (group | np.uint64(((off >> 32) & 0xF) << 28)) & _MASK32
+    blocks = []
+    for sub in range(6):
+        hi = ((((step >> 32) & 0xFF) << 24) | ((RNG_PURPOSE["predict"] & 0xF) << 20) | (filter_id & 0xFFFF)) | (sub << 16)
+        ctr = np.stack([c0, np.full_like(e, off & 0xFFFFFFFF), np.full_like(e, step & 0xFFFFFFFF), np.full_like(e, hi)],
+                       axis=-1)
+        blocks.append(philox4x32_10(ctr, key))
+    words = np.concatenate(blocks[:5], axis=-1).astype(np.float64)            # (M, 20): ten Box-Muller pairs
+    normals = np.zeros((len(e), 20))
+    for pair in range(10):
+        u1 = (words[:, 2 * pair] + 0.5) / 2.0 ** 32
+        ang = words[:, 2 * pair + 1] / 2.0 ** 32
+        r = np.sqrt(-2.0 * np.log(u1))
+        normals[:, 2 * pair] = r * np.cos(2 * np.pi * ang)
+        normals[:, 2 * pair + 1] = r * np.sin(2 * np.pi * ang)
+    rows = np.arange(len(e))
+    mine = normals[rows[:, None], 5 * slot[:, None] + np.arange(5)[None, :]]  # (M, 5)
+    uc = (blocks[5][rows, slot] >> np.uint64(8)).astype(np.float64) / 2.0 ** 24
+    cw = np.cumsum(mixture.weights.astype(np.float64))
+    cw = (cw / cw[-1]).astype(np.float32).astype(np.float64)
+    comp = np.zeros(len(e), dtype=np.int64)
+    for d in range(mixture.nd - 1):
+        comp += (uc >= cw[d]).astype(np.int64)
+    out = np.zeros((len(e), mixture.nx))
+    for d in range(mixture.nd):
+        chol = np.linalg.cholesky(mixture.covariances[d].astype(np.float64)).astype(np.float32).astype(np.float64)
+        sel = comp == d
+        out[sel] = mixture.means[d].astype(np.float64) + mine[sel, :mixture.nx] @ chol.T
+    return out, comp

@@ -449,7 +449,7 @@ def test_single_launch_philox_cycle_against_oracle(n):
     launch per cycle -- against the oracle fed the same Philox words (oracle.predict_noise), at BASELINE config 2's size,
     at config 4's shard size, and one tile beyond it where the class switches to cumsum + fused step.  Per cycle:
     ancestors vs oracle.systematic_index on the device's fp32 weights (<= 2 last-bit ties of the fp64 cumulative sums),
-    particles within 1e-3 sigma of the oracle's ODE step + mapped draw, weights to 2e-6 of the oracle's update on
+    particles within 1e-3 sigma (+ one fp32 rounding) of the oracle's ODE step + mapped draw, weights to 2e-6 of the oracle's update on
     the device's particles."""
     gpu_se_amd.seed(2020)
     _, _, _, pf = sim_base.get_parts(N_particles=n)
@@ -485,7 +485,11 @@ def test_single_launch_philox_cycle_against_oracle(n):
         noise, comp = orc.predict_noise(pf._seed, c, np.arange(n), osp)
         o.predict_vec(u, dt, noise=noise.astype(np.float32))
         sd = np.sqrt(np.diagonal(osp.covariances, axis1=1, axis2=2))[comp]
-        assert np.max(np.abs(x_new - o.particles) / sd) < 1e-3
+        # (1e-3 sigma of the noise component; plus one rounding of the fp32 state where the 2e-5-sigma difference between
+        #  the device's fp32 fast-math normal and the fp64 one flips the last bit of the sum -- Cx = 26 has an fp32 ulp of
+        #  1.9e-6 against a noise sigma of 3e-4)
+        bound = 1e-3 * sd + 1.2e-7 * np.abs(o.particles)
+        assert np.all(np.abs(x_new - o.particles) <= bound), float(np.max(np.abs(x_new - o.particles) / bound))
         o.particles = x_new
         o.weights = w.copy()
         o.update_vec(u, z)
