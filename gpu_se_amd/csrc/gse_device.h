@@ -401,6 +401,27 @@ __device__ __forceinline__ double block_exclusive_scan(double v, double* lds, do
     return base + exc;
 }
 
+// Two independent exclusive scans over the workgroup at once (one value of each per thread) with ONE exchange through
+// LDS: per value the arithmetic -- and therefore every bit -- of block_exclusive_scan.  lds: >= 8 doubles.
+__device__ __forceinline__ void block_exclusive_scan2(double v0, double v1, double* lds, double& e0, double& e1) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double inc0 = wave_inclusive_scan(v0, lane), inc1 = wave_inclusive_scan(v1, lane);
+    __syncthreads();
+    if (lane == 63) {
+        lds[wv] = inc0;
+        lds[4 + wv] = inc1;
+    }
+    __syncthreads();
+    double b0 = 0.0, b1 = 0.0;
+    if (wv > 0) { b0 = lds[0]; b1 = lds[4]; }
+    if (wv > 1) { b0 += lds[1]; b1 += lds[5]; }
+    if (wv > 2) { b0 += lds[2]; b1 += lds[6]; }
+    double x0 = __shfl_up(inc0, 1, 64), x1 = __shfl_up(inc1, 1, 64);
+    if (lane == 0) { x0 = 0.0; x1 = 0.0; }
+    e0 = b0 + x0;
+    e1 = b1 + x1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Weight rows and searches in the normalised cumulative weights
 // ------------------------------------------------------------------------------------------------
@@ -472,6 +493,66 @@ __device__ __forceinline__ double smallest_with_quotient_ge(double u, double W) 
         x = __longlong_as_double(__double_as_longlong(x) + 1);                   // next above
     }
     return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inverse map of the systematic resample: instead of searching, for every output j, the first key c[k] >= u_j
+// (particle.py:96-100), every KEY says how many outputs lie at or below it,
+//     F(k) = #{ j in [0, N) : u_j <= c[k] },     u_j = fl(fl(j + r) / N),   c[k] = fl(x[k] / W)
+// (x = un-normalised cumulative weight) -- the outputs F(k-1) .. F(k) - 1 are exactly the offspring of particle k.  The
+// thresholds are an arithmetic progression, so F is arithmetic, not a search: F = floor(x N / W - r) + 1 whenever that real
+// number is not within `guard` of an integer; inside the guard band (a few keys per million launches) the count is settled
+// with the reference's own comparison on the correctly rounded quotient, so the result is EXACTLY the reference's.
+// Error budget: the exact comparison differs from the real-number one by at most N 2^-52 (roundings of x / W and of j + r,
+// both <= 1) and the fused evaluation of x (N / W) - r by at most N 2^-51; guard = N 2^-48.
+// ------------------------------------------------------------------------------------------------
+#ifdef GSE_STAMPS
+static __device__ unsigned long long g_slow_hits;      // diagnostic build: guard-band evaluations
+#endif
+struct OffspringCount {
+    double r, Nd, invN, W, NoverW, guard;
+    int32_t N;
+    bool pow2;
+    __device__ __forceinline__ void init(int64_t N_, double r_, double W_) {
+        N = (int32_t)N_; r = r_; W = W_; Nd = (double)N_;
+        invN = 1.0 / Nd; NoverW = Nd / W_; guard = Nd * 0x1p-48;
+        pow2 = (N_ & (N_ - 1)) == 0;
+    }
+    // the threshold of output j, bit for bit as the kernels and the reference form it
+    __device__ __forceinline__ double u_of(int32_t j) const {
+        const double jr = (double)j + r;
+        return pow2 ? jr * invN : jr / Nd;
+    }
+    __device__ __forceinline__ int32_t operator()(double x) const {
+        const double s = fma(x, NoverW, -r);
+        const double fl = floor(s);
+        const double frac = s - fl;
+        int32_t J = (int32_t)fl;                                     // s lies in [-1, N]: fits
+        if (!(frac >= guard && frac <= 1.0 - guard)) {               // (NaN lands here too)
+#ifdef GSE_STAMPS
+            atomicAdd(&g_slow_hits, 1ull);
+#endif
+            const double c = x / W;
+            J = min(max(J, -1), N - 1);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+                if (J + 1 < N && u_of(J + 1) <= c) ++J;
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+                if (J >= 0 && u_of(J) > c) --J;
+        }
+        return J + 1;
+    }
+};
+
+// Inclusive max-scan across the 64 lanes of a wavefront (unsigned).
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= d) v = max(v, o);
+    }
+    return v;
 }
 
 #ifndef GSE_SPAN_MAX

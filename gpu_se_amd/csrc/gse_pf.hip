@@ -119,6 +119,10 @@ __device__ __forceinline__ int xcd_contiguous_tile(unsigned bx, int T) {
 #endif
     return (int)bx;
 }
+#ifndef GSE_INVMAP
+#define GSE_INVMAP 1             // SCAN_IN gather: 1 = inverse map from the weights (no stored scans, no search); 0 = the
+                                 // round-1 path (tile-local scans stored by the update stage, staged in LDS and bisected)
+#endif
 #ifndef GSE_GATHER_STRIDED
 #define GSE_GATHER_STRIDED 1     // gather variants: a thread's 4 outputs are 256 apart (1) or consecutive (0)
 #endif
@@ -182,6 +186,54 @@ __device__ __forceinline__ void store_out4(float* p, v4f_t v) {                 
 //                     into LDS.  Same arithmetic, same bits as cumsum_kernel.
 //   bit 1 (SCAN_OUT)  the update stage also writes L and the tile sums of the new weights (8 B / particle).
 // With both bits the steady-state cycle is ONE launch: no cumsum kernel, no second pass over the weights.
+// Inverse map, one step: the keys of one or two ancestor tiles (tq1 < 0: one) -> marks.  Thread t of the workgroup holds keys
+// 4t .. 4t+3 of each tile, formed from the tile's weights exactly as cumsum_kernel forms them -- x[k] = min(Pfx[tq] + (excl +
+// s_p), Pfx[tq+1]), the tile's last key pinned to Pfx[tq+1] -- and every key whose slot e = clamp(F(x) - j0, 0, 1024) is below
+// 1024 raises mark[e] to k + 1 (a thread's equal neighbours are folded first).  All threads of the workgroup must call this.
+__device__ __forceinline__ void expand_tiles(const OffspringCount& F, const double* pfx_s, uint32_t* mark, double* red2,
+                                             int64_t N, int32_t j0, int tq0, const float4 wv0, int tq1, const float4 wv1) {
+    const int tid = threadIdx.x;
+    const bool two = tq1 >= 0;                                           // workgroup-uniform
+    const int tq[2] = {tq0, two ? tq1 : tq0};
+    const float w[2][kPerThread] = {{wv0.x, wv0.y, wv0.z, wv0.w}, {wv1.x, wv1.y, wv1.z, wv1.w}};
+    double sc[2][kPerThread];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int64_t k0 = (int64_t)tq[c] * kTile + (int64_t)tid * kPerThread;
+        sc[c][0] = (k0 + 0 < N) ? (double)w[c][0] : 0.0;
+        sc[c][1] = sc[c][0] + ((k0 + 1 < N) ? (double)w[c][1] : 0.0);
+        sc[c][2] = sc[c][1] + ((k0 + 2 < N) ? (double)w[c][2] : 0.0);
+        sc[c][3] = sc[c][2] + ((k0 + 3 < N) ? (double)w[c][3] : 0.0);
+    }
+    double excl[2];
+    if (two) {
+        block_exclusive_scan2(sc[0][3], sc[1][3], red2, excl[0], excl[1]);
+    } else {
+        double tile_total;
+        excl[0] = block_exclusive_scan(sc[0][3], red2, tile_total);
+        excl[1] = 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (c == 0 || two) {
+            const int64_t k0 = (int64_t)tq[c] * kTile + (int64_t)tid * kPerThread;
+            const double P0 = pfx_s[tq[c]], P1 = pfx_s[tq[c] + 1];
+            const int64_t tile_last = min((int64_t)(tq[c] + 1) * kTile, N) - 1;
+            int32_t es[kPerThread];
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) {
+                const double x = (k0 + p >= tile_last) ? P1 : fmin(P0 + (excl[c] + sc[c][p]), P1);
+                es[p] = min(max(F(x) - j0, 0), (int32_t)kTile);
+            }
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) {
+                const bool last_of_run = (p == kPerThread - 1) ? true : (k0 + p == tile_last || es[(p + 1) % kPerThread] != es[p]);
+                if (k0 + p <= tile_last && es[p] < kTile && last_of_run) atomicMax(&mark[es[p]], (uint32_t)(k0 + p) + 1u);
+            }
+        }
+    }
+}
+
 template <bool kGather, bool kPredict, bool kInjected, bool kUpdate, int kNd, int kScan>
 __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     const float* __restrict__ x_in, float* __restrict__ x_out, const float* __restrict__ w_in, float* __restrict__ w_out,
@@ -200,7 +252,12 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     static_assert(!kScanIn || kGather, "SCAN_IN belongs to the gather stage");
     static_assert(!kScanOut || kUpdate, "SCAN_OUT belongs to the update stage");
     __shared__ DrawParams dp;
-    __shared__ double seg[kGather ? kSpanMax : 2];
+    constexpr bool kInvMap = kScanIn && (GSE_INVMAP != 0);
+    __shared__ double seg[(kGather && !kInvMap) ? kSpanMax : 2];
+    __shared__ __attribute__((aligned(16))) uint32_t mark[kInvMap ? kTile : 4];     // inverse map: see the gather stage
+    __shared__ int32_t act_list[kInvMap ? kTile : 1];
+    __shared__ int32_t act_n;
+    __shared__ double red2[kInvMap ? 8 : 1];
     __shared__ __attribute__((aligned(16))) float wtile[(kStrided && kUpdate) ? kTile : 4];
     __shared__ int64_t span[2];
     __shared__ double red[4];
@@ -262,17 +319,29 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     if (kGather) {
         double W;
         if (kScanIn) {
-            // tile prefix into LDS: thread j owns chunk [j*m, (j+1)*m) of the tile sums (as inline_tile_prefix)
+            // tile prefix into LDS: thread j owns chunk [j*m, (j+1)*m) of the tile sums (as inline_tile_prefix).  The scan
+            // modes run up to 2048 tiles, so a chunk has at most 8 sums: all loads are issued at once and the values stay
+            // in registers for the second sweep (one memory latency instead of 2 m dependent ones).
             const double* sums = scan_in_sums + (int64_t)b * T;
             const int m = (T + kBlock - 1) / kBlock;
-            const int qlo = tid * m, qhi = min(qlo + m, T);
+            const int qlo = tid * m;
+            constexpr int kMaxChunk = 8;
+            double sv[kMaxChunk];
+#pragma unroll
+            for (int i = 0; i < kMaxChunk; ++i) sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
+            if (kInvMap) {
+                *reinterpret_cast<uint4*>(&mark[tid * kPerThread]) = make_uint4(0u, 0u, 0u, 0u);
+                if (tid == 0) act_n = 0;
+            }
             double chunk = 0.0;
-            for (int q = qlo; q < qhi; ++q) chunk += sums[q];
+#pragma unroll
+            for (int i = 0; i < kMaxChunk; ++i) chunk += sv[i];            // (+ 0.0 beyond the chunk: exact)
             double total;
             double run = block_exclusive_scan(chunk, red, total);
-            for (int q = qlo; q < qhi; ++q) {
-                pfx_s[q] = run;
-                run += sums[q];
+#pragma unroll
+            for (int i = 0; i < kMaxChunk; ++i) {
+                if (i < m && qlo + i < T) pfx_s[qlo + i] = run;
+                run += sv[i];
             }
             if (tid == 0) pfx_s[T] = total;
             __syncthreads();
@@ -290,6 +359,99 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         // Weights that do not sum to a positive finite number: the reference's normalised cumsum is all-NaN and its
         // sweep never advances (filter/particle.py:98), so every offspring copies particle 0 (anc stays 0).
         if ((W > 0.0) && (W < INFINITY)) {
+          if constexpr (kInvMap) {
+            // ---- inverse map (gse_device.h, OffspringCount).  No stored scans, no search: the keys of an ancestor tile are
+            //      re-formed from its WEIGHTS exactly as cumsum_kernel forms them -- x[k] = min(Pfx[t] + (excl + s_p),
+            //      Pfx[t+1]), thread t of the workgroup holding keys 4t .. 4t+3 -- and every key with e = F(k) - j0 in
+            //      [0, 1024) raises mark[e] to k + 1 (LDS atomic max; a thread's equal neighbours are folded first).  F is
+            //      monotone, so the ancestor of output slot i is  1 + max{k : e_k <= i}  (the key after the last one whose
+            //      offspring all lie before i) = an inclusive max-scan of the marks, floored at the first key of the first
+            //      tile that can hold an ancestor.
+            OffspringCount F;
+            F.init(N, r, W);
+            const int32_t j0 = (int32_t)tile0;
+            const int32_t j1 = (int32_t)min(tile0 + kTile, N);
+            auto slot_of = [&](double x) -> int32_t { return min(max(F(x) - j0, 0), (int32_t)kTile); };
+            // which tiles can hold ancestors: conservative on both sides by 2^-50 (see the round-1 path below)
+            const double p_lo = (F.u_of(j0) * W) * (1.0 - 0x1p-50);
+            const double p_hi = (F.u_of(j1 - 1) * W) * (1.0 + 0x1p-50);
+            const int tl0 = (int)wave_search_ge([&](int64_t q) { return pfx_s[q + 1]; }, T, p_lo, lane);
+            const int tl1 = (int)wave_search_ge([&](int64_t q) { return pfx_s[q + 1]; }, T, p_hi, lane);
+            const float* wrow = w_in + (int64_t)b * ld;
+    GSE_STAMP(11);
+            auto tile_weights = [&](int tq) {
+                return load_weights4(wrow, (int64_t)tq * kTile + (int64_t)tid * kPerThread, N, ld);
+            };
+            // Which tiles to expand.  One or two (the common case): both.  A wider range (a stretch of light particles):
+            // census first -- all keys of tile q lie in [Pfx[q], Pfx[q+1]]; when both ends fall into the same slot the whole
+            // tile does and its LAST key stands for it; only tiles that some output of this workgroup descends from are
+            // listed.  The listed tiles are expanded two at a time, the weights of the next pair in flight meanwhile.
+            const bool direct = tl1 - tl0 < 2;                                     // workgroup-uniform
+            int n_act = tl1 - tl0 + 1;
+            if (!direct) {
+                for (int q = tl0 + tid; q <= tl1; q += kBlock) {
+                    const int32_t e0 = slot_of(pfx_s[q]), e1 = slot_of(pfx_s[q + 1]);
+                    if (e0 == e1) {
+                        if (e1 < kTile) atomicMax(&mark[e1], (uint32_t)(min((int64_t)(q + 1) * kTile, N) - 1) + 1u);
+                    } else {
+                        act_list[atomicAdd(&act_n, 1)] = q;                        // at most 1024: the slots e0 < e1 are disjoint
+                    }
+                }
+                __syncthreads();
+                n_act = act_n;
+            }
+            auto tile_at = [&](int i) { return direct ? tl0 + i : act_list[i]; };
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 c0 = zero4, c1 = zero4;
+            if (n_act > 0) c0 = tile_weights(tile_at(0));
+            if (n_act > 1) c1 = tile_weights(tile_at(1));
+            if (kDraw && draw_at == 2) {
+                draw_all();
+                drawn2 = true;
+            }
+            for (int i = 0; i < n_act; i += 2) {
+                float4 n0 = zero4, n1 = zero4;
+                if (i + 2 < n_act) n0 = tile_weights(tile_at(i + 2));
+                if (i + 3 < n_act) n1 = tile_weights(tile_at(i + 3));
+                expand_tiles(F, pfx_s, mark, red2, N, j0, tile_at(i), c0, (i + 1 < n_act) ? tile_at(i + 1) : -1, c1);
+                c0 = n0;
+                c1 = n1;
+            }
+    GSE_STAMP(3);
+#ifdef GSE_STAMPS
+            if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+                g_block_info[2 * blockIdx.x] = (long long)(tl1 - tl0 + 1) | ((long long)act_n << 20);
+                g_block_info[2 * blockIdx.x + 1] = draw_at;
+            }
+#endif
+            __syncthreads();
+            // inclusive max-scan of the 1024 marks: thread t owns slots 4t .. 4t+3
+            {
+                const uint4 mk = *reinterpret_cast<const uint4*>(&mark[tid * kPerThread]);
+                const uint32_t m0 = mk.x, m1 = max(m0, mk.y), m2 = max(m1, mk.z), m3 = max(m2, mk.w);
+                const uint32_t inc = wave_inclusive_max(m3, lane);
+                uint32_t before = (uint32_t)__shfl_up((int)inc, 1, 64);
+                if (lane == 0) before = 0u;
+                uint32_t* wmax = reinterpret_cast<uint32_t*>(red);                 // (free since the tile prefix)
+                if (lane == 63) wmax[wv] = inc;
+                __syncthreads();
+                if (wv > 0) before = max(before, wmax[0]);
+                if (wv > 1) before = max(before, wmax[1]);
+                if (wv > 2) before = max(before, wmax[2]);
+                // marks hold k + 1 = the key that FOLLOWS the last exhausted one: that is the ancestor itself
+                const uint32_t floor_key = (uint32_t)tl0 * (uint32_t)kTile;        // first key of the range
+                const uint32_t last_key = (uint32_t)N - 1u;
+                uint4 av;
+                av.x = min(max(max(before, m0), floor_key), last_key);
+                av.y = min(max(max(before, m1), floor_key), last_key);
+                av.z = min(max(max(before, m2), floor_key), last_key);
+                av.w = min(max(max(before, m3), floor_key), last_key);
+                *reinterpret_cast<uint4*>(&mark[tid * kPerThread]) = av;           // the slots this thread alone has read
+                __syncthreads();
+#pragma unroll
+                for (int p = 0; p < kPerThread; ++p) anc[p] = (int32_t)mark[tid + p * kBlock];
+            }
+          } else {
             const double* cb = kScanIn ? scan_in + (int64_t)b * N : c + (int64_t)b * N;
             // The search key of ancestor k.
             //   materialised c[] : ckey(k) = c[k]                                   (normalised by cumsum_kernel)
@@ -439,6 +601,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                     anc[p] = (int32_t)lo;
                 }
             }
+          }
         }
     }
     if (kDraw && draw_at == 2 && !drawn2) draw_all();      // (weights that do not sum to a positive number: no search)
@@ -625,8 +788,12 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         const double excl = block_exclusive_scan(sc[3], red, total);
         if (tid == 0) tile_sums[(int64_t)b * T + tile_id] = total;
         if (kScanOut) {
-            // tile-local inclusive scan of the new weights, the expression cumsum_kernel uses: L = excl + s_p
+            // the tile sums the NEXT launch's gather stage builds its prefix from (a slot of their own: this launch may
+            // still be reading the previous ones)
             if (tid == 0) scan_out_sums[(int64_t)b * T + tile_id] = total;
+        }
+        if (kScanOut && GSE_INVMAP == 0) {
+            // round-1 path: the tile-local inclusive scan of the new weights, the expression cumsum_kernel uses: L = excl + s_p
             double* lb = scan_out + (int64_t)b * N;
             if (i0 + 3 < N && (N & 1) == 0) {
                 store_out2<4>(lb + i0, excl + sc[0], excl + sc[1]);
@@ -698,6 +865,7 @@ __global__ __launch_bounds__(kBlock) void tile_scan_kernel(const double* __restr
 // (thread j owns chunk [j*m, (j+1)*m); excl = workgroup exclusive scan of the chunk sums).  Larger T: a scan
 // kernel of its own writes the prefix once.
 constexpr int kInlinePrefixMaxT = 4096;
+constexpr int kScanMaxT = kBlock * 8;        // scan modes of the step kernel: a prefix chunk of at most 8 tile sums per thread
 
 __device__ __forceinline__ void inline_tile_prefix(const double* __restrict__ s, int T, int t, double* red,
                                                    double* out3) {
@@ -1053,8 +1221,8 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const int scan = ((ops & GSE_OP_SCAN_IN) ? 1 : 0) | ((ops & GSE_OP_SCAN_OUT) ? 2 : 0);
     GSE_REQUIRE(!(scan & 1) || G, "%s: GSE_OP_SCAN_IN needs GSE_OP_GATHER", fn);
     GSE_REQUIRE(!(scan & 2) || U, "%s: GSE_OP_SCAN_OUT needs GSE_OP_UPDATE", fn);
-    GSE_REQUIRE(scan == 0 || tiles_of(N) <= kInlinePrefixMaxT, "%s: the scan modes support at most %d tiles (N <= %d)", fn,
-                kInlinePrefixMaxT, kInlinePrefixMaxT * kTile);
+    GSE_REQUIRE(scan == 0 || tiles_of(N) <= kScanMaxT, "%s: the scan modes support at most %d tiles (N <= %d)", fn,
+                kScanMaxT, kScanMaxT * kTile);
     GSE_REQUIRE(x_in && aligned16(x_in), "%s: x_in must be a 16-byte aligned device pointer", fn);
     GSE_REQUIRE((workspace && aligned16(workspace)) || !(ops & (GSE_OP_GATHER | GSE_OP_UPDATE)),
                 "%s: gather / update need a 16-byte aligned device workspace", fn);
@@ -1232,6 +1400,11 @@ int gse_pf_shard_gather(const float* x_in, int64_t ld, int64_t N_local, const do
 int gse_debug_stamps(unsigned long long* out32) {
     GSE_HIP_CHECK(hipDeviceSynchronize());
     GSE_HIP_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32));
+    return GSE_OK;
+}
+int gse_debug_slow_hits(unsigned long long* out) {
+    GSE_HIP_CHECK(hipDeviceSynchronize());
+    GSE_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slow_hits), sizeof(unsigned long long)));
     return GSE_OK;
 }
 int gse_debug_block_times(unsigned long long* out8192, long long* info8192) {

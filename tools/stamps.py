@@ -10,17 +10,19 @@ gpu_se_amd.seed(1)
 _, _, _, pf = sim_base.get_parts(N_particles=n)
 io = bench.make_inputs(60, 1.0)
 lib = ctypes.CDLL(_lib.LIB_PATH)
-names = ["start", "draw@0", "prefix", "bracket", "search done", "loads issued", "draw@3", "rows landed", "ODE done",
-         "update done", "scan-out done"]
+names = ["start", "draw@0", "prefix", "marks done", "ancestors done", "loads issued", "draw@3", "rows landed", "ODE done",
+         "update done", "scan-out done", "tiles found"]
+order = [0, 1, 2, 11, 3, 4, 5, 6, 7, 8, 9, 10]
 acc = []
 for c, (u, z) in enumerate(io):
     pf.predict(u, 1.0); pf.update(u, z); pf.resample()
     if c >= 20:
         buf = (ctypes.c_ulonglong * 32)()
         lib.gse_debug_stamps(buf)
-        acc.append(np.array(buf[:11], dtype=np.float64))
+        acc.append(np.array(buf[:12], dtype=np.float64))
 a = np.median(np.array(acc), axis=0)
-# s_memtime ticks: shader clock cycles?  report in ticks and assume 100 MHz REFCLK vs shader clock unknown: print raw deltas
 d = a - a[0]
-for i, nm in enumerate(names):
-    print("%-14s +%9.0f ticks   (phase %8.0f)" % (nm, d[i], d[i] - d[i - 1] if i else 0))
+prev = 0.0
+for i in order:
+    print("%-16s +%9.0f ticks   (phase %8.0f)" % (names[i], d[i], d[i] - prev))
+    prev = d[i]
