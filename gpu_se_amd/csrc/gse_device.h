@@ -342,15 +342,36 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// Inclusive scan across the 64 lanes of a wavefront.
-__device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+// Data-parallel-primitive moves (no LDS traffic): lanes without a source read 0, which is the identity of every scan here
+// (sums of non-negative weights, maxima of unsigned marks).
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, kRowMask, 0xf, true);
+}
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_or_zero(double v) {
+    const uint64_t bits = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = dpp_or_zero<kCtrl, kRowMask>((uint32_t)bits), hi = dpp_or_zero<kCtrl, kRowMask>((uint32_t)(bits >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138;
+
+// Inclusive scan across the 64 lanes of a wavefront: four shift-and-add steps inside each row of 16 lanes, then the row
+// totals are handed on (lane 15 of rows 0 and 2 to rows 1 and 3, lane 31 to rows 2 and 3).  Fixed association -- every
+// kernel that forms cumulative weights goes through this function, so they all produce the same bits.
+__device__ __forceinline__ double wave_inclusive_scan(double v, int /*lane*/) {
+    v += dpp_or_zero<kDppRowShr1, 0xf>(v);
+    v += dpp_or_zero<kDppRowShr2, 0xf>(v);
+    v += dpp_or_zero<kDppRowShr4, 0xf>(v);
+    v += dpp_or_zero<kDppRowShr8, 0xf>(v);
+    v += dpp_or_zero<kDppRowBcast15, 0xa>(v);
+    v += dpp_or_zero<kDppRowBcast31, 0xc>(v);
     return v;
 }
+// the value of the lane below (lane 0: 0)
+__device__ __forceinline__ double wave_shift_up1(double v) { return dpp_or_zero<kDppWaveShr1, 0xf>(v); }
+__device__ __forceinline__ uint32_t wave_shift_up1(uint32_t v) { return dpp_or_zero<kDppWaveShr1, 0xf>(v); }
 
 // Sum over the 256-thread workgroup; result valid in every thread.  lds: >= 4 doubles.
 __device__ __forceinline__ double block_sum(double v, double* lds) {
@@ -396,9 +417,7 @@ __device__ __forceinline__ double block_exclusive_scan(double v, double* lds, do
     if (wv > 1) base += w1;
     if (wv > 2) base += w2;
     total = ((w0 + w1) + w2) + w3;
-    double exc = __shfl_up(inc, 1, 64);
-    if (lane == 0) exc = 0.0;
-    return base + exc;
+    return base + wave_shift_up1(inc);
 }
 
 // Two independent exclusive scans over the workgroup at once (one value of each per thread) with ONE exchange through
@@ -416,10 +435,8 @@ __device__ __forceinline__ void block_exclusive_scan2(double v0, double v1, doub
     if (wv > 0) { b0 = lds[0]; b1 = lds[4]; }
     if (wv > 1) { b0 += lds[1]; b1 += lds[5]; }
     if (wv > 2) { b0 += lds[2]; b1 += lds[6]; }
-    double x0 = __shfl_up(inc0, 1, 64), x1 = __shfl_up(inc1, 1, 64);
-    if (lane == 0) { x0 = 0.0; x1 = 0.0; }
-    e0 = b0 + x0;
-    e1 = b1 + x1;
+    e0 = b0 + wave_shift_up1(inc0);
+    e1 = b1 + wave_shift_up1(inc1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -545,13 +562,14 @@ struct OffspringCount {
     }
 };
 
-// Inclusive max-scan across the 64 lanes of a wavefront (unsigned).
-__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
-        if (lane >= d) v = max(v, o);
-    }
+// Inclusive max-scan across the 64 lanes of a wavefront (unsigned), same structure as wave_inclusive_scan.
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
+    v = max(v, dpp_or_zero<kDppRowShr1, 0xf>(v));
+    v = max(v, dpp_or_zero<kDppRowShr2, 0xf>(v));
+    v = max(v, dpp_or_zero<kDppRowShr4, 0xf>(v));
+    v = max(v, dpp_or_zero<kDppRowShr8, 0xf>(v));
+    v = max(v, dpp_or_zero<kDppRowBcast15, 0xa>(v));
+    v = max(v, dpp_or_zero<kDppRowBcast31, 0xc>(v));
     return v;
 }
 

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_cycle_kernel(float* __restr
         sc[3] = sc[2] + ((i0 + 3 < N) ? (double)w_s[min(i0 + 3, kSmallBank - 1)] : 0.0);
         const double inc = wave_inclusive_scan(sc[3], tid);
         const double W = __shfl(inc, 63, 64);                       // workgroup total: wavefronts 1.. hold zeros
-        double excl = __shfl_up(inc, 1, 64);
+        double excl = wave_shift_up1(inc);
         if (tid == 0) excl = 0.0;
         const double top = W / W;
 #pragma unroll

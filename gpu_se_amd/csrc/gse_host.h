@@ -54,7 +54,7 @@ struct Workspace {
     double* partials;      // [B][kMomentBlocks][kMomentWidth]
     double* totals;        // [B]          sum of the weights of each filter
     double* scan_sums[2];  // [B][T]       tile sums that go with scan[slot]
-    double* scan[2];       // [B][N]       tile-local inclusive scans of the weights (GSE_OP_SCAN_OUT / _IN), two slots
+    double* scan[2];       // [B][T][256]  per-thread exclusive prefixes inside each tile (GSE_OP_SCAN_OUT / _IN), two slots
     double* cumsum;        // [B][N]       normalised cumulative weights
     int64_t bytes;
 };

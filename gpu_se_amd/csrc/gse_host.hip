@@ -94,7 +94,7 @@ Workspace carve_workspace(void* base, int B, int64_t N) {
         ws.scan_sums[k] = reinterpret_cast<double*>(p + at);
         at += round256((int64_t)B * T * 8);
         ws.scan[k] = reinterpret_cast<double*>(p + at);
-        at += round256((int64_t)B * N * 8);
+        at += round256((int64_t)B * T * kBlock * 8);
     }
     ws.cumsum = reinterpret_cast<double*>(p + at);
     at += round256((int64_t)B * N * 8);

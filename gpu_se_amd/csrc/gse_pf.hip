@@ -186,51 +186,31 @@ __device__ __forceinline__ void store_out4(float* p, v4f_t v) {                 
 //                     into LDS.  Same arithmetic, same bits as cumsum_kernel.
 //   bit 1 (SCAN_OUT)  the update stage also writes L and the tile sums of the new weights (8 B / particle).
 // With both bits the steady-state cycle is ONE launch: no cumsum kernel, no second pass over the weights.
-// Inverse map, one step: the keys of one or two ancestor tiles (tq1 < 0: one) -> marks.  Thread t of the workgroup holds keys
-// 4t .. 4t+3 of each tile, formed from the tile's weights exactly as cumsum_kernel forms them -- x[k] = min(Pfx[tq] + (excl +
-// s_p), Pfx[tq+1]), the tile's last key pinned to Pfx[tq+1] -- and every key whose slot e = clamp(F(x) - j0, 0, 1024) is below
-// 1024 raises mark[e] to k + 1 (a thread's equal neighbours are folded first).  All threads of the workgroup must call this.
-__device__ __forceinline__ void expand_tiles(const OffspringCount& F, const double* pfx_s, uint32_t* mark, double* red2,
-                                             int64_t N, int32_t j0, int tq0, const float4 wv0, int tq1, const float4 wv1) {
-    const int tid = threadIdx.x;
-    const bool two = tq1 >= 0;                                           // workgroup-uniform
-    const int tq[2] = {tq0, two ? tq1 : tq0};
-    const float w[2][kPerThread] = {{wv0.x, wv0.y, wv0.z, wv0.w}, {wv1.x, wv1.y, wv1.z, wv1.w}};
-    double sc[2][kPerThread];
+// Inverse map, one step: the 1024 keys of ancestor tile tq -> marks.  Thread t holds keys 4t .. 4t+3, formed exactly as
+// cumsum_kernel forms them -- x[k] = min(Pfx[tq] + (excl + s_p), Pfx[tq+1]), the tile's last key pinned to Pfx[tq+1] -- from the
+// tile's weights (s_p: running sums of the thread's four) and the thread's exclusive prefix `excl` inside the tile, which the
+// update stage that produced the weights left behind (8 bytes per 4 particles).  Every key whose slot e = clamp(F(x) - j0, 0,
+// 1024) is below 1024 raises mark[e] to k + 1 (LDS atomic max; a thread's equal neighbours are folded first).  No barrier.
+__device__ __forceinline__ void expand_tile(const OffspringCount& F, const double* pfx_s, uint32_t* mark, int64_t N,
+                                            int32_t j0, int tq, const float4 wv, double excl) {
+    const int64_t k0 = (int64_t)tq * kTile + (int64_t)threadIdx.x * kPerThread;
+    double sc[kPerThread];
+    sc[0] = (k0 + 0 < N) ? (double)wv.x : 0.0;
+    sc[1] = sc[0] + ((k0 + 1 < N) ? (double)wv.y : 0.0);
+    sc[2] = sc[1] + ((k0 + 2 < N) ? (double)wv.z : 0.0);
+    sc[3] = sc[2] + ((k0 + 3 < N) ? (double)wv.w : 0.0);
+    const double P0 = pfx_s[tq], P1 = pfx_s[tq + 1];
+    const int64_t tile_last = min((int64_t)(tq + 1) * kTile, N) - 1;
+    int32_t es[kPerThread];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int64_t k0 = (int64_t)tq[c] * kTile + (int64_t)tid * kPerThread;
-        sc[c][0] = (k0 + 0 < N) ? (double)w[c][0] : 0.0;
-        sc[c][1] = sc[c][0] + ((k0 + 1 < N) ? (double)w[c][1] : 0.0);
-        sc[c][2] = sc[c][1] + ((k0 + 2 < N) ? (double)w[c][2] : 0.0);
-        sc[c][3] = sc[c][2] + ((k0 + 3 < N) ? (double)w[c][3] : 0.0);
-    }
-    double excl[2];
-    if (two) {
-        block_exclusive_scan2(sc[0][3], sc[1][3], red2, excl[0], excl[1]);
-    } else {
-        double tile_total;
-        excl[0] = block_exclusive_scan(sc[0][3], red2, tile_total);
-        excl[1] = 0.0;
+    for (int p = 0; p < kPerThread; ++p) {
+        const double x = (k0 + p >= tile_last) ? P1 : fmin(P0 + (excl + sc[p]), P1);
+        es[p] = min(max(F(x) - j0, 0), (int32_t)kTile);
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        if (c == 0 || two) {
-            const int64_t k0 = (int64_t)tq[c] * kTile + (int64_t)tid * kPerThread;
-            const double P0 = pfx_s[tq[c]], P1 = pfx_s[tq[c] + 1];
-            const int64_t tile_last = min((int64_t)(tq[c] + 1) * kTile, N) - 1;
-            int32_t es[kPerThread];
-#pragma unroll
-            for (int p = 0; p < kPerThread; ++p) {
-                const double x = (k0 + p >= tile_last) ? P1 : fmin(P0 + (excl[c] + sc[c][p]), P1);
-                es[p] = min(max(F(x) - j0, 0), (int32_t)kTile);
-            }
-#pragma unroll
-            for (int p = 0; p < kPerThread; ++p) {
-                const bool last_of_run = (p == kPerThread - 1) ? true : (k0 + p == tile_last || es[(p + 1) % kPerThread] != es[p]);
-                if (k0 + p <= tile_last && es[p] < kTile && last_of_run) atomicMax(&mark[es[p]], (uint32_t)(k0 + p) + 1u);
-            }
-        }
+    for (int p = 0; p < kPerThread; ++p) {
+        const bool last_of_run = (p == kPerThread - 1) ? true : (k0 + p == tile_last || es[(p + 1) % kPerThread] != es[p]);
+        if (k0 + p <= tile_last && es[p] < kTile && last_of_run) atomicMax(&mark[es[p]], (uint32_t)(k0 + p) + 1u);
     }
 }
 
@@ -257,7 +237,6 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     __shared__ __attribute__((aligned(16))) uint32_t mark[kInvMap ? kTile : 4];     // inverse map: see the gather stage
     __shared__ int32_t act_list[kInvMap ? kTile : 1];
     __shared__ int32_t act_n;
-    __shared__ double red2[kInvMap ? 8 : 1];
     __shared__ __attribute__((aligned(16))) float wtile[(kStrided && kUpdate) ? kTile : 4];
     __shared__ int64_t span[2];
     __shared__ double red[4];
@@ -379,13 +358,14 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             const int tl1 = (int)wave_search_ge([&](int64_t q) { return pfx_s[q + 1]; }, T, p_hi, lane);
             const float* wrow = w_in + (int64_t)b * ld;
     GSE_STAMP(11);
+            const double* qx = scan_in + (int64_t)b * T * kBlock;                  // [T][256] per-thread exclusive prefixes
             auto tile_weights = [&](int tq) {
                 return load_weights4(wrow, (int64_t)tq * kTile + (int64_t)tid * kPerThread, N, ld);
             };
             // Which tiles to expand.  One or two (the common case): both.  A wider range (a stretch of light particles):
             // census first -- all keys of tile q lie in [Pfx[q], Pfx[q+1]]; when both ends fall into the same slot the whole
             // tile does and its LAST key stands for it; only tiles that some output of this workgroup descends from are
-            // listed.  The listed tiles are expanded two at a time, the weights of the next pair in flight meanwhile.
+            // listed.  The listed tiles are expanded two at a time, the loads of the next pair in flight meanwhile.
             const bool direct = tl1 - tl0 < 2;                                     // workgroup-uniform
             int n_act = tl1 - tl0 + 1;
             if (!direct) {
@@ -402,20 +382,24 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             }
             auto tile_at = [&](int i) { return direct ? tl0 + i : act_list[i]; };
             const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            int t0 = (n_act > 0) ? tile_at(0) : 0, t1 = (n_act > 1) ? tile_at(1) : 0;
             float4 c0 = zero4, c1 = zero4;
-            if (n_act > 0) c0 = tile_weights(tile_at(0));
-            if (n_act > 1) c1 = tile_weights(tile_at(1));
+            double x0 = 0.0, x1 = 0.0;
+            if (n_act > 0) { c0 = tile_weights(t0); x0 = qx[t0 * kBlock + tid]; }
+            if (n_act > 1) { c1 = tile_weights(t1); x1 = qx[t1 * kBlock + tid]; }
             if (kDraw && draw_at == 2) {
                 draw_all();
                 drawn2 = true;
             }
             for (int i = 0; i < n_act; i += 2) {
+                const int u0 = (i + 2 < n_act) ? tile_at(i + 2) : 0, u1 = (i + 3 < n_act) ? tile_at(i + 3) : 0;
                 float4 n0 = zero4, n1 = zero4;
-                if (i + 2 < n_act) n0 = tile_weights(tile_at(i + 2));
-                if (i + 3 < n_act) n1 = tile_weights(tile_at(i + 3));
-                expand_tiles(F, pfx_s, mark, red2, N, j0, tile_at(i), c0, (i + 1 < n_act) ? tile_at(i + 1) : -1, c1);
-                c0 = n0;
-                c1 = n1;
+                double y0 = 0.0, y1 = 0.0;
+                if (i + 2 < n_act) { n0 = tile_weights(u0); y0 = qx[u0 * kBlock + tid]; }
+                if (i + 3 < n_act) { n1 = tile_weights(u1); y1 = qx[u1 * kBlock + tid]; }
+                expand_tile(F, pfx_s, mark, N, j0, t0, c0, x0);
+                if (i + 1 < n_act) expand_tile(F, pfx_s, mark, N, j0, t1, c1, x1);
+                c0 = n0; c1 = n1; x0 = y0; x1 = y1; t0 = u0; t1 = u1;
             }
     GSE_STAMP(3);
 #ifdef GSE_STAMPS
@@ -429,9 +413,8 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             {
                 const uint4 mk = *reinterpret_cast<const uint4*>(&mark[tid * kPerThread]);
                 const uint32_t m0 = mk.x, m1 = max(m0, mk.y), m2 = max(m1, mk.z), m3 = max(m2, mk.w);
-                const uint32_t inc = wave_inclusive_max(m3, lane);
-                uint32_t before = (uint32_t)__shfl_up((int)inc, 1, 64);
-                if (lane == 0) before = 0u;
+                const uint32_t inc = wave_inclusive_max(m3);
+                uint32_t before = wave_shift_up1(inc);
                 uint32_t* wmax = reinterpret_cast<uint32_t*>(red);                 // (free since the tile prefix)
                 if (lane == 63) wmax[wv] = inc;
                 __syncthreads();
@@ -792,17 +775,10 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             // still be reading the previous ones)
             if (tid == 0) scan_out_sums[(int64_t)b * T + tile_id] = total;
         }
-        if (kScanOut && GSE_INVMAP == 0) {
-            // round-1 path: the tile-local inclusive scan of the new weights, the expression cumsum_kernel uses: L = excl + s_p
-            double* lb = scan_out + (int64_t)b * N;
-            if (i0 + 3 < N && (N & 1) == 0) {
-                store_out2<4>(lb + i0, excl + sc[0], excl + sc[1]);
-                store_out2<4>(lb + i0 + 2, excl + sc[2], excl + sc[3]);
-            } else {
-#pragma unroll
-                for (int p = 0; p < kPerThread; ++p)
-                    if (i0 + p < N) lb[i0 + p] = excl + sc[p];
-            }
+        if (kScanOut) {
+            // ... and this thread's exclusive prefix inside the tile: with the four weights it gives back the tile-local
+            // cumulative weights excl + s_p, the expression cumsum_kernel uses (8 bytes per 4 particles)
+            scan_out[((int64_t)b * T + tile_id) * kBlock + tid] = excl;
         }
     }
     GSE_STAMP(10);
