@@ -355,7 +355,7 @@ __device__ __forceinline__ double dpp_or_zero(double v) {
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
-constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;
 
 // Inclusive scan across the 64 lanes of a wavefront: four shift-and-add steps inside each row of 16 lanes, then the row
 // totals are handed on (lane 15 of rows 0 and 2 to rows 1 and 3, lane 31 to rows 2 and 3).  Fixed association -- every
@@ -372,6 +372,8 @@ __device__ __forceinline__ double wave_inclusive_scan(double v, int /*lane*/) {
 // the value of the lane below (lane 0: 0)
 __device__ __forceinline__ double wave_shift_up1(double v) { return dpp_or_zero<kDppWaveShr1, 0xf>(v); }
 __device__ __forceinline__ uint32_t wave_shift_up1(uint32_t v) { return dpp_or_zero<kDppWaveShr1, 0xf>(v); }
+// the value of the lane above (lane 63: 0)
+__device__ __forceinline__ uint32_t wave_shift_down1(uint32_t v) { return dpp_or_zero<kDppWaveShl1, 0xf>(v); }
 
 // Sum over the 256-thread workgroup; result valid in every thread.  lds: >= 4 doubles.
 __device__ __forceinline__ double block_sum(double v, double* lds) {

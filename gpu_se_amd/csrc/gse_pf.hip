@@ -128,16 +128,15 @@ __device__ __forceinline__ int xcd_contiguous_tile(unsigned bx, int T) {
 #endif
 
 #ifndef GSE_WT_STORES
-#define GSE_WT_STORES 0          // bit mask of step-kernel outputs stored write-through (sc1): 1 states, 2 weights, 4 scans
+#define GSE_WT_STORES 7          // bit mask of step-kernel outputs stored write-through (sc1): 1 states, 2 weights, 4 tile prefixes
 #endif
-// Output stores of the step kernel.  A launch at N = 2^20 writes 33 MB; what stays dirty in the eight L2s is written back
+// Output stores of the step kernel.  A launch at N = 2^20 writes 27 MB; what stays dirty in the eight L2s is written back
 // by the release at the END of the kernel, a serial tail (tools/micro/store_tail.hip: 32 MB of plain stores trail a
-// launch by +2.9 us, write-through ones by +0.7).  But the next launch re-reads the states and the scans from the L2
-// of the XCD that wrote them (XCD-contiguous tiles), and write-through stores drop their lines: measured, the lost hits
-// cost more than the tail (all outputs write-through: 29.2 us against 27.7; scans alone +2.5 us), and dword-wide
-// write-through stores inflate the bytes written to HBM (weights only: WRITE_SIZE 45 MB per launch instead of 33.5 for a
-// gain inside the noise).  Off by default; kept as a knob.  Relaxed agent-scope
-// atomic stores are plain `global_store ... sc1` instructions, counted and padded by the compiler.
+// launch by +2.9 us, write-through ones by +0.7).  Write-through stores drop their lines from the L2, so the next launch
+// finds less of its input there: in round 1, when the gather stage re-read 16-24 B per particle of stored scans, the lost
+// hits cost more than the tail (29.2 us against 27.7); with the inverse-map gather (4-8 B of weights + 2-4 B of tile
+// prefixes per particle) the tail is the larger term: all outputs write-through 20.6 us against 21.9 (r02 A/B, knob kept).
+// Relaxed agent-scope atomic stores are plain `global_store ... sc1` instructions, counted and padded by the compiler.
 template <int kBit>
 __device__ __forceinline__ void store_out(float* p, float v) {
     if constexpr ((GSE_WT_STORES & kBit) != 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -207,9 +206,14 @@ __device__ __forceinline__ void expand_tile(const OffspringCount& F, const doubl
         const double x = (k0 + p >= tile_last) ? P1 : fmin(P0 + (excl + sc[p]), P1);
         es[p] = min(max(F(x) - j0, 0), (int32_t)kTile);
     }
+    // Only the LAST key of a run of equal slots needs to speak (it has the largest index).  Runs are folded inside the thread
+    // and across the lanes of the wavefront (the next lane holds the next four keys): in a stretch of light particles
+    // hundreds of consecutive keys share a slot, and their atomics on one LDS address would be served one by one.
+    const uint32_t next_first = wave_shift_down1((uint32_t)es[0] + 1u);          // (0 in lane 63: nothing known -> speak)
 #pragma unroll
     for (int p = 0; p < kPerThread; ++p) {
-        const bool last_of_run = (p == kPerThread - 1) ? true : (k0 + p == tile_last || es[(p + 1) % kPerThread] != es[p]);
+        const bool last_of_run = k0 + p == tile_last ||
+                                 ((p == kPerThread - 1) ? (next_first != (uint32_t)es[p] + 1u) : (es[(p + 1) % kPerThread] != es[p]));
         if (k0 + p <= tile_last && es[p] < kTile && last_of_run) atomicMax(&mark[es[p]], (uint32_t)(k0 + p) + 1u);
     }
 }
@@ -283,6 +287,17 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     GSE_STAMP(0);
     GSE_BLOCK_TIME(0);
     if (kGather) GSE_PRIO_MEM();
+    // SCAN_IN: this thread's chunk of the tile sums (the scan modes run up to 2048 tiles, so at most 8), requested before
+    // anything else -- also before an early noise draw, which then covers their latency
+    constexpr int kMaxChunk = 8;
+    double sv[kMaxChunk];
+    if (kScanIn) {
+        const double* sums = scan_in_sums + (int64_t)b * T;
+        const int m = (T + kBlock - 1) / kBlock;
+        const int qlo = tid * m;
+#pragma unroll
+        for (int i = 0; i < kMaxChunk; ++i) sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
+    }
     if (kDraw) __syncthreads();                          // dp staged
     if (kDraw && draw_at == 0) draw_all();
     GSE_STAMP(1);
@@ -298,16 +313,10 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     if (kGather) {
         double W;
         if (kScanIn) {
-            // tile prefix into LDS: thread j owns chunk [j*m, (j+1)*m) of the tile sums (as inline_tile_prefix).  The scan
-            // modes run up to 2048 tiles, so a chunk has at most 8 sums: all loads are issued at once and the values stay
-            // in registers for the second sweep (one memory latency instead of 2 m dependent ones).
-            const double* sums = scan_in_sums + (int64_t)b * T;
+            // tile prefix into LDS: thread j owns chunk [j*m, (j+1)*m) of the tile sums (as inline_tile_prefix); the sums were
+            // loaded at kernel entry and stay in registers for the second sweep
             const int m = (T + kBlock - 1) / kBlock;
             const int qlo = tid * m;
-            constexpr int kMaxChunk = 8;
-            double sv[kMaxChunk];
-#pragma unroll
-            for (int i = 0; i < kMaxChunk; ++i) sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
             if (kInvMap) {
                 *reinterpret_cast<uint4*>(&mark[tid * kPerThread]) = make_uint4(0u, 0u, 0u, 0u);
                 if (tid == 0) act_n = 0;
@@ -369,10 +378,16 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             const bool direct = tl1 - tl0 < 2;                                     // workgroup-uniform
             int n_act = tl1 - tl0 + 1;
             if (!direct) {
-                for (int q = tl0 + tid; q <= tl1; q += kBlock) {
-                    const int32_t e0 = slot_of(pfx_s[q]), e1 = slot_of(pfx_s[q + 1]);
+                for (int q0 = tl0; q0 <= tl1; q0 += kBlock) {                       // (whole wavefronts take part: DPP below)
+                    const int q = q0 + tid;
+                    const bool have = q <= tl1;
+                    const int32_t e0 = have ? slot_of(pfx_s[q]) : 0, e1 = have ? slot_of(pfx_s[q + 1]) : -1;
+                    // a run of tiles that all fall into one slot: the last of the run speaks for it
+                    const uint32_t next_e1 = wave_shift_down1((uint32_t)(e1 + 2));     // (0 in lane 63 -> speak)
+                    if (!have) continue;
                     if (e0 == e1) {
-                        if (e1 < kTile) atomicMax(&mark[e1], (uint32_t)(min((int64_t)(q + 1) * kTile, N) - 1) + 1u);
+                        if (e1 < kTile && next_e1 != (uint32_t)(e1 + 2))
+                            atomicMax(&mark[e1], (uint32_t)(min((int64_t)(q + 1) * kTile, N) - 1) + 1u);
                     } else {
                         act_list[atomicAdd(&act_n, 1)] = q;                        // at most 1024: the slots e0 < e1 are disjoint
                     }
@@ -778,7 +793,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         if (kScanOut) {
             // ... and this thread's exclusive prefix inside the tile: with the four weights it gives back the tile-local
             // cumulative weights excl + s_p, the expression cumsum_kernel uses (8 bytes per 4 particles)
-            scan_out[((int64_t)b * T + tile_id) * kBlock + tid] = excl;
+            double* qo = scan_out + ((int64_t)b * T + tile_id) * kBlock + tid;
+            if constexpr ((GSE_WT_STORES & 4) != 0) __hip_atomic_store(qo, excl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *qo = excl;
         }
     }
     GSE_STAMP(10);
