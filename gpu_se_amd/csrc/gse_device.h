@@ -542,24 +542,34 @@ struct OffspringCount {
         const double jr = (double)j + r;
         return pow2 ? jr * invN : jr / Nd;
     }
-    __device__ __forceinline__ int32_t operator()(double x) const {
+    // The arithmetic part: candidate J = floor(x N / W - r) (the count is J + 1) and whether the guard band was hit.  Straight-
+    // line code: callers evaluate several keys side by side and settle the rare hits afterwards, in one branch.
+    __device__ __forceinline__ int32_t candidate(double x, bool& near) const {
         const double s = fma(x, NoverW, -r);
         const double fl = floor(s);
         const double frac = s - fl;
-        int32_t J = (int32_t)fl;                                     // s lies in [-1, N]: fits
-        if (!(frac >= guard && frac <= 1.0 - guard)) {               // (NaN lands here too)
+        near = !(frac >= guard && frac <= 1.0 - guard);                  // (NaN lands here too)
+        return (int32_t)fl;                                              // s lies in [-1, N]: fits
+    }
+    // ... and the exact one, for a key inside the guard band: the reference's comparison on the correctly rounded quotient
+    __device__ __forceinline__ int32_t settle(double x, int32_t J) const {
 #ifdef GSE_STAMPS
-            atomicAdd(&g_slow_hits, 1ull);
+        atomicAdd(&g_slow_hits, 1ull);
 #endif
-            const double c = x / W;
-            J = min(max(J, -1), N - 1);
+        const double c = x / W;
+        J = min(max(J, -1), N - 1);
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
-                if (J + 1 < N && u_of(J + 1) <= c) ++J;
+        for (int it = 0; it < 2; ++it)
+            if (J + 1 < N && u_of(J + 1) <= c) ++J;
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
-                if (J >= 0 && u_of(J) > c) --J;
-        }
+        for (int it = 0; it < 2; ++it)
+            if (J >= 0 && u_of(J) > c) --J;
+        return J;
+    }
+    __device__ __forceinline__ int32_t operator()(double x) const {
+        bool near;
+        int32_t J = candidate(x, near);
+        if (near) J = settle(x, J);
         return J + 1;
     }
 };

@@ -190,9 +190,12 @@ __device__ __forceinline__ void store_out4(float* p, v4f_t v) {                 
 // tile's weights (s_p: running sums of the thread's four) and the thread's exclusive prefix `excl` inside the tile, which the
 // update stage that produced the weights left behind (8 bytes per 4 particles).  Every key whose slot e = clamp(F(x) - j0, 0,
 // 1024) is below 1024 raises mark[e] to k + 1 (LDS atomic max; a thread's equal neighbours are folded first).  No barrier.
-__device__ __forceinline__ void expand_tile(const OffspringCount& F, const double* pfx_s, uint32_t* mark, int64_t N,
-                                            int32_t j0, int tq, const float4 wv, double excl) {
-    const int64_t k0 = (int64_t)tq * kTile + (int64_t)threadIdx.x * kPerThread;
+// kNeighbours: the lanes of the wavefront hold consecutive quads of one tile (t = threadIdx.x), so runs of equal slots are
+// folded across lanes too; false: the lanes hold unrelated quads (the work list of a wide ancestor range).
+template <bool kNeighbours>
+__device__ __forceinline__ void expand_quad(const OffspringCount& F, const double* pfx_s, uint32_t* mark, int64_t N,
+                                            int32_t j0, int tq, int t, const float4 wv, double excl) {
+    const int64_t k0 = (int64_t)tq * kTile + (int64_t)t * kPerThread;
     double sc[kPerThread];
     sc[0] = (k0 + 0 < N) ? (double)wv.x : 0.0;
     sc[1] = sc[0] + ((k0 + 1 < N) ? (double)wv.y : 0.0);
@@ -200,16 +203,27 @@ __device__ __forceinline__ void expand_tile(const OffspringCount& F, const doubl
     sc[3] = sc[2] + ((k0 + 3 < N) ? (double)wv.w : 0.0);
     const double P0 = pfx_s[tq], P1 = pfx_s[tq + 1];
     const int64_t tile_last = min((int64_t)(tq + 1) * kTile, N) - 1;
+    // the four counts side by side (independent chains), the rare guard-band hits settled afterwards
+    double xs[kPerThread];
     int32_t es[kPerThread];
+    bool near[kPerThread];
 #pragma unroll
     for (int p = 0; p < kPerThread; ++p) {
-        const double x = (k0 + p >= tile_last) ? P1 : fmin(P0 + (excl + sc[p]), P1);
-        es[p] = min(max(F(x) - j0, 0), (int32_t)kTile);
+        xs[p] = (k0 + p >= tile_last) ? P1 : fmin(P0 + (excl + sc[p]), P1);
+        es[p] = F.candidate(xs[p], near[p]);
     }
+    if (near[0] || near[1] || near[2] || near[3]) {
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p)
+            if (near[p]) es[p] = F.settle(xs[p], es[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p) es[p] = min(max(es[p] + 1 - j0, 0), (int32_t)kTile);
     // Only the LAST key of a run of equal slots needs to speak (it has the largest index).  Runs are folded inside the thread
     // and across the lanes of the wavefront (the next lane holds the next four keys): in a stretch of light particles
     // hundreds of consecutive keys share a slot, and their atomics on one LDS address would be served one by one.
-    const uint32_t next_first = wave_shift_down1((uint32_t)es[0] + 1u);          // (0 in lane 63: nothing known -> speak)
+    uint32_t next_first = 0u;                                                     // (0: nothing known -> speak)
+    if (kNeighbours) next_first = wave_shift_down1((uint32_t)es[0] + 1u);         // (0 in lane 63)
 #pragma unroll
     for (int p = 0; p < kPerThread; ++p) {
         const bool last_of_run = k0 + p == tile_last ||
@@ -241,6 +255,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     __shared__ __attribute__((aligned(16))) uint32_t mark[kInvMap ? kTile : 4];     // inverse map: see the gather stage
     __shared__ int32_t act_list[kInvMap ? kTile : 1];
     __shared__ int32_t act_n;
+    constexpr int kWorkMax = 1280;                 // quads of a wide ancestor range that need their four keys looked at
+    __shared__ uint32_t work[kInvMap ? kWorkMax : 1];
+    __shared__ int32_t work_n;
     __shared__ __attribute__((aligned(16))) float wtile[(kStrided && kUpdate) ? kTile : 4];
     __shared__ int64_t span[2];
     __shared__ double red[4];
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             const int qlo = tid * m;
             if (kInvMap) {
                 *reinterpret_cast<uint4*>(&mark[tid * kPerThread]) = make_uint4(0u, 0u, 0u, 0u);
-                if (tid == 0) act_n = 0;
+                if (tid == 0) { act_n = 0; work_n = 0; }
             }
             double chunk = 0.0;
 #pragma unroll
@@ -397,24 +414,94 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             }
             auto tile_at = [&](int i) { return direct ? tl0 + i : act_list[i]; };
             const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            int t0 = (n_act > 0) ? tile_at(0) : 0, t1 = (n_act > 1) ? tile_at(1) : 0;
-            float4 c0 = zero4, c1 = zero4;
-            double x0 = 0.0, x1 = 0.0;
-            if (n_act > 0) { c0 = tile_weights(t0); x0 = qx[t0 * kBlock + tid]; }
-            if (n_act > 1) { c1 = tile_weights(t1); x1 = qx[t1 * kBlock + tid]; }
-            if (kDraw && draw_at == 2) {
-                draw_all();
-                drawn2 = true;
+#ifndef GSE_EXPAND_ALL
+#define GSE_EXPAND_ALL 32
+#endif
+            constexpr int kExpandAll = GSE_EXPAND_ALL;         // up to this many tiles: every key is looked at
+            bool all_keys = n_act <= kExpandAll;                                   // workgroup-uniform
+            if (!all_keys) {
+                // Many tiles, each with only a few of this workgroup's outputs (a long stretch of light particles): going
+                // through all their keys is work in proportion to the stretch, although at most 1024 slot boundaries exist.
+                // A second census, per quad: the keys of thread t's quad lie between its exclusive prefix and the next
+                // thread's (up to the roundings of the scans, ~2^-49 of the tile sum); when both ends land in one slot, at
+                // a safe distance (N 2^-44, 16 times the guard of the exact count) from the slot boundaries, so do the four
+                // keys, and the quad's last key speaks for them.  The other quads -- at most one per boundary -- go on a work
+                // list and get the full treatment, densely packed.
+                const double qguard = F.Nd * 0x1p-44;
+                bool overflow = false;
+                // (the prefixes of the next two tiles are requested before this one is looked at)
+                const int tnext = min(tid + 1, kBlock - 1);
+                auto quad_prefixes = [&](int i, double& p0, double& p1) {
+                    if (i < n_act) {
+                        const double* qt = qx + (int64_t)act_list[i] * kBlock;
+                        p0 = qt[tid];
+                        p1 = qt[tnext];
+                    }
+                };
+                double b0 = 0.0, b1 = 0.0, c0_ = 0.0, c1_ = 0.0;
+                quad_prefixes(0, b0, b1);
+                quad_prefixes(1, c0_, c1_);
+                for (int i = 0; i < n_act; ++i) {
+                    const int tq = act_list[i];
+                    const double P0 = pfx_s[tq], P1 = pfx_s[tq + 1];
+                    const int64_t k0 = (int64_t)tq * kTile + (int64_t)tid * kPerThread;
+                    const int64_t tile_last = min((int64_t)(tq + 1) * kTile, N) - 1;
+                    const bool have = k0 <= tile_last;
+                    const double a0 = b0, a1 = b1;
+                    b0 = c0_; b1 = c1_;
+                    quad_prefixes(i + 2, c0_, c1_);
+                    const double xb = fmin(P0 + a0, P1);                           // (quad 0: its exclusive prefix is 0 -> P0)
+                    const double xe = (tid == kBlock - 1 || k0 + kPerThread - 1 >= tile_last) ? P1 : fmin(P0 + a1, P1);
+                    const double sb = fma(xb, F.NoverW, -F.r), se = fma(xe, F.NoverW, -F.r);
+                    const double fb = floor(sb), fe = floor(se);
+                    const bool safe = (sb - fb >= qguard) && (sb - fb <= 1.0 - qguard) && (se - fe >= qguard) &&
+                                      (se - fe <= 1.0 - qguard);
+                    const int32_t eb = min(max((int32_t)fb + 1 - j0, 0), (int32_t)kTile);
+                    const int32_t ee = min(max((int32_t)fe + 1 - j0, 0), (int32_t)kTile);
+                    const bool uniform = have && safe && eb == ee;
+                    // (fold: the next lane's quad is uniform with the same slot -> it, or a later one, speaks)
+                    const uint32_t next_tag = wave_shift_down1(uniform ? (uint32_t)ee + 1u : 0u);
+                    if (uniform) {
+                        if (ee < kTile && next_tag != (uint32_t)ee + 1u)
+                            atomicMax(&mark[ee], (uint32_t)min(k0 + kPerThread - 1, tile_last) + 1u);
+                    } else if (have) {
+                        const int at = atomicAdd(&work_n, 1);
+                        if (at < kWorkMax) work[at] = (uint32_t)tq * (uint32_t)kBlock + (uint32_t)tid;
+                        else overflow = true;
+                    }
+                }
+                // (an overflowing work list cannot happen short of ~250 quads inside the safety band at once; if it does,
+                //  every key is looked at instead -- marks are maxima, doing some twice changes nothing)
+                all_keys = __syncthreads_or(overflow ? 1 : 0) != 0;
             }
-            for (int i = 0; i < n_act; i += 2) {
-                const int u0 = (i + 2 < n_act) ? tile_at(i + 2) : 0, u1 = (i + 3 < n_act) ? tile_at(i + 3) : 0;
-                float4 n0 = zero4, n1 = zero4;
-                double y0 = 0.0, y1 = 0.0;
-                if (i + 2 < n_act) { n0 = tile_weights(u0); y0 = qx[u0 * kBlock + tid]; }
-                if (i + 3 < n_act) { n1 = tile_weights(u1); y1 = qx[u1 * kBlock + tid]; }
-                expand_tile(F, pfx_s, mark, N, j0, t0, c0, x0);
-                if (i + 1 < n_act) expand_tile(F, pfx_s, mark, N, j0, t1, c1, x1);
-                c0 = n0; c1 = n1; x0 = y0; x1 = y1; t0 = u0; t1 = u1;
+            if (all_keys) {
+                int t0 = (n_act > 0) ? tile_at(0) : 0, t1 = (n_act > 1) ? tile_at(1) : 0;
+                float4 c0 = zero4, c1 = zero4;
+                double x0 = 0.0, x1 = 0.0;
+                if (n_act > 0) { c0 = tile_weights(t0); x0 = qx[t0 * kBlock + tid]; }
+                if (n_act > 1) { c1 = tile_weights(t1); x1 = qx[t1 * kBlock + tid]; }
+                if (kDraw && draw_at == 2) {
+                    draw_all();
+                    drawn2 = true;
+                }
+                for (int i = 0; i < n_act; i += 2) {
+                    const int u0 = (i + 2 < n_act) ? tile_at(i + 2) : 0, u1 = (i + 3 < n_act) ? tile_at(i + 3) : 0;
+                    float4 n0 = zero4, n1 = zero4;
+                    double y0 = 0.0, y1 = 0.0;
+                    if (i + 2 < n_act) { n0 = tile_weights(u0); y0 = qx[u0 * kBlock + tid]; }
+                    if (i + 3 < n_act) { n1 = tile_weights(u1); y1 = qx[u1 * kBlock + tid]; }
+                    expand_quad<true>(F, pfx_s, mark, N, j0, t0, tid, c0, x0);
+                    if (i + 1 < n_act) expand_quad<true>(F, pfx_s, mark, N, j0, t1, tid, c1, x1);
+                    c0 = n0; c1 = n1; x0 = y0; x1 = y1; t0 = u0; t1 = u1;
+                }
+            } else {
+                const int n_work = min(work_n, kWorkMax);
+                for (int i = tid; i < n_work; i += kBlock) {
+                    const uint32_t id = work[i];
+                    const int tq = (int)(id / (uint32_t)kBlock), t = (int)(id % (uint32_t)kBlock);
+                    const float4 wv = load_weights4(wrow, (int64_t)tq * kTile + (int64_t)t * kPerThread, N, ld);
+                    expand_quad<false>(F, pfx_s, mark, N, j0, tq, t, wv, qx[id]);
+                }
             }
     GSE_STAMP(3);
 #ifdef GSE_STAMPS
