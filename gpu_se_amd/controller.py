@@ -153,8 +153,23 @@ class MPC:
                                       "(bound fewer outputs / moves, or shorten the horizons)" % (m, MAX_ROWS))
         Cin = numpy.array(rows_d).reshape(m, nd)
         Pin = numpy.array(rows_t).reshape(m, nt)
-        chol = numpy.linalg.cholesky(Hc)
-        solve = lambda rhs: numpy.linalg.solve(chol.T, numpy.linalg.solve(chol, rhs))
+        try:
+            chol = numpy.linalg.cholesky(Hc)
+            solve = lambda rhs: numpy.linalg.solve(chol.T, numpy.linalg.solve(chol, rhs))
+        except numpy.linalg.LinAlgError:
+            # R = 0 with D = 0 (the reference's tank tests): the last move du_M enters no state and no output, so the cost
+            # is flat along it and Hc is only positive SEMI-definite.  OSQP copes (any minimiser will do); here the
+            # minimiser of least norm is taken -- du_0 and y_1, all the loop uses, are the same for every minimiser as
+            # long as no bounded row pulls along a flat direction (refused below).
+            evals, evecs = numpy.linalg.eigh((Hc + Hc.T) / 2)
+            curved = evals > 1e-12 * evals.max()
+            if not curved.any() or evals.min() < -1e-9 * evals.max():
+                raise
+            if m and numpy.max(numpy.abs(Cin @ evecs[:, ~curved])) > 1e-9:
+                raise NotImplementedError("a bounded row acts along a direction in which the MPC cost is flat (R is "
+                                          "singular there): give those moves a weight")
+            pinv = (evecs[:, curved] / evals[curved]) @ evecs[:, curved].T
+            solve = lambda rhs: pinv @ rhs
         HiF, Hif0, HiCt = solve(F), solve(f0), solve(Cin.T)
         law = dict(
             Gc=-Cin @ HiF + Pin, gc0=-Cin @ Hif0, S=Cin @ HiCt, lo=numpy.array(lo, dtype=float), hi=numpy.array(hi, dtype=float),

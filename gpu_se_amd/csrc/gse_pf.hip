@@ -245,8 +245,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     // draw are shared by the four particles a thread owns in THIS mapping (gse_device.h, rng_block_of_group)
     constexpr bool kStrided = GSE_GATHER_STRIDED && (kGather || kDraw);
     static_assert(!kDraw || kStrided, "the grouped draw needs the strided mapping");
-    constexpr bool kDevIO = (kScan & 4) != 0;      // u / z may come from device memory (variants without gather only:
-    static_assert(!kDevIO || !kGather, "");         //  the fused gather kernel has no registers to spare for them)
+    constexpr bool kDevIO = (kScan & 4) != 0;      // u / z may come from device memory (a closed loop on the device)
     static_assert(!kScanIn || kGather, "SCAN_IN belongs to the gather stage");
     static_assert(!kScanOut || kUpdate, "SCAN_OUT belongs to the update stage");
     __shared__ DrawParams dp;
@@ -1265,6 +1264,9 @@ bool step_pick_scan(int scan, const StepLaunch& L) {
         if (scan == 4) { step_go<G, P, I, U, ND, 4>(L); return true; }
         if constexpr (kScanOk && U) if (scan == 6) { step_go<G, P, I, U, ND, 6>(L); return true; }
     }
+    if constexpr (G && P && !I && U && kScanOk) {                // ... also in the single-launch cycle (resident closed loop)
+        if (scan == 7) { step_go<G, P, I, U, ND, 7>(L); return true; }
+    }
     return false;
 }
 template <bool G, bool P, bool I, bool U>
@@ -1312,8 +1314,10 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const bool u_on_device = (ops & GSE_OP_U_DEVICE) != 0, z_on_device = (ops & GSE_OP_Z_DEVICE) != 0;
     GSE_REQUIRE(!u_on_device || (P && u), "%s: GSE_OP_U_DEVICE needs GSE_OP_PREDICT and a device pointer u", fn);
     GSE_REQUIRE(!z_on_device || (U && z), "%s: GSE_OP_Z_DEVICE needs GSE_OP_UPDATE and a device pointer z", fn);
-    GSE_REQUIRE(!(u_on_device || z_on_device) || (!G && !noise),
-                "%s: device-resident u / z are not available in a launch that gathers or injects noise", fn);
+    GSE_REQUIRE(!(u_on_device || z_on_device) || !noise, "%s: device-resident u / z are not available with injected noise", fn);
+    GSE_REQUIRE(!(u_on_device || z_on_device) || !G || (P && U && scan == 3),
+                "%s: with a gather, device-resident u / z need the whole single-launch cycle (gather + predict + update, scans "
+                "in and out)", fn);
     pack_io(a.io, B, ((P || U) && !u_on_device ? u : nullptr), (U && !z_on_device ? z : nullptr));   // (g may read u)
     a.u_dev = u_on_device ? u : nullptr;
     a.z_dev = z_on_device ? z : nullptr;
