@@ -17,6 +17,8 @@
 // to feed the matrix cores (a 16x16x4 fp32 MFMA tile would be >90 % padding) and nowhere near a bound.
 #include "gse_host.h"
 
+#include <stdlib.h>
+
 namespace gse {
 
 constexpr int kGroup = 16;                       // lanes per Gaussian in the per-sigma-point parts
@@ -26,7 +28,6 @@ constexpr int kGaussPerBlock = kBlock / kGroup;  // 16 (gsukf_sigma_kernel only)
 #endif
 constexpr int kWideBank = GSE_GSUKF_WIDE_BANK;   // Gaussians per workgroup of the separate predict / update kernels
 constexpr int kBank = 64;                        // Gaussians per workgroup of the one-launch cycle kernel
-constexpr int kBankBlock = kBank * kGroup;       // 1024 threads
 constexpr int kFacStride = 21;                   // LDS row: m[5], L[15] (+1: odd stride)
 constexpr int kTileStride = GSE_NSIGMA * 5 + 2;  // 57 floats
 constexpr int kEtaStride = GSE_NSIGMA * 2 + 1;   // 23 doubles
@@ -37,6 +38,9 @@ __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) 
 // Cholesky factor of a symmetric 5x5 matrix given by its packed lower triangle (fp32, like LAPACK spotrf on
 // the fp32 covariances).  Returns false when a pivot is not positive.
 __device__ __forceinline__ bool chol5(const float (&A)[15], float (&L)[15]) {
+    // (no contraction into FMAs left to the compiler: the same source inlined into different kernels must give the same
+    //  bits, and whether `s - a * b` is fused depends on the surrounding code)
+#pragma clang fp contract(off)
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -130,6 +134,37 @@ struct GsukfPredictArgs {
     double dt;
 };
 
+// Mean and covariance of the 11 propagated sigma points of one Gaussian (filter/gs_ukf.py:96-103), shared by every
+// kernel that predicts: mean = (sum_j sigma_j w_j) / sum(w) in fp32, j in order, no FMA contraction (numpy.average);
+// P = sum_j d_j (d_j w_j)^T entry by entry of the upper triangle, mirrored.  P_o: 25 floats, row-major.
+__device__ __forceinline__ void sigma_mean_cov(const float (&sg)[GSE_NSIGMA * 5], const SigmaWeights& sw, float (&mean)[5],
+                                               float* P_o) {
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float acc = sg[k] * sw.w[0];
+#pragma unroll
+            for (int q = 1; q < GSE_NSIGMA; ++q) acc = acc + sg[q * 5 + k] * sw.w[q];
+            mean[k] = acc / sw.scl32;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int c = r; c < 5; ++c) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < GSE_NSIGMA; ++q) {
+                const float dr = sg[q * 5 + r] - mean[r];
+                const float dc = sg[q * 5 + c] - mean[c];
+                acc = fmaf(dr, dc * sw.w[q], acc);
+            }
+            P_o[r * 5 + c] = acc;
+            P_o[c * 5 + r] = acc;
+        }
+}
+
 // Phase A of predict and update: lane t < nloc of the workgroup factorises local Gaussian t and leaves (m, L) in fac[t].
 // Src: t -> (mu pointer, P pointer); global memory or LDS.  Ends with a workgroup barrier.
 template <class Src>
@@ -194,35 +229,10 @@ __device__ __forceinline__ void gsukf_predict_block(Src src, Dst dst, float (*fa
         float sg[GSE_NSIGMA * 5];
 #pragma unroll
         for (int i = 0; i < GSE_NSIGMA * 5; ++i) sg[i] = tile[t][i];
-        // mean = (sum_j sigma_j * w_j) / sum(w)  -- fp32, j in order, no FMA contraction  (numpy.average)
         float mean[5];
-        {
-#pragma clang fp contract(off)
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                float acc = sg[k] * a.sw.w[0];
-#pragma unroll
-                for (int q = 1; q < GSE_NSIGMA; ++q) acc = acc + sg[q * 5 + k] * a.sw.w[q];
-                mean[k] = acc / a.sw.scl32;
-            }
-        }
         float *mu_o, *P_o;
         dst(t, mu_o, P_o);
-        // P = sum_j d_j (d_j w_j)^T, entry by entry of the upper triangle, mirrored
-#pragma unroll
-        for (int r = 0; r < 5; ++r)
-#pragma unroll
-            for (int c = r; c < 5; ++c) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int q = 0; q < GSE_NSIGMA; ++q) {
-                    const float dr = sg[q * 5 + r] - mean[r];
-                    const float dc = sg[q * 5 + c] - mean[c];
-                    acc = fmaf(dr, dc * a.sw.w[q], acc);
-                }
-                P_o[r * 5 + c] = acc;
-                P_o[c * 5 + r] = acc;
-            }
+        sigma_mean_cov(sg, a.sw, mean, P_o);
 #pragma unroll
         for (int k = 0; k < 5; ++k) mu_o[k] = mean[k];
     }
@@ -263,6 +273,7 @@ struct GsukfUpdateArgs {
 // Pseudo-inverse of a symmetric 2x2 matrix with numpy.linalg.pinv's default cut-off (singular values
 // <= 1e-15 * largest are dropped; filter/gs_ukf.py:132).
 __device__ __forceinline__ void pinv_sym2(double a, double s, double d, double (&X)[2][2]) {
+#pragma clang fp contract(off)
     const double half_tr = 0.5 * (a + d);
     const double disc = sqrt(0.25 * (a - d) * (a - d) + s * s);
     const double big = (fabs(half_tr + disc) >= fabs(half_tr - disc)) ? half_tr + disc : half_tr - disc;
@@ -282,6 +293,93 @@ __device__ __forceinline__ void pinv_sym2(double a, double s, double d, double (
         const double sc = (n2 > 0.0) ? 1.0 / (n2 * big) : 0.0;
         X[0][0] = v0 * v0 * sc; X[0][1] = v0 * v1 * sc; X[1][0] = X[0][1]; X[1][1] = v1 * v1 * sc;
     }
+}
+
+// The per-Gaussian algebra of the update (filter/gs_ukf.py:116-149): eta_mean, P_yy, P_xy in fp64 with j in order (the CPU
+// class keeps the etas in fp64), K = P_xy pinv(P_yy), mu += K (z - eta_mean), P -= (K P_yy) K^T, w *= pdf(z - g(mu_new)).
+// eta(q, c): output c of sigma point q (fp64); dev(q, k): sigma_q[k] - mu[k] (fp32); m: the prior mean; P_in / P_o: 25 floats
+// row-major (may be the same memory: every entry is read before it is written).  kUnrolled: the 11-term loop is unrolled
+// (operands in registers) or kept as a loop (operands in LDS: unrolled, the compiler hoists all 77 reads and spills).
+// One definition for every kernel that updates, so they agree to the bit.
+template <bool kUnrolled, class Eta, class Dev>
+__device__ __forceinline__ void gsukf_update_gaussian(Eta eta, Dev dev, const float* m, const float* P_in, float* mu_o,
+                                                      float* P_o, const float* w_in, float* w_out, double z0, double z1,
+                                                      const Pdf2& pdf, const SigmaWeights& sw) {
+    // (only the fma() calls written out below are fused: see chol5)
+#pragma clang fp contract(off)
+    double em[2];
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+#pragma clang fp contract(off)
+        double acc = eta(0, q2) * (double)sw.w[0];
+#pragma unroll
+        for (int q = 1; q < GSE_NSIGMA; ++q) acc = acc + eta(q, q2) * (double)sw.w[q];
+        em[q2] = acc / sw.scl64;
+    }
+    double pyy[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    double pxy[5][2];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) pxy[k][0] = pxy[k][1] = 0.0;
+    auto term = [&](int q) {
+        const double wq = (double)sw.w[q];
+        const double e0 = eta(q, 0) - em[0], e1 = eta(q, 1) - em[1];
+        const double ew0 = e0 * wq, ew1 = e1 * wq;
+        pyy[0][0] = fma(e0, ew0, pyy[0][0]);
+        pyy[0][1] = fma(e0, ew1, pyy[0][1]);
+        pyy[1][0] = fma(e1, ew0, pyy[1][0]);
+        pyy[1][1] = fma(e1, ew1, pyy[1][1]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const double dk = (double)dev(q, k);
+            pxy[k][0] = fma(dk, ew0, pxy[k][0]);
+            pxy[k][1] = fma(dk, ew1, pxy[k][1]);
+        }
+    };
+    if constexpr (kUnrolled) {
+#pragma unroll
+        for (int q = 0; q < GSE_NSIGMA; ++q) term(q);
+    } else {
+#pragma unroll 1
+        for (int q = 0; q < GSE_NSIGMA; ++q) term(q);
+    }
+    double X[2][2];
+    pinv_sym2(pyy[0][0], 0.5 * (pyy[0][1] + pyy[1][0]), pyy[1][1], X);
+    double K[5][2];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        K[k][0] = pxy[k][0] * X[0][0] + pxy[k][1] * X[1][0];
+        K[k][1] = pxy[k][0] * X[0][1] + pxy[k][1] * X[1][1];
+    }
+    const double i0 = z0 - em[0], i1 = z1 - em[1];
+    float mnew[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) mnew[k] = (float)((double)m[k] + (K[k][0] * i0 + K[k][1] * i1));
+    // P -= (K P_yy) K^T, entry (r, c) and its mirror (which uses (K P_yy)[c] . K[r]; identical when P_yy is symmetric to
+    // rounding).  Every entry is read before it is written, and by this lane only.
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const double t0 = K[r][0] * pyy[0][0] + K[r][1] * pyy[1][0];     // row r of K P_yy
+        const double t1 = K[r][0] * pyy[0][1] + K[r][1] * pyy[1][1];
+#pragma unroll
+        for (int c = r; c < 5; ++c) {
+            const float prc = (float)((double)P_in[r * 5 + c] - (t0 * K[c][0] + t1 * K[c][1]));
+            float pcr = prc;
+            if (r != c) {
+                const double u0 = K[c][0] * pyy[0][0] + K[c][1] * pyy[1][0];
+                const double u1 = K[c][0] * pyy[0][1] + K[c][1] * pyy[1][1];
+                pcr = (float)((double)P_in[c * 5 + r] - (u0 * K[r][0] + u1 * K[r][1]));
+            }
+            P_o[r * 5 + c] = prc;
+            if (r != c) P_o[c * 5 + r] = pcr;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) mu_o[k] = mnew[k];
+    // global update: w *= pdf(z - g(mu_new))
+    float y0, y1;
+    bioreactor_output(mnew[0], mnew[2], y0, y1);
+    const double lik = mixture_pdf2<0>(pdf, z0 - (double)y0, z1 - (double)y1);
+    *w_out = (float)((double)(*w_in) * lik);
 }
 
 // Update of the workgroup's nloc Gaussians, in place where src / dst point (global memory or LDS); weights are read
@@ -311,81 +409,12 @@ __device__ __forceinline__ void gsukf_update_block(Src src, Dst dst, Win w_in, W
     if (t >= nloc) return;
     const double* eta_g = eta[t];
     const float* dev_g = dev[t];
-    // eta_mean, P_yy, P_xy in fp64, j in order (the CPU class keeps etas in fp64: filter/gs_ukf.py:116-131)
-    double em[2];
-#pragma unroll
-    for (int q2 = 0; q2 < 2; ++q2) {
-#pragma clang fp contract(off)
-        double acc = eta_g[q2] * (double)sw.w[0];
-#pragma unroll
-        for (int q = 1; q < GSE_NSIGMA; ++q) acc = acc + eta_g[q * 2 + q2] * (double)sw.w[q];
-        em[q2] = acc / sw.scl64;
-    }
-    double pyy[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-    double pxy[5][2];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) pxy[k][0] = pxy[k][1] = 0.0;
-#pragma unroll 1          // (fully unrolled, the compiler hoists all 77 LDS reads of this loop and spills)
-    for (int q = 0; q < GSE_NSIGMA; ++q) {
-        const double wq = (double)sw.w[q];
-        const double e0 = eta_g[q * 2 + 0] - em[0], e1 = eta_g[q * 2 + 1] - em[1];
-        const double ew0 = e0 * wq, ew1 = e1 * wq;
-        pyy[0][0] = fma(e0, ew0, pyy[0][0]);
-        pyy[0][1] = fma(e0, ew1, pyy[0][1]);
-        pyy[1][0] = fma(e1, ew0, pyy[1][0]);
-        pyy[1][1] = fma(e1, ew1, pyy[1][1]);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const double dk = (double)dev_g[q * 5 + k];
-            pxy[k][0] = fma(dk, ew0, pxy[k][0]);
-            pxy[k][1] = fma(dk, ew1, pxy[k][1]);
-        }
-    }
-    double X[2][2];
-    pinv_sym2(pyy[0][0], 0.5 * (pyy[0][1] + pyy[1][0]), pyy[1][1], X);
-    double K[5][2];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        K[k][0] = pxy[k][0] * X[0][0] + pxy[k][1] * X[1][0];
-        K[k][1] = pxy[k][0] * X[0][1] + pxy[k][1] * X[1][1];
-    }
-    const double z0 = io.f[b].z0, z1 = io.f[b].z1;
-    const double i0 = z0 - em[0], i1 = z1 - em[1];
-    const float* m = fac[t];
-    float mnew[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) mnew[k] = (float)((double)m[k] + (K[k][0] * i0 + K[k][1] * i1));
-
-    // P -= (K P_yy) K^T, entry (r, c) and its mirror (which uses (K P_yy)[c] . K[r]; identical when P_yy is symmetric to
-    // rounding).  Every entry is read before it is written, and by this lane only.
     const float *mu_g, *P_g;
     src(t, mu_g, P_g);
     float *mu_o, *P_o;
     dst(t, mu_o, P_o);
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const double t0 = K[r][0] * pyy[0][0] + K[r][1] * pyy[1][0];     // row r of K P_yy
-        const double t1 = K[r][0] * pyy[0][1] + K[r][1] * pyy[1][1];
-#pragma unroll
-        for (int c = r; c < 5; ++c) {
-            const float prc = (float)((double)P_g[r * 5 + c] - (t0 * K[c][0] + t1 * K[c][1]));
-            float pcr = prc;
-            if (r != c) {
-                const double u0 = K[c][0] * pyy[0][0] + K[c][1] * pyy[1][0];
-                const double u1 = K[c][0] * pyy[0][1] + K[c][1] * pyy[1][1];
-                pcr = (float)((double)P_g[c * 5 + r] - (u0 * K[r][0] + u1 * K[r][1]));
-            }
-            P_o[r * 5 + c] = prc;
-            if (r != c) P_o[c * 5 + r] = pcr;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) mu_o[k] = mnew[k];
-    // global update: w *= pdf(z - g(mu_new))
-    float y0, y1;
-    bioreactor_output(mnew[0], mnew[2], y0, y1);
-    const double lik = mixture_pdf2<0>(pdf, z0 - (double)y0, z1 - (double)y1);
-    *w_out(t) = (float)((double)(*w_in(t)) * lik);
+    gsukf_update_gaussian<false>([&](int q, int c) { return eta_g[q * 2 + c]; }, [&](int q, int k) { return dev_g[q * 5 + k]; },
+                                 fac[t], P_g, mu_o, P_o, w_in(t), w_out(t), io.f[b].z0, io.f[b].z1, pdf, sw);
 }
 
 template <int kBankT>
@@ -406,6 +435,143 @@ __global__ __launch_bounds__(kBankT * kGroup) void gsukf_update_kernel(float* __
     auto dst = [&](int t, float*& m_, float*& p_) { m_ = mu_b + t * 5; p_ = P_b + t * 25; };
     gsukf_update_block(src, dst, [&](int t) { return (const float*)(w_b + t); }, [&](int t) { return w_b + t; }, fac, dev, eta,
                        nloc, b, status, a.io, a.pdf, a.sw);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large banks: ONE LANE PER GAUSSIAN.  The kernels above give a Gaussian 16 lanes for its 11 sigma points and one lane for
+// its algebra, handing over through LDS -- right for a few hundred Gaussians (parallelism is scarce, latency rules), wrong
+// for 2^18: the single-lane phases run in one wavefront of sixteen while the workgroup holds a whole CU (round 1: 143 us
+// per cycle, 0.17 of the HBM roofline).  Here a workgroup of 256 threads takes 256 Gaussians and a lane does everything for
+// its own: factorisation, the 11 sigma points one after the other (model step + noise draw, or output function), the
+// contractions -- all in registers, no hand-off, no barrier inside, every lane busy in every phase.  (mu, P) travel through
+// LDS only to make the global traffic coalesced: the workgroup's rows are one contiguous block of 256 x 120 bytes, staged
+// with stride 31 floats (conflict-free when a lane walks its row).  Same device functions, same sigma-point order and the
+// same random-number elements as the kernels above: results agree bit for bit.
+constexpr int kLaneBank = 256;
+constexpr int kStageStride = 31;                 // 5 + 25 floats per Gaussian, padded to an odd stride
+
+__device__ __forceinline__ void stage_bank_in(float* stage, const float* mu_b, const float* P_b, int nloc) {
+    for (int i = threadIdx.x; i < nloc * 5; i += kLaneBank) {
+        const int g = i / 5;
+        stage[g * kStageStride + (i - g * 5)] = mu_b[i];
+    }
+    for (int i = threadIdx.x; i < nloc * 25; i += kLaneBank) {
+        const int g = i / 25;
+        stage[g * kStageStride + 5 + (i - g * 25)] = P_b[i];
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void stage_bank_out(const float* stage, float* mu_b, float* P_b, int nloc) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nloc * 5; i += kLaneBank) {
+        const int g = i / 5;
+        mu_b[i] = stage[g * kStageStride + (i - g * 5)];
+    }
+    for (int i = threadIdx.x; i < nloc * 25; i += kLaneBank) {
+        const int g = i / 25;
+        P_b[i] = stage[g * kStageStride + 5 + (i - g * 25)];
+    }
+}
+
+#ifndef GSE_GSUKF_PRED_WAVES
+#define GSE_GSUKF_PRED_WAVES 1   // waves per SIMD the register allocator must leave room for (tuning knob)
+#endif
+#ifndef GSE_GSUKF_PRED_SERIAL
+#define GSE_GSUKF_PRED_SERIAL 0  // 1: a scheduling barrier between the sigma points of a lane (tuning knob)
+#endif
+template <bool kInjected>
+__global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict_lanes_kernel(float* __restrict__ mu, float* __restrict__ P,
+                                                                        const float* __restrict__ noise, int64_t N,
+                                                                        int32_t* __restrict__ status,
+                                                                        const GsukfPredictArgs a) {
+    __shared__ DrawParams dp;
+    __shared__ float stage[kLaneBank * kStageStride];
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
+    const int nloc = (int)min((int64_t)kLaneBank, N - g0);
+    float* mu_b = mu + ((int64_t)b * N + g0) * 5;
+    float* P_b = P + ((int64_t)b * N + g0) * 25;
+    if (!kInjected) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.draw);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
+        for (int i = t; i < (int)(sizeof(DrawParams) / 4); i += kLaneBank) dst[i] = src[i];
+    }
+    stage_bank_in(stage, mu_b, P_b, nloc);
+    if (t < nloc) {
+        float* mine = stage + t * kStageStride;
+        float m[5], L[15];
+        bool ok;
+        load_and_factor(mine, mine + 5, m, L, ok);
+        if (!ok && status) atomicAdd(status, 1);
+        float sg[GSE_NSIGMA * 5];
+#pragma unroll
+        for (int j = 0; j < GSE_NSIGMA; ++j) {
+            float s[5], e[5];
+            sigma_point(m, L, j, s);
+            bioreactor_step(s, a.io.f[b].u0, a.io.f[b].u1, a.dt);
+            if (kInjected) {
+                const float* nz = noise + (((int64_t)b * N + g0 + t) * GSE_NSIGMA + j) * 5;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) e[k] = nz[k];
+            } else {
+                uint32_t wd[8];
+                rng_words8(a.rng, (uint64_t)((g0 + t) * GSE_NSIGMA + j), (uint32_t)b, wd);
+                mixture_draw5(dp, wd, e);
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sg[j * 5 + k] = s[k] + e[k];
+#if GSE_GSUKF_PRED_SERIAL
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        float mean[5];
+        sigma_mean_cov(sg, a.sw, mean, mine + 5);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) mine[k] = mean[k];
+    }
+    stage_bank_out(stage, mu_b, P_b, nloc);
+}
+
+__global__ __launch_bounds__(kLaneBank) void gsukf_update_lanes_kernel(float* __restrict__ mu, float* __restrict__ P,
+                                                                       float* __restrict__ w, int64_t N,
+                                                                       int32_t* __restrict__ status, const GsukfUpdateArgs a) {
+    __shared__ float stage[kLaneBank * kStageStride];
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
+    const int nloc = (int)min((int64_t)kLaneBank, N - g0);
+    float* mu_b = mu + ((int64_t)b * N + g0) * 5;
+    float* P_b = P + ((int64_t)b * N + g0) * 25;
+    float* w_b = w + (int64_t)b * N + g0;
+    stage_bank_in(stage, mu_b, P_b, nloc);
+    if (t < nloc) {
+        float* mine = stage + t * kStageStride;
+        float m[5], L[15];
+        bool ok;
+        load_and_factor(mine, mine + 5, m, L, ok);
+        if (!ok && status) atomicAdd(status, 1);
+        // outputs of the 11 sigma points (fp64, as the kernels above keep them); the deviations sigma_j - mu are re-formed
+        // from the factor where the contraction needs them (a select and a subtraction) instead of being kept
+        double eta[GSE_NSIGMA][2];
+#pragma unroll
+        for (int j = 0; j < GSE_NSIGMA; ++j) {
+            float s[5], y0, y1;
+            sigma_point(m, L, j, s);
+            bioreactor_output(s[0], s[2], y0, y1);
+            eta[j][0] = (double)y0;
+            eta[j][1] = (double)y1;
+        }
+        float prior[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) prior[k] = m[k];
+        gsukf_update_gaussian<true>([&](int q, int c) { return eta[q][c]; },
+                                    [&](int q, int k) {
+                                        float s[5];
+                                        sigma_point(m, L, q, s);
+                                        return s[k] - m[k];
+                                    },
+                                    prior, mine + 5, mine, mine + 5, w_b + t, w_b + t, a.io.f[b].z0, a.io.f[b].z1, a.pdf, a.sw);
+    }
+    stage_bank_out(stage, mu_b, P_b, nloc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -573,6 +739,17 @@ static int pack_sigma_weights(SigmaWeights& sw, const float* w_sigma) {
     return 0;
 }
 
+// Which family of kernels: one lane per Gaussian once the bank fills the chip that way (256 CUs x 256 lanes = 2^16
+// Gaussians give every CU one workgroup); GSE_GSUKF_LANES=0 / 1 in the environment forces one or the other (tests, A/B).
+static bool lane_per_gaussian(int B, int64_t N) {
+    static const int forced = [] {
+        const char* e = getenv("GSE_GSUKF_LANES");
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0) return forced != 0;
+    return (int64_t)B * N >= (int64_t)1 << 16;
+}
+
 static int check_gsukf(const char* fn, int B, int64_t N) {
     GSE_REQUIRE(B >= 1 && B <= GSE_MAX_B, "%s: B = %d is outside 1..%d", fn, B, GSE_MAX_B);
     GSE_REQUIRE(N >= 1 && N < ((int64_t)1 << 31) / GSE_NSIGMA, "%s: N = %lld out of range", fn, (long long)N);
@@ -605,18 +782,20 @@ int gse_gsukf_predict(float* mu, float* P, int B, int64_t N, const double* u, do
     pack_io(a.io, B, u, nullptr);
     pack_sigma_weights(a.sw, w_sigma);
     a.dt = dt;
-    const unsigned gx = (unsigned)((N + kWideBank - 1) / kWideBank);
+    const bool lanes = lane_per_gaussian(B, N);
+    const unsigned gx = lanes ? (unsigned)((N + kLaneBank - 1) / kLaneBank) : (unsigned)((N + kWideBank - 1) / kWideBank);
+    const dim3 block(lanes ? kLaneBank : kWideBank * kGroup);
     if (noise) {
         a.draw = DrawParams{};
         a.rng = RngKey{};
-        hipLaunchKernelGGL((gsukf_predict_kernel<true, kWideBank>), dim3(gx, B), dim3(kWideBank * kGroup), 0,
-                           (hipStream_t)stream, mu, P, noise, N, status, a);
+        if (lanes) hipLaunchKernelGGL(gsukf_predict_lanes_kernel<true>, dim3(gx, B), block, 0, (hipStream_t)stream, mu, P, noise, N, status, a);
+        else hipLaunchKernelGGL((gsukf_predict_kernel<true, kWideBank>), dim3(gx, B), block, 0, (hipStream_t)stream, mu, P, noise, N, status, a);
     } else {
         if (int rc = check_mixture("gse_gsukf_predict", state_pdf, GSE_NX)) return rc;
         pack_draw(a.draw, *state_pdf);
         a.rng = make_rng_key(*rng, kPurposeGsukf);
-        hipLaunchKernelGGL((gsukf_predict_kernel<false, kWideBank>), dim3(gx, B), dim3(kWideBank * kGroup), 0,
-                           (hipStream_t)stream, mu, P, (const float*)nullptr, N, status, a);
+        if (lanes) hipLaunchKernelGGL(gsukf_predict_lanes_kernel<false>, dim3(gx, B), block, 0, (hipStream_t)stream, mu, P, (const float*)nullptr, N, status, a);
+        else hipLaunchKernelGGL((gsukf_predict_kernel<false, kWideBank>), dim3(gx, B), block, 0, (hipStream_t)stream, mu, P, (const float*)nullptr, N, status, a);
     }
     GSE_LAUNCH_CHECK("gsukf_predict_kernel");
     return GSE_OK;
@@ -633,9 +812,13 @@ int gse_gsukf_update(float* mu, float* P, float* w, int B, int64_t N, const doub
     pack_io(a.io, B, u, z);
     pack_pdf2(a.pdf, *measurement_pdf);
     pack_sigma_weights(a.sw, w_sigma);
-    const unsigned gx = (unsigned)((N + kWideBank - 1) / kWideBank);
-    hipLaunchKernelGGL(gsukf_update_kernel<kWideBank>, dim3(gx, B), dim3(kWideBank * kGroup), 0, (hipStream_t)stream, mu, P, w,
-                       N, status, a);
+    if (lane_per_gaussian(B, N)) {
+        hipLaunchKernelGGL(gsukf_update_lanes_kernel, dim3((unsigned)((N + kLaneBank - 1) / kLaneBank), B), dim3(kLaneBank), 0,
+                           (hipStream_t)stream, mu, P, w, N, status, a);
+    } else {
+        hipLaunchKernelGGL(gsukf_update_kernel<kWideBank>, dim3((unsigned)((N + kWideBank - 1) / kWideBank), B),
+                           dim3(kWideBank * kGroup), 0, (hipStream_t)stream, mu, P, w, N, status, a);
+    }
     GSE_LAUNCH_CHECK("gsukf_update_kernel");
     return GSE_OK;
 }
