@@ -61,6 +61,7 @@ PROTOTYPES = {
     "gse_pf_step": (ctypes.c_int, [c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_d, P_D, P_D,
                                    P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_vp, c_vp]),
     "gse_pf_moments": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
+    "gse_pf_moments_resampled": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_i64, P_D, ctypes.c_int, c_vp, c_vp, c_vp]),
     "gse_gsukf_sigma_points": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
     "gse_gsukf_predict": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_F, P_MIX, P_RNG, c_vp, c_vp, c_vp]),
     "gse_gsukf_update": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, P_D, P_F, P_MIX, c_vp, c_vp, c_vp]),

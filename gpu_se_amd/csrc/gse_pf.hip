@@ -712,15 +712,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             GSE_LOAD_DWORDX4(r3, xb + 3 * ld);
             GSE_LOAD_DWORDX4(r4, xb + 4 * ld);
         }
-        if (kUpdate && !kGather) {
-            const float* wb = w_in + (int64_t)b * ld;
-            if (kStrided) {
-#pragma unroll
-                for (int p = 0; p < kPerThread; ++p) wnew[p] = (jp[p] < Nu) ? wb[jp[p]] : 0.f;
-            } else {
-                const float4 w4 = *reinterpret_cast<const float4*>(wb + i0);
-                wnew[0] = w4.x; wnew[1] = w4.y; wnew[2] = w4.z; wnew[3] = w4.w;
-            }
+        if (kUpdate && !kGather && !kStrided) {
+            const float4 w4 = *reinterpret_cast<const float4*>(w_in + (int64_t)b * ld + i0);
+            wnew[0] = w4.x; wnew[1] = w4.y; wnew[2] = w4.z; wnew[3] = w4.w;
         }
         float nz[kPerThread][GSE_NX];
         if (kPredict && kInjected) {
@@ -822,6 +816,13 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         // particle keeps both sets live, overflows the scalar registers and spills ~100 VGPRs
         __builtin_amdgcn_sched_barrier(0);
         GSE_STAMP(8);
+        if (kUpdate && !kGather && kStrided) {
+            // (the old weights of a launch that draws but does not resample: fetched here, not ahead of the draw and the
+            //  model step -- four more live registers there spill)
+            const float* wb = w_in + (int64_t)b * ld;
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) wnew[p] = (jp[p] < Nu) ? wb[jp[p]] : 0.f;
+        }
         if (kUpdate) {
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p) {
@@ -1140,6 +1141,129 @@ __global__ __launch_bounds__(kBlock) void pf_moments_kernel(const float* __restr
                 }
             }
         }
+    }
+    double* out = partials + ((int64_t)b * kMomentBlocks + blockIdx.x) * kMomentWidth;
+    block_sums<21>(acc, red, [&](int c, double total) { out[c] = total; });
+}
+
+// Moments of the resampled ensemble without resampling (gse_pf_moments_resampled): as pf_moments_kernel, but particle k
+// weighs n_k * fp32(1 / N) with n_k = F(k) - F(k-1) its offspring count under the systematic resample with this r -- the
+// inverse map of the gather stage (OffspringCount; keys re-formed from weights + per-thread tile prefixes exactly as there).
+// A workgroup builds the tile prefix of its filter in LDS, then its wavefronts stride over the tiles.
+__global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                      const double* __restrict__ tile_sums,
+                                                                      const double* __restrict__ qx_all,
+                                                                      double* __restrict__ partials, int64_t N, int64_t ld,
+                                                                      int T, const ResampleArgs ra) {
+    __shared__ double red[4 * 21];
+    extern __shared__ double pfx_m[];              // [T + 1]
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* xb = x + (int64_t)b * GSE_NX * ld;
+    const float* wb = w + (int64_t)b * ld;
+    const double* qx = qx_all + (int64_t)b * T * kBlock;
+    // tile prefix (the arithmetic of the step kernel's gather stage)
+    {
+        const double* sums = tile_sums + (int64_t)b * T;
+        const int m = (T + kBlock - 1) / kBlock;
+        const int qlo = tid * m;
+        double sv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
+        double chunk = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) chunk += sv[i];
+        double total;
+        double run = block_exclusive_scan(chunk, red, total);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < m && qlo + i < T) pfx_m[qlo + i] = run;
+            run += sv[i];
+        }
+        if (tid == 0) pfx_m[T] = total;
+        __syncthreads();
+    }
+    const double W = pfx_m[T];
+    double pv[GSE_NX];
+#pragma unroll
+    for (int k = 0; k < GSE_NX; ++k) pv[k] = (double)xb[k * ld];          // pivot = particle 0
+    double acc[21];
+#pragma unroll
+    for (int c = 0; c < 21; ++c) acc[c] = 0.0;
+    const bool valid = (W > 0.0) && (W < INFINITY);
+    OffspringCount F;
+    F.init(N, ra.r[b], valid ? W : 1.0);
+    const double wu = (double)(float)(1.0 / (double)N);
+    // One WAVEFRONT per tile, four quarters of 64 quads one after the other: the count below a lane's first key comes from
+    // the lane before (DPP) and, for lane 0, from the previous quarter's last lane (kept in a scalar) -- no barrier, and the
+    // four wavefronts of the workgroup are at different tiles.  The states of a particle are fetched only if it has
+    // offspring: under the usual degenerate weights that is about one particle in a hundred, so the pass moves ~6 bytes
+    // per particle (weights and tile prefixes) instead of 26.
+    for (int tq = blockIdx.x * (kBlock / 64) + wv; valid && tq < T; tq += gridDim.x * (kBlock / 64)) {
+        const double P0 = pfx_m[tq], P1 = pfx_m[tq + 1];
+        const int64_t tile_last = min((int64_t)(tq + 1) * kTile, N) - 1;
+        int32_t below = F(P0);                                           // (the previous tile's last key is pinned to P0)
+#pragma unroll 1
+        for (int sub = 0; sub < kTile / (64 * kPerThread); ++sub) {
+            const int t = sub * 64 + lane;
+            const int64_t k0 = (int64_t)tq * kTile + (int64_t)t * kPerThread;
+            const float4 wq = load_weights4(wb, k0, N, ld);
+            const double excl = qx[tq * kBlock + t];
+            double sc[kPerThread];
+            sc[0] = (k0 + 0 < N) ? (double)wq.x : 0.0;
+            sc[1] = sc[0] + ((k0 + 1 < N) ? (double)wq.y : 0.0);
+            sc[2] = sc[1] + ((k0 + 2 < N) ? (double)wq.z : 0.0);
+            sc[3] = sc[2] + ((k0 + 3 < N) ? (double)wq.w : 0.0);
+            double xs[kPerThread];
+            int32_t fs[kPerThread];
+            bool near[kPerThread];
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) {
+                xs[p] = (k0 + p >= tile_last) ? P1 : fmin(P0 + (excl + sc[p]), P1);
+                fs[p] = F.candidate(xs[p], near[p]);
+            }
+            if (near[0] || near[1] || near[2] || near[3]) {
+#pragma unroll
+                for (int p = 0; p < kPerThread; ++p)
+                    if (near[p]) fs[p] = F.settle(xs[p], fs[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) fs[p] += 1;             // counts
+            int32_t prev = (int32_t)wave_shift_up1((uint32_t)fs[3]);
+            if (lane == 0) prev = below;
+            below = __builtin_amdgcn_readlane(fs[3], 63);
+            int32_t n_off[kPerThread];
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p)
+                n_off[p] = (k0 + p <= tile_last) ? fs[p] - (p == 0 ? prev : fs[(p + 3) % kPerThread]) : 0;
+            float xv[kPerThread][GSE_NX];
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p)
+                if (n_off[p] > 0) {
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) xv[p][k] = xb[k * ld + k0 + p];
+                }
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p)
+                if (n_off[p] > 0) {
+                    const double wp = (double)n_off[p] * wu;
+                    double d[GSE_NX];
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) d[k] = (double)xv[p][k] - pv[k];
+                    acc[0] += wp;
+                    int c = 6;
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) {
+                        const double wd = wp * d[k];
+                        acc[1 + k] += wd;
+#pragma unroll
+                        for (int l = k; l < GSE_NX; ++l) acc[c++] += wd * d[l];
+                    }
+                }
+        }
+    }
+    if (!valid && blockIdx.x == 0 && tid == 0) {
+        // weights that do not sum to a positive finite number: every offspring copies particle 0 (see the gather stage)
+        acc[0] = (double)N * wu;
     }
     double* out = partials + ((int64_t)b * kMomentBlocks + blockIdx.x) * kMomentWidth;
     block_sums<21>(acc, red, [&](int c, double total) { out[c] = total; });
@@ -1515,6 +1639,30 @@ int gse_pf_moments(const float* x, const float* w, int64_t ld, int B, int64_t N,
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pf_moments_kernel, dim3(nblk, B), dim3(kBlock), 0, st, x, w, ws.partials, N, ld);
     GSE_LAUNCH_CHECK("pf_moments_kernel");
+    launch_moments_finish(ws.partials, nblk, 21, out, 26, B, x, GSE_NX * ld, ld, 21, st);
+    GSE_LAUNCH_CHECK("moments_finish_kernel");
+    return GSE_OK;
+}
+
+int gse_pf_moments_resampled(const float* x, const float* w, int64_t ld, int B, int64_t N, const double* r, int slot,
+                             double* out, void* workspace, void* stream) {
+    if (int rc = check_pf_geometry("gse_pf_moments_resampled", B, N, ld)) return rc;
+    GSE_REQUIRE(x && w && r && out && workspace, "gse_pf_moments_resampled: null argument");
+    GSE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(workspace), "gse_pf_moments_resampled: pointers must be 16-byte aligned");
+    GSE_REQUIRE(slot == 0 || slot == 1, "gse_pf_moments_resampled: slot must be 0 or 1");
+    const int T = (int)tiles_of(N);
+    GSE_REQUIRE(T <= kScanMaxT, "gse_pf_moments_resampled: at most %d tiles (N <= %d)", kScanMaxT, kScanMaxT * kTile);
+    ResampleArgs ra;
+    for (int b = 0; b < B; ++b) {
+        GSE_REQUIRE(r[b] >= 0.0 && r[b] < 1.0, "gse_pf_moments_resampled: r[%d] = %g is outside [0, 1)", b, r[b]);
+        ra.r[b] = r[b];
+    }
+    Workspace ws = carve_workspace(workspace, B, N);
+    const int nblk = (int)std::min<int64_t>(std::min<int64_t>(kMomentBlocks, T), std::max<int64_t>(GSE_MOMENT_TOTAL_BLOCKS / B, 32));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pf_moments_resampled_kernel, dim3(nblk, B), dim3(kBlock), (size_t)(T + 1) * sizeof(double), st, x, w,
+                       ws.scan_sums[slot], ws.scan[slot], ws.partials, N, ld, T, ra);
+    GSE_LAUNCH_CHECK("pf_moments_resampled_kernel");
     launch_moments_finish(ws.partials, nblk, 21, out, 26, B, x, GSE_NX * ld, ld, 21, st);
     GSE_LAUNCH_CHECK("moments_finish_kernel");
     return GSE_OK;

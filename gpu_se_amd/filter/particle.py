@@ -203,8 +203,11 @@ class ParallelParticleFilter:
             self._launch_step(update=None)                      # one launch carries one u: predict with its own first
         device_io = (self._pend_predict is not None and torch.is_tensor(self._pend_predict[0])) or \
             (update is not None and torch.is_tensor(update[1]))
-        if device_io and self._pend_gather:
-            # inputs that live on the device are read by the variants without gather: copy the ancestors first
+        whole_cycle = (self._pend_gather and self._gather_slot is not None and self._pend_predict is not None and
+                       update is not None and not injected and self._scan_capable and self.measurement_pdf._Nd == 2)
+        if device_io and self._pend_gather and not whole_cycle:
+            # inputs that live on the device are read by the single-launch cycle or by the variants without gather: in any
+            # other combination copy the ancestors first
             pend, self._pend_predict = self._pend_predict, None
             self._launch_step(update=None)
             self._pend_predict = pend
@@ -373,6 +376,17 @@ class ParallelParticleFilter:
         s2[:, iu[0], iu[1]] = m[:, 6:21]
         s2[:, iu[1], iu[0]] = m[:, 6:21]
         return m[:, 0].copy(), m[:, 1:6].copy(), s2, m[:, 21:26].copy()
+
+    def _resampled_moments_into(self, out):
+        """Moments of the ensemble the pending resample WILL produce, written to the device tensor ``out`` [B, 26] without
+        copying a particle (gse_pf_moments_resampled) -- for loops on the device that need the estimate between
+        resample() and the next predict() while the resample's copy rides the next cycle's single launch.  Returns False
+        (nothing done) unless a resample is pending on stored tile prefixes and nothing else is."""
+        if not (self._pend_gather and self._gather_slot is not None and self._pend_predict is None):
+            return False
+        self._call("gse_pf_moments_resampled", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
+                   self._c_r, int(self._gather_slot), out.data_ptr(), self._ws.data_ptr(), stream_ptr(self._dev_index))
+        return True
 
     def _raw_moments_all(self):
         s0, s1, s2, pv = self._raw_moments_arrays()

@@ -363,7 +363,11 @@ class BatchedSimulation:
             if now > t_next_control:
                 f.update(u, z)
                 f.resample()
-                record_moments(t)                         # the estimate the controller acts on, and this tick's record
+                # the estimate the controller acts on, and this tick's record: the moments of the resampled ensemble taken
+                # from the weighted one (offspring counts), so that the resample's copy is deferred into the next tick's
+                # single launch (gather + predict + update); where that does not apply, resample now and take them after
+                if not f._resampled_moments_into(moments[t]):
+                    record_moments(t)
                 K.loop_control(moments[t], ys_meas[t - 1], u, (y_pred, known, status[t]), _U_FALLBACK)
                 n_control += 1
                 last_control = t

@@ -150,7 +150,8 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
 #define GSE_OP_SCAN_OUT_SLOT1 64u
 #define GSE_OP_U_DEVICE 128u     /* (with PREDICT) u is a DEVICE pointer [B][2] fp64, read when the kernel runs */
 #define GSE_OP_Z_DEVICE 256u     /* (with UPDATE)  z is a DEVICE pointer [B][2] fp64                            */
-                                 /* (both: launches without GSE_OP_GATHER and without injected noise only)      */
+                                 /* (both: not with injected noise; with GSE_OP_GATHER only in the whole single- */
+                                 /*  launch cycle GATHER | PREDICT | UPDATE | SCAN_IN | SCAN_OUT)                */
 int gse_pf_step(uint32_t ops, const float *x_in, float *x_out, const float *w_in, float *w_out, int32_t *idx,
                 int64_t ld, int B, int64_t N, const double *u, double dt, const double *z, const double *r,
                 const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,
@@ -162,6 +163,16 @@ int gse_pf_step(uint32_t ops, const float *x_in, float *x_out, const float *w_in
  * cancellation).  The host forms  w@x = S1 + p S0  and the covariance from these. */
 int gse_pf_moments(const float *x, const float *w, int64_t ld, int B, int64_t N, double *out,
                    void *workspace, void *stream);
+
+/* The same moments for the ensemble a systematic resample of (x, w) WOULD produce (every offspring weighing
+ * fp32(1 / N)), without moving a particle: particle k enters with its offspring count n_k = F(k) - F(k-1), the counts of
+ * the very resample the next GSE_OP_GATHER | GSE_OP_SCAN_IN launch will perform with the same r (same tile sums and tile
+ * prefixes: `slot` = the scan slot the preceding GSE_OP_SCAN_OUT update wrote).  This is what lets a closed loop on the
+ * device run  update -> resample -> point_estimate -> control -> predict  (sim_base.py:253-262) with the resample's copy
+ * deferred into the next cycle's single launch.  Sums are formed in a different order than gse_pf_moments forms them after
+ * the copy: equal to fp64 rounding, not to the bit.  N <= 2^21.  r: host, [B]. */
+int gse_pf_moments_resampled(const float *x, const float *w, int64_t ld, int B, int64_t N, const double *r, int slot,
+                             double *out, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------- Gaussian-sum UKF --------------- */
 

@@ -533,6 +533,41 @@ def test_fused_step_against_oracle():
     np.testing.assert_allclose(host(wo)[:n], o.weights, rtol=1.2e-7)
 
 
+def test_resampled_moments_equal_the_moments_after_the_copy():
+    """gse_pf_moments_resampled: the moments of the ensemble a pending resample will produce, from the weighted ensemble
+    and the offspring counts of the inverse map -- against gse_pf_moments of the particles once they have been copied
+    (different summation order: equal to fp64 rounding).  One filter and a batch; also after a second cycle, when the
+    single launch gather + predict + update has consumed the deferred resample."""
+    from gpu_se_amd.filter import BatchedParticleFilter
+    from gpu_se_amd.filter.particle import moments_to_mean_cov
+    xss = orc.steady_state()
+    for n, B in ((5003, 1), (1 << 18, 1), (40000, 3)):
+        gpu_se_amd.seed(11)
+        sp, mp = sim_base.get_noise()
+        x0, _ = sim_base.get_noise()
+        x0.means += xss[None, :].astype(np.float32)
+        pf = BatchedParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, sp, mp, batch=B)
+        rng = np.random.default_rng(n)
+        for c in range(3):
+            u = np.repeat([[rng.uniform(0.03, 0.09), rng.uniform(0.1, 0.3)]], B, axis=0)
+            z = np.array(orc.bioreactor_g(xss))[None, :] + rng.normal(0, 0.3, (B, 2))
+            pf.predict(u, 0.1)
+            pf.update(u, z)
+            pf.resample(r=rng.random(B))
+            out = torch.empty((B, 26), dtype=torch.float64, device="cuda")
+            assert pf._resampled_moments_into(out)
+            assert pf._pend_gather                                  # nothing was copied
+            ahead = out.cpu().numpy()
+            after = np.array([np.concatenate([[s0], s1, s2[np.triu_indices(5)], pv]) for s0, s1, s2, pv in pf._raw_moments_all()])
+            assert not pf._pend_gather                              # (that one did copy)
+            for b in range(B):
+                s0a, ma, ca = moments_to_mean_cov(ahead[b, 0], ahead[b, 1:6], ahead[b, 6:21], ahead[b, 21:26])
+                s0b, mb, cb = moments_to_mean_cov(after[b, 0], after[b, 1:6], after[b, 6:21], after[b, 21:26])
+                np.testing.assert_allclose(s0a, s0b, rtol=1e-12)
+                np.testing.assert_allclose(ma, mb, rtol=1e-12)
+                np.testing.assert_allclose(ca, cb, rtol=1e-9, atol=1e-18)
+
+
 # ------------------------------------------------------------------------------ batches of independent filters
 def test_batch_of_filters_equals_single_filters():
     """B independent filters in one launch (leading dimension of every array; per-filter u, z, r, Philox stream) give,
