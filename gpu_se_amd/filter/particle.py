@@ -283,9 +283,19 @@ class ParallelParticleFilter:
             self._scan_slot = scan_out
 
     # ------------------------------------------------------------------ attributes
+    def _handed_out(self):
+        """``particles`` / ``weights`` return writable views of the internal buffers (the reference's attributes are plain
+        arrays that callers mutate in place: ``pf.weights[:] = ...``).  Whatever was derived from the old contents -- the
+        cached moments, the tile sums and tile prefixes a deferred resample would use -- is therefore dropped the moment a
+        view leaves: the next estimate / resample recomputes it (one small kernel) instead of using stale values."""
+        self._moments_host = None
+        self._tiles_valid = False
+        self._scan_slot = None
+
     @property
     def particles(self):
         self._flush()
+        self._moments_host = None
         v = self._x[:, :self._nx, :self.N_particles].transpose(1, 2)   # (B, N, Nx) strided view
         return DevArray.wrap(v[0] if self._B == 1 else v)
 
@@ -299,6 +309,7 @@ class ParallelParticleFilter:
     @property
     def weights(self):
         self._flush()
+        self._handed_out()
         v = self._w[:, :self.N_particles]
         return DevArray.wrap(v[0] if self._B == 1 else v)
 

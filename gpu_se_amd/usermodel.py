@@ -29,7 +29,9 @@ import ctypes
 import hashlib
 import inspect
 import os
+import shutil
 import subprocess
+import tempfile
 import textwrap
 
 from gpu_se_amd import _lib, build
@@ -260,14 +262,23 @@ def compile_model(f, g, verbose=False):
     if key in _cache:
         return _cache[key]
     nx, nu, text = translate(f, g)
-    digest = hashlib.sha256((text + open(os.path.join(build.CSRC, "gse_pf.hip")).read()
-                             + open(os.path.join(build.CSRC, "gse_device.h")).read()).encode()).hexdigest()
+    # the cache key covers everything the library is made of: the generated model, every source it compiles, every header
+    # they include (workspace layout, struct ABI) and the ABI version
+    h = hashlib.sha256(text.encode())
+    for name in sorted(set(USER_SOURCES) | {n for n in os.listdir(build.CSRC) if n.endswith(".h")}):
+        with open(os.path.join(build.CSRC, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    with open(os.path.join(build.ROOT, "include", "gse.h"), "rb") as fh:
+        h.update(b"gse.h\0" + fh.read())
+    digest = h.hexdigest()
     tag = int(digest[:15], 16) | 1                                       # non-zero, fits a signed 64-bit literal
     folder = os.path.join(USER_DIR, digest[:16])
     path = os.path.join(folder, "libgse_user.so")
     if not os.path.exists(path):
         os.makedirs(folder, exist_ok=True)
-        header = os.path.join(folder, "gse_user_model.h")
+        final_folder = folder
+        folder = tempfile.mkdtemp(prefix="build%d_" % os.getpid(), dir=final_folder)   # ranks building the same model at once
+        header = os.path.join(folder, "gse_user_model.h")                              # never share a half-written file
         with open(header, "w") as fh:
             fh.write(text)
         flags = ["-DGSE_USER_MODEL=\"%s\"" % header, "-DGSE_USER_MODEL_TAG=%dull" % tag]
@@ -285,9 +296,10 @@ def compile_model(f, g, verbose=False):
             out, _ = p.communicate()
             if p.returncode != 0:
                 raise ModelError("hipcc failed on %s for the user model:\n%s\n--- generated source ---\n%s" % (src, out, text))
-        tmp = path + ".tmp%d" % os.getpid()
+        tmp = os.path.join(folder, "libgse_user.so")
         subprocess.run([build._hipcc(), "--offload-arch=" + build.ARCH, "-shared", "-fPIC", "-o", tmp] + objs, check=True)
-        os.replace(tmp, path)
+        os.replace(tmp, path)                                                          # atomic: readers see all or nothing
+        shutil.rmtree(folder, ignore_errors=True)
     model = CompiledModel(nx, nu, tag, path)
     _cache[key] = model
     return model

@@ -497,6 +497,28 @@ def test_single_launch_philox_cycle_against_oracle(n):
         x, w = x_new, w_new
 
 
+def test_in_place_writes_through_the_attribute_views_are_seen():
+    """The reference's attributes are plain arrays that callers may change in place (pf.weights[:] = ...).  The views this
+    class hands out write through to the device buffers; whatever was cached from the old contents (moments, the tile sums
+    and prefixes a deferred resample would use) must not survive."""
+    n = 6000
+    gpu_se_amd.seed(3)
+    _, _, _, pf = sim_base.get_parts(N_particles=n)
+    xss = orc.steady_state()
+    pf.predict([0.06, 0.2], 0.1)
+    pf.update([0.06, 0.2], np.array(orc.bioreactor_g(xss)))
+    first = pf.point_estimate()
+    rng = np.random.default_rng(0)
+    w_new = (rng.random(n) ** 5).astype(np.float32)
+    view = pf.weights
+    view[:] = torch.as_tensor(w_new, device="cuda")                  # in place, not through the setter
+    np.testing.assert_array_equal(pf.weights.get(), w_new)
+    assert not np.allclose(pf.point_estimate(), first)               # the cached estimate was dropped
+    want = orc.systematic_index(w_new.astype(np.float64), 0.3)
+    idx = pf.resample(r=0.3, return_index=True).get()
+    np.testing.assert_array_equal(idx, want)                         # the resample used the new weights
+
+
 def test_fused_step_against_oracle():
     """gather + predict(injected) + update in one launch (gse_pf_step) vs the oracle's three separate steps."""
     n = 6000
