@@ -62,6 +62,16 @@ PROTOTYPES = {
                                    P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_vp, c_vp]),
     "gse_pf_moments": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
     "gse_pf_moments_resampled": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_i64, P_D, ctypes.c_int, c_vp, c_vp, c_vp]),
+    "gse_model_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, c_u64, ctypes.c_char_p, ctypes.c_char_p,
+                                        ctypes.c_char_p, ctypes.POINTER(c_vp)]),
+    "gse_model_destroy": (ctypes.c_int, [c_vp]),
+    "gse_model_prepare": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
+    "gse_model_compile_check": (c_i64, [c_vp, ctypes.c_char_p]),
+    "gse_model_kernels": (c_i64, [c_vp]),
+    "gse_pf_step_model": (ctypes.c_int, [c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_d, P_D, P_D,
+                                         P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_vp, c_vp]),
+    "gse_model_f_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, P_D, c_d, c_vp]),
+    "gse_model_g_u_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, P_D, c_vp]),
     "gse_gsukf_sigma_points": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
     "gse_gsukf_predict": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_F, P_MIX, P_RNG, c_vp, c_vp, c_vp]),
     "gse_gsukf_update": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, P_D, P_F, P_MIX, c_vp, c_vp, c_vp]),

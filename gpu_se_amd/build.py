@@ -9,7 +9,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgse_hip.so")
-SOURCES = ["gse_host.hip", "gse_pf.hip", "gse_gsukf.hip", "gse_rows.hip", "gse_mpc.hip"]
+SOURCES = ["gse_host.hip", "gse_pf.hip", "gse_gsukf.hip", "gse_rows.hip", "gse_mpc.hip", "gse_rtc.hip"]
 ARCH = "gfx950"
 
 
@@ -50,7 +50,7 @@ def build(force=False, verbose=True):
             print(out)
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -9,8 +9,14 @@
 // Written for CDNA4 only: wavefront = 64, no dual paths.
 #pragma once
 
+#ifndef __HIPCC_RTC__               // (hiprtc brings the device runtime itself and has no C library headers)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+#ifndef INFINITY
+#define INFINITY __builtin_huge_valf()
+#endif
+#endif
 
 #include "gse.h"
 
@@ -494,6 +500,37 @@ __device__ __forceinline__ int64_t wave_search_ge(Value value, int64_t N, double
         lo = nlo;
         hi = nhi;
     }
+}
+
+// Two searches of that kind at once in ONE monotone array of N <= 32768 values: lanes 0..31 look for the first k with
+// value(k) >= u_lo, lanes 32..63 for the first k with value(k) >= u_hi, 32 probes per round each (two rounds up to 1024
+// values, three beyond) -- half the dependent LDS round trips of two 64-ary searches in a row.  Results are uniform over
+// the wavefront; N - 1 where no element qualifies.
+template <class Value>
+__device__ __forceinline__ void wave_search_ge_pair(Value value, int N, double u_lo, double u_hi, int lane, int& k_lo, int& k_hi) {
+    const int half = lane >> 5, l = lane & 31;
+    const double u = half ? u_hi : u_lo;
+    int lo = 0, hi = N;                                           // per half: answer in [lo, hi)
+    const int rounds = (N <= 32) ? 1 : ((N <= 1024) ? 2 : 3);
+    for (int round = 0; round < rounds; ++round) {
+        const int n = hi - lo;
+        const int step = (n + 31) >> 5;
+        const int probe = min(lo + (l + 1) * step, hi) - 1;
+        const bool ge = value(probe) >= u;
+        const unsigned long long mask = __ballot(ge);
+        const uint32_t mine = half ? (uint32_t)(mask >> 32) : (uint32_t)mask;
+        if (mine == 0u) {                                         // nothing qualifies: settle on the last element
+            lo = N - 1;
+            hi = N;
+        } else {
+            const int first = __ffs((int)mine) - 1;
+            const int nlo = lo + first * step;
+            hi = min(lo + (first + 1) * step, hi);
+            lo = nlo;
+        }
+    }
+    k_lo = __builtin_amdgcn_readlane(lo, 0);
+    k_hi = __builtin_amdgcn_readlane(lo, 32);
 }
 
 // Smallest fp64 x >= 0 with fl(x / W) >= u  (W > 0 finite).  x -> fl(x / W) is monotone non-decreasing, so for any

@@ -1,14 +1,21 @@
 // gse_host.h -- host-side helpers of the C ABI: error reporting, argument checks, kernel-argument packing.
 #pragma once
 
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#endif
 
 #include "gse.h"
 #include "gse_device.h"
 
 namespace gse {
+
+constexpr int kMomentBlocks = 512;      // partial sums per filter of the moment kernels
+constexpr int kMomentWidth = 48;
+
+#ifndef __HIPCC_RTC__               // ---- host only (this header is also seen by the run-time compilation of the kernels)
 
 // Thread-local message behind gse_last_error().
 char* last_error_buffer();
@@ -58,9 +65,9 @@ struct Workspace {
     double* cumsum;        // [B][N]       normalised cumulative weights
     int64_t bytes;
 };
-constexpr int kMomentBlocks = 512;
-constexpr int kMomentWidth = 48;
 Workspace carve_workspace(void* base, int B, int64_t N);
+
+#endif  // !__HIPCC_RTC__
 
 // ---- shared between gse_pf.hip (definitions) and gse_gsukf.hip ------------------------------------------
 struct ResampleArgs {
@@ -120,11 +127,14 @@ struct GsukfPayload {                 // row-major (mu[5], P[25]) per Gaussian
     }
 };
 
+#ifndef __HIPCC_RTC__
 int launch_cumsum(const float* w, int64_t ldw, int B, int64_t N, uint32_t flags, double* island, const Workspace& ws,
                   double* c_out, hipStream_t st);
 int launch_gsukf_gather(const GsukfPayload& pl, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra,
                         const Workspace& ws, hipStream_t st);
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
                            const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, hipStream_t st);
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace gse

@@ -1,0 +1,1317 @@
+// gse_pf_kernels.h -- the device code of the particle filter (kernels and their helpers), split from its host side
+// (gse_pf.hip) so that the SAME text can be compiled a second way: at run time, by hiprtc, for a user model (gse_rtc.hip;
+// gpu_se_amd/usermodel.py).  Nothing here may need a host header.
+//
+// gse_pf.hip -- bootstrap particle filter on gfx950: predict / update / systematic resample / moments.
+//
+// One workgroup = 256 threads = 4 wavefronts owns one TILE of 1024 consecutive particles of one filter;
+// every thread owns 4 consecutive particles, so each state row is read and written with one dwordx4 per
+// lane (1 KiB per wave-instruction, fully coalesced) from the state-major layout x[b][k][i].
+// Everything here is HBM-bound streaming work (140 algorithmic bytes / particle / cycle), and at
+// N = 2^20 one kernel is a single generation of workgroups (4 tiles per CU), so every launch costs a fixed
+// 3.5-5 us of ramp-up / latency chain whatever it computes.  The design therefore minimises LAUNCHES and passes:
+//
+//   pf_step_kernel<gather, predict, update>   ONE fused pass over the particles that does any subset of
+//        gather    the offspring's ancestor (resample, second half): 64-ary wavefront search + LDS binary search
+//                  in the normalised cumulative weights, then an indexed read of the 5 state rows
+//        predict   ODE step (fp64 in registers) + Philox/Box-Muller mixture draw (no memory: hides the loads)
+//        update    likelihood in fp64, w *= pdf, workgroup sum of the new weights -> one tile sum
+//   cumsum_kernel   tile prefix + fp64 scan of the weights -> normalised cumulative weights (resample, first half)
+//
+// The steady-state cycle  resample -> predict -> update  is two launches: cumsum, then step<gather,predict,update>
+// (r 8 + 20 B, w 24 B per particle, nothing else touches HBM).  The classic one-method-one-kernel entry points are
+// the same kernel with a single stage enabled.
+#pragma once
+
+#include "gse_host.h"
+
+namespace gse {
+
+// ------------------------------------------------------------------------------------------------
+// the fused step
+// ------------------------------------------------------------------------------------------------
+struct StepArgs {
+    FilterIOs io;          // u, z per filter
+    ResampleArgs ra;       // r per filter
+    DrawParams draw;       // state noise (predict)
+    Pdf2 pdf;              // measurement noise (update)
+    RngKey rng;
+    double dt;
+    const double* u_dev;   // GSE_OP_U_DEVICE / GSE_OP_Z_DEVICE: [B][2] in device memory instead of io (a closed loop
+    const double* z_dev;   // whose controller and plant run on the device never brings them to the host)
+};
+
+#ifndef GSE_STEP_MIN_WAVES
+#define GSE_STEP_MIN_WAVES 4     // waves per SIMD the register allocator must leave room for (tuning knob)
+#endif
+
+#ifndef GSE_STAGGER
+#define GSE_STAGGER 1            // gather variants: half of the workgroups draw their noise before the memory phases
+#endif
+// Where a workgroup of a gather launch draws its noise (tuning knob, see the kernel comment): 0 = before anything,
+// 1 = after the tile prefix, 2 = while the span is being staged, 3 = behind the state loads.
+// GSE_STAGGER = 0: everybody at 3; 1: two groups (0 and 3); 2: four groups.
+__device__ __forceinline__ int draw_position(unsigned bx) {
+#if GSE_STAGGER == 0
+    return 3;
+#elif GSE_STAGGER == 2
+    return (int)(((bx >> 8) ^ bx) & 3u);
+#elif GSE_STAGGER == 3
+    return (int)((((bx >> 8) ^ bx) & 3u) % 3u == 0 ? 0 : ((((bx >> 8) ^ bx) & 3u) % 3u == 1 ? 2 : 3));
+#else
+    return (((bx >> 8) ^ bx) & 1u) ? 0 : 3;
+#endif
+}
+// In-kernel phase stamps (diagnostic build only, -DGSE_STAMPS): workgroup 0's thread 0 records s_memtime at the phase
+// boundaries into a buffer of its own; read back with gse_debug_stamps().  No stamp executes in the normal build.
+#ifdef GSE_STAMPS
+__device__ unsigned long long g_block_times[2 * 4096];     // s_memrealtime (100 MHz) at entry / exit of every workgroup
+#define GSE_BLOCK_TIME(which)                                                                      \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {                            \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            g_block_times[2 * blockIdx.x + which] = t_;                                            \
+        }                                                                                          \
+    } while (0)
+__device__ long long g_block_info[2 * 4096];               // (ancestor span length, draw position) per workgroup
+__device__ unsigned long long g_stamps[32];
+#define GSE_STAMP(i)                                                              \
+    do {                                                                          \
+        if (blockIdx.x == GSE_STAMPS && blockIdx.y == 0 && threadIdx.x == 0) {    \
+            unsigned long long t_;                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            g_stamps[i] = t_;                                                     \
+        }                                                                         \
+    } while (0)
+#else
+#define GSE_STAMP(i)
+#define GSE_BLOCK_TIME(which)
+#endif
+#ifndef GSE_PRIO
+#define GSE_PRIO 4               // gather variants: issue priority by phase.  0: none; 1: memory phases high, the noise draw
+                                 // and the arithmetic tail low; 2: the reverse; 3: as 1 without touching the draw; 4 / 5: as
+                                 // 1 / 3 with s_setprio as an asm statement (the builtin is a scheduling barrier for hipcc
+                                 // and costs 11 VGPRs -> 28 B of scratch per lane, 11 MB of spill writes per launch)
+#endif
+#if GSE_PRIO == 4 || GSE_PRIO == 5
+#define GSE_PRIO_MEM() asm volatile("s_setprio 3")
+#define GSE_PRIO_ALU() asm volatile("s_setprio 0")
+#elif GSE_PRIO == 1 || GSE_PRIO == 3
+#define GSE_PRIO_MEM() __builtin_amdgcn_s_setprio(3)
+#define GSE_PRIO_ALU() __builtin_amdgcn_s_setprio(0)
+#elif GSE_PRIO == 2
+#define GSE_PRIO_MEM() __builtin_amdgcn_s_setprio(0)
+#define GSE_PRIO_ALU() __builtin_amdgcn_s_setprio(3)
+#else
+#define GSE_PRIO_MEM()
+#define GSE_PRIO_ALU()
+#endif
+#if GSE_PRIO == 1 || GSE_PRIO == 2 || GSE_PRIO == 4       // (3, 5: the draw keeps the priority of the phase it sits in)
+#define GSE_PRIO_DRAW_BEGIN() GSE_PRIO_ALU()
+#define GSE_PRIO_DRAW_END() GSE_PRIO_MEM()
+#else
+#define GSE_PRIO_DRAW_BEGIN()
+#define GSE_PRIO_DRAW_END()
+#endif
+#ifndef GSE_XCD_REMAP
+#define GSE_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int xcd_contiguous_tile(unsigned bx, int T) {
+#if GSE_XCD_REMAP
+    if ((T & 7) == 0) return (int)((bx & 7u) * (unsigned)(T >> 3) + (bx >> 3));
+#endif
+    return (int)bx;
+}
+#ifndef GSE_INVMAP
+#define GSE_INVMAP 1             // SCAN_IN gather: 1 = inverse map from the weights (no stored scans, no search); 0 = the
+                                 // round-1 path (tile-local scans stored by the update stage, staged in LDS and bisected)
+#endif
+#ifndef GSE_GATHER_STRIDED
+#define GSE_GATHER_STRIDED 1     // gather variants: a thread's 4 outputs are 256 apart (1) or consecutive (0)
+#endif
+
+#ifndef GSE_WT_STORES
+#define GSE_WT_STORES 7          // bit mask of step-kernel outputs stored write-through (sc1): 1 states, 2 weights, 4 tile prefixes
+#endif
+// Output stores of the step kernel.  A launch at N = 2^20 writes 27 MB; what stays dirty in the eight L2s is written back
+// by the release at the END of the kernel, a serial tail (tools/micro/store_tail.hip: 32 MB of plain stores trail a
+// launch by +2.9 us, write-through ones by +0.7).  Write-through stores drop their lines from the L2, so the next launch
+// finds less of its input there: in round 1, when the gather stage re-read 16-24 B per particle of stored scans, the lost
+// hits cost more than the tail (29.2 us against 27.7); with the inverse-map gather (4-8 B of weights + 2-4 B of tile
+// prefixes per particle) the tail is the larger term: all outputs write-through 20.6 us against 21.9 (r02 A/B, knob kept).
+// Relaxed agent-scope atomic stores are plain `global_store ... sc1` instructions, counted and padded by the compiler.
+template <int kBit>
+__device__ __forceinline__ void store_out(float* p, float v) {
+    if constexpr ((GSE_WT_STORES & kBit) != 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <int kBit>
+__device__ __forceinline__ void store_out2(double* p, double a_, double b_) {      // p 16-byte aligned
+    if constexpr ((GSE_WT_STORES & kBit) != 0) {
+        __hip_atomic_store(p, a_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 1, b_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *reinterpret_cast<double2*>(p) = make_double2(a_, b_);
+    }
+}
+using v4f_t = float __attribute__((ext_vector_type(4)));
+template <int kBit>
+__device__ __forceinline__ void store_out4(float* p, v4f_t v) {                     // p 16-byte aligned
+    if constexpr ((GSE_WT_STORES & kBit) != 0) {
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+        const unsigned long long lo = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+        const unsigned long long hi = ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
+        __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *reinterpret_cast<v4f_t*>(p) = v;
+    }
+}
+
+#define GSE_LOAD_DWORD(dst, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+// scalar base (uniform row pointer) + 32-bit byte offset per lane
+// (hipcc pads nothing inside an asm statement: an SGPR written by the scalar unit just before needs 5 wait states
+// before a vector-memory instruction may read it as its base -- the s_nop opens the string)
+#define GSE_LOAD_DWORD_S(dst, voff, sbase) \
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
+#define GSE_LOAD_DWORDX4(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+
+// Particle <-> thread mapping.  Without gather a thread owns 4 CONSECUTIVE particles (one dwordx4 per state row).
+// With gather the reads are indexed anyway, so a thread owns 4 outputs 256 apart: for each of them the 64 lanes of a
+// wavefront then touch consecutive outputs and (near-)consecutive ancestors -- every dword load / store instruction
+// covers whole cache lines, where the consecutive mapping would use a quarter of each line it touches.
+//
+// kScan: where the gather finds the cumulative weights and what the update leaves behind for the NEXT gather.
+//   bit 0 (SCAN_IN)   c[k] is not read from a materialised array (cumsum_kernel) but formed on the fly as
+//                     (Pfx[tile(k)] + L[k]) / W  from the tile sums and the tile-local inclusive scans L that the update
+//                     stage of the PREVIOUS step wrote; the tile prefix Pfx (T + 1 values) is computed by every workgroup
+//                     into LDS.  Same arithmetic, same bits as cumsum_kernel.
+//   bit 1 (SCAN_OUT)  the update stage also writes L and the tile sums of the new weights (8 B / particle).
+// With both bits the steady-state cycle is ONE launch: no cumsum kernel, no second pass over the weights.
+// Inverse map, one step: the 1024 keys of ancestor tile tq -> marks.  Thread t holds keys 4t .. 4t+3, formed exactly as
+// cumsum_kernel forms them -- x[k] = min(Pfx[tq] + (excl + s_p), Pfx[tq+1]), the tile's last key pinned to Pfx[tq+1] -- from the
+// tile's weights (s_p: running sums of the thread's four) and the thread's exclusive prefix `excl` inside the tile, which the
+// update stage that produced the weights left behind (8 bytes per 4 particles).  Every key whose slot e = clamp(F(x) - j0, 0,
+// 1024) is below 1024 raises mark[e] to k + 1 (LDS atomic max; a thread's equal neighbours are folded first).  No barrier.
+// kNeighbours: the lanes of the wavefront hold consecutive quads of one tile (t = threadIdx.x), so runs of equal slots are
+// folded across lanes too; false: the lanes hold unrelated quads (the work list of a wide ancestor range).
+template <bool kNeighbours>
+__device__ __forceinline__ void expand_quad(const OffspringCount& F, const double* pfx_s, uint32_t* mark, int64_t N,
+                                            int32_t j0, int tq, int t, const float4 wv, double excl) {
+    const int64_t k0 = (int64_t)tq * kTile + (int64_t)t * kPerThread;
+    double sc[kPerThread];
+    sc[0] = (k0 + 0 < N) ? (double)wv.x : 0.0;
+    sc[1] = sc[0] + ((k0 + 1 < N) ? (double)wv.y : 0.0);
+    sc[2] = sc[1] + ((k0 + 2 < N) ? (double)wv.z : 0.0);
+    sc[3] = sc[2] + ((k0 + 3 < N) ? (double)wv.w : 0.0);
+    const double P0 = pfx_s[tq], P1 = pfx_s[tq + 1];
+    const int64_t tile_last = min((int64_t)(tq + 1) * kTile, N) - 1;
+    // the four counts side by side (independent chains), the rare guard-band hits settled afterwards
+    double xs[kPerThread];
+    int32_t es[kPerThread];
+    bool near[kPerThread];
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p) {
+        xs[p] = (k0 + p >= tile_last) ? P1 : fmin(P0 + (excl + sc[p]), P1);
+        es[p] = F.candidate(xs[p], near[p]);
+    }
+    if (near[0] || near[1] || near[2] || near[3]) {
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p)
+            if (near[p]) es[p] = F.settle(xs[p], es[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p) es[p] = min(max(es[p] + 1 - j0, 0), (int32_t)kTile);
+    // Only the LAST key of a run of equal slots needs to speak (it has the largest index).  Runs are folded inside the thread
+    // and across the lanes of the wavefront (the next lane holds the next four keys): in a stretch of light particles
+    // hundreds of consecutive keys share a slot, and their atomics on one LDS address would be served one by one.
+    uint32_t next_first = 0u;                                                     // (0: nothing known -> speak)
+    if (kNeighbours) next_first = wave_shift_down1((uint32_t)es[0] + 1u);         // (0 in lane 63)
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p) {
+        const bool last_of_run = k0 + p == tile_last ||
+                                 ((p == kPerThread - 1) ? (next_first != (uint32_t)es[p] + 1u) : (es[(p + 1) % kPerThread] != es[p]));
+        if (k0 + p <= tile_last && es[p] < kTile && last_of_run) atomicMax(&mark[es[p]], (uint32_t)(k0 + p) + 1u);
+    }
+}
+
+template <bool kGather, bool kPredict, bool kInjected, bool kUpdate, int kNd, int kScan>
+__global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
+    const float* __restrict__ x_in, float* __restrict__ x_out, const float* __restrict__ w_in, float* __restrict__ w_out,
+    const float* __restrict__ noise, int32_t* __restrict__ idx_out, const double* __restrict__ c,
+    const double* __restrict__ totals, double* __restrict__ tile_sums, const double* __restrict__ scan_in_sums,
+    const double* __restrict__ scan_in, double* __restrict__ scan_out_sums, double* __restrict__ scan_out,
+    double* __restrict__ island, int64_t N, int64_t ld, int T, const StepArgs a) {
+    constexpr bool kScanIn = (kScan & 1) != 0, kScanOut = (kScan & 2) != 0;
+    constexpr bool kDraw = kPredict && !kInjected;      // noise from Philox (registers only) rather than from memory
+    // strided particle <-> thread mapping (see below): whenever the launch gathers or draws -- the Philox blocks of the
+    // draw are shared by the four particles a thread owns in THIS mapping (gse_device.h, rng_block_of_group)
+    constexpr bool kStrided = GSE_GATHER_STRIDED && (kGather || kDraw);
+    static_assert(!kDraw || kStrided, "the grouped draw needs the strided mapping");
+    constexpr bool kDevIO = (kScan & 4) != 0;      // u / z may come from device memory (a closed loop on the device)
+    static_assert(!kScanIn || kGather, "SCAN_IN belongs to the gather stage");
+    static_assert(!kScanOut || kUpdate, "SCAN_OUT belongs to the update stage");
+    __shared__ DrawParams dp;
+    constexpr bool kInvMap = kScanIn && (GSE_INVMAP != 0);
+    __shared__ double seg[(kGather && !kInvMap) ? kSpanMax : 2];
+    __shared__ __attribute__((aligned(16))) uint32_t mark[kInvMap ? kTile : 4];     // inverse map: see the gather stage
+    __shared__ int32_t act_list[kInvMap ? kTile : 1];
+    __shared__ int32_t act_n;
+    constexpr int kWorkMax = 1280;                 // quads of a wide ancestor range that need their four keys looked at
+    __shared__ uint32_t work[kInvMap ? kWorkMax : 1];
+    __shared__ int32_t work_n;
+    __shared__ __attribute__((aligned(16))) float wtile[(kStrided && kUpdate) ? kTile : 4];
+    __shared__ int64_t span[2];
+    __shared__ double red[4];
+    extern __shared__ double pfx_s[];         // [T + 1] with SCAN_IN (dynamic; statics above total a multiple of 16 B)
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // Tile of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD); an output
+    // tile reads ancestors from its own and the neighbouring tiles, which the previous launch wrote.  Giving each XCD a
+    // CONTIGUOUS range of tiles keeps those neighbours -- and the lines they left in that XCD's L2 -- on one XCD
+    // (speed only: nothing depends on the placement).
+    const int tile_id = xcd_contiguous_tile(blockIdx.x, T);
+    const int64_t tile0 = (int64_t)tile_id * kTile;
+    const int64_t i0 = tile0 + (int64_t)tid * kPerThread;       // consecutive mapping: first of this thread's 4
+    const double Nd = (double)N;
+    const float w_uniform = (float)(1.0 / Nd);
+    const float* xin_b = x_in + (int64_t)b * GSE_NX * ld;
+
+    // index of this thread's p-th particle (N < 2^31 is checked by the host: 32-bit offsets from uniform row pointers
+    // let the loads and stores use the scalar-base + 32-bit-offset form instead of a 64-bit address per access)
+    uint32_t jp[kPerThread];
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p)
+        jp[p] = (uint32_t)(kStrided ? tile0 + tid + (int64_t)p * kBlock : i0 + p);
+    const uint32_t Nu = (uint32_t)N;
+
+    if (kPredict && !kInjected) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.draw);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
+        for (int i = tid; i < (int)(sizeof(DrawParams) / 4); i += kBlock) dst[i] = src[i];
+    }
+
+    // ---- noise: Philox + Box-Muller, registers only.  At N = 2^20 all workgroups of a launch are resident at once and
+    //      march through the same phases together, so while they wait on memory (tile prefix, searches, staging,
+    //      gather) no wavefront on the CU has arithmetic to do.  The draw is the one block of arithmetic that depends
+    //      on nothing: half of the workgroups do it up front, the other half between issuing their state loads and
+    //      using them, so that on every CU one group computes while the other waits.
+    float e[kPerThread][GSE_NX];
+    auto draw_all = [&]() {
+        if (kGather) GSE_PRIO_DRAW_BEGIN();
+        mixture_draw5x4(dp, a.rng, (uint32_t)tile_id * kBlock + (uint32_t)tid, (uint32_t)b, e);
+        if (kGather) GSE_PRIO_DRAW_END();
+    };
+    const int draw_at = (kDraw && kGather) ? draw_position(blockIdx.x) : 3;      // workgroup-uniform
+    GSE_STAMP(0);
+    GSE_BLOCK_TIME(0);
+    if (kGather) GSE_PRIO_MEM();
+    // SCAN_IN: this thread's chunk of the tile sums (the scan modes run up to 2048 tiles, so at most 8), requested before
+    // anything else -- also before an early noise draw, which then covers their latency
+    constexpr int kMaxChunk = 8;
+    double sv[kMaxChunk];
+    if (kScanIn) {
+        const double* sums = scan_in_sums + (int64_t)b * T;
+        const int m = (T + kBlock - 1) / kBlock;
+        const int qlo = tid * m;
+#pragma unroll
+        for (int i = 0; i < kMaxChunk; ++i) sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
+    }
+    if (kDraw) __syncthreads();                          // dp staged
+    if (kDraw && draw_at == 0) draw_all();
+    GSE_STAMP(1);
+
+    // ---- gather: ancestors of this thread's 4 outputs -------------------------------------------------
+    int32_t anc[kPerThread] = {0, 0, 0, 0};
+    if (kStrided && !kGather) {
+        // no resample in this launch: every particle is its own "ancestor" (clipped: lanes beyond N read a valid row)
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p) anc[p] = (int32_t)min(jp[p], Nu - 1u);
+    }
+    bool drawn2 = false;
+    if (kGather) {
+        double W;
+        if (kScanIn) {
+            // tile prefix into LDS: thread j owns chunk [j*m, (j+1)*m) of the tile sums (as inline_tile_prefix); the sums were
+            // loaded at kernel entry and stay in registers for the second sweep
+            const int m = (T + kBlock - 1) / kBlock;
+            const int qlo = tid * m;
+            if (kInvMap) {
+                *reinterpret_cast<uint4*>(&mark[tid * kPerThread]) = make_uint4(0u, 0u, 0u, 0u);
+                if (tid == 0) { act_n = 0; work_n = 0; }
+            }
+            double chunk = 0.0;
+#pragma unroll
+            for (int i = 0; i < kMaxChunk; ++i) chunk += sv[i];            // (+ 0.0 beyond the chunk: exact)
+            double total;
+            double run = block_exclusive_scan(chunk, red, total);
+#pragma unroll
+            for (int i = 0; i < kMaxChunk; ++i) {
+                if (i < m && qlo + i < T) pfx_s[qlo + i] = run;
+                run += sv[i];
+            }
+            if (tid == 0) pfx_s[T] = total;
+            __syncthreads();
+            W = pfx_s[T];
+    GSE_STAMP(2);
+            if (island && tile_id == 0 && tid == 0) {      // shard bookkeeping (see gse_pf_resample)
+                island[b] += log(W);
+                island[gridDim.y + b] = W;
+            }
+        } else {
+            W = totals[b];
+        }
+        if (kDraw && draw_at == 1) draw_all();
+        const double r = a.ra.r[b];
+        // Weights that do not sum to a positive finite number: the reference's normalised cumsum is all-NaN and its
+        // sweep never advances (filter/particle.py:98), so every offspring copies particle 0 (anc stays 0).
+        if ((W > 0.0) && (W < INFINITY)) {
+          if constexpr (kInvMap) {
+            // ---- inverse map (gse_device.h, OffspringCount).  No stored scans, no search: the keys of an ancestor tile are
+            //      re-formed from its WEIGHTS exactly as cumsum_kernel forms them -- x[k] = min(Pfx[t] + (excl + s_p),
+            //      Pfx[t+1]), thread t of the workgroup holding keys 4t .. 4t+3 -- and every key with e = F(k) - j0 in
+            //      [0, 1024) raises mark[e] to k + 1 (LDS atomic max; a thread's equal neighbours are folded first).  F is
+            //      monotone, so the ancestor of output slot i is  1 + max{k : e_k <= i}  (the key after the last one whose
+            //      offspring all lie before i) = an inclusive max-scan of the marks, floored at the first key of the first
+            //      tile that can hold an ancestor.
+            OffspringCount F;
+            F.init(N, r, W);
+            const int32_t j0 = (int32_t)tile0;
+            const int32_t j1 = (int32_t)min(tile0 + kTile, N);
+            auto slot_of = [&](double x) -> int32_t { return min(max(F(x) - j0, 0), (int32_t)kTile); };
+            // which tiles can hold ancestors: conservative on both sides by 2^-50 (see the round-1 path below)
+            const double p_lo = (F.u_of(j0) * W) * (1.0 - 0x1p-50);
+            const double p_hi = (F.u_of(j1 - 1) * W) * (1.0 + 0x1p-50);
+            int tl0, tl1;
+            wave_search_ge_pair([&](int q) { return pfx_s[q + 1]; }, T, p_lo, p_hi, lane, tl0, tl1);
+            const float* wrow = w_in + (int64_t)b * ld;
+    GSE_STAMP(11);
+            const double* qx = scan_in + (int64_t)b * T * kBlock;                  // [T][256] per-thread exclusive prefixes
+            auto tile_weights = [&](int tq) {
+                return load_weights4(wrow, (int64_t)tq * kTile + (int64_t)tid * kPerThread, N, ld);
+            };
+            // Which tiles to expand.  One or two (the common case): both.  A wider range (a stretch of light particles):
+            // census first -- all keys of tile q lie in [Pfx[q], Pfx[q+1]]; when both ends fall into the same slot the whole
+            // tile does and its LAST key stands for it; only tiles that some output of this workgroup descends from are
+            // listed.  The listed tiles are expanded two at a time, the loads of the next pair in flight meanwhile.
+            const bool direct = tl1 - tl0 < 2;                                     // workgroup-uniform
+            int n_act = tl1 - tl0 + 1;
+            if (!direct) {
+                for (int q0 = tl0; q0 <= tl1; q0 += kBlock) {                       // (whole wavefronts take part: DPP below)
+                    const int q = q0 + tid;
+                    const bool have = q <= tl1;
+                    const int32_t e0 = have ? slot_of(pfx_s[q]) : 0, e1 = have ? slot_of(pfx_s[q + 1]) : -1;
+                    // a run of tiles that all fall into one slot: the last of the run speaks for it
+                    const uint32_t next_e1 = wave_shift_down1((uint32_t)(e1 + 2));     // (0 in lane 63 -> speak)
+                    if (!have) continue;
+                    if (e0 == e1) {
+                        if (e1 < kTile && next_e1 != (uint32_t)(e1 + 2))
+                            atomicMax(&mark[e1], (uint32_t)(min((int64_t)(q + 1) * kTile, N) - 1) + 1u);
+                    } else {
+                        act_list[atomicAdd(&act_n, 1)] = q;                        // at most 1024: the slots e0 < e1 are disjoint
+                    }
+                }
+                __syncthreads();
+                n_act = act_n;
+            }
+            auto tile_at = [&](int i) { return direct ? tl0 + i : act_list[i]; };
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef GSE_EXPAND_ALL
+#define GSE_EXPAND_ALL 32
+#endif
+            constexpr int kExpandAll = GSE_EXPAND_ALL;         // up to this many tiles: every key is looked at
+            bool all_keys = n_act <= kExpandAll;                                   // workgroup-uniform
+            if (!all_keys) {
+                // Many tiles, each with only a few of this workgroup's outputs (a long stretch of light particles): going
+                // through all their keys is work in proportion to the stretch, although at most 1024 slot boundaries exist.
+                // A second census, per quad: the keys of thread t's quad lie between its exclusive prefix and the next
+                // thread's (up to the roundings of the scans, ~2^-49 of the tile sum); when both ends land in one slot, at
+                // a safe distance (N 2^-44, 16 times the guard of the exact count) from the slot boundaries, so do the four
+                // keys, and the quad's last key speaks for them.  The other quads -- at most one per boundary -- go on a work
+                // list and get the full treatment, densely packed.
+                const double qguard = F.Nd * 0x1p-44;
+                bool overflow = false;
+                // (the prefixes of the next two tiles are requested before this one is looked at)
+                const int tnext = min(tid + 1, kBlock - 1);
+                auto quad_prefixes = [&](int i, double& p0, double& p1) {
+                    if (i < n_act) {
+                        const double* qt = qx + (int64_t)act_list[i] * kBlock;
+                        p0 = qt[tid];
+                        p1 = qt[tnext];
+                    }
+                };
+                double b0 = 0.0, b1 = 0.0, c0_ = 0.0, c1_ = 0.0;
+                quad_prefixes(0, b0, b1);
+                quad_prefixes(1, c0_, c1_);
+                for (int i = 0; i < n_act; ++i) {
+                    const int tq = act_list[i];
+                    const double P0 = pfx_s[tq], P1 = pfx_s[tq + 1];
+                    const int64_t k0 = (int64_t)tq * kTile + (int64_t)tid * kPerThread;
+                    const int64_t tile_last = min((int64_t)(tq + 1) * kTile, N) - 1;
+                    const bool have = k0 <= tile_last;
+                    const double a0 = b0, a1 = b1;
+                    b0 = c0_; b1 = c1_;
+                    quad_prefixes(i + 2, c0_, c1_);
+                    const double xb = fmin(P0 + a0, P1);                           // (quad 0: its exclusive prefix is 0 -> P0)
+                    const double xe = (tid == kBlock - 1 || k0 + kPerThread - 1 >= tile_last) ? P1 : fmin(P0 + a1, P1);
+                    const double sb = fma(xb, F.NoverW, -F.r), se = fma(xe, F.NoverW, -F.r);
+                    const double fb = floor(sb), fe = floor(se);
+                    const bool safe = (sb - fb >= qguard) && (sb - fb <= 1.0 - qguard) && (se - fe >= qguard) &&
+                                      (se - fe <= 1.0 - qguard);
+                    const int32_t eb = min(max((int32_t)fb + 1 - j0, 0), (int32_t)kTile);
+                    const int32_t ee = min(max((int32_t)fe + 1 - j0, 0), (int32_t)kTile);
+                    const bool uniform = have && safe && eb == ee;
+                    // (fold: the next lane's quad is uniform with the same slot -> it, or a later one, speaks)
+                    const uint32_t next_tag = wave_shift_down1(uniform ? (uint32_t)ee + 1u : 0u);
+                    if (uniform) {
+                        if (ee < kTile && next_tag != (uint32_t)ee + 1u)
+                            atomicMax(&mark[ee], (uint32_t)min(k0 + kPerThread - 1, tile_last) + 1u);
+                    } else if (have) {
+                        const int at = atomicAdd(&work_n, 1);
+                        if (at < kWorkMax) work[at] = (uint32_t)tq * (uint32_t)kBlock + (uint32_t)tid;
+                        else overflow = true;
+                    }
+                }
+                // (an overflowing work list cannot happen short of ~250 quads inside the safety band at once; if it does,
+                //  every key is looked at instead -- marks are maxima, doing some twice changes nothing)
+                all_keys = __syncthreads_or(overflow ? 1 : 0) != 0;
+            }
+            if (all_keys) {
+                int t0 = (n_act > 0) ? tile_at(0) : 0, t1 = (n_act > 1) ? tile_at(1) : 0;
+                float4 c0 = zero4, c1 = zero4;
+                double x0 = 0.0, x1 = 0.0;
+                if (n_act > 0) { c0 = tile_weights(t0); x0 = qx[t0 * kBlock + tid]; }
+                if (n_act > 1) { c1 = tile_weights(t1); x1 = qx[t1 * kBlock + tid]; }
+                if (kDraw && draw_at == 2) {
+                    draw_all();
+                    drawn2 = true;
+                }
+                for (int i = 0; i < n_act; i += 2) {
+                    const int u0 = (i + 2 < n_act) ? tile_at(i + 2) : 0, u1 = (i + 3 < n_act) ? tile_at(i + 3) : 0;
+                    float4 n0 = zero4, n1 = zero4;
+                    double y0 = 0.0, y1 = 0.0;
+                    if (i + 2 < n_act) { n0 = tile_weights(u0); y0 = qx[u0 * kBlock + tid]; }
+                    if (i + 3 < n_act) { n1 = tile_weights(u1); y1 = qx[u1 * kBlock + tid]; }
+                    expand_quad<true>(F, pfx_s, mark, N, j0, t0, tid, c0, x0);
+                    if (i + 1 < n_act) expand_quad<true>(F, pfx_s, mark, N, j0, t1, tid, c1, x1);
+                    c0 = n0; c1 = n1; x0 = y0; x1 = y1; t0 = u0; t1 = u1;
+                }
+            } else {
+                const int n_work = min(work_n, kWorkMax);
+                for (int i = tid; i < n_work; i += kBlock) {
+                    const uint32_t id = work[i];
+                    const int tq = (int)(id / (uint32_t)kBlock), t = (int)(id % (uint32_t)kBlock);
+                    const float4 wv = load_weights4(wrow, (int64_t)tq * kTile + (int64_t)t * kPerThread, N, ld);
+                    expand_quad<false>(F, pfx_s, mark, N, j0, tq, t, wv, qx[id]);
+                }
+            }
+    GSE_STAMP(3);
+#ifdef GSE_STAMPS
+            if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+                g_block_info[2 * blockIdx.x] = (long long)(tl1 - tl0 + 1) | ((long long)act_n << 20);
+                g_block_info[2 * blockIdx.x + 1] = draw_at;
+            }
+#endif
+            __syncthreads();
+            // inclusive max-scan of the 1024 marks: thread t owns slots 4t .. 4t+3
+            {
+                const uint4 mk = *reinterpret_cast<const uint4*>(&mark[tid * kPerThread]);
+                const uint32_t m0 = mk.x, m1 = max(m0, mk.y), m2 = max(m1, mk.z), m3 = max(m2, mk.w);
+                const uint32_t inc = wave_inclusive_max(m3);
+                uint32_t before = wave_shift_up1(inc);
+                uint32_t* wmax = reinterpret_cast<uint32_t*>(red);                 // (free since the tile prefix)
+                if (lane == 63) wmax[wv] = inc;
+                __syncthreads();
+                if (wv > 0) before = max(before, wmax[0]);
+                if (wv > 1) before = max(before, wmax[1]);
+                if (wv > 2) before = max(before, wmax[2]);
+                // marks hold k + 1 = the key that FOLLOWS the last exhausted one: that is the ancestor itself
+                const uint32_t floor_key = (uint32_t)tl0 * (uint32_t)kTile;        // first key of the range
+                const uint32_t last_key = (uint32_t)N - 1u;
+                uint4 av;
+                av.x = min(max(max(before, m0), floor_key), last_key);
+                av.y = min(max(max(before, m1), floor_key), last_key);
+                av.z = min(max(max(before, m2), floor_key), last_key);
+                av.w = min(max(max(before, m3), floor_key), last_key);
+                *reinterpret_cast<uint4*>(&mark[tid * kPerThread]) = av;           // the slots this thread alone has read
+                __syncthreads();
+#pragma unroll
+                for (int p = 0; p < kPerThread; ++p) anc[p] = (int32_t)mark[tid + p * kBlock];
+            }
+          } else {
+            const double* cb = kScanIn ? scan_in + (int64_t)b * N : c + (int64_t)b * N;
+            // The search key of ancestor k.
+            //   materialised c[] : ckey(k) = c[k]                                   (normalised by cumsum_kernel)
+            //   SCAN_IN          : xkey(k) = min(Pfx[t] + L[k], Pfx[t+1])           (un-normalised; tile's last: Pfx[t+1])
+            //                      ckey(k) = fl(xkey(k) / W)                         -- the bits cumsum_kernel would store
+            // Outputs compare ckey with u = (j + r) / N, the reference's comparison verbatim.  Where a division per probe
+            // would sit on a dependent chain (the bracket search, the long-span fallback) the un-normalised key is
+            // compared with tau(u) = the smallest fp64 x with fl(x / W) >= u instead: x -> fl(x / W) is monotone, so
+            // fl(xkey / W) >= u  <=>  xkey >= tau(u) -- exactly the same decision, no division in the loop.
+            auto xkey = [&](int64_t k) -> double {
+                if (!kScanIn) return cb[k];
+                const int t = (int)(k / kTile);
+                const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
+                return (k == last) ? pfx_s[t + 1] : fmin(pfx_s[t] + cb[k], pfx_s[t + 1]);
+            };
+            // u_j = (j + r) / N as the reference forms it; for N a power of two the division is an exact scaling and
+            // (j + r) * (1 / N) gives the same bits without a division
+            const bool pow2 = (N & (N - 1)) == 0;
+            const double invN = 1.0 / Nd;
+            auto u_of = [&](uint32_t j) -> double {
+                const double jr = (double)j + r;
+                return pow2 ? jr * invN : jr / Nd;
+            };
+            auto tau_of = [&](double u) -> double { return kScanIn ? smallest_with_quotient_ge(u, W) : u; };
+            const int64_t j0 = tile0;
+            const int64_t j1 = min(j0 + kTile, N);
+            double thr[kPerThread];                       // thresholds of this thread's four outputs
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) thr[p] = u_of(jp[p]);
+            // Where the ancestors of this tile's outputs live.  SCAN_IN, the common case: the span lies inside one or
+            // two ancestor TILES, found in the LDS prefix alone (every wavefront for itself: two 64-ary rounds per end,
+            // no memory access, no barrier) -- the whole tiles are staged and bisected, a superset of the exact span,
+            // which changes nothing in the result.  The tile range is conservative by construction: a tile is excluded
+            // at the low end only if its last key is below u_first W (1 - 2^-50), at the high end the first tile whose
+            // last key reaches u_last W (1 + 2^-50) closes the range; the margins dwarf the roundings (2^-52) of the
+            // products and of the quotient the exact comparison uses.
+            int64_t klo = 0, khi = -1;
+            bool whole_tiles = false;
+            int tl0 = 0;
+            if (kScanIn) {
+                const double p_lo = (u_of((uint32_t)j0) * W) * (1.0 - 0x1p-50);
+                const double p_hi = (u_of((uint32_t)(j1 - 1)) * W) * (1.0 + 0x1p-50);
+                tl0 = (int)wave_search_ge([&](int64_t q) { return pfx_s[q + 1]; }, T, p_lo, lane);
+                const int tl1 = (int)wave_search_ge([&](int64_t q) { return pfx_s[q + 1]; }, T, p_hi, lane);
+                if (tl1 - tl0 < kSpanMax / kTile) {                            // workgroup-uniform
+                    whole_tiles = true;
+                    klo = (int64_t)tl0 * kTile;
+                    khi = min((int64_t)(tl1 + 1) * kTile, N) - 1;
+                }
+            }
+            if (!whole_tiles) {
+                // exact bracket: wavefront 0 searches the ancestor of the first output, wavefront 1 that of the last
+                if (wv < 2) {
+                    const int64_t j = (wv == 0) ? j0 : j1 - 1;
+                    const double t_e = tau_of(u_of((uint32_t)j));
+                    int64_t lo_k = 0, hi_k = N - 1;
+                    if (kScanIn) {
+                        // narrow to one tile in the LDS prefix first (no memory access), then a 64-ary search inside it
+                        int tl = 0, th = T - 1;                                    // first tile whose end key >= t_e
+                        while (tl < th) {
+                            const int mid = (tl + th) >> 1;
+                            if (pfx_s[mid + 1] < t_e) tl = mid + 1; else th = mid;
+                        }
+                        lo_k = (int64_t)tl * kTile;
+                        hi_k = min((int64_t)(tl + 1) * kTile, N) - 1;
+                    }
+                    const int64_t k =
+                        lo_k + wave_search_ge([&](int64_t q) { return xkey(lo_k + q); }, hi_k - lo_k + 1, t_e, lane);
+                    if (lane == 0) span[wv] = k;
+                }
+                __syncthreads();
+                klo = span[0];
+                khi = span[1];
+            }
+    GSE_STAMP(3);
+            const int64_t len = khi - klo + 1;
+#ifdef GSE_STAMPS
+            if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+                g_block_info[2 * blockIdx.x] = len;
+                g_block_info[2 * blockIdx.x + 1] = draw_at;
+            }
+#endif
+            if (kDraw && draw_at == 2) {
+                draw_all();
+                drawn2 = true;
+            }
+            if (len <= kSpanMax) {
+                // the span fits LDS (the common case: ~1000 ancestors at the median): stage the normalised keys (all
+                // loads, then all divisions, in flight together) and bisect there against u
+                {
+                    constexpr int kPer = kSpanMax / kBlock;
+                    double kv[kPer];
+                    if (kScanIn && whole_tiles) {
+                        // whole tiles: the tile of a round is uniform, so are its two prefix entries
+#pragma unroll
+                        for (int m = 0; m < kPer; ++m) {
+                            if ((int64_t)m * kBlock < len) {                   // workgroup-uniform: whole rounds are skipped
+                                const int tm = tl0 + (m * kBlock) / kTile;
+                                const int64_t k = klo + m * kBlock + tid;
+                                const int64_t tile_last = min((int64_t)(tm + 1) * kTile, N) - 1;
+                                const double below = pfx_s[tm], top = pfx_s[tm + 1];
+                                const double l = cb[min(k, tile_last)];
+                                kv[m] = (k >= tile_last) ? top : fmin(below + l, top);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < kPer; ++m) {
+                            if ((int64_t)m * kBlock < len) {
+                                const int q = tid + m * kBlock;
+                                kv[m] = xkey(klo + min((int64_t)q, len - 1));
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < kPer; ++m) {
+                        if ((int64_t)m * kBlock < len) {
+                            const int q = tid + m * kBlock;
+                            if (q < (int)len) seg[q] = kScanIn ? kv[m] / W : kv[m];
+                        }
+                    }
+                }
+                __syncthreads();
+                int found[kPerThread];
+                span_search4(seg, (int)len, thr, found);
+#pragma unroll
+                for (int p = 0; p < kPerThread; ++p) anc[p] = (int32_t)klo + found[p];
+            } else {
+                // A long span: the tile's ancestors are spread over a stretch of (nearly) weightless particles.  Two
+                // levels: LDS gets every s-th key (the last of each group of s, so seg[g] = max of group g); an output
+                // bisects the groups in LDS, then the <= s keys of its group in memory (log2 s probes inside a few
+                // cache lines).  One staging pass and one short dependent chain whatever the length of the span.
+                const int64_t s_ = (len + kSpanMax - 1) / kSpanMax;              // group size, >= 2
+                const int groups = (int)((len + s_ - 1) / s_);                    // <= kSpanMax
+                for (int q = tid; q < groups; q += kBlock) seg[q] = xkey(min(klo + (int64_t)(q + 1) * s_, khi + 1) - 1);
+                __syncthreads();
+#pragma unroll
+                for (int p = 0; p < kPerThread; ++p) {
+                    const double t_p = tau_of(thr[p]);                            // un-normalised keys here
+                    const int g_ = span_search(seg, groups, t_p);
+                    int64_t lo = klo + (int64_t)g_ * s_;
+                    int64_t hi = min(lo + s_, khi + 1) - 1;
+                    while (lo < hi) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (xkey(mid) < t_p) lo = mid + 1; else hi = mid;
+                    }
+                    anc[p] = (int32_t)lo;
+                }
+            }
+          }
+        }
+    }
+    if (kDraw && draw_at == 2 && !drawn2) draw_all();      // (weights that do not sum to a positive number: no search)
+    GSE_STAMP(4);
+    // a thread is live if it owns at least one particle (its first one)
+    const bool live = jp[0] < Nu;
+    float wnew[kPerThread] = {w_uniform, w_uniform, w_uniform, w_uniform};
+    if (live) {
+        // ---- issue every load now; the RNG arithmetic below needs no memory and hides their latency.  (Plain loads
+        //      get sunk below the RNG by the compiler to save registers, which serialises "RNG, then wait for HBM";
+        //      the asm statements pin the issue point and the wait is tied to the registers -- guide 5.7.)
+        float g[2][GSE_NX];                   // indexed rows of the current half (strided mapping)
+        v4f r0, r1, r2, r3, r4;               // contiguous rows (consecutive mapping)
+        if (kStrided) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < GSE_NX; ++k) GSE_LOAD_DWORD_S(g[q][k], (uint32_t)anc[q] * 4u, xin_b + k * ld);
+        } else {
+            const float* xb = xin_b + i0;
+            GSE_LOAD_DWORDX4(r0, xb);
+            GSE_LOAD_DWORDX4(r1, xb + ld);
+            GSE_LOAD_DWORDX4(r2, xb + 2 * ld);
+            GSE_LOAD_DWORDX4(r3, xb + 3 * ld);
+            GSE_LOAD_DWORDX4(r4, xb + 4 * ld);
+        }
+        if (kUpdate && !kGather && !kStrided) {
+            const float4 w4 = *reinterpret_cast<const float4*>(w_in + (int64_t)b * ld + i0);
+            wnew[0] = w4.x; wnew[1] = w4.y; wnew[2] = w4.z; wnew[3] = w4.w;
+        }
+        float nz[kPerThread][GSE_NX];
+        if (kPredict && kInjected) {
+            const float* nb = noise + (int64_t)b * GSE_NX * ld;
+            if (kStrided) {
+#pragma unroll
+                for (int p = 0; p < kPerThread; ++p)
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) nz[p][k] = (jp[p] < Nu) ? (nb + k * ld)[jp[p]] : 0.f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < GSE_NX; ++k) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(nb + k * ld + i0);
+                    nz[0][k] = t4.x; nz[1][k] = t4.y; nz[2][k] = t4.z; nz[3][k] = t4.w;
+                }
+            }
+        }
+
+        // ---- two halves of two particles each (keeps the live register set small): the noise of a half is drawn
+        //      first -- registers only -- and the first half's draw is what hides the latency of the loads above.
+        v4f row[GSE_NX];
+        float gq[2][GSE_NX];
+        float obs[kPerThread][kObsKept];              // what g reads of the (new) state (bioreactor: Cg, Cfa)
+        // per-filter inputs: kernel arguments, or two uniform (scalar) loads each when they live on the device
+        double fg = a.io.f[b].u0, fm = a.io.f[b].u1, z0 = a.io.f[b].z0, z1 = a.io.f[b].z1;
+        if constexpr (kDevIO) {
+            if (a.u_dev) { fg = a.u_dev[2 * b]; fm = a.u_dev[2 * b + 1]; }
+            if (a.z_dev) { z0 = a.z_dev[2 * b]; z1 = a.z_dev[2 * b + 1]; }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 0) {
+                GSE_STAMP(5);
+                if (kDraw && draw_at == 3) draw_all();
+                GSE_STAMP(6);
+                if (kPredict && kInjected) {
+#pragma unroll
+                    for (int p = 0; p < kPerThread; ++p)
+#pragma unroll
+                        for (int k = 0; k < GSE_NX; ++k) e[p][k] = nz[p][k];
+                }
+            }
+            // the state rows of this half must have landed now; in the strided mapping the other half's loads are issued
+            // right behind the wait so that they fly during this half's ODE step
+            if (kStrided) {
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[0][2]), "+v"(g[0][3]), "+v"(g[0][4]),
+                               "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[1][2]), "+v"(g[1][3]), "+v"(g[1][4])::"memory");
+                if (h == 0) GSE_STAMP(7);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) gq[q][k] = g[q][k];
+                if (h == 0) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int k = 0; k < GSE_NX; ++k)
+                            GSE_LOAD_DWORD_S(g[q][k], (uint32_t)anc[2 + q] * 4u, xin_b + k * ld);
+                    if (kGather) GSE_PRIO_ALU();
+                }
+            } else if (h == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4)::"memory");
+                row[0] = r0; row[1] = r1; row[2] = r2; row[3] = r3; row[4] = r4;
+            }
+            // predict: ODE step + noise.  In the strided mapping the particle's new state goes out at once (dword stores,
+            // contiguous across the wavefront) and only the two observed states stay in registers for the update.
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int p = 2 * h + q;
+                float s[GSE_NX];
+#pragma unroll
+                for (int k = 0; k < GSE_NX; ++k) s[k] = kStrided ? gq[q][k] : row[k][p];
+                if (kPredict) {
+                    model_step(s, fg, fm, a.dt);
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) s[k] += e[p][k];
+                }
+                if (kStrided) {
+                    if ((kGather || kPredict) && jp[p] < Nu) {
+                        float* xb = x_out + (int64_t)b * GSE_NX * ld;
+#pragma unroll
+                        for (int k = 0; k < GSE_NX; ++k) store_out<1>(xb + k * ld + jp[p], s[k]);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) row[k][p] = s[k];
+                }
+                model_keep(s, obs[p]);
+            }
+        }
+        // the new state goes out now, ahead of the update phase (consecutive mapping: one dwordx4 per row)
+        if (!kStrided && kPredict) {
+            float* xb = x_out + (int64_t)b * GSE_NX * ld + i0;
+#pragma unroll
+            for (int k = 0; k < GSE_NX; ++k) store_out4<1>(xb + k * ld, row[k]);
+        }
+        // update as a phase of its own: the ODE and the likelihood each need ~20 fp64 constants; interleaving them per
+        // particle keeps both sets live, overflows the scalar registers and spills ~100 VGPRs
+        __builtin_amdgcn_sched_barrier(0);
+        GSE_STAMP(8);
+        if (kUpdate && !kGather && kStrided) {
+            // (the old weights of a launch that draws but does not resample: fetched here, not ahead of the draw and the
+            //  model step -- four more live registers there spill)
+            const float* wb = w_in + (int64_t)b * ld;
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) wnew[p] = (jp[p] < Nu) ? wb[jp[p]] : 0.f;
+        }
+        if (kUpdate) {
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) {
+                float y0, y1;
+                model_output_kept(obs[p], fg, fm, y0, y1);
+                const double lik = mixture_pdf2<kNd>(a.pdf, z0 - (double)y0, z1 - (double)y1);
+                wnew[p] = (float)((double)wnew[p] * lik);
+            }
+        }
+
+        // ---- ancestor indices; the uniform weights of a resample without update (an update stores its weights below,
+        //      once they are back in consecutive order)
+        if (kGather) {
+            float* wb = w_out + (int64_t)b * ld;
+            int32_t* ib = idx_out ? idx_out + (int64_t)b * ld : nullptr;
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p)
+                if (jp[p] < Nu) {
+                    if (!kUpdate) store_out<2>(wb + jp[p], wnew[p]);
+                    if (ib) ib[jp[p]] = anc[p];
+                }
+        }
+    }
+    GSE_STAMP(9);
+    if (kUpdate) {
+        // tile sum of the new weights, always formed in the same order (4 consecutive per thread, then the workgroup
+        // tree) so that fused and separate launches leave bit-identical sums; the strided mapping goes through LDS.
+        if (kStrided) {
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) wtile[tid + p * kBlock] = wnew[p];
+            __syncthreads();
+            const float4 t4 = *reinterpret_cast<const float4*>(&wtile[tid * kPerThread]);
+            wnew[0] = t4.x; wnew[1] = t4.y; wnew[2] = t4.z; wnew[3] = t4.w;
+        }
+        // the new weights, four consecutive ones per thread: one dwordx4 store (rows are padded to a multiple of 4)
+        if (i0 < N) {
+            const v4f w4o = {wnew[0], wnew[1], wnew[2], wnew[3]};
+            store_out4<2>(w_out + (int64_t)b * ld + i0, w4o);
+        }
+        // (the tile sum is DEFINED as the total of the workgroup scan of the per-thread sums -- tile_scan_total -- in
+        // every kernel that forms one, so one reduction serves both the sum and the tile-local scan)
+        double sc[kPerThread];
+        sc[0] = (i0 + 0 < N) ? (double)wnew[0] : 0.0;
+        sc[1] = sc[0] + ((i0 + 1 < N) ? (double)wnew[1] : 0.0);
+        sc[2] = sc[1] + ((i0 + 2 < N) ? (double)wnew[2] : 0.0);
+        sc[3] = sc[2] + ((i0 + 3 < N) ? (double)wnew[3] : 0.0);
+        double total;
+        const double excl = block_exclusive_scan(sc[3], red, total);
+        if (tid == 0) tile_sums[(int64_t)b * T + tile_id] = total;
+        if (kScanOut) {
+            // the tile sums the NEXT launch's gather stage builds its prefix from (a slot of their own: this launch may
+            // still be reading the previous ones)
+            if (tid == 0) scan_out_sums[(int64_t)b * T + tile_id] = total;
+        }
+        if (kScanOut) {
+            // ... and this thread's exclusive prefix inside the tile: with the four weights it gives back the tile-local
+            // cumulative weights excl + s_p, the expression cumsum_kernel uses (8 bytes per 4 particles)
+            double* qo = scan_out + ((int64_t)b * T + tile_id) * kBlock + tid;
+            if constexpr ((GSE_WT_STORES & 4) != 0) __hip_atomic_store(qo, excl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *qo = excl;
+        }
+    }
+    GSE_STAMP(10);
+    GSE_BLOCK_TIME(1);
+}
+
+// Tile sums for a resample that does not directly follow an update (weights assigned by the caller).
+__global__ __launch_bounds__(kBlock) void tile_sum_kernel(const float* __restrict__ w, double* __restrict__ tile_sums,
+                                                          int64_t N, int64_t ldw, int T) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    const int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kPerThread;
+    const float4 wv = load_weights4(w + (int64_t)b * ldw, i0, N, ldw);
+    const double mine = masked_sum4(wv.x, wv.y, wv.z, wv.w, i0, N);
+    double total;
+    block_exclusive_scan(mine, red, total);
+    if (threadIdx.x == 0) tile_sums[(int64_t)b * T + blockIdx.x] = total;
+}
+
+// Exclusive prefix over the T tile sums of each filter: prefix[q] = s_0 + ... + s_{q-1}, prefix[T] = total.
+// One workgroup per filter; thread j owns the contiguous chunk [j*m, (j+1)*m).
+__global__ __launch_bounds__(kBlock) void tile_scan_kernel(const double* __restrict__ tile_sums,
+                                                           double* __restrict__ prefix, int T) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    const double* s = tile_sums + (int64_t)b * T;
+    double* p = prefix + (int64_t)b * (T + 1);
+    const int m = (T + kBlock - 1) / kBlock;
+    const int lo = threadIdx.x * m;
+    const int hi = min(lo + m, T);
+    double chunk = 0.0;
+    for (int q = lo; q < hi; ++q) chunk += s[q];
+    double total;
+    double run = block_exclusive_scan(chunk, red, total);
+    if (threadIdx.x == 0) p[0] = 0.0;
+    for (int q = lo; q < hi; ++q) {
+        run += s[q];
+        p[q + 1] = run;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// systematic resample
+// ------------------------------------------------------------------------------------------------
+// Two kernels, both perfectly balanced whatever the weights look like (a degenerate posterior -- a handful of
+// particles carrying all the weight -- is the normal state of this filter, see tests/test_oracle_golden.py):
+//
+//   cumsum_kernel   one workgroup per tile of 1024 ANCESTORS: tile prefix (from the tile sums the update kernel
+//                   left behind) + fp64 scan of the tile's weights -> normalised cumulative weights c[k], fp64,
+//                   monotone, c[N-1] = 1.                                     r 4 B, w 8 B per particle
+//   gather          one workgroup per tile of 1024 OUTPUTS: two 64-ary wavefront searches bracket the tile's
+//   (stage of        ancestor span in c[], the span is staged in LDS, every output finds its ancestor
+//   pf_step_kernel;  (first k with c[k] >= (j + r)/N, the reference's comparison verbatim) by binary search in
+//   gather_kernel    LDS and copies it; stores are contiguous in j.           r 8 + 20 B, w 24 B per particle
+//   for GS-UKF rows)
+//
+// Tile prefix computed inside the cumsum kernel (T <= 4096 tiles): every workgroup scans the T tile sums itself
+// -- identical code on identical data, hence identical bits in every workgroup -- and picks out
+//   Pfx(t), Pfx(t+1), Pfx(T) = total,   Pfx(q) = excl[q / m] + s[(q/m)*m] + ... + s[q-1]
+// (thread j owns chunk [j*m, (j+1)*m); excl = workgroup exclusive scan of the chunk sums).  Larger T: a scan
+// kernel of its own writes the prefix once.
+constexpr int kInlinePrefixMaxT = 4096;
+constexpr int kScanMaxT = kBlock * 8;        // scan modes of the step kernel: a prefix chunk of at most 8 tile sums per thread
+
+__device__ __forceinline__ void inline_tile_prefix(const double* __restrict__ s, int T, int t, double* red,
+                                                   double* out3) {
+    const int m = (T + kBlock - 1) / kBlock;
+    const int lo = threadIdx.x * m;
+    const int hi = min(lo + m, T);
+    double chunk = 0.0;
+    for (int q = lo; q < hi; ++q) chunk += s[q];
+    double total;
+    const double excl = block_exclusive_scan(chunk, red, total);
+    if (t >= lo && t < hi) {
+        double run = excl;
+        for (int q = lo; q < t; ++q) run += s[q];
+        out3[0] = run;
+    }
+    if (t + 1 < T) {
+        if (t + 1 >= lo && t + 1 < hi) {
+            double run = excl;
+            for (int q = lo; q <= t; ++q) run += s[q];
+            out3[1] = run;
+        }
+    } else if (threadIdx.x == 0) {
+        out3[1] = total;
+    }
+    if (threadIdx.x == 0) out3[2] = total;
+    __syncthreads();
+}
+
+// tile_src: kInlinePrefix ? tile sums [B][T] : exclusive tile prefix [B][T + 1] (from tile_scan_kernel).
+// c: [B][N] fp64.  totals: [B] fp64 (sum of the weights).  island: optional [2][B] shard bookkeeping.
+// Shards of a sharded ensemble (exact global resampling, gse_pf_shard_cumsum): tile_src is the prefix over the tiles of
+// ALL shards, this shard's tiles start at tile_offset and the total sits at total_at.
+template <bool kInlinePrefix>
+__global__ __launch_bounds__(kBlock) void cumsum_kernel(const float* __restrict__ w, double* __restrict__ c,
+                                                        const double* __restrict__ tile_src,
+                                                        double* __restrict__ totals, double* __restrict__ island,
+                                                        int64_t N, int64_t ldw, int T, int64_t prefix_stride,
+                                                        int64_t tile_offset, int64_t total_at) {
+    __shared__ double red[4];
+    __shared__ double pfx[3];
+    const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    double P0, P1, W;
+    if (kInlinePrefix) {
+        inline_tile_prefix(tile_src + (int64_t)b * T, T, t, red, pfx);
+        P0 = pfx[0]; P1 = pfx[1]; W = pfx[2];
+    } else {
+        const double* pf = tile_src + (int64_t)b * prefix_stride;
+        P0 = pf[tile_offset + t]; P1 = pf[tile_offset + t + 1]; W = pf[total_at];
+    }
+    if (t == 0 && tid == 0 && totals) {
+        totals[b] = W;
+        if (island) {                          // shard bookkeeping: accumulated log-weight and this cycle's sum
+            island[b] += log(W);
+            island[gridDim.y + b] = W;
+        }
+    }
+    const int64_t i0 = (int64_t)t * kTile + (int64_t)tid * kPerThread;
+    const float4 wv = load_weights4(w + (int64_t)b * ldw, i0, N, ldw);
+    double s[kPerThread];
+    s[0] = (i0 + 0 < N) ? (double)wv.x : 0.0;
+    s[1] = s[0] + ((i0 + 1 < N) ? (double)wv.y : 0.0);
+    s[2] = s[1] + ((i0 + 2 < N) ? (double)wv.z : 0.0);
+    s[3] = s[2] + ((i0 + 3 < N) ? (double)wv.w : 0.0);
+    double tile_total;
+    const double excl = block_exclusive_scan(s[3], red, tile_total);
+    // The tile's last entry is pinned to prefix[t+1]/W and everything before it clamped to that value, so the
+    // array is monotone across tiles although prefix and in-tile sums associate differently; c[N-1] = W/W = 1.
+    const double top = P1 / W;
+    const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
+    double* cb = c + (int64_t)b * N;
+    double v[kPerThread];
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p) v[p] = (i0 + p == last) ? top : fmin((P0 + (excl + s[p])) / W, top);
+    if (i0 + 3 < N && (N & 1) == 0) {          // 16-byte aligned pairs
+        *reinterpret_cast<double2*>(cb + i0) = make_double2(v[0], v[1]);
+        *reinterpret_cast<double2*>(cb + i0 + 2) = make_double2(v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p)
+            if (i0 + p < N) cb[i0 + p] = v[p];
+    }
+}
+
+// Outputs j_base .. j_base + count - 1 of an ensemble of n_total particles, whose ancestors all lie among the N keys
+// of c (the whole ensemble: j_base = 0, count = n_total = N; one shard of a sharded ensemble: its own keys, the outputs
+// that descend from it, and everything written relative to j_base).  w_out may be null.
+template <class Payload>
+__global__ __launch_bounds__(kBlock) void gather_kernel(const Payload pl, const double* __restrict__ c,
+                                                        const double* __restrict__ totals, float* __restrict__ w_out,
+                                                        int32_t* __restrict__ idx_out, int64_t N, int64_t ldw,
+                                                        const ResampleArgs ra, int64_t j_base, int64_t count,
+                                                        int64_t n_total) {
+    __shared__ double seg[kSpanMax];
+    __shared__ int64_t span[2];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t j0 = j_base + (int64_t)blockIdx.x * kTile;
+    const int64_t j1 = min(j0 + kTile, j_base + count);
+    const double r = ra.r[b];
+    const double Nd = (double)n_total;
+    const double W = totals ? totals[b] : 1.0;
+    const double* cb = c + (int64_t)b * N;
+    const float w_uniform = (float)(1.0 / Nd);
+    float* wo = w_out ? w_out + (int64_t)b * ldw - j_base : nullptr;      // indexed by j below
+    int32_t* io = idx_out ? idx_out + (int64_t)b * ldw - j_base : nullptr;
+
+    // Weights that do not sum to a positive finite number: the reference's normalised cumsum is all-NaN and its
+    // sweep never advances (filter/particle.py:98), so every offspring copies particle 0.
+    if (!(W > 0.0) || !(W < INFINITY)) {
+        for (int64_t j = j0 + tid; j < j1; j += kBlock) {
+            pl.copy(b, 0, j - j_base);
+            if (wo) wo[j] = w_uniform;
+            if (io) io[j] = 0;
+        }
+        return;
+    }
+
+    // 1. bracket the ancestors of this output tile: wavefront 0 searches for the first output, wavefront 1 for the last
+    if (wv < 2) {
+        const int64_t j = (wv == 0) ? j0 : j1 - 1;
+        const int64_t k = wave_search_ge([&](int64_t q) { return cb[q]; }, N, ((double)j + r) / Nd, lane);
+        if (lane == 0) span[wv] = k;
+    }
+    __syncthreads();
+    const int64_t klo = span[0], khi = span[1];
+    const int64_t len = khi - klo + 1;
+
+    if (len <= kSpanMax) {
+        // 2a. stage c[klo..khi] in LDS, binary search there (<= 11 steps)
+        for (int q = tid; q < (int)len; q += kBlock) seg[q] = cb[klo + q];
+        __syncthreads();
+        for (int64_t j = j0 + tid; j < j1; j += kBlock) {
+            const double u = ((double)j + r) / Nd;
+            const int lo = span_search(seg, (int)len, u);
+            const int64_t anc = klo + lo;
+            pl.copy(b, anc, j - j_base);
+            if (wo) wo[j] = w_uniform;
+            if (io) io[j] = (int32_t)anc;
+        }
+    } else {
+        // 2b. the tile's ancestors are spread over a long stretch of (nearly) weightless particles: search c[] itself
+        for (int64_t j = j0 + tid; j < j1; j += kBlock) {
+            const double u = ((double)j + r) / Nd;
+            int64_t lo = klo, hi = khi;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (cb[mid] < u) lo = mid + 1; else hi = mid;
+            }
+            pl.copy(b, lo, j - j_base);
+            if (wo) wo[j] = w_uniform;
+            if (io) io[j] = (int32_t)lo;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// moments
+// ------------------------------------------------------------------------------------------------
+// Per-workgroup partial sums of {w, w d, w d d^T} with d = x - pivot, fp64; blocks stride over the tiles.
+__global__ __launch_bounds__(kBlock) void pf_moments_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            double* __restrict__ partials, int64_t N, int64_t ld) {
+    __shared__ double red[4 * 21];
+    const int b = blockIdx.y;
+    const float* xb = x + (int64_t)b * GSE_NX * ld;
+    const float* wb = w + (int64_t)b * ld;
+    double pv[GSE_NX];
+#pragma unroll
+    for (int k = 0; k < GSE_NX; ++k) pv[k] = (double)xb[k * ld];          // pivot = particle 0
+    double acc[21];
+#pragma unroll
+    for (int c = 0; c < 21; ++c) acc[c] = 0.0;
+    const int64_t groups = (N + 3) / 4;
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
+        const int64_t i0 = g * 4;
+        const float4 wv = *reinterpret_cast<const float4*>(wb + i0);
+        float4 row[GSE_NX];
+#pragma unroll
+        for (int k = 0; k < GSE_NX; ++k) row[k] = *reinterpret_cast<const float4*>(xb + k * ld + i0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (i0 + p < N) {
+                const double wp = (double)reinterpret_cast<const float*>(&wv)[p];
+                double d[GSE_NX];
+#pragma unroll
+                for (int k = 0; k < GSE_NX; ++k) d[k] = (double)reinterpret_cast<const float*>(&row[k])[p] - pv[k];
+                acc[0] += wp;
+                int c = 6;
+#pragma unroll
+                for (int k = 0; k < GSE_NX; ++k) {
+                    const double wd = wp * d[k];
+                    acc[1 + k] += wd;
+#pragma unroll
+                    for (int l = k; l < GSE_NX; ++l) acc[c++] += wd * d[l];
+                }
+            }
+        }
+    }
+    double* out = partials + ((int64_t)b * kMomentBlocks + blockIdx.x) * kMomentWidth;
+    block_sums<21>(acc, red, [&](int c, double total) { out[c] = total; });
+}
+
+// Moments of the resampled ensemble without resampling (gse_pf_moments_resampled): as pf_moments_kernel, but particle k
+// weighs n_k * fp32(1 / N) with n_k = F(k) - F(k-1) its offspring count under the systematic resample with this r -- the
+// inverse map of the gather stage (OffspringCount; keys re-formed from weights + per-thread tile prefixes exactly as there).
+// A workgroup builds the tile prefix of its filter in LDS, then its wavefronts stride over the tiles.
+__global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                      const double* __restrict__ tile_sums,
+                                                                      const double* __restrict__ qx_all,
+                                                                      double* __restrict__ partials, int64_t N, int64_t ld,
+                                                                      int T, const ResampleArgs ra) {
+    __shared__ double red[4 * 21];
+    extern __shared__ double pfx_m[];              // [T + 1]
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* xb = x + (int64_t)b * GSE_NX * ld;
+    const float* wb = w + (int64_t)b * ld;
+    const double* qx = qx_all + (int64_t)b * T * kBlock;
+    // tile prefix (the arithmetic of the step kernel's gather stage)
+    {
+        const double* sums = tile_sums + (int64_t)b * T;
+        const int m = (T + kBlock - 1) / kBlock;
+        const int qlo = tid * m;
+        double sv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
+        double chunk = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) chunk += sv[i];
+        double total;
+        double run = block_exclusive_scan(chunk, red, total);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < m && qlo + i < T) pfx_m[qlo + i] = run;
+            run += sv[i];
+        }
+        if (tid == 0) pfx_m[T] = total;
+        __syncthreads();
+    }
+    const double W = pfx_m[T];
+    double pv[GSE_NX];
+#pragma unroll
+    for (int k = 0; k < GSE_NX; ++k) pv[k] = (double)xb[k * ld];          // pivot = particle 0
+    double acc[21];
+#pragma unroll
+    for (int c = 0; c < 21; ++c) acc[c] = 0.0;
+    const bool valid = (W > 0.0) && (W < INFINITY);
+    OffspringCount F;
+    F.init(N, ra.r[b], valid ? W : 1.0);
+    const double wu = (double)(float)(1.0 / (double)N);
+    // One WAVEFRONT per tile, four quarters of 64 quads one after the other: the count below a lane's first key comes from
+    // the lane before (DPP) and, for lane 0, from the previous quarter's last lane (kept in a scalar) -- no barrier, and the
+    // four wavefronts of the workgroup are at different tiles.  The states of a particle are fetched only if it has
+    // offspring: under the usual degenerate weights that is about one particle in a hundred, so the pass moves ~6 bytes
+    // per particle (weights and tile prefixes) instead of 26.
+    for (int tq = blockIdx.x * (kBlock / 64) + wv; valid && tq < T; tq += gridDim.x * (kBlock / 64)) {
+        const double P0 = pfx_m[tq], P1 = pfx_m[tq + 1];
+        const int64_t tile_last = min((int64_t)(tq + 1) * kTile, N) - 1;
+        int32_t below = F(P0);                                           // (the previous tile's last key is pinned to P0)
+#pragma unroll 1
+        for (int sub = 0; sub < kTile / (64 * kPerThread); ++sub) {
+            const int t = sub * 64 + lane;
+            const int64_t k0 = (int64_t)tq * kTile + (int64_t)t * kPerThread;
+            const float4 wq = load_weights4(wb, k0, N, ld);
+            const double excl = qx[tq * kBlock + t];
+            double sc[kPerThread];
+            sc[0] = (k0 + 0 < N) ? (double)wq.x : 0.0;
+            sc[1] = sc[0] + ((k0 + 1 < N) ? (double)wq.y : 0.0);
+            sc[2] = sc[1] + ((k0 + 2 < N) ? (double)wq.z : 0.0);
+            sc[3] = sc[2] + ((k0 + 3 < N) ? (double)wq.w : 0.0);
+            double xs[kPerThread];
+            int32_t fs[kPerThread];
+            bool near[kPerThread];
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) {
+                xs[p] = (k0 + p >= tile_last) ? P1 : fmin(P0 + (excl + sc[p]), P1);
+                fs[p] = F.candidate(xs[p], near[p]);
+            }
+            if (near[0] || near[1] || near[2] || near[3]) {
+#pragma unroll
+                for (int p = 0; p < kPerThread; ++p)
+                    if (near[p]) fs[p] = F.settle(xs[p], fs[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) fs[p] += 1;             // counts
+            int32_t prev = (int32_t)wave_shift_up1((uint32_t)fs[3]);
+            if (lane == 0) prev = below;
+            below = __builtin_amdgcn_readlane(fs[3], 63);
+            int32_t n_off[kPerThread];
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p)
+                n_off[p] = (k0 + p <= tile_last) ? fs[p] - (p == 0 ? prev : fs[(p + 3) % kPerThread]) : 0;
+            float xv[kPerThread][GSE_NX];
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p)
+                if (n_off[p] > 0) {
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) xv[p][k] = xb[k * ld + k0 + p];
+                }
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p)
+                if (n_off[p] > 0) {
+                    const double wp = (double)n_off[p] * wu;
+                    double d[GSE_NX];
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) d[k] = (double)xv[p][k] - pv[k];
+                    acc[0] += wp;
+                    int c = 6;
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) {
+                        const double wd = wp * d[k];
+                        acc[1 + k] += wd;
+#pragma unroll
+                        for (int l = k; l < GSE_NX; ++l) acc[c++] += wd * d[l];
+                    }
+                }
+        }
+    }
+    if (!valid && blockIdx.x == 0 && tid == 0) {
+        // weights that do not sum to a positive finite number: every offspring copies particle 0 (see the gather stage)
+        acc[0] = (double)N * wu;
+    }
+    double* out = partials + ((int64_t)b * kMomentBlocks + blockIdx.x) * kMomentWidth;
+    block_sums<21>(acc, red, [&](int c, double total) { out[c] = total; });
+}
+
+// Fixed-order reduction of the per-workgroup partials -> out[b][0..width); appends `tail` pivot values.
+constexpr int kFinishGroups = 16;        // 1024 threads: (group, column) = (tid / 64, tid % 64)
+__global__ __launch_bounds__(64 * kFinishGroups) void moments_finish_kernel(const double* __restrict__ partials, int nblk,
+                                                                           int width, double* __restrict__ out,
+                                                                           int out_stride,
+                                                                           const float* __restrict__ pivot_src,
+                                                                           int64_t pivot_filter_stride,
+                                                                           int64_t pivot_elem_stride, int pivot_at) {
+    // Thread (g, c) adds the partials q = g, g + 16, ... of column c into 8 interleaved accumulators (8 loads in flight),
+    // folds them pairwise, and the 16 group totals are folded pairwise after one barrier: a fixed order, so the result
+    // does not depend on timing; <= 4 dependent load rounds for 512 partials.
+    __shared__ double part[kFinishGroups][64];
+    const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const double* pb = partials + (int64_t)b * kMomentBlocks * kMomentWidth;
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (c < width) {
+        for (int q0 = g; q0 < nblk; q0 += 8 * kFinishGroups) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = q0 + j * kFinishGroups;
+                if (q < nblk) a[j] += pb[(int64_t)q * kMomentWidth + c];
+            }
+        }
+    }
+    part[g][c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (g == 0 && c < width) {
+        double t[kFinishGroups];
+#pragma unroll
+        for (int k = 0; k < kFinishGroups; ++k) t[k] = part[k][c];
+#pragma unroll
+        for (int span = 1; span < kFinishGroups; span *= 2)
+#pragma unroll
+            for (int k = 0; k < kFinishGroups; k += 2 * span) t[k] += t[k + span];
+        out[(int64_t)b * out_stride + c] = t[0];
+    }
+    if (threadIdx.x < GSE_NX)
+        out[(int64_t)b * out_stride + pivot_at + threadIdx.x] =
+            (double)pivot_src[(int64_t)b * pivot_filter_stride + threadIdx.x * pivot_elem_stride];
+}
+
+}  // namespace gse

@@ -2,38 +2,13 @@
 // (results/pf_openloop/pf_run_seq.py:134-296): row-wise f / g, mixture pdf / draw, normalised cumulative sum,
 // systematic index from a cumulative sum, and the raw RNG words.  The filters themselves use the fused
 // kernels in gse_pf.hip / gse_gsukf.hip; these exist for API completeness and for the parity tests.
-#include "gse_host.h"
+#include "gse_rows_kernels.h"
+#include "gse_rtc.h"
 
 #include <string.h>
 
 namespace gse {
 
-// out[i] = f(x[i], u, dt): the Euler INCREMENT, stored fp32 (what f_vectorize returns, particle.py:176-191)
-__global__ __launch_bounds__(kBlock) void model_f_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t M,
-                                                         double fg, double fm, double dt) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= M) return;
-    float s[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) s[k] = x[i * 5 + k];
-    double dx[5];
-    model_increment(s, fg, fm, dt, dx);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) out[i * 5 + k] = (float)dx[k];
-}
-
-__global__ __launch_bounds__(kBlock) void model_g_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t M,
-                                                         double u0, double u1) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= M) return;
-    float s[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) s[k] = x[i * 5 + k];
-    float y0, y1;
-    model_output(s, u0, u1, y0, y1);
-    out[i * 2 + 0] = y0;
-    out[i * 2 + 1] = y1;
-}
 
 // General mixture density, nx <= 5, nd <= 4  (MultivariateGaussianSum.py:39-63)
 struct PdfN {
@@ -160,6 +135,24 @@ int gse_model_g_u(const float* x, float* out, int64_t M, const double* u, void* 
 int gse_model_g(const float* x, float* out, int64_t M, void* stream) { return gse_model_g_u(x, out, M, nullptr, stream); }
 
 // 0: the built-in bioreactor model; otherwise the tag of the user model this library was compiled for
+int gse_model_f_model(void* model, const float* x, float* out, int64_t M, const double* u, double dt, void* stream) {
+    GSE_REQUIRE(model && x && out && u && M >= 0, "gse_model_f_model: bad argument");
+    if (M == 0) return GSE_OK;
+    double fg = u[0], fm = u[1];
+    void* params[] = {(void*)&x, (void*)&out, (void*)&M, (void*)&fg, (void*)&fm, (void*)&dt};
+    return launch_user_kernel(static_cast<UserModel*>(model), "gse::model_f_kernel", dim3(blocks_for(M)), dim3(kBlock), 0,
+                              (hipStream_t)stream, params);
+}
+
+int gse_model_g_u_model(void* model, const float* x, float* out, int64_t M, const double* u, void* stream) {
+    GSE_REQUIRE(model && x && out && u && M >= 0, "gse_model_g_u_model: bad argument");
+    if (M == 0) return GSE_OK;
+    double u0 = u[0], u1 = u[1];
+    void* params[] = {(void*)&x, (void*)&out, (void*)&M, (void*)&u0, (void*)&u1};
+    return launch_user_kernel(static_cast<UserModel*>(model), "gse::model_g_kernel", dim3(blocks_for(M)), dim3(kBlock), 0,
+                              (hipStream_t)stream, params);
+}
+
 // (-DGSE_USER_MODEL_TAG, gpu_se_amd/usermodel.py)
 uint64_t gse_model_tag(void) {
 #ifdef GSE_USER_MODEL_TAG

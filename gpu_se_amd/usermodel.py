@@ -230,7 +230,7 @@ def translate(f, g):
 
 
 USER_DIR = os.path.join(build.LIBDIR, "user")
-USER_SOURCES = ["gse_host.hip", "gse_pf.hip", "gse_rows.hip"]          # everything the particle filter calls
+USER_SOURCES = ["gse_host.hip", "gse_pf.hip", "gse_rows.hip", "gse_rtc.hip"]          # everything the particle filter calls
 
 
 class CompiledModel:
@@ -253,12 +253,72 @@ class CompiledModel:
             raise _lib.GseError("libgse_user: error %d: %s" % (rc, msg.decode() if msg else "?"))
 
 
+class _ModelEntryPoints:
+    """The C ABI as a particle filter with a run-time compiled model sees it: the step and the row helpers go to their
+    ``*_model`` forms with the model handle in front, everything else (workspace, resample_begin, moments, draws -- none of
+    which contains the model) is the shipped library's."""
+    _ROUTED = ("gse_pf_step", "gse_model_f", "gse_model_g_u")
+
+    def __init__(self, lib, handle):
+        self._lib, self._handle = lib, handle
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name in self._ROUTED:
+            routed = getattr(self._lib, name + "_model")
+            handle = self._handle
+            return lambda *args: routed(handle, *args)
+        return fn
+
+
+class RuntimeModel:
+    """A user model whose kernels are compiled IN THE PROCESS by hiprtc, one template instance at a time, the first time a
+    launch needs it (about a second each; gse_rtc.hip): no compiler binary, no files, nothing to pre-build."""
+
+    def __init__(self, nx, nu, tag, text):
+        import torch
+        self.nx, self.nu, self.tag, self.path = nx, nu, tag, None
+        base = _lib.load()
+        handle = ctypes.c_void_p()
+        # the hiprtc that belongs to the HIP runtime in the process (torch's), else ROCm's
+        rtc = os.path.join(os.path.dirname(torch.__file__), "lib", "libhiprtc.so")
+        if not os.path.exists(rtc):
+            rtc = "/opt/rocm/lib/libhiprtc.so"
+        _lib.check(base.gse_model_create(text.encode(), nx, nu, tag, build.CSRC.encode(),
+                                         os.path.join(build.ROOT, "include").encode(), rtc.encode(), ctypes.byref(handle)))
+        self._base, self._handle = base, handle
+        self.lib = _ModelEntryPoints(base, handle)
+
+    def check(self, rc):
+        _lib.check(rc)
+
+    def prepare(self, name_expression):
+        """Compile a kernel instance now, e.g. "gse::pf_step_kernel<true, true, false, true, 2, 3>" (needs the device)."""
+        _lib.check(self._base.gse_model_prepare(self._handle, name_expression.encode()))
+
+    def compile_check(self, name_expression):
+        """Compile only (works without a device): size of the code object in bytes."""
+        n = self._base.gse_model_compile_check(self._handle, name_expression.encode())
+        if n < 0:
+            _lib.check(int(n))
+        return int(n)
+
+    @property
+    def kernels(self):
+        return int(self._base.gse_model_kernels(self._handle))
+
+
 _cache = {}
 
 
-def compile_model(f, g, verbose=False):
-    """Translate, build (or find in the cache) and load the library for (f, g)."""
-    key = (f, g)
+def compile_model(f, g, verbose=False, backend=None):
+    """Translate (f, g) and make their kernels available.  backend "rtc" (default; GSE_USERMODEL_BACKEND overrides): run-time
+    compilation in the process, on demand (RuntimeModel).  "hipcc": the whole particle-filter library rebuilt for the model
+    by the hipcc binary into gpu_se_amd/lib/user/<hash>/ (~13 s once, then cached on disk; CompiledModel)."""
+    backend = backend or os.environ.get("GSE_USERMODEL_BACKEND", "rtc")
+    if backend not in ("rtc", "hipcc"):
+        raise ValueError("unknown user-model backend %r" % backend)
+    key = (f, g, backend)
     if key in _cache:
         return _cache[key]
     nx, nu, text = translate(f, g)
@@ -271,6 +331,10 @@ def compile_model(f, g, verbose=False):
     with open(os.path.join(build.ROOT, "include", "gse.h"), "rb") as fh:
         h.update(b"gse.h\0" + fh.read())
     digest = h.hexdigest()
+    if backend == "rtc":
+        model = RuntimeModel(nx, nu, int(digest[:15], 16) | 1, text)
+        _cache[key] = model
+        return model
     tag = int(digest[:15], 16) | 1                                       # non-zero, fits a signed 64-bit literal
     folder = os.path.join(USER_DIR, digest[:16])
     path = os.path.join(folder, "libgse_user.so")
@@ -297,7 +361,7 @@ def compile_model(f, g, verbose=False):
             if p.returncode != 0:
                 raise ModelError("hipcc failed on %s for the user model:\n%s\n--- generated source ---\n%s" % (src, out, text))
         tmp = os.path.join(folder, "libgse_user.so")
-        subprocess.run([build._hipcc(), "--offload-arch=" + build.ARCH, "-shared", "-fPIC", "-o", tmp] + objs, check=True)
+        subprocess.run([build._hipcc(), "--offload-arch=" + build.ARCH, "-shared", "-fPIC", "-o", tmp] + objs + ["-ldl"], check=True)
         os.replace(tmp, path)                                                          # atomic: readers see all or nothing
         shutil.rmtree(folder, ignore_errors=True)
     model = CompiledModel(nx, nu, tag, path)

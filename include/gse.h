@@ -27,7 +27,14 @@
 #ifndef GSE_H
 #define GSE_H
 
+#ifdef __HIPCC_RTC__            /* compiled at run time (hiprtc has no C library headers): the types of this ABI */
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long int64_t;
+typedef unsigned long uint64_t;
+#else
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -231,6 +238,32 @@ int gse_model_g_u(const float *x, float *out, int64_t M, const double *u, void *
  * otherwise the tag of a user model translated and compiled at run time (gpu_se_amd/usermodel.py -- the counterpart of
  * the reference's Numba JIT of arbitrary f / g, filter/particle.py:176-208). */
 uint64_t gse_model_tag(void);
+
+/* ---------------------------------------------------------------- user models at run time --------- */
+
+/* The reference hands arbitrary Python f / g to Numba's JIT (filter/particle.py:176-208).  Here a model is two device
+ * functions, `user_increment` and `user_output`, in a generated header `model_header` (gpu_se_amd/usermodel.py translates a
+ * restricted form of Python; GSE_USER_NX / GSE_USER_NU inside say how many states and inputs it uses), and the
+ * particle-filter kernels are compiled FOR it in the process by hiprtc (opened from `hiprtc_path`, or found by name) the
+ * first time a launch needs them -- one template instance at a time, about a second each, no compiler binary and no files.
+ * include_csrc / include_abi: the directories of the kernel sources (gse_pf_kernels.h, ...) and of this header.
+ * A model handle is not thread-safe against itself beyond its internal lock; destroy it when no launch is in flight. */
+int gse_model_create(const char *model_header, int nx, int nu, uint64_t tag, const char *include_csrc,
+                     const char *include_abi, const char *hiprtc_path, void **model_out);
+int gse_model_destroy(void *model);
+/* Compile and load a kernel instance now, e.g. "gse::pf_step_kernel<true, true, false, true, 2, 3>" (otherwise: first use). */
+int gse_model_prepare(void *model, const char *name_expression);
+/* Compile only -- works without a device; returns the size of the code object in bytes, or a negative status. */
+int64_t gse_model_compile_check(void *model, const char *name_expression);
+int64_t gse_model_kernels(void *model);            /* instances compiled and loaded so far */
+/* gse_pf_step / gse_model_f / gse_model_g_u with the model's kernels: same arguments, same checks, same results as a
+ * library built for the model would give. */
+int gse_pf_step_model(void *model, uint32_t ops, const float *x_in, float *x_out, const float *w_in, float *w_out,
+                      int32_t *idx, int64_t ld, int B, int64_t N, const double *u, double dt, const double *z,
+                      const double *r, const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,
+                      const gse_mixture *measurement_pdf, double *island, void *workspace, void *stream);
+int gse_model_f_model(void *model, const float *x, float *out, int64_t M, const double *u, double dt, void *stream);
+int gse_model_g_u_model(void *model, const float *x, float *out, int64_t M, const double *u, void *stream);
 /* MultivariateGaussianSum.pdf (MultivariateGaussianSum.py:39-63): e [M][nx] fp32 or fp64 -> out [M] fp64. */
 int gse_mixture_pdf_f32(const float *e, int64_t M, const gse_mixture *m, double *out, void *stream);
 int gse_mixture_pdf_f64(const double *e, int64_t M, const gse_mixture *m, double *out, void *stream);

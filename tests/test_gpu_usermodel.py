@@ -114,6 +114,56 @@ def test_user_model_with_philox_noise_and_fused_cycle():
     assert np.all(np.isfinite(est)) and abs(est[1] - truth[1]) < 0.6 and abs(est[0] * est[1] - truth[0] * truth[1]) < 2.5
 
 
+def test_a_model_nobody_prebuilt_is_compiled_in_the_process_and_both_backends_agree():
+    """Run-time compilation where the model is first seen: a model defined HERE (nothing on disk, nothing built by
+    __graft_entry__.build()), kernels compiled by hiprtc in this process when the launches ask for them -- and, bit for bit,
+    the results of the library the hipcc binary builds for the same model."""
+    import time
+    from gpu_se_amd import usermodel
+
+    def drift_f(x, u, dt):
+        a, b = x
+        return (u[0] - 0.31 * a * b) * dt, (0.17 * a - 0.05 * b + u[0] * 0.01) * dt
+
+    def drift_g(x, u):
+        return x[0] * 1.7 + u[0], x[1] - x[0] * 0.25
+
+    t0 = time.perf_counter()
+    model = usermodel.compile_model(drift_f, drift_g)
+    assert isinstance(model, usermodel.RuntimeModel) and model.kernels == 0 and time.perf_counter() - t0 < 1.0
+    import os
+    results = {}
+    for backend in ("rtc", "hipcc"):
+        if backend == "hipcc":
+            os.environ["GSE_USERMODEL_BACKEND"] = "hipcc"
+        try:
+            gpu_se_amd.seed(9)
+            x0, state, meas = _two_state_parts()           # (fresh: the mixtures carry their own draw counters)
+            pf = ParallelParticleFilter(drift_f, drift_g, 1 << 14, x0, state, meas)
+            t0 = time.perf_counter()
+            for c in range(4):
+                pf.predict([0.8], 0.02)
+                pf.update([0.8], np.array([15.0, -2.0]))
+                pf.resample(r=0.1 + 0.2 * c)
+            results[backend] = (pf.particles.get().copy(), pf.weights.get().copy(), time.perf_counter() - t0)
+        finally:
+            os.environ.pop("GSE_USERMODEL_BACKEND", None) if backend == "hipcc" else None
+    assert model.kernels >= 2                              # (the first cycle's launch and the single-launch cycle)
+    assert results["rtc"][2] < 15.0                        # a few instances at about a second each
+    np.testing.assert_array_equal(results["rtc"][0], results["hipcc"][0])
+    np.testing.assert_array_equal(results["rtc"][1], results["hipcc"][1])
+    # against the same Python functions in NumPy: one predict with injected noise
+    x0, state_d, meas = _two_state_parts(deterministic=True)
+    n = 2000
+    noise = (np.random.default_rng(1).standard_normal((n, 2)) * [1e-2, 3e-3]).astype(np.float32)
+    gsd.DeterministicGaussianSum.preload(noise)
+    pf = ParallelParticleFilter(drift_f, drift_g, n, x0, state_d, meas)
+    before = pf.particles.get().copy()
+    pf.predict([0.8], 0.02)
+    want = (before.astype(np.float64) + _python_rows(drift_f, before, [0.8], 0.02)).astype(np.float32) + noise
+    np.testing.assert_array_equal(pf.particles.get(), want)
+
+
 def test_other_classes_refuse_user_models_loudly():
     x0, state, meas = _two_state_parts()
     with pytest.raises(NotImplementedError):

@@ -34,8 +34,24 @@ def _one_output(x, u):
     return x[0] + u[0],
 
 
-def test_library_builds_for_a_user_model():
+def test_kernels_compile_at_run_time_for_a_user_model():
+    """The default backend: hiprtc in the process, one kernel instance at a time.  Compilation needs no device (loading the
+    code object does: tests/test_gpu_usermodel.py)."""
     model = usermodel.compile_model(um.two_state_f, um.two_state_g)
+    assert isinstance(model, usermodel.RuntimeModel) and (model.nx, model.nu) == (2, 1) and model.kernels == 0
+    for name in ("gse::pf_step_kernel<true, true, false, true, 2, 3>",        # the single-launch cycle
+                 "gse::pf_step_kernel<false, true, false, false, 0, 0>",     # predict alone
+                 "gse::model_f_kernel", "gse::model_g_kernel"):
+        assert model.compile_check(name) > 10000
+    with pytest.raises(Exception, match="failed"):
+        model.compile_check("gse::no_such_kernel")
+    assert usermodel.compile_model(um.two_state_f, um.two_state_g) is model          # cached
+    assert usermodel.compile_model(um.three_state_f, um.three_state_g).nx == 3
+
+
+def test_library_builds_for_a_user_model():
+    """The other backend: the whole particle-filter library rebuilt by the hipcc binary (cached on disk)."""
+    model = usermodel.compile_model(um.two_state_f, um.two_state_g, backend="hipcc")
     assert os.path.exists(model.path) and (model.nx, model.nu) == (2, 1)
     assert int(model.lib.gse_model_tag()) == model.tag != 0
     for name in ("gse_pf_step", "gse_pf_resample_begin", "gse_pf_moments", "gse_model_f", "gse_model_g_u", "gse_last_error"):
@@ -44,5 +60,4 @@ def test_library_builds_for_a_user_model():
     assert model.lib.gse_pf_step(512, 16, 16, None, None, None, 8, 1, 8, None, 0.0, None, None, None, None, None, None,
                                  None, None, None) < 0
     assert b"bad ops mask" in model.lib.gse_last_error()
-    assert usermodel.compile_model(um.two_state_f, um.two_state_g) is model          # cached
-    usermodel.compile_model(um.three_state_f, um.three_state_g)
+    assert usermodel.compile_model(um.two_state_f, um.two_state_g, backend="hipcc") is model          # cached
