@@ -354,6 +354,8 @@ class BatchedSimulation:
         import time
         record_moments(0)
         t_next_control, t_next_predict = 0, 0
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()                                      # device time of the loop: first to last kernel of the ticks
         clock = [time.perf_counter()]
         for t in range(1, ticks):
             now = self.ts[t]
@@ -380,9 +382,11 @@ class BatchedSimulation:
             if last_control != t:                         # (a control tick has recorded this state already)
                 record_moments(t)
         # one synchronisation, one copy: histories to the host, estimates from the recorded moments
+        ev1.record()
         clock.append(time.perf_counter())
         torch.cuda.synchronize()
         clock.append(time.perf_counter())
+        device_s = ev0.elapsed_time(ev1) * 1e-3
         host = flat.cpu().numpy()
         clock.append(time.perf_counter())
         back, at = {}, 0
@@ -409,3 +413,4 @@ class BatchedSimulation:
         self.mpc_frac = 1.0 - float(status.sum().item()) / max(n_control * B, 1)
         clock.append(time.perf_counter())
         self.timing = dict(zip(("enqueue", "device_drain", "copy_back", "host_post"), numpy.diff(clock)))
+        self.timing["device_loop"] = device_s             # (HIP events around the ticks; >= the time the host needs to enqueue them)

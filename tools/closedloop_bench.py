@@ -62,4 +62,5 @@ print("closed loop: B=%d rollouts x 2^%d particles, %d ticks in %.3f s -> %.1f t
       % (B, log2n, ticks, el, ticks / el, ticks * B * (1 << log2n) / el, 1e3 * el / ticks,
          "resident loop" if resident else "host plant", np.median(sim.performance)))
 if resident:
-    print("  resident loop seconds:", {k: round(float(v), 4) for k, v in sim.timing.items()})
+    print("  resident loop seconds:", {k: round(float(v), 4) for k, v in sim.timing.items()},
+          "(device_loop: HIP events around the ticks)")
