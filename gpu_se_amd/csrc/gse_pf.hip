@@ -375,7 +375,7 @@ int gse_pf_moments_resampled(const float* x, const float* w, int64_t ld, int B, 
     GSE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(workspace), "gse_pf_moments_resampled: pointers must be 16-byte aligned");
     GSE_REQUIRE(slot == 0 || slot == 1, "gse_pf_moments_resampled: slot must be 0 or 1");
     const int T = (int)tiles_of(N);
-    GSE_REQUIRE(T <= kScanMaxT, "gse_pf_moments_resampled: at most %d tiles (N <= %d)", kScanMaxT, kScanMaxT * kTile);
+    GSE_REQUIRE(T <= 2048, "gse_pf_moments_resampled: at most 2048 tiles (N <= 2^21)");
     ResampleArgs ra;
     for (int b = 0; b < B; ++b) {
         GSE_REQUIRE(r[b] >= 0.0 && r[b] < 1.0, "gse_pf_moments_resampled: r[%d] = %g is outside [0, 1)", b, r[b]);

@@ -342,14 +342,27 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                 if (tid == 0) { act_n = 0; work_n = 0; }
             }
             double chunk = 0.0;
-#pragma unroll
-            for (int i = 0; i < kMaxChunk; ++i) chunk += sv[i];            // (+ 0.0 beyond the chunk: exact)
             double total;
-            double run = block_exclusive_scan(chunk, red, total);
+            if (m <= kMaxChunk) {                                          // workgroup-uniform; up to 2048 tiles
 #pragma unroll
-            for (int i = 0; i < kMaxChunk; ++i) {
-                if (i < m && qlo + i < T) pfx_s[qlo + i] = run;
-                run += sv[i];
+                for (int i = 0; i < kMaxChunk; ++i) chunk += sv[i];        // (+ 0.0 beyond the chunk: exact)
+                double run = block_exclusive_scan(chunk, red, total);
+#pragma unroll
+                for (int i = 0; i < kMaxChunk; ++i) {
+                    if (i < m && qlo + i < T) pfx_s[qlo + i] = run;
+                    run += sv[i];
+                }
+            } else {
+                // longer chunks (2049 .. 4096 tiles: several generations of workgroups hide the second sweep's loads): the
+                // sums are read again instead of kept -- same order, same bits
+                const double* sums = scan_in_sums + (int64_t)b * T;
+                const int qhi = min(qlo + m, T);
+                for (int q = qlo; q < qhi; ++q) chunk += sums[q];
+                double run = block_exclusive_scan(chunk, red, total);
+                for (int q = qlo; q < qhi; ++q) {
+                    pfx_s[q] = run;
+                    run += sums[q];
+                }
             }
             if (tid == 0) pfx_s[T] = total;
             __syncthreads();
@@ -949,7 +962,7 @@ __global__ __launch_bounds__(kBlock) void tile_scan_kernel(const double* __restr
 // (thread j owns chunk [j*m, (j+1)*m); excl = workgroup exclusive scan of the chunk sums).  Larger T: a scan
 // kernel of its own writes the prefix once.
 constexpr int kInlinePrefixMaxT = 4096;
-constexpr int kScanMaxT = kBlock * 8;        // scan modes of the step kernel: a prefix chunk of at most 8 tile sums per thread
+constexpr int kScanMaxT = 4096;              // scan modes of the step kernel: the tile prefix (T + 1 doubles) lives in LDS
 
 __device__ __forceinline__ void inline_tile_prefix(const double* __restrict__ s, int T, int t, double* red,
                                                    double* out3) {

@@ -393,7 +393,8 @@ class ParallelParticleFilter:
         copying a particle (gse_pf_moments_resampled) -- for loops on the device that need the estimate between
         resample() and the next predict() while the resample's copy rides the next cycle's single launch.  Returns False
         (nothing done) unless a resample is pending on stored tile prefixes and nothing else is."""
-        if not (self._pend_gather and self._gather_slot is not None and self._pend_predict is None):
+        if not (self._pend_gather and self._gather_slot is not None and self._pend_predict is None) or \
+                self.N_particles > (1 << 21):
             return False
         self._call("gse_pf_moments_resampled", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
                    self._c_r, int(self._gather_slot), out.data_ptr(), self._ws.data_ptr(), stream_ptr(self._dev_index))
