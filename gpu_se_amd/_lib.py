@@ -18,6 +18,7 @@ GSE_OP_U_DEVICE, GSE_OP_Z_DEVICE = 128, 256
 GSE_SCAN_MAX_TILES = 2048      # policy: beyond 2^21 particles the two-kernel resample is faster (every workgroup
                                # builds the whole tile prefix: at 4096 tiles the single launch takes 131 us against 102)
 GSE_GSUKF_CYCLE_MAX = 64
+GSE_GSUKF_LANES_MIN = 1 << 16    # from this many Gaussians on: one lane per Gaussian, predict + update in one launch
 
 c_f = ctypes.c_float
 c_d = ctypes.c_double
@@ -76,6 +77,8 @@ PROTOTYPES = {
     "gse_gsukf_sigma_points": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
     "gse_gsukf_predict": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_F, P_MIX, P_RNG, c_vp, c_vp, c_vp]),
     "gse_gsukf_update": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, P_D, P_F, P_MIX, c_vp, c_vp, c_vp]),
+    "gse_gsukf_predict_update": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_D, P_F, P_MIX, P_RNG, c_vp, P_MIX,
+                                                c_vp, c_vp]),
     "gse_gsukf_cycle": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_D, P_D, P_F, P_MIX, P_RNG,
                                        c_vp, P_MIX, c_vp, c_vp]),
     "gse_gsukf_resample": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_u32, c_vp, c_vp]),

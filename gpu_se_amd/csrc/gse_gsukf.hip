@@ -479,11 +479,81 @@ __device__ __forceinline__ void stage_bank_out(const float* stage, float* mu_b, 
 #ifndef GSE_GSUKF_PRED_SERIAL
 #define GSE_GSUKF_PRED_SERIAL 0  // 1: a scheduling barrier between the sigma points of a lane (tuning knob)
 #endif
+// predict of ONE Gaussian held in `mine` (mu[5], P[25]); g: its index in the filter (random-number element)
 template <bool kInjected>
-__global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict_lanes_kernel(float* __restrict__ mu, float* __restrict__ P,
-                                                                        const float* __restrict__ noise, int64_t N,
-                                                                        int32_t* __restrict__ status,
-                                                                        const GsukfPredictArgs a) {
+__device__ __forceinline__ void gsukf_predict_lane(float* mine, int b, int64_t g, int64_t N, const float* noise,
+                                                   const DrawParams& dp, int32_t* status, const GsukfPredictArgs& a) {
+    float m[5], L[15];
+    bool ok;
+    load_and_factor(mine, mine + 5, m, L, ok);
+    if (!ok && status) atomicAdd(status, 1);
+    float sg[GSE_NSIGMA * 5];
+#pragma unroll
+    for (int j = 0; j < GSE_NSIGMA; ++j) {
+        float s[5], e[5];
+        sigma_point(m, L, j, s);
+        bioreactor_step(s, a.io.f[b].u0, a.io.f[b].u1, a.dt);
+        if (kInjected) {
+            const float* nz = noise + (((int64_t)b * N + g) * GSE_NSIGMA + j) * 5;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) e[k] = nz[k];
+        } else {
+            uint32_t wd[8];
+            rng_words8(a.rng, (uint64_t)(g * GSE_NSIGMA + j), (uint32_t)b, wd);
+            mixture_draw5(dp, wd, e);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) sg[j * 5 + k] = s[k] + e[k];
+#if GSE_GSUKF_PRED_SERIAL
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    float mean[5];
+    sigma_mean_cov(sg, a.sw, mean, mine + 5);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) mine[k] = mean[k];
+}
+
+// update of ONE Gaussian held in `mine`; its weight at *w
+__device__ __forceinline__ void gsukf_update_lane(float* mine, float* w, double z0, double z1, int32_t* status, const Pdf2& pdf,
+                                                  const SigmaWeights& sw) {
+    float m[5], L[15];
+    bool ok;
+    load_and_factor(mine, mine + 5, m, L, ok);
+    if (!ok && status) atomicAdd(status, 1);
+    // outputs of the 11 sigma points (fp64, as the kernels above keep them); the deviations sigma_j - mu are re-formed
+    // from the factor where the contraction needs them (a select and a subtraction) instead of being kept
+    double eta[GSE_NSIGMA][2];
+#pragma unroll
+    for (int j = 0; j < GSE_NSIGMA; ++j) {
+        float s[5], y0, y1;
+        sigma_point(m, L, j, s);
+        bioreactor_output(s[0], s[2], y0, y1);
+        eta[j][0] = (double)y0;
+        eta[j][1] = (double)y1;
+    }
+    float prior[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) prior[k] = m[k];
+    gsukf_update_gaussian<true>([&](int q, int c) { return eta[q][c]; },
+                                [&](int q, int k) {
+                                    float s[5];
+                                    sigma_point(m, L, q, s);
+                                    return s[k] - m[k];
+                                },
+                                prior, mine + 5, mine, mine + 5, w, w, z0, z1, pdf, sw);
+}
+
+#ifndef GSE_GSUKF_PRED_WAVES
+#define GSE_GSUKF_PRED_WAVES 1   // waves per SIMD the register allocator must leave room for (tuning knob)
+#endif
+#ifndef GSE_GSUKF_PRED_SERIAL
+#define GSE_GSUKF_PRED_SERIAL 0  // 1: a scheduling barrier between the sigma points of a lane (tuning knob)
+#endif
+template <bool kInjected>
+__global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict_lanes_kernel(
+    float* __restrict__ mu, float* __restrict__ P, const float* __restrict__ noise, int64_t N, int32_t* __restrict__ status,
+    const GsukfPredictArgs a) {
     __shared__ DrawParams dp;
     __shared__ float stage[kLaneBank * kStageStride];
     const int t = threadIdx.x, b = blockIdx.y;
@@ -497,38 +567,7 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
         for (int i = t; i < (int)(sizeof(DrawParams) / 4); i += kLaneBank) dst[i] = src[i];
     }
     stage_bank_in(stage, mu_b, P_b, nloc);
-    if (t < nloc) {
-        float* mine = stage + t * kStageStride;
-        float m[5], L[15];
-        bool ok;
-        load_and_factor(mine, mine + 5, m, L, ok);
-        if (!ok && status) atomicAdd(status, 1);
-        float sg[GSE_NSIGMA * 5];
-#pragma unroll
-        for (int j = 0; j < GSE_NSIGMA; ++j) {
-            float s[5], e[5];
-            sigma_point(m, L, j, s);
-            bioreactor_step(s, a.io.f[b].u0, a.io.f[b].u1, a.dt);
-            if (kInjected) {
-                const float* nz = noise + (((int64_t)b * N + g0 + t) * GSE_NSIGMA + j) * 5;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) e[k] = nz[k];
-            } else {
-                uint32_t wd[8];
-                rng_words8(a.rng, (uint64_t)((g0 + t) * GSE_NSIGMA + j), (uint32_t)b, wd);
-                mixture_draw5(dp, wd, e);
-            }
-#pragma unroll
-            for (int k = 0; k < 5; ++k) sg[j * 5 + k] = s[k] + e[k];
-#if GSE_GSUKF_PRED_SERIAL
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-        float mean[5];
-        sigma_mean_cov(sg, a.sw, mean, mine + 5);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) mine[k] = mean[k];
-    }
+    if (t < nloc) gsukf_predict_lane<kInjected>(stage + t * kStageStride, b, g0 + t, N, noise, dp, status, a);
     stage_bank_out(stage, mu_b, P_b, nloc);
 }
 
@@ -541,35 +580,40 @@ __global__ __launch_bounds__(kLaneBank) void gsukf_update_lanes_kernel(float* __
     const int nloc = (int)min((int64_t)kLaneBank, N - g0);
     float* mu_b = mu + ((int64_t)b * N + g0) * 5;
     float* P_b = P + ((int64_t)b * N + g0) * 25;
-    float* w_b = w + (int64_t)b * N + g0;
+    stage_bank_in(stage, mu_b, P_b, nloc);
+    if (t < nloc)
+        gsukf_update_lane(stage + t * kStageStride, w + (int64_t)b * N + g0 + t, a.io.f[b].z0, a.io.f[b].z1, status, a.pdf, a.sw);
+    stage_bank_out(stage, mu_b, P_b, nloc);
+}
+
+// predict and update of a large bank in ONE launch (the class defers predict() until update()): what predict leaves in
+// the staged rows is what update picks up -- the same fp32 values the separate launches pass through memory, so the same
+// bits, without writing 120 bytes per Gaussian and reading them back, and one launch less.
+struct GsukfPredictUpdateArgs {
+    GsukfPredictArgs pred;      // (its io carries u and z)
+    Pdf2 pdf;
+};
+template <bool kInjected>
+__global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict_update_lanes_kernel(
+    float* __restrict__ mu, float* __restrict__ P, float* __restrict__ w, const float* __restrict__ noise, int64_t N,
+    int32_t* __restrict__ status, const GsukfPredictUpdateArgs a) {
+    __shared__ DrawParams dp;
+    __shared__ float stage[kLaneBank * kStageStride];
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
+    const int nloc = (int)min((int64_t)kLaneBank, N - g0);
+    float* mu_b = mu + ((int64_t)b * N + g0) * 5;
+    float* P_b = P + ((int64_t)b * N + g0) * 25;
+    if (!kInjected) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.pred.draw);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
+        for (int i = t; i < (int)(sizeof(DrawParams) / 4); i += kLaneBank) dst[i] = src[i];
+    }
     stage_bank_in(stage, mu_b, P_b, nloc);
     if (t < nloc) {
         float* mine = stage + t * kStageStride;
-        float m[5], L[15];
-        bool ok;
-        load_and_factor(mine, mine + 5, m, L, ok);
-        if (!ok && status) atomicAdd(status, 1);
-        // outputs of the 11 sigma points (fp64, as the kernels above keep them); the deviations sigma_j - mu are re-formed
-        // from the factor where the contraction needs them (a select and a subtraction) instead of being kept
-        double eta[GSE_NSIGMA][2];
-#pragma unroll
-        for (int j = 0; j < GSE_NSIGMA; ++j) {
-            float s[5], y0, y1;
-            sigma_point(m, L, j, s);
-            bioreactor_output(s[0], s[2], y0, y1);
-            eta[j][0] = (double)y0;
-            eta[j][1] = (double)y1;
-        }
-        float prior[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) prior[k] = m[k];
-        gsukf_update_gaussian<true>([&](int q, int c) { return eta[q][c]; },
-                                    [&](int q, int k) {
-                                        float s[5];
-                                        sigma_point(m, L, q, s);
-                                        return s[k] - m[k];
-                                    },
-                                    prior, mine + 5, mine, mine + 5, w_b + t, w_b + t, a.io.f[b].z0, a.io.f[b].z1, a.pdf, a.sw);
+        gsukf_predict_lane<kInjected>(mine, b, g0 + t, N, noise, dp, status, a.pred);
+        gsukf_update_lane(mine, w + (int64_t)b * N + g0 + t, a.pred.io.f[b].z0, a.pred.io.f[b].z1, status, a.pdf, a.pred.sw);
     }
     stage_bank_out(stage, mu_b, P_b, nloc);
 }
@@ -820,6 +864,34 @@ int gse_gsukf_update(float* mu, float* P, float* w, int B, int64_t N, const doub
                            dim3(kWideBank * kGroup), 0, (hipStream_t)stream, mu, P, w, N, status, a);
     }
     GSE_LAUNCH_CHECK("gsukf_update_kernel");
+    return GSE_OK;
+}
+
+int gse_gsukf_predict_update(float* mu, float* P, float* w, int B, int64_t N, const double* u, double dt, const double* z,
+                             const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng, const float* noise,
+                             const gse_mixture* measurement_pdf, int32_t* status, void* stream) {
+    if (int rc = check_gsukf("gse_gsukf_predict_update", B, N)) return rc;
+    GSE_REQUIRE(mu && P && w && u && z && w_sigma && measurement_pdf, "gse_gsukf_predict_update: null argument");
+    GSE_REQUIRE(noise || (state_pdf && rng), "gse_gsukf_predict_update: need either noise or (state_pdf, rng)");
+    if (int rc = check_mixture("gse_gsukf_predict_update", measurement_pdf, GSE_NY)) return rc;
+    GsukfPredictUpdateArgs a;
+    pack_io(a.pred.io, B, u, z);
+    pack_sigma_weights(a.pred.sw, w_sigma);
+    a.pred.dt = dt;
+    pack_pdf2(a.pdf, *measurement_pdf);
+    const dim3 grid((unsigned)((N + kLaneBank - 1) / kLaneBank), B), block(kLaneBank);
+    if (noise) {
+        a.pred.draw = DrawParams{};
+        a.pred.rng = RngKey{};
+        hipLaunchKernelGGL(gsukf_predict_update_lanes_kernel<true>, grid, block, 0, (hipStream_t)stream, mu, P, w, noise, N, status, a);
+    } else {
+        if (int rc = check_mixture("gse_gsukf_predict_update", state_pdf, GSE_NX)) return rc;
+        pack_draw(a.pred.draw, *state_pdf);
+        a.pred.rng = make_rng_key(*rng, kPurposeGsukf);
+        hipLaunchKernelGGL(gsukf_predict_update_lanes_kernel<false>, grid, block, 0, (hipStream_t)stream, mu, P, w,
+                           (const float*)nullptr, N, status, a);
+    }
+    GSE_LAUNCH_CHECK("gsukf_predict_update_lanes_kernel");
     return GSE_OK;
 }
 

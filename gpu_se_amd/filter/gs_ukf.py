@@ -67,6 +67,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._pend_predict = None
         self._pend_update = None
         self._fusable = n <= _lib.GSE_GSUKF_CYCLE_MAX
+        self._fuse_pu = n >= _lib.GSE_GSUKF_LANES_MIN      # large banks: predict() is deferred and rides update()'s launch
         self._c_u = (_lib.c_d * _lib.GSE_NU)()
         self._c_z = (_lib.c_d * _lib.GSE_NY)()
         self._c_r = (_lib.c_d * 1)()
@@ -138,7 +139,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     def predict(self, u, dt):
         """Prediction step (gs_ukf.py:348-367).  With at most 64 Gaussians the step is deferred so that resample() can
         run predict + update + resample as one launch (the bank is launch-latency-bound)."""
-        if self.lazy and self._fusable and self._pend_predict is None and self._pend_update is None:
+        if self.lazy and (self._fusable or self._fuse_pu) and self._pend_predict is None and self._pend_update is None:
             self._pend_predict = ([float(v) for v in u], float(dt))
             return
         self._flush()
@@ -164,8 +165,30 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         if self.lazy and self._fusable and self._pend_predict is not None and self._pend_update is None:
             self._pend_update = ([float(v) for v in u], [float(v) for v in z])
             return
+        if self.lazy and self._fuse_pu and self._pend_predict is not None and self._pend_update is None:
+            (up, dt), self._pend_predict = self._pend_predict, None
+            self._predict_update_now(up, dt, z)
+            return
         self._flush()
         self._update_now(u, z)
+
+    def _predict_update_now(self, u, dt, z):
+        """predict(u, dt) and update(., z) of a large bank in one launch (gse_gsukf_predict_update): same bits as the two."""
+        uu, zz = _lib.doubles(u, _lib.GSE_NU), _lib.doubles(z, _lib.GSE_NY)
+        n = self.N_particles
+        pod_m = self.measurement_pdf._pod()
+        if isinstance(self.state_pdf, DeterministicGaussianSum):
+            noise = self.state_pdf.draw((n, self._N_sigmas)).as_subclass(torch.Tensor).contiguous()
+            _lib.call("gse_gsukf_predict_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), 1, n, uu,
+                      float(dt), zz, self._w_sigma_c, None, None, noise.data_ptr(), ctypes.byref(pod_m),
+                      self._status.data_ptr(), stream_ptr())
+        else:
+            pod_s = self.state_pdf._pod()
+            rng = _lib.Rng(seed=self._seed, step=self._step)
+            self._step += 1
+            _lib.call("gse_gsukf_predict_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), 1, n, uu,
+                      float(dt), zz, self._w_sigma_c, ctypes.byref(pod_s), ctypes.byref(rng), None, ctypes.byref(pod_m),
+                      self._status.data_ptr(), stream_ptr())
 
     def _update_now(self, u, z):
         uu = _lib.doubles(u, _lib.GSE_NU)

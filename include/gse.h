@@ -204,6 +204,12 @@ int gse_gsukf_predict(float *mu, float *P, int B, int64_t N, const double *u, do
 int gse_gsukf_update(float *mu, float *P, float *w, int B, int64_t N, const double *u, const double *z,
                      const float *w_sigma, const gse_mixture *measurement_pdf, int32_t *status,
                      void *workspace, void *stream);
+/* gse_gsukf_predict followed by gse_gsukf_update (same u) in ONE launch, one lane per Gaussian: the same bits, without
+ * writing (mu, P) out and reading them back in between.  For large banks (the class uses it from 2^16 Gaussians). */
+int gse_gsukf_predict_update(float *mu, float *P, float *w, int B, int64_t N, const double *u, double dt,
+                             const double *z, const float *w_sigma, const gse_mixture *state_pdf,
+                             const gse_rng *rng, const float *noise, const gse_mixture *measurement_pdf,
+                             int32_t *status, void *stream);
 
 /* The whole cycle predict -> update -> resample (filter/gs_ukf.py:348-436) of a bank of at most 64 Gaussians in ONE
  * launch of one workgroup per filter (mu, P stay in LDS between the phases): the 64-Gaussian configuration is

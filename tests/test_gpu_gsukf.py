@@ -168,6 +168,52 @@ def test_gsukf_philox_cycle_and_errors():
         gf.point_estimate()
 
 
+def test_large_bank_lane_kernels_against_the_oracle_and_the_group_kernels():
+    """2^16 Gaussians: the class runs one lane per Gaussian with predict + update in ONE launch.  Against the same calls
+    one kernel each (lazy = False: bit-identical), against the 16-lanes-per-Gaussian kernels through the C ABI
+    (GSE_GSUKF_LANES is read once per process, so those are reached with a bank just below the threshold: same
+    arithmetic, same element numbers), and against the NumPy oracle on a slice."""
+    n = 1 << 16
+    xss = orc.steady_state()
+    z = np.array(orc.bioreactor_g(xss)) + [0.2, -0.1]
+    rng = np.random.default_rng(3)
+    means = (xss[None, :] + rng.standard_normal((n, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    banks = []
+    for lazy in (True, False):
+        gf = make(n, means)
+        gf.lazy = lazy
+        banks.append(gf)
+    small = make(n - 64, means[:n - 64])                          # below the threshold: the group kernels
+    small._seed = banks[0]._seed
+    for c in range(2):
+        u = [0.05 + 0.01 * c, 0.2]
+        for gf in banks + [small]:
+            gf.predict(u, 0.1)
+            gf.update(u, z)
+        np.testing.assert_array_equal(banks[0].means.get(), banks[1].means.get())
+        np.testing.assert_array_equal(banks[0].covariances.get(), banks[1].covariances.get())
+        np.testing.assert_array_equal(banks[0].weights.get(), banks[1].weights.get())
+        np.testing.assert_array_equal(banks[0].means.get()[:n - 64], small.means.get())
+        np.testing.assert_array_equal(banks[0].covariances.get()[:n - 64], small.covariances.get())
+        # (the smaller bank starts from weights 1 / (n - 64): same likelihood factors, another scale)
+        np.testing.assert_allclose(banks[0].weights.get()[:n - 64] * (n / (n - 64.0)), small.weights.get(), rtol=3e-7)
+    # oracle: one cycle with injected noise on a fresh pair
+    m = 4096
+    sp, mp = orc.bioreactor_noise()
+    o = orc.GSUKFOracle(m, None, sp, mp, means=means[:m])
+    gf = make(n, means, deterministic=True)
+    noise = (rng.standard_normal((n, 11, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    DeterministicGaussianSum.preload(noise)
+    gf.predict([0.05, 0.2], 0.1)
+    gf.update([0.05, 0.2], z)
+    o.predict([0.05, 0.2], 0.1, noise=noise[:m], loop=False)
+    prior_cov = o.covariances.copy()
+    o.update([0.05, 0.2], z)
+    assert_mean_close(gf.means.get()[:m], o.means, prior_cov, rel_sigma=2e-4)
+    assert_cov_close(gf.covariances.get()[:m], o.covariances, 2e-4)
+    np.testing.assert_allclose(gf.weights.get()[:m] * (n / m), o.weights, rtol=2e-3)
+
+
 @pytest.mark.parametrize("n", [1, 7, 33, 64])
 def test_fused_cycle_equals_separate_launches(n):
     """predict + update + resample of a small bank in ONE launch (gse_gsukf_cycle) vs the three methods run one kernel
