@@ -215,7 +215,24 @@ __device__ __forceinline__ void bioreactor_increment(const T (&x)[5], double fg,
     const double f_out = fg + fm;
     const double r_x = 0.0 * cx;
     const double r_h = 280.0 / 180.0 - cg;
-    const double monod = cg / (1e-2 + cg);
+    // cg / (0.01 + cg): the correctly rounded quotient without the range scaling of the general division (v_div_scale x 2,
+    // v_div_fmas, v_div_fixup) -- for fp32-born states the operands sit far from the exponent limits, where the general
+    // sequence reduces to exactly these operations (reciprocal estimate, two Newton steps, quotient, one residual
+    // correction), hence the same bits; 8 instructions instead of 12.  (fp64 states -- the plant -- keep the general one.)
+    double monod;
+    if constexpr (sizeof(T) == 4) {
+        const double den = 1e-2 + cg;
+        const double y0 = __builtin_amdgcn_rcp(den);
+        const double e0 = fma(-den, y0, 1.0);
+        const double y1 = fma(y0, e0, y0);
+        const double e1 = fma(-den, y1, 1.0);
+        const double y2 = fma(y1, e1, y1);
+        const double q = cg * y2;
+        const double rr = fma(-den, q, cg);
+        monod = fma(rr, y2, q);
+    } else {
+        monod = cg / (1e-2 + cg);
+    }
     const double r_fa = (0.25 / 116.0 * cx * 24.6) * monod;
     const double th1_max = (0.4 - 0.25) / 180.0 * cx * 24.6;
     // th1_max / 2000 / (0.28/180): division by a CONSTANT c, correctly rounded without a divide (Markstein): with
