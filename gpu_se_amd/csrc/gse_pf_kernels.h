@@ -258,9 +258,6 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     __shared__ __attribute__((aligned(16))) uint32_t mark[kInvMap ? kTile : 4];     // inverse map: see the gather stage
     __shared__ int32_t act_list[kInvMap ? kTile : 1];
     __shared__ int32_t act_n;
-    constexpr int kWorkMax = 1280;                 // quads of a wide ancestor range that need their four keys looked at
-    __shared__ uint32_t work[kInvMap ? kWorkMax : 1];
-    __shared__ int32_t work_n;
     __shared__ __attribute__((aligned(16))) float wtile[(kStrided && kUpdate) ? kTile : 4];
     __shared__ int64_t span[2];
     __shared__ double red[4];
@@ -339,7 +336,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             const int qlo = tid * m;
             if (kInvMap) {
                 *reinterpret_cast<uint4*>(&mark[tid * kPerThread]) = make_uint4(0u, 0u, 0u, 0u);
-                if (tid == 0) { act_n = 0; work_n = 0; }
+                if (tid == 0) act_n = 0;
             }
             double chunk = 0.0;
             double total;
@@ -401,13 +398,12 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             const float* wrow = w_in + (int64_t)b * ld;
     GSE_STAMP(11);
             const double* qx = scan_in + (int64_t)b * T * kBlock;                  // [T][256] per-thread exclusive prefixes
-            auto tile_weights = [&](int tq) {
-                return load_weights4(wrow, (int64_t)tq * kTile + (int64_t)tid * kPerThread, N, ld);
-            };
             // Which tiles to expand.  One or two (the common case): both.  A wider range (a stretch of light particles):
             // census first -- all keys of tile q lie in [Pfx[q], Pfx[q+1]]; when both ends fall into the same slot the whole
             // tile does and its LAST key stands for it; only tiles that some output of this workgroup descends from are
             // listed.  The listed tiles are expanded two at a time, the loads of the next pair in flight meanwhile.
+            // (A second census per quad for very wide ranges -- only the quads that contain a slot boundary get the full
+            // treatment -- was measured and dropped: no faster than this loop once its loads really ran ahead.)
             const bool direct = tl1 - tl0 < 2;                                     // workgroup-uniform
             int n_act = tl1 - tl0 + 1;
             if (!direct) {
@@ -429,94 +425,29 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                 n_act = act_n;
             }
             auto tile_at = [&](int i) { return direct ? tl0 + i : act_list[i]; };
-            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef GSE_EXPAND_ALL
-#define GSE_EXPAND_ALL 32
-#endif
-            constexpr int kExpandAll = GSE_EXPAND_ALL;         // up to this many tiles: every key is looked at
-            bool all_keys = n_act <= kExpandAll;                                   // workgroup-uniform
-            if (!all_keys) {
-                // Many tiles, each with only a few of this workgroup's outputs (a long stretch of light particles): going
-                // through all their keys is work in proportion to the stretch, although at most 1024 slot boundaries exist.
-                // A second census, per quad: the keys of thread t's quad lie between its exclusive prefix and the next
-                // thread's (up to the roundings of the scans, ~2^-49 of the tile sum); when both ends land in one slot, at
-                // a safe distance (N 2^-44, 16 times the guard of the exact count) from the slot boundaries, so do the four
-                // keys, and the quad's last key speaks for them.  The other quads -- at most one per boundary -- go on a work
-                // list and get the full treatment, densely packed.
-                const double qguard = F.Nd * 0x1p-44;
-                bool overflow = false;
-                // (the prefixes of the next two tiles are requested before this one is looked at)
-                const int tnext = min(tid + 1, kBlock - 1);
-                auto quad_prefixes = [&](int i, double& p0, double& p1) {
-                    if (i < n_act) {
-                        const double* qt = qx + (int64_t)act_list[i] * kBlock;
-                        p0 = qt[tid];
-                        p1 = qt[tnext];
-                    }
+            if (n_act > 0) {                                                       // (a census may list nothing)
+                // (every load below is unconditional, its index clamped instead: with loads under conditions the compiler
+                //  cannot count what is in flight and waits for ALL of it before the first use -- the next pair's loads
+                //  included, which is the opposite of a prefetch)
+                const int last = max(n_act - 1, 0);
+                auto weights_nc = [&](int tq) {
+                    const int64_t k0 = min((int64_t)tq * kTile + (int64_t)tid * kPerThread, ld - kPerThread);
+                    return *reinterpret_cast<const float4*>(wrow + k0);          // (beyond N: masked where it is used)
                 };
-                double b0 = 0.0, b1 = 0.0, c0_ = 0.0, c1_ = 0.0;
-                quad_prefixes(0, b0, b1);
-                quad_prefixes(1, c0_, c1_);
-                for (int i = 0; i < n_act; ++i) {
-                    const int tq = act_list[i];
-                    const double P0 = pfx_s[tq], P1 = pfx_s[tq + 1];
-                    const int64_t k0 = (int64_t)tq * kTile + (int64_t)tid * kPerThread;
-                    const int64_t tile_last = min((int64_t)(tq + 1) * kTile, N) - 1;
-                    const bool have = k0 <= tile_last;
-                    const double a0 = b0, a1 = b1;
-                    b0 = c0_; b1 = c1_;
-                    quad_prefixes(i + 2, c0_, c1_);
-                    const double xb = fmin(P0 + a0, P1);                           // (quad 0: its exclusive prefix is 0 -> P0)
-                    const double xe = (tid == kBlock - 1 || k0 + kPerThread - 1 >= tile_last) ? P1 : fmin(P0 + a1, P1);
-                    const double sb = fma(xb, F.NoverW, -F.r), se = fma(xe, F.NoverW, -F.r);
-                    const double fb = floor(sb), fe = floor(se);
-                    const bool safe = (sb - fb >= qguard) && (sb - fb <= 1.0 - qguard) && (se - fe >= qguard) &&
-                                      (se - fe <= 1.0 - qguard);
-                    const int32_t eb = min(max((int32_t)fb + 1 - j0, 0), (int32_t)kTile);
-                    const int32_t ee = min(max((int32_t)fe + 1 - j0, 0), (int32_t)kTile);
-                    const bool uniform = have && safe && eb == ee;
-                    // (fold: the next lane's quad is uniform with the same slot -> it, or a later one, speaks)
-                    const uint32_t next_tag = wave_shift_down1(uniform ? (uint32_t)ee + 1u : 0u);
-                    if (uniform) {
-                        if (ee < kTile && next_tag != (uint32_t)ee + 1u)
-                            atomicMax(&mark[ee], (uint32_t)min(k0 + kPerThread - 1, tile_last) + 1u);
-                    } else if (have) {
-                        const int at = atomicAdd(&work_n, 1);
-                        if (at < kWorkMax) work[at] = (uint32_t)tq * (uint32_t)kBlock + (uint32_t)tid;
-                        else overflow = true;
-                    }
-                }
-                // (an overflowing work list cannot happen short of ~250 quads inside the safety band at once; if it does,
-                //  every key is looked at instead -- marks are maxima, doing some twice changes nothing)
-                all_keys = __syncthreads_or(overflow ? 1 : 0) != 0;
-            }
-            if (all_keys) {
-                int t0 = (n_act > 0) ? tile_at(0) : 0, t1 = (n_act > 1) ? tile_at(1) : 0;
-                float4 c0 = zero4, c1 = zero4;
-                double x0 = 0.0, x1 = 0.0;
-                if (n_act > 0) { c0 = tile_weights(t0); x0 = qx[t0 * kBlock + tid]; }
-                if (n_act > 1) { c1 = tile_weights(t1); x1 = qx[t1 * kBlock + tid]; }
+                int t0 = tile_at(0), t1 = tile_at(min(1, last));
+                float4 c0 = weights_nc(t0), c1 = weights_nc(t1);
+                double x0 = qx[t0 * kBlock + tid], x1 = qx[t1 * kBlock + tid];
                 if (kDraw && draw_at == 2) {
                     draw_all();
                     drawn2 = true;
                 }
                 for (int i = 0; i < n_act; i += 2) {
-                    const int u0 = (i + 2 < n_act) ? tile_at(i + 2) : 0, u1 = (i + 3 < n_act) ? tile_at(i + 3) : 0;
-                    float4 n0 = zero4, n1 = zero4;
-                    double y0 = 0.0, y1 = 0.0;
-                    if (i + 2 < n_act) { n0 = tile_weights(u0); y0 = qx[u0 * kBlock + tid]; }
-                    if (i + 3 < n_act) { n1 = tile_weights(u1); y1 = qx[u1 * kBlock + tid]; }
+                    const int u0 = tile_at(min(i + 2, last)), u1 = tile_at(min(i + 3, last));
+                    const float4 n0 = weights_nc(u0), n1 = weights_nc(u1);
+                    const double y0 = qx[u0 * kBlock + tid], y1 = qx[u1 * kBlock + tid];
                     expand_quad<true>(F, pfx_s, mark, N, j0, t0, tid, c0, x0);
                     if (i + 1 < n_act) expand_quad<true>(F, pfx_s, mark, N, j0, t1, tid, c1, x1);
                     c0 = n0; c1 = n1; x0 = y0; x1 = y1; t0 = u0; t1 = u1;
-                }
-            } else {
-                const int n_work = min(work_n, kWorkMax);
-                for (int i = tid; i < n_work; i += kBlock) {
-                    const uint32_t id = work[i];
-                    const int tq = (int)(id / (uint32_t)kBlock), t = (int)(id % (uint32_t)kBlock);
-                    const float4 wv = load_weights4(wrow, (int64_t)tq * kTile + (int64_t)t * kPerThread, N, ld);
-                    expand_quad<false>(F, pfx_s, mark, N, j0, tq, t, wv, qx[id]);
                 }
             }
     GSE_STAMP(3);
