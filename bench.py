@@ -313,6 +313,9 @@ def main():
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("GSE_FORCE_DIST") == "1"      # the latter: exercise RCCL with one rank
     if use_dist:
+        # stdout carries ONE JSON line: keep RCCL's version banner (printed at NCCL_DEBUG=VERSION, which some images set)
+        # out of it; GSE_NCCL_DEBUG passes another level through
+        os.environ["NCCL_DEBUG"] = os.environ.get("GSE_NCCL_DEBUG", "WARN")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
