@@ -497,6 +497,66 @@ def test_single_launch_philox_cycle_against_oracle(n):
         x, w = x_new, w_new
 
 
+@pytest.mark.parametrize("n", [8, 1000, 4096, 100003, 1 << 20])
+def test_inverse_map_resample_on_adversarial_weights(n):
+    """The single-launch cycle's resample (inverse map from the weights, tools of DESIGN.md section 3) on weight patterns
+    chosen to hurt: exact ties (one-hot, interleaved zeros: runs of equal cumulative weights), a single heavy particle at
+    tile edges, a bump over the index (ancestor ranges of a few keys next to ranges of many tiles: the census path), a
+    long weightless stretch over a floor, weights that sum to zero or to NaN, r at both ends of [0, 1) -- r = 0 puts
+    every threshold ON an integer of the offspring count, i.e. into the guard band, where the count is settled with the
+    reference's own comparison.  All particles sit on one state, so the update multiplies the assigned weights by ONE
+    likelihood and leaves the pattern in place (plus the tile sums and prefixes the next launch resamples from); the
+    ancestors of that launch must be those of the materialised-cumsum route exactly, and the oracle's up to last-bit ties."""
+    gpu_se_amd.seed(17)
+    _, _, _, pf = sim_base.get_parts(N_particles=n)
+    xss = orc.steady_state().astype(np.float32)
+    u, z = [0.06, 0.2], np.array(orc.bioreactor_g(orc.steady_state()))
+    rng = np.random.default_rng(n)
+    idx_of = np.arange(n)
+    patterns = {
+        "uniform": np.ones(n),
+        "one_hot_first": (idx_of == 0).astype(float),
+        "one_hot_last": (idx_of == n - 1).astype(float),
+        "one_hot_tile_edge": ((idx_of == min(1023, n - 1)) | (idx_of == min(1024, n - 1))).astype(float),
+        "zeros_interleaved": rng.random(n) * (rng.random(n) > 0.7),
+        "bump": np.exp(-0.5 * ((idx_of - 0.3 * n) / (0.01 * n + 1)) ** 2) + 1e-30,
+        "floor_and_spikes": np.where(rng.random(n) < 8.0 / n, 1.0, 1e-7),
+        "weightless_stretch": np.where((idx_of > 0.2 * n) & (idx_of < 0.9 * n), 0.0, rng.random(n) ** 8),
+        "zero_sum": np.zeros(n),
+        "nan": np.full(n, np.nan),
+    }
+    for name, w in patterns.items():
+        for r in (0.0, 0.37, 1.0 - 2.0 ** -53):
+            pf.particles = np.repeat(xss[None, :], n, axis=0)
+            pf.weights = (w / np.nansum(w) if np.nansum(w) > 0 else w).astype(np.float32)
+            pf.update(u, z)                                    # weights <- weights * one likelihood; tile sums + prefixes out
+            assert pf._scan_slot is not None
+            stored32 = host(pf._w)[0, :n].copy()                # (not through the attribute: that would drop the prefixes)
+            stored = stored32.astype(np.float64)
+            total = stored.sum()
+            want = orc.systematic_index(stored, r) if (total > 0 and np.isfinite(total)) else np.zeros(n, dtype=np.int64)
+            # ... and this library's other route to the same ancestors: materialised cumulative weights (cumsum_kernel, the
+            # same tile-wise association of the sums) + the staged search of gse_pf_resample -- bit for bit
+            eager = run_resample(stored32, r)[0] if r < 1.0 else None
+            pf.resample(r=r)
+            assert pf._pend_gather and pf._gather_slot is not None
+            pf._want_index = True
+            pf.predict(u, 0.1)
+            pf.update(u, z)                                    # the single launch: gather (inverse map) + predict + update
+            got = host(pf._last_index)[0, :n]
+            np.testing.assert_array_equal(got, eager, err_msg="%s, r = %r" % (name, r))
+            # against the oracle's left-to-right cumulative sum: equal, except where a threshold meets a cumulative weight
+            # to the last bit (the symmetric bump puts c = 1/2 exactly ON a threshold) and the two associations round
+            # that bit differently -- then the neighbour
+            off = np.flatnonzero(got != want)
+            if len(off):
+                c_or = orc.normalised_cumsum(stored)
+                lo, hi = np.minimum(got[off], want[off]), np.maximum(got[off], want[off])
+                # (every key between the two answers carries the same cumulative weight to the last bits: a plateau of
+                #  weightless particles, or neighbours)
+                assert len(off) <= 2 and np.all(c_or[hi] - c_or[lo] <= 4.5e-16), "%s, r = %r: %s" % (name, r, off[:10])
+
+
 def test_in_place_writes_through_the_attribute_views_are_seen():
     """The reference's attributes are plain arrays that callers may change in place (pf.weights[:] = ...).  The views this
     class hands out write through to the device buffers; whatever was cached from the old contents (moments, the tile sums
