@@ -136,6 +136,9 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
                 "%s: bad ops mask 0x%x", fn, ops);
     const int scan = ((ops & GSE_OP_SCAN_IN) ? 1 : 0) | ((ops & GSE_OP_SCAN_OUT) ? 2 : 0);
     GSE_REQUIRE(!(scan & 1) || G, "%s: GSE_OP_SCAN_IN needs GSE_OP_GATHER", fn);
+    GSE_REQUIRE(!(scan & 1) || (w_in && aligned16(w_in)),
+                "%s: GSE_OP_SCAN_IN re-forms the cumulative weights from w_in (the weights the tile sums and prefixes of the slot "
+                "were taken from): it must be given", fn);
     GSE_REQUIRE(!(scan & 2) || U, "%s: GSE_OP_SCAN_OUT needs GSE_OP_UPDATE", fn);
     GSE_REQUIRE(scan == 0 || tiles_of(N) <= kScanMaxT, "%s: the scan modes support at most %d tiles (N <= %d)", fn,
                 kScanMaxT, kScanMaxT * kTile);
