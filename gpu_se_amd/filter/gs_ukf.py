@@ -26,7 +26,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     _parallel_resample = _KernelLauncher(_parallel_resample)
 
-    def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf):
+    def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, _batch=1):
         _require_builtin_model(f, g)
         _lib.load()
         self.f = f
@@ -35,12 +35,15 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self.state_pdf = state_pdf
         self.measurement_pdf = measurement_pdf
         n = self.N_particles
+        B = self._B = int(_batch)                     # independent banks sharing every launch (1 for this class)
+        if not 1 <= B <= _lib.GSE_MAX_B:
+            raise ValueError("batch size must be in 1..%d" % _lib.GSE_MAX_B)
         dev = device()
 
-        self._means = x0.draw(n).as_subclass(torch.Tensor).reshape(n, _lib.GSE_NX).contiguous()          # (gs_ukf.py:50)
+        self._means = x0.draw((B, n)).as_subclass(torch.Tensor).reshape(B, n, _lib.GSE_NX).contiguous()  # (gs_ukf.py:50)
         cov0 = torch.as_tensor(numpy.asarray(state_pdf.covariances[0], dtype=numpy.float32), device=dev)
-        self._covs = cov0[None, :, :].repeat(n, 1, 1).contiguous()                                        # (:52)
-        self._w = torch.full((n,), 1.0 / n, dtype=torch.float32, device=dev)                              # (:54)
+        self._covs = cov0[None, None, :, :].repeat(B, n, 1, 1).contiguous()                               # (:52)
+        self._w = torch.full((B, n), 1.0 / n, dtype=torch.float32, device=dev)                            # (:54)
         self._means_alt = torch.empty_like(self._means)
         self._covs_alt = torch.empty_like(self._covs)
         self._w_alt = torch.empty_like(self._w)
@@ -55,11 +58,12 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._w_sigma_c = (_lib.c_f * self._N_sigmas)(*[float(v) for v in w_sigma])
         self._w_sigma = DevArray.wrap(torch.as_tensor(w_sigma, device=dev))
 
-        self._ws = torch.empty(_lib.load().gse_workspace_bytes(1, n), dtype=torch.uint8, device=dev)
-        self._moments = torch.empty(46, dtype=torch.float64, device=dev)
+        self._ws = torch.empty(_lib.load().gse_workspace_bytes(B, n), dtype=torch.uint8, device=dev)
+        self._moments = torch.empty((B, 46), dtype=torch.float64, device=dev)
         self._status = torch.zeros(1, dtype=torch.int32, device=dev)
         self._seed = gpu_se_amd._new_stream_seed()
         self._step = 0
+        self._filter_offset = 0                       # stream number of bank 0 (bank b of a batch draws from stream b)
         self._host_rng = numpy.random.default_rng(self._seed & 0xFFFFFFFF)
 
         # deferred stages (small banks): predict() and update() are recorded and resample() runs all three in ONE launch
@@ -67,10 +71,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._pend_predict = None
         self._pend_update = None
         self._fusable = n <= _lib.GSE_GSUKF_CYCLE_MAX
-        self._fuse_pu = n >= _lib.GSE_GSUKF_LANES_MIN      # large banks: predict() is deferred and rides update()'s launch
-        self._c_u = (_lib.c_d * _lib.GSE_NU)()
-        self._c_z = (_lib.c_d * _lib.GSE_NY)()
-        self._c_r = (_lib.c_d * 1)()
+        self._fuse_pu = B * n >= _lib.GSE_GSUKF_LANES_MIN  # large banks: predict() is deferred and rides update()'s launch
 
         self._threads_per_block = self._tpb = 1024
         self._blocks_per_grid = self._bpg = (n - 1) // 1024 + 1
@@ -91,32 +92,42 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     @property
     def means(self):
         self._flush()
-        return DevArray.wrap(self._means)
+        return DevArray.wrap(self._means[0] if self._B == 1 else self._means)
 
     @means.setter
     def means(self, value):
         self._flush()
-        self._means.copy_(as_device(value, torch.float32).reshape(self.N_particles, self._Nx))
+        self._means.copy_(as_device(value, torch.float32).reshape(self._B, self.N_particles, self._Nx))
 
     @property
     def covariances(self):
         self._flush()
-        return DevArray.wrap(self._covs)
+        return DevArray.wrap(self._covs[0] if self._B == 1 else self._covs)
 
     @covariances.setter
     def covariances(self, value):
         self._flush()
-        self._covs.copy_(as_device(value, torch.float32).reshape(self.N_particles, self._Nx, self._Nx))
+        self._covs.copy_(as_device(value, torch.float32).reshape(self._B, self.N_particles, self._Nx, self._Nx))
 
     @property
     def weights(self):
         self._flush()
-        return DevArray.wrap(self._w)
+        return DevArray.wrap(self._w[0] if self._B == 1 else self._w)
 
     @weights.setter
     def weights(self, value):
         self._flush()
-        self._w.copy_(as_device(value, torch.float32).reshape(self.N_particles))
+        self._w.copy_(as_device(value, torch.float32).reshape(self._B, self.N_particles))
+
+    def _per_bank(self, values, width):
+        """Host values for every bank as the C ABI takes them ([B][width] doubles; one row is broadcast to all banks)."""
+        a = numpy.asarray(values, dtype=numpy.float64)
+        a = numpy.broadcast_to(a.reshape(-1, width), (self._B, width))
+        return _lib.doubles(a.ravel(), self._B * width)
+
+    def _noise_rows(self):
+        """Replayed noise of a DeterministicGaussianSum for every sigma point of every bank."""
+        return self.state_pdf.draw((self._B, self.N_particles, self._N_sigmas)).as_subclass(torch.Tensor).contiguous()
 
     def _check_status(self):
         """Raise like the reference does when a covariance is not positive definite even after the
@@ -130,40 +141,40 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     def _get_sigma_points(self):
         """Return the sigma points for the current Gaussians, device array (N x 11 x Nx) (gs_ukf.py:332-346)."""
         self._flush()
-        n = self.N_particles
-        out = torch.empty((n, self._N_sigmas, self._Nx), dtype=torch.float32, device=self._means.device)
-        _lib.call("gse_gsukf_sigma_points", self._means.data_ptr(), self._covs.data_ptr(), out.data_ptr(), 1, n,
+        n, B = self.N_particles, self._B
+        out = torch.empty((B, n, self._N_sigmas, self._Nx), dtype=torch.float32, device=self._means.device)
+        _lib.call("gse_gsukf_sigma_points", self._means.data_ptr(), self._covs.data_ptr(), out.data_ptr(), B, n,
                   self._status.data_ptr(), stream_ptr())
-        return DevArray.wrap(out)
+        return DevArray.wrap(out[0] if B == 1 else out)
 
     def predict(self, u, dt):
         """Prediction step (gs_ukf.py:348-367).  With at most 64 Gaussians the step is deferred so that resample() can
         run predict + update + resample as one launch (the bank is launch-latency-bound)."""
         if self.lazy and (self._fusable or self._fuse_pu) and self._pend_predict is None and self._pend_update is None:
-            self._pend_predict = ([float(v) for v in u], float(dt))
+            self._pend_predict = (numpy.array(u, dtype=numpy.float64), float(dt))
             return
         self._flush()
         self._predict_now(u, dt)
 
-    def _predict_now(self, u, dt):
-        uu = _lib.doubles(u, _lib.GSE_NU)
-        n = self.N_particles
+    def _draw_args(self):
+        """(state_pdf pod, rng, noise pointer) of a predict: replayed noise for a DeterministicGaussianSum, else Philox."""
         if isinstance(self.state_pdf, DeterministicGaussianSum):
-            noise = self.state_pdf.draw((n, self._N_sigmas)).as_subclass(torch.Tensor).contiguous()
-            _lib.call("gse_gsukf_predict", self._means.data_ptr(), self._covs.data_ptr(), 1, n, uu, float(dt),
-                      self._w_sigma_c, None, None, noise.data_ptr(), self._status.data_ptr(), stream_ptr())
-        else:
-            pod = self.state_pdf._pod()
-            rng = _lib.Rng(seed=self._seed, step=self._step)
-            self._step += 1
-            _lib.call("gse_gsukf_predict", self._means.data_ptr(), self._covs.data_ptr(), 1, n, uu, float(dt),
-                      self._w_sigma_c, ctypes.byref(pod), ctypes.byref(rng), None, self._status.data_ptr(),
-                      stream_ptr())
+            self._noise = self._noise_rows()
+            return None, None, self._noise.data_ptr()
+        rng = _lib.Rng(seed=self._seed, step=self._step, filter_offset=self._filter_offset)
+        self._step += 1
+        return ctypes.byref(self.state_pdf._pod()), ctypes.byref(rng), None
+
+    def _predict_now(self, u, dt):
+        pod, rng, noise = self._draw_args()
+        _lib.call("gse_gsukf_predict", self._means.data_ptr(), self._covs.data_ptr(), self._B, self.N_particles,
+                  self._per_bank(u, _lib.GSE_NU), float(dt), self._w_sigma_c, pod, rng, noise, self._status.data_ptr(),
+                  stream_ptr())
 
     def update(self, u, z):
         """Update step: local UKF update of every Gaussian, then the global weight update (gs_ukf.py:369-407)."""
         if self.lazy and self._fusable and self._pend_predict is not None and self._pend_update is None:
-            self._pend_update = ([float(v) for v in u], [float(v) for v in z])
+            self._pend_update = (numpy.array(u, dtype=numpy.float64), numpy.array(z, dtype=numpy.float64))
             return
         if self.lazy and self._fuse_pu and self._pend_predict is not None and self._pend_update is None:
             (up, dt), self._pend_predict = self._pend_predict, None
@@ -174,80 +185,61 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     def _predict_update_now(self, u, dt, z):
         """predict(u, dt) and update(., z) of a large bank in one launch (gse_gsukf_predict_update): same bits as the two."""
-        uu, zz = _lib.doubles(u, _lib.GSE_NU), _lib.doubles(z, _lib.GSE_NY)
-        n = self.N_particles
-        pod_m = self.measurement_pdf._pod()
-        if isinstance(self.state_pdf, DeterministicGaussianSum):
-            noise = self.state_pdf.draw((n, self._N_sigmas)).as_subclass(torch.Tensor).contiguous()
-            _lib.call("gse_gsukf_predict_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), 1, n, uu,
-                      float(dt), zz, self._w_sigma_c, None, None, noise.data_ptr(), ctypes.byref(pod_m),
-                      self._status.data_ptr(), stream_ptr())
-        else:
-            pod_s = self.state_pdf._pod()
-            rng = _lib.Rng(seed=self._seed, step=self._step)
-            self._step += 1
-            _lib.call("gse_gsukf_predict_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), 1, n, uu,
-                      float(dt), zz, self._w_sigma_c, ctypes.byref(pod_s), ctypes.byref(rng), None, ctypes.byref(pod_m),
-                      self._status.data_ptr(), stream_ptr())
+        pod, rng, noise = self._draw_args()
+        _lib.call("gse_gsukf_predict_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B,
+                  self.N_particles, self._per_bank(u, _lib.GSE_NU), float(dt), self._per_bank(z, _lib.GSE_NY),
+                  self._w_sigma_c, pod, rng, noise, ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(),
+                  stream_ptr())
 
     def _update_now(self, u, z):
-        uu = _lib.doubles(u, _lib.GSE_NU)
-        zz = _lib.doubles(z, _lib.GSE_NY)
-        pod = self.measurement_pdf._pod()
-        _lib.call("gse_gsukf_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), 1,
-                  self.N_particles, uu, zz, self._w_sigma_c, ctypes.byref(pod), self._status.data_ptr(),
-                  self._ws.data_ptr(), stream_ptr())
+        _lib.call("gse_gsukf_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B,
+                  self.N_particles, self._per_bank(u, _lib.GSE_NU), self._per_bank(z, _lib.GSE_NY), self._w_sigma_c,
+                  ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(), self._ws.data_ptr(), stream_ptr())
 
     def resample(self, r=None, return_index=False):
         """Systematic resample of the Gaussians based on their weights (gs_ukf.py:409-436)."""
-        rr = _lib.doubles([self._host_rng.random() if r is None else r], 1)
-        n = self.N_particles
-        idx = torch.empty(n, dtype=torch.int32, device=self._w.device) if return_index else None
+        n, B = self.N_particles, self._B
+        rr = self._per_bank(self._host_rng.random(B) if r is None else r, 1)
+        idx = torch.empty((B, n), dtype=torch.int32, device=self._w.device) if return_index else None
         if self._pend_predict is not None and self._pend_update is not None:
-            # the whole cycle in one launch of one workgroup (gse_gsukf_cycle); in place
+            # the whole cycle in one launch, one workgroup per bank (gse_gsukf_cycle); in place
             (u, dt), (_, z) = self._pend_predict, self._pend_update
             self._pend_predict = self._pend_update = None
-            uu, zz = _lib.doubles(u, _lib.GSE_NU), _lib.doubles(z, _lib.GSE_NY)
-            pod_m = self.measurement_pdf._pod()
-            if isinstance(self.state_pdf, DeterministicGaussianSum):
-                noise = self.state_pdf.draw((n, self._N_sigmas)).as_subclass(torch.Tensor).contiguous()
-                _lib.call("gse_gsukf_cycle", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
-                          idx.data_ptr() if return_index else None, 1, n, uu, dt, zz, rr, self._w_sigma_c, None, None,
-                          noise.data_ptr(), ctypes.byref(pod_m), self._status.data_ptr(), stream_ptr())
-            else:
-                pod_s = self.state_pdf._pod()
-                rng = _lib.Rng(seed=self._seed, step=self._step)
-                self._step += 1
-                _lib.call("gse_gsukf_cycle", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
-                          idx.data_ptr() if return_index else None, 1, n, uu, dt, zz, rr, self._w_sigma_c,
-                          ctypes.byref(pod_s), ctypes.byref(rng), None, ctypes.byref(pod_m), self._status.data_ptr(),
-                          stream_ptr())
-            if return_index:
-                return DevArray.wrap(idx)
-            return
-        self._flush()
-        _lib.call("gse_gsukf_resample", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
-                  self._means_alt.data_ptr(), self._covs_alt.data_ptr(), self._w_alt.data_ptr(),
-                  idx.data_ptr() if return_index else None, 1, n, rr, 0, self._ws.data_ptr(), stream_ptr())
-        self._means, self._means_alt = self._means_alt, self._means
-        self._covs, self._covs_alt = self._covs_alt, self._covs
-        self._w, self._w_alt = self._w_alt, self._w
+            pod, rng, noise = self._draw_args()
+            _lib.call("gse_gsukf_cycle", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
+                      idx.data_ptr() if return_index else None, B, n, self._per_bank(u, _lib.GSE_NU), dt,
+                      self._per_bank(z, _lib.GSE_NY), rr, self._w_sigma_c, pod, rng, noise,
+                      ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(), stream_ptr())
+        else:
+            self._flush()
+            _lib.call("gse_gsukf_resample", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
+                      self._means_alt.data_ptr(), self._covs_alt.data_ptr(), self._w_alt.data_ptr(),
+                      idx.data_ptr() if return_index else None, B, n, rr, 0, self._ws.data_ptr(), stream_ptr())
+            self._means, self._means_alt = self._means_alt, self._means
+            self._covs, self._covs_alt = self._covs_alt, self._covs
+            self._w, self._w_alt = self._w_alt, self._w
         if return_index:
-            return DevArray.wrap(idx)
+            return DevArray.wrap(idx[0] if B == 1 else idx)
 
     # ------------------------------------------------------------------ estimates
-    def _moment_sums(self):
+    def _moment_sums_all(self):
+        """Per bank (sum w, w @ mu, sum w P + sum w (mu - mean)(mu - mean)^T) from one device pass (synchronises)."""
         self._flush()
-        _lib.call("gse_gsukf_moments", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), 1,
+        _lib.call("gse_gsukf_moments", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B,
                   self.N_particles, self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
-        m = self._moments.cpu().numpy()
+        mm = self._moments.cpu().numpy()
         self._check_status()
         from gpu_se_amd.filter.particle import moments_to_mean_cov
-        s0, mean, cov_mean = moments_to_mean_cov(m[0], m[1:6], m[6:21], m[36:41])
-        cc = numpy.zeros((self._Nx, self._Nx))
-        cc[numpy.triu_indices(self._Nx)] = m[21:36]
-        cov_cov = cc + cc.T - numpy.diag(numpy.diag(cc))
-        return s0, mean, cov_cov + cov_mean
+        out = []
+        for m in mm:
+            s0, mean, cov_mean = moments_to_mean_cov(m[0], m[1:6], m[6:21], m[36:41])
+            cc = numpy.zeros((self._Nx, self._Nx))
+            cc[numpy.triu_indices(self._Nx)] = m[21:36]
+            out.append((s0, mean, cc + cc.T - numpy.diag(numpy.diag(cc)) + cov_mean))
+        return out
+
+    def _moment_sums(self):
+        return self._moment_sums_all()[0]
 
     def point_estimate(self):
         """Returns the point estimate of the filter: weights @ means (gs_ukf.py:438-440)."""
@@ -265,3 +257,31 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     def g_vectorize(self, particles, u, _y_dummy=None):
         """out[..., :] = g(particles[..., :], u), device array (.. x Ny) fp32 (gs_ukf.py:260-275; gsf_run_seq.py:285)."""
         return rows_g(_lib.call, self._Nx, particles, [float(v) for v in numpy.asarray(u, dtype=numpy.float64).reshape(-1)])
+
+
+class BatchedGaussianSumUnscentedKalmanFilter(ParallelGaussianSumUnscentedKalmanFilter):
+    """B independent Gaussian-sum filters (same model and noise; separate Gaussians, inputs, measurements and random
+    streams) advanced by the same kernel launches -- the batch dimension of the C ABI.  The reference repeats its GS-UKF
+    closed loops as a sequential Python loop (results/gsf_closedloop/bioreactor_performance_gsf.py:104-118); here they share
+    a GPU.  Methods as the plain class with a leading batch axis: u (B, 2) or (2,), z (B, 2); means (B, N, 5); covariances
+    (B, N, 5, 5); weights (B, N); point_estimate() -> (B, 5); point_covariance() -> (B,)."""
+
+    def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, batch):
+        super().__init__(f, g, N_particles, x0, state_pdf, measurement_pdf, _batch=batch)
+
+    @property
+    def batch(self):
+        return self._B
+
+    def estimates(self):
+        """(point estimates (B, 5), covariance sizes (B,)) from ONE device pass and one synchronisation."""
+        sums = self._moment_sums_all()
+        mean = numpy.stack([s[1] for s in sums])
+        cov = numpy.stack([s[2] for s in sums])
+        return mean, numpy.linalg.svd(cov, compute_uv=False)[:, 0]
+
+    def point_estimate(self):
+        return self.estimates()[0]
+
+    def point_covariance(self):
+        return self.estimates()[1]

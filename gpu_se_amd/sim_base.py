@@ -217,15 +217,20 @@ class Simulation:
 
 class BatchedSimulation:
     """B independent closed loops advanced together: the Monte-Carlo repetitions of the reference's closed-loop
-    performance study (results/pf_closedloop/bioreactor_performance_pf.py:104-118, a sequential Python loop there)
-    become the batch dimension of every kernel launch.  Plants are vectorised NumPy on the host; per tick there is one
-    fused estimator launch and one synchronisation (the estimates of all rollouts)."""
+    performance studies (results/pf_closedloop/bioreactor_performance_pf.py:104-118 and, with pf=False,
+    results/gsf_closedloop/bioreactor_performance_gsf.py:104-118: sequential Python loops there) become the batch
+    dimension of every kernel launch.  Plants are vectorised NumPy on the host; per tick there is one fused estimator
+    launch and one synchronisation (the estimates of all rollouts)."""
 
-    def __init__(self, batch, N_particles, dt_control, dt_predict, end_time=50, controller=None, seed=0, resident=False):
+    def __init__(self, batch, N_particles, dt_control, dt_predict, end_time=50, pf=True, controller=None, seed=0,
+                 resident=False):
         self.B = int(batch)
         self.resident = bool(resident)          # True: plant, controller and histories live on the device too
         if self.resident and controller is not None:
             raise ValueError("a resident loop runs the MPC on the device; host callables cannot replace it")
+        if self.resident and not pf:
+            raise NotImplementedError("the device-resident loop is written for the particle filter; the batched "
+                                      "Gaussian-sum filter runs with resident=False")
         self.ts = numpy.linspace(0, end_time, int(end_time * 10))
         self.dt = self.ts[1]
         self.dt_control, self.dt_predict = dt_control, dt_predict
@@ -234,8 +239,9 @@ class BatchedSimulation:
         state_pdf, measurement_pdf = get_noise()
         x0, _ = get_noise()
         x0.means += numpy.asarray(xss[numpy.newaxis, :], dtype=numpy.float32)
-        self.f = _filter.BatchedParticleFilter(model.Bioreactor.homeostatic_DEs, model.Bioreactor.static_outputs,
-                                               N_particles, x0, state_pdf, measurement_pdf, batch=self.B)
+        batched = _filter.BatchedParticleFilter if pf else _filter.BatchedGaussianSumUnscentedKalmanFilter
+        self.f = batched(model.Bioreactor.homeostatic_DEs, model.Bioreactor.static_outputs, N_particles, x0, state_pdf,
+                         measurement_pdf, batch=self.B)
         self.controller = controller
         self._rng = numpy.random.default_rng(seed)
         self.X = numpy.repeat(xss[None, :], self.B, axis=0)

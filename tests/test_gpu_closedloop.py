@@ -84,6 +84,29 @@ def test_batched_closed_loops():
     assert len(np.unique(np.round(sim.performance, 6))) == 4                      # independent rollouts
 
 
+def test_closed_loops_with_the_gaussian_sum_filter():
+    """pf=False: the reference's closed loop with the GS-UKF as the estimator (sim_base.py:215-219;
+    results/gsf_closedloop/bioreactor_performance_gsf.py:20-56), one rollout and a batch of rollouts."""
+    gpu_se_amd.seed(4)
+    one = sim_base.Simulation(N_particles=64, dt_control=0.1, dt_predict=0.1, end_time=4, pf=False, seed=3,
+                              controller=sim_base.hold_controller)
+    one.simulate()
+    steps = len(one.ts)
+    assert one.xs_f.shape[1] == 5 and one.ys_f.shape == (steps, 2)
+    err = np.abs(one.ys_f[5:] - one.ys[4:-1, [0, 2]])
+    assert np.median(err[:, 0]) < 0.6 and np.median(err[:, 1]) < 0.8
+    sim = sim_base.BatchedSimulation(batch=4, N_particles=64, dt_control=0.1, dt_predict=0.1, end_time=4, pf=False, seed=7,
+                                     controller=sim_base.hold_controller)
+    sim.simulate()
+    assert sim.xs.shape == (steps, 4, 5) and sim.ys_f.shape == (steps, 4, 2)
+    assert sim.performance.shape == (4,) and np.all(np.isfinite(sim.performance))
+    err = np.abs(sim.ys_f[5:] - sim.ys[4:-1][:, :, [0, 2]])
+    assert np.median(err[..., 0]) < 0.6 and np.median(err[..., 1]) < 0.8
+    assert len(np.unique(np.round(sim.performance, 6))) == 4                      # independent rollouts
+    with pytest.raises(NotImplementedError):
+        sim_base.BatchedSimulation(batch=2, N_particles=64, dt_control=0.1, dt_predict=0.1, pf=False, resident=True)
+
+
 # ------------------------------------------------------------------------------ sharded filter across two ranks
 def _sharded_worker(rank, world, port, out, n_local=1 << 15):
     import os

@@ -10,6 +10,7 @@ if not torch.cuda.is_available():
 
 import gpu_se_amd                                            # noqa: E402
 from gpu_se_amd import sim_base                              # noqa: E402
+from gpu_se_amd.filter import BatchedGaussianSumUnscentedKalmanFilter as BatchedGSF   # noqa: E402
 from gpu_se_amd.filter import ParallelGaussianSumUnscentedKalmanFilter as GSF   # noqa: E402
 from gpu_se_amd.gaussian_sum_dist import DeterministicGaussianSum               # noqa: E402
 from gpu_se_amd.model import Bioreactor                      # noqa: E402
@@ -243,3 +244,79 @@ def test_fused_cycle_equals_separate_launches(n):
             np.testing.assert_array_equal(banks[0].covariances.get(), banks[1].covariances.get())
             np.testing.assert_array_equal(banks[0].weights.get(), banks[1].weights.get())
         np.testing.assert_array_equal(banks[0].point_estimate(), banks[1].point_estimate())
+
+
+# ------------------------------------------------------------------------------ B banks in one launch
+def make_batch(B, n, means, deterministic=False):
+    gpu_se_amd.seed(21)
+    state_pdf, measurement_pdf = sim_base.get_noise(deterministic=deterministic)
+    x0, _ = sim_base.get_noise()
+    x0.means += orc.steady_state()[None, :].astype(np.float32)
+    gf = BatchedGSF(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, state_pdf, measurement_pdf, batch=B)
+    gf.means = means
+    return gf
+
+
+@pytest.mark.parametrize("n", [7, 64, 300, 1 << 15])
+def test_batch_of_banks_equals_single_banks(n):
+    """B independent banks through the batch dimension of every launch (per-bank u, z, r and Philox stream) give, bank by
+    bank, bit-identical results to B separate filters: the one-launch cycle (n <= 64), the group kernels (300) and the
+    lane kernels (B * 2^15 Gaussians reach the threshold, the single banks stay below it)."""
+    B = 3 if n < (1 << 15) else 2
+    xss = orc.steady_state()
+    rng = np.random.default_rng(n)
+    means = (xss[None, None, :] + rng.standard_normal((B, n, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    batch = make_batch(B, n, means)
+    assert tuple(batch.means.shape) == (B, n, 5) and tuple(batch.covariances.shape) == (B, n, 5, 5)
+    assert tuple(batch.weights.shape) == (B, n) and batch.batch == B
+    singles = []
+    for b in range(B):
+        gf = make(n, means[b])
+        gf._seed, gf._filter_offset = batch._seed, b
+        singles.append(gf)
+    for c in range(3):
+        u = rng.uniform([0.03, 0.1], [0.09, 0.3], size=(B, 2))
+        z = np.array(orc.bioreactor_g(xss))[None, :] + rng.normal(0, 0.3, size=(B, 2))
+        r = rng.random(B)
+        batch.predict(u, 0.1)
+        batch.update(u, z)
+        idx = batch.resample(r=r, return_index=True).get()
+        for b, gf in enumerate(singles):
+            gf.predict(u[b], 0.1)
+            gf.update(u[b], z[b])
+            np.testing.assert_array_equal(idx[b], gf.resample(r=r[b], return_index=True).get())
+            np.testing.assert_array_equal(batch.means.get()[b], gf.means.get())
+            np.testing.assert_array_equal(batch.covariances.get()[b], gf.covariances.get())
+            np.testing.assert_array_equal(batch.weights.get()[b], gf.weights.get())
+    est, cov = batch.estimates()
+    assert est.shape == (B, 5) and cov.shape == (B,)
+    for b, gf in enumerate(singles):
+        np.testing.assert_array_equal(est[b], gf.point_estimate())
+        np.testing.assert_allclose(cov[b], gf.point_covariance(), rtol=1e-12)
+    assert not np.array_equal(est[0], est[1])
+    sig = batch._get_sigma_points().get()
+    np.testing.assert_array_equal(sig[1], singles[1]._get_sigma_points().get())
+
+
+def test_batch_of_banks_with_injected_noise_tracks_the_oracle():
+    """The batched class in the parity mode: every bank against its own NumPy oracle fed the same noise."""
+    B, n = 2, 40
+    xss = orc.steady_state()
+    rng = np.random.default_rng(8)
+    means = (xss[None, None, :] + rng.standard_normal((B, n, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    batch = make_batch(B, n, means, deterministic=True)
+    sp, mp = orc.bioreactor_noise()
+    oracles = [orc.GSUKFOracle(n, None, sp, mp, means=means[b]) for b in range(B)]
+    u = np.array([[0.05, 0.2], [0.07, 0.15]])
+    z = np.array(orc.bioreactor_g(xss))[None, :] + np.array([[0.2, -0.1], [-0.3, 0.2]])
+    noise = (rng.standard_normal((B, n, 11, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    DeterministicGaussianSum.preload(noise)
+    batch.predict(u, 0.1)
+    batch.update(u, z)
+    for b, o in enumerate(oracles):
+        o.predict(u[b], 0.1, noise=noise[b], loop=False)
+        prior_cov = o.covariances.copy()
+        o.update(u[b], z[b])
+        assert_mean_close(batch.means.get()[b], o.means, prior_cov, rel_sigma=2e-4)
+        assert_cov_close(batch.covariances.get()[b], o.covariances, 2e-4)
+        np.testing.assert_allclose(batch.weights.get()[b], o.weights, rtol=2e-3)
