@@ -18,6 +18,7 @@ GSE_OP_U_DEVICE, GSE_OP_Z_DEVICE = 128, 256
 GSE_SCAN_MAX_TILES = 2048      # policy: beyond 2^21 particles the two-kernel resample is faster (every workgroup
                                # builds the whole tile prefix: at 4096 tiles the single launch takes 131 us against 102)
 GSE_GSUKF_CYCLE_MAX = 64
+GSE_GSUKF_MOMENTS = 46             # doubles per row of gse_gsukf_moments
 GSE_GSUKF_LANES_MIN = 1 << 16    # from this many Gaussians on: one lane per Gaussian, predict + update in one launch
 
 c_f = ctypes.c_float
@@ -83,6 +84,16 @@ PROTOTYPES = {
                                        c_vp, P_MIX, c_vp, c_vp]),
     "gse_gsukf_resample": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_u32, c_vp, c_vp]),
     "gse_gsukf_moments": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
+    "gse_gsukf_sigma_points_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
+    "gse_gsukf_predict_model": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_F, P_MIX, P_RNG, c_vp, c_vp, c_vp]),
+    "gse_gsukf_update_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, P_D, P_F, P_MIX, c_vp, c_vp, c_vp]),
+    "gse_gsukf_predict_update_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_D, P_F, P_MIX, P_RNG,
+                                                      c_vp, P_MIX, c_vp, c_vp]),
+    "gse_gsukf_cycle_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_D, P_D, P_F, P_MIX, P_RNG,
+                                             c_vp, P_MIX, c_vp, c_vp]),
+    "gse_gsukf_resample_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_u32, c_vp,
+                                                c_vp]),
+    "gse_gsukf_moments_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
     "gse_model_f": (ctypes.c_int, [c_vp, c_vp, c_i64, P_D, c_d, c_vp]),
     "gse_model_g": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "gse_model_g_u": (ctypes.c_int, [c_vp, c_vp, c_i64, P_D, c_vp]),

@@ -1,786 +1,40 @@
-// gse_gsukf.hip -- Gaussian-sum unscented Kalman filter on gfx950.
+// gse_gsukf.hip -- Gaussian-sum unscented Kalman filter on gfx950: the C ABI over the kernels of gse_gsukf_kernels.h.
 //
-// A bank of N Gaussians (mu_i, P_i, w_i); each is a UKF with 2*5+1 = 11 unscaled sigma points (filter/gs_ukf.py).
-// A workgroup of 1024 threads takes 64 Gaussians and every phase alternates between two mappings:
-//   * per SIGMA POINT, 16 lanes per Gaussian (lane j < 11 owns sigma point j): the model step with its noise draw
-//     (predict) and the output function (update) -- the part with 11-fold parallelism per Gaussian;
-//   * per GAUSSIAN, one lane each (the 64 lanes of wavefront 0): the 5x5 Cholesky, the 11-term contractions (mean, P,
-//     P_xy, P_yy), the 2x2 pseudo-inverse, the gain and the covariance update.  A wavefront issues an instruction once
-//     whatever the number of lanes that need it, so doing this per-Gaussian algebra in all 16 lanes of every Gaussian
-//     (the first version) cost 16 wavefronts' worth of issue slots per 64 Gaussians instead of one: at 2^18 Gaussians
-//     update 138 -> 55 us (predict, whose sigma-point part dominates, stays at ~75 us: its single-wavefront parts are
-//     not overlapped, one workgroup fills a CU), the cycle 236 -> 143 us.  The 64-Gaussian configuration (BASELINE
-//     config 3) is launch-latency-bound and gains most: 19.2 -> 11.2 us per cycle -- the per-Gaussian algebra is the
-//     same instruction stream but its loads and LDS traffic are no longer multiplied by 16.
-// Hand-offs go through LDS (rows padded to odd strides: a lane per Gaussian walks rows).  Sums run in the reference's
-// order (j = 0..10) so that results track the NumPy class closely.  These contractions are 5x11x5 at most: far too small
-// to feed the matrix cores (a 16x16x4 fp32 MFMA tile would be >90 % padding) and nowhere near a bound.
-#include "gse_host.h"
+// Every entry point exists twice: `gse_gsukf_x(...)` launches the kernels compiled into this library (the model it was
+// built for: the bioreactor, or -- the hipcc backend of gpu_se_amd/usermodel.py -- a user model), `gse_gsukf_x_model(model,
+// ...)` launches the same kernels compiled at run time for a user model (gse_rtc.hip) with the same argument list.
+#include "gse_gsukf_kernels.h"
+#include "gse_rtc.h"
 
 #include <stdlib.h>
 
+#include <tuple>
+
 namespace gse {
 
-constexpr int kGroup = 16;                       // lanes per Gaussian in the per-sigma-point parts
-constexpr int kGaussPerBlock = kBlock / kGroup;  // 16 (gsukf_sigma_kernel only)
-#ifndef GSE_GSUKF_WIDE_BANK
-#define GSE_GSUKF_WIDE_BANK 64   // (16 / 32 / 64 Gaussians per workgroup, 2^18 Gaussians: 64 is 15 % faster than 16 or 32)
-#endif
-constexpr int kWideBank = GSE_GSUKF_WIDE_BANK;   // Gaussians per workgroup of the separate predict / update kernels
-constexpr int kBank = 64;                        // Gaussians per workgroup of the one-launch cycle kernel
-constexpr int kFacStride = 21;                   // LDS row: m[5], L[15] (+1: odd stride)
-constexpr int kTileStride = GSE_NSIGMA * 5 + 2;  // 57 floats
-constexpr int kEtaStride = GSE_NSIGMA * 2 + 1;   // 23 doubles
-
-// Packed lower-triangular index helpers: entry (i, j), j <= i, lives at i*(i+1)/2 + j.
-__device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-
-// Cholesky factor of a symmetric 5x5 matrix given by its packed lower triangle (fp32, like LAPACK spotrf on
-// the fp32 covariances).  Returns false when a pivot is not positive.
-__device__ __forceinline__ bool chol5(const float (&A)[15], float (&L)[15]) {
-    // (no contraction into FMAs left to the compiler: the same source inlined into different kernels must give the same
-    //  bits, and whether `s - a * b` is fused depends on the surrounding code)
-#pragma clang fp contract(off)
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            float s = A[tri(i, j)];
-#pragma unroll
-            for (int k = 0; k < j; ++k) s -= L[tri(i, k)] * L[tri(j, k)];
-            if (i == j) {
-                ok = ok && (s > 0.0f);
-                L[tri(i, i)] = sqrtf(s);
-            } else {
-                L[tri(i, j)] = s / L[tri(j, j)];
-            }
-        }
+// numpy.average divides by sum(w): pairwise_sum's order for n values (n < 8: left to right; 8 <= n < 128: eight interleaved
+// accumulators folded as ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), then the n % 8 remaining values in order).
+template <class T>
+static T numpy_sum(const float* a, int n) {
+    if (n < 8) {
+        T res = (T)0;
+        for (int i = 0; i < n; ++i) res += (T)a[i];
+        return res;
     }
-    return ok;
+    T r[8];
+    for (int k = 0; k < 8; ++k) r[k] = (T)a[k];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int k = 0; k < 8; ++k) r[k] += (T)a[i + k];
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += (T)a[i];
+    return res;
 }
 
-// Loads (mu, lower triangle of P) of one Gaussian and factorises P, retrying once with 1e-10 on the diagonal
-// (filter/gs_ukf.py:72-75).  ok = false if the matrix is still not positive definite.
-__device__ __forceinline__ void load_and_factor(const float* __restrict__ mu_g, const float* __restrict__ P_g,
-                                                float (&mu)[5], float (&L)[15], bool& ok) {
-    float A[15];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) mu[k] = mu_g[k];
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) A[tri(i, j)] = P_g[i * 5 + j];
-    ok = chol5(A, L);
-    if (!ok) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) A[tri(i, i)] += 1e-10f;
-        ok = chol5(A, L);
-    }
-}
-
-// Sigma point j (0..10) of N(mu, L L^T): mu, mu + L[:, c], mu - L[:, c]   (filter/gs_ukf.py:76-80).
-__device__ __forceinline__ void sigma_point(const float (&mu)[5], const float (&L)[15], int j, float (&s)[5]) {
-    const int c = (j == 0) ? -1 : (j - 1) % 5;
-    const float sign = (j <= 5) ? 1.0f : -1.0f;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        float col = 0.0f;
-#pragma unroll
-        for (int cc = 0; cc <= k; ++cc) col = (c == cc) ? L[tri(k, cc)] : col;
-        s[k] = (c < 0) ? mu[k] : mu[k] + sign * col;
-    }
-}
-
-// (row, col) of packed symmetric entry l (0..14), row <= col, row-major upper triangle; nibble tables.
-__device__ __forceinline__ void sym_entry(int l, int& r, int& c) {
-    const uint64_t R = 0x433222111100000ull, C = 0x443432432143210ull;
-    r = (int)((R >> (4 * l)) & 0xf);
-    c = (int)((C >> (4 * l)) & 0xf);
-}
-
-struct SigmaWeights {
-    float w[GSE_NSIGMA];
-    float scl32;          // sum(w) in fp32  -- the divisor numpy.average uses for fp32 data
-    double scl64;         // sum(w) accumulated in fp64 -- its divisor for fp64 data
-};
-
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void gsukf_sigma_kernel(const float* __restrict__ mu, const float* __restrict__ P,
-                                                             float* __restrict__ sigmas, int64_t N,
-                                                             int32_t* __restrict__ status) {
-    const int b = blockIdx.y;
-    const int j = threadIdx.x & (kGroup - 1);
-    const int64_t g = (int64_t)blockIdx.x * kGaussPerBlock + (threadIdx.x / kGroup);
-    if (g >= N) return;
-    const int64_t gi = (int64_t)b * N + g;
-    float m[5], L[15], s[5];
-    bool ok;
-    load_and_factor(mu + gi * 5, P + gi * 25, m, L, ok);
-    if (j >= GSE_NSIGMA) return;
-    sigma_point(m, L, j, s);
-    if (!ok && j == 0 && status) atomicAdd(status, 1);
-    float* out = sigmas + (gi * GSE_NSIGMA + j) * 5;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) out[k] = s[k];
-}
-
-// ------------------------------------------------------------------------------------------------
-struct GsukfPredictArgs {
-    FilterIOs io;
-    DrawParams draw;
-    RngKey rng;
-    SigmaWeights sw;
-    double dt;
-};
-
-// Mean and covariance of the 11 propagated sigma points of one Gaussian (filter/gs_ukf.py:96-103), shared by every
-// kernel that predicts: mean = (sum_j sigma_j w_j) / sum(w) in fp32, j in order, no FMA contraction (numpy.average);
-// P = sum_j d_j (d_j w_j)^T entry by entry of the upper triangle, mirrored.  P_o: 25 floats, row-major.
-__device__ __forceinline__ void sigma_mean_cov(const float (&sg)[GSE_NSIGMA * 5], const SigmaWeights& sw, float (&mean)[5],
-                                               float* P_o) {
-    {
-#pragma clang fp contract(off)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            float acc = sg[k] * sw.w[0];
-#pragma unroll
-            for (int q = 1; q < GSE_NSIGMA; ++q) acc = acc + sg[q * 5 + k] * sw.w[q];
-            mean[k] = acc / sw.scl32;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 5; ++r)
-#pragma unroll
-        for (int c = r; c < 5; ++c) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int q = 0; q < GSE_NSIGMA; ++q) {
-                const float dr = sg[q * 5 + r] - mean[r];
-                const float dc = sg[q * 5 + c] - mean[c];
-                acc = fmaf(dr, dc * sw.w[q], acc);
-            }
-            P_o[r * 5 + c] = acc;
-            P_o[c * 5 + r] = acc;
-        }
-}
-
-// Phase A of predict and update: lane t < nloc of the workgroup factorises local Gaussian t and leaves (m, L) in fac[t].
-// Src: t -> (mu pointer, P pointer); global memory or LDS.  Ends with a workgroup barrier.
-template <class Src>
-__device__ __forceinline__ void gsukf_factor_block(Src src, float (*fac)[kFacStride], int nloc, int32_t* status) {
-    const int t = threadIdx.x;
-    if (t < nloc) {
-        float m[5], L[15];
-        bool ok;
-        const float *mu_g, *P_g;
-        src(t, mu_g, P_g);
-        load_and_factor(mu_g, P_g, m, L, ok);
-        if (!ok && status) atomicAdd(status, 1);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) fac[t][k] = m[k];
-#pragma unroll
-        for (int k = 0; k < 15; ++k) fac[t][5 + k] = L[k];
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ void read_factor(const float* fac_g, float (&m)[5], float (&L)[15]) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) m[k] = fac_g[k];
-#pragma unroll
-    for (int k = 0; k < 15; ++k) L[k] = fac_g[5 + k];
-}
-
-// Predict of the workgroup's nloc Gaussians (local index gl = tid / 16, lane j = tid % 16).  src / dst: local index ->
-// where (mu, P) are read / written (may be the same memory: every read precedes a barrier that every write follows).
-// g0: filter index of local Gaussian 0 (RNG element), noise: injected rows [N][11][5] of this filter or null.
-// Must be called by every thread of the workgroup.
-template <bool kInjected, class Src, class Dst>
-__device__ __forceinline__ void gsukf_predict_block(Src src, Dst dst, float (*fac)[kFacStride], float (*tile)[kTileStride],
-                                                    int nloc, int b, int64_t g0, const float* noise, const DrawParams& dp,
-                                                    int32_t* status, const GsukfPredictArgs& a) {
-    gsukf_factor_block(src, fac, nloc, status);
-    // B. one sigma point per lane, packed densely (11 per Gaussian: 704 points keep 11 of the 16 wavefronts busy, the
-    //    other five skip the model step and the noise draw altogether)
-    const int gl = (int)threadIdx.x / GSE_NSIGMA, j = (int)threadIdx.x - gl * GSE_NSIGMA;
-    if (gl < nloc) {
-        float m[5], L[15], s[5];
-        read_factor(fac[gl], m, L);
-        sigma_point(m, L, j, s);
-        bioreactor_step(s, a.io.f[b].u0, a.io.f[b].u1, a.dt);
-        float e[5];
-        if (kInjected) {
-            const float* nz = noise + (g0 + gl) * GSE_NSIGMA * 5;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) e[k] = nz[j * 5 + k];
-        } else {
-            uint32_t wd[8];
-            rng_words8(a.rng, (uint64_t)((g0 + gl) * GSE_NSIGMA + j), (uint32_t)b, wd);
-            mixture_draw5(dp, wd, e);
-        }
-#pragma unroll
-        for (int k = 0; k < 5; ++k) tile[gl][j * 5 + k] = s[k] + e[k];
-    }
-    __syncthreads();
-    // C. one Gaussian per lane: mean and covariance of its 11 points
-    const int t = threadIdx.x;
-    if (t < nloc) {
-        float sg[GSE_NSIGMA * 5];
-#pragma unroll
-        for (int i = 0; i < GSE_NSIGMA * 5; ++i) sg[i] = tile[t][i];
-        float mean[5];
-        float *mu_o, *P_o;
-        dst(t, mu_o, P_o);
-        sigma_mean_cov(sg, a.sw, mean, P_o);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) mu_o[k] = mean[k];
-    }
-}
-
-template <bool kInjected, int kBankT>
-__global__ __launch_bounds__(kBankT * kGroup) void gsukf_predict_kernel(float* __restrict__ mu, float* __restrict__ P,
-                                                                        const float* __restrict__ noise, int64_t N,
-                                                                        int32_t* __restrict__ status,
-                                                                        const GsukfPredictArgs a) {
-    __shared__ DrawParams dp;
-    __shared__ float fac[kBankT][kFacStride];
-    __shared__ float tile[kBankT][kTileStride];
-    if (!kInjected) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.draw);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
-        for (int i = threadIdx.x; i < (int)(sizeof(DrawParams) / 4); i += kBankT * kGroup) dst[i] = src[i];
-        __syncthreads();
-    }
-    const int b = blockIdx.y;
-    const int64_t g0 = (int64_t)blockIdx.x * kBankT;
-    const int nloc = (int)min((int64_t)kBankT, N - g0);
-    float* mu_b = mu + ((int64_t)b * N + g0) * 5;
-    float* P_b = P + ((int64_t)b * N + g0) * 25;
-    auto src = [&](int t, const float*& m_, const float*& p_) { m_ = mu_b + t * 5; p_ = P_b + t * 25; };
-    auto dst = [&](int t, float*& m_, float*& p_) { m_ = mu_b + t * 5; p_ = P_b + t * 25; };
-    gsukf_predict_block<kInjected>(src, dst, fac, tile, nloc, b, g0, kInjected ? noise + (int64_t)b * N * GSE_NSIGMA * 5 : nullptr,
-                                   dp, status, a);
-}
-
-// ------------------------------------------------------------------------------------------------
-struct GsukfUpdateArgs {
-    FilterIOs io;
-    Pdf2 pdf;
-    SigmaWeights sw;
-};
-
-// Pseudo-inverse of a symmetric 2x2 matrix with numpy.linalg.pinv's default cut-off (singular values
-// <= 1e-15 * largest are dropped; filter/gs_ukf.py:132).
-__device__ __forceinline__ void pinv_sym2(double a, double s, double d, double (&X)[2][2]) {
-#pragma clang fp contract(off)
-    const double half_tr = 0.5 * (a + d);
-    const double disc = sqrt(0.25 * (a - d) * (a - d) + s * s);
-    const double big = (fabs(half_tr + disc) >= fabs(half_tr - disc)) ? half_tr + disc : half_tr - disc;
-    const double det = a * d - s * s;
-    const double small = (big != 0.0) ? det / big : 0.0;
-    const double cut = 1e-15 * fabs(big);
-    if (!(fabs(big) > 0.0)) {
-        X[0][0] = X[0][1] = X[1][0] = X[1][1] = 0.0;
-    } else if (fabs(small) > cut) {
-        const double inv = 1.0 / det;
-        X[0][0] = d * inv; X[0][1] = -s * inv; X[1][0] = -s * inv; X[1][1] = a * inv;
-    } else {                                   // rank one: v v^T / big
-        double v0 = s, v1 = big - a;
-        const double w0 = big - d, w1 = s;
-        if (w0 * w0 + w1 * w1 > v0 * v0 + v1 * v1) { v0 = w0; v1 = w1; }
-        const double n2 = v0 * v0 + v1 * v1;
-        const double sc = (n2 > 0.0) ? 1.0 / (n2 * big) : 0.0;
-        X[0][0] = v0 * v0 * sc; X[0][1] = v0 * v1 * sc; X[1][0] = X[0][1]; X[1][1] = v1 * v1 * sc;
-    }
-}
-
-// The per-Gaussian algebra of the update (filter/gs_ukf.py:116-149): eta_mean, P_yy, P_xy in fp64 with j in order (the CPU
-// class keeps the etas in fp64), K = P_xy pinv(P_yy), mu += K (z - eta_mean), P -= (K P_yy) K^T, w *= pdf(z - g(mu_new)).
-// eta(q, c): output c of sigma point q (fp64); dev(q, k): sigma_q[k] - mu[k] (fp32); m: the prior mean; P_in / P_o: 25 floats
-// row-major (may be the same memory: every entry is read before it is written).  kUnrolled: the 11-term loop is unrolled
-// (operands in registers) or kept as a loop (operands in LDS: unrolled, the compiler hoists all 77 reads and spills).
-// One definition for every kernel that updates, so they agree to the bit.
-template <bool kUnrolled, class Eta, class Dev>
-__device__ __forceinline__ void gsukf_update_gaussian(Eta eta, Dev dev, const float* m, const float* P_in, float* mu_o,
-                                                      float* P_o, const float* w_in, float* w_out, double z0, double z1,
-                                                      const Pdf2& pdf, const SigmaWeights& sw) {
-    // (only the fma() calls written out below are fused: see chol5)
-#pragma clang fp contract(off)
-    double em[2];
-#pragma unroll
-    for (int q2 = 0; q2 < 2; ++q2) {
-#pragma clang fp contract(off)
-        double acc = eta(0, q2) * (double)sw.w[0];
-#pragma unroll
-        for (int q = 1; q < GSE_NSIGMA; ++q) acc = acc + eta(q, q2) * (double)sw.w[q];
-        em[q2] = acc / sw.scl64;
-    }
-    double pyy[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-    double pxy[5][2];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) pxy[k][0] = pxy[k][1] = 0.0;
-    auto term = [&](int q) {
-        const double wq = (double)sw.w[q];
-        const double e0 = eta(q, 0) - em[0], e1 = eta(q, 1) - em[1];
-        const double ew0 = e0 * wq, ew1 = e1 * wq;
-        pyy[0][0] = fma(e0, ew0, pyy[0][0]);
-        pyy[0][1] = fma(e0, ew1, pyy[0][1]);
-        pyy[1][0] = fma(e1, ew0, pyy[1][0]);
-        pyy[1][1] = fma(e1, ew1, pyy[1][1]);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const double dk = (double)dev(q, k);
-            pxy[k][0] = fma(dk, ew0, pxy[k][0]);
-            pxy[k][1] = fma(dk, ew1, pxy[k][1]);
-        }
-    };
-    if constexpr (kUnrolled) {
-#pragma unroll
-        for (int q = 0; q < GSE_NSIGMA; ++q) term(q);
-    } else {
-#pragma unroll 1
-        for (int q = 0; q < GSE_NSIGMA; ++q) term(q);
-    }
-    double X[2][2];
-    pinv_sym2(pyy[0][0], 0.5 * (pyy[0][1] + pyy[1][0]), pyy[1][1], X);
-    double K[5][2];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        K[k][0] = pxy[k][0] * X[0][0] + pxy[k][1] * X[1][0];
-        K[k][1] = pxy[k][0] * X[0][1] + pxy[k][1] * X[1][1];
-    }
-    const double i0 = z0 - em[0], i1 = z1 - em[1];
-    float mnew[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) mnew[k] = (float)((double)m[k] + (K[k][0] * i0 + K[k][1] * i1));
-    // P -= (K P_yy) K^T, entry (r, c) and its mirror (which uses (K P_yy)[c] . K[r]; identical when P_yy is symmetric to
-    // rounding).  Every entry is read before it is written, and by this lane only.
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const double t0 = K[r][0] * pyy[0][0] + K[r][1] * pyy[1][0];     // row r of K P_yy
-        const double t1 = K[r][0] * pyy[0][1] + K[r][1] * pyy[1][1];
-#pragma unroll
-        for (int c = r; c < 5; ++c) {
-            const float prc = (float)((double)P_in[r * 5 + c] - (t0 * K[c][0] + t1 * K[c][1]));
-            float pcr = prc;
-            if (r != c) {
-                const double u0 = K[c][0] * pyy[0][0] + K[c][1] * pyy[1][0];
-                const double u1 = K[c][0] * pyy[0][1] + K[c][1] * pyy[1][1];
-                pcr = (float)((double)P_in[c * 5 + r] - (u0 * K[r][0] + u1 * K[r][1]));
-            }
-            P_o[r * 5 + c] = prc;
-            if (r != c) P_o[c * 5 + r] = pcr;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) mu_o[k] = mnew[k];
-    // global update: w *= pdf(z - g(mu_new))
-    float y0, y1;
-    bioreactor_output(mnew[0], mnew[2], y0, y1);
-    const double lik = mixture_pdf2<0>(pdf, z0 - (double)y0, z1 - (double)y1);
-    *w_out = (float)((double)(*w_in) * lik);
-}
-
-// Update of the workgroup's nloc Gaussians, in place where src / dst point (global memory or LDS); weights are read
-// through w_in(t) and written through w_out(t).  Must be called by every thread of the workgroup.
-template <class Src, class Dst, class Win, class Wout>
-__device__ __forceinline__ void gsukf_update_block(Src src, Dst dst, Win w_in, Wout w_out, float (*fac)[kFacStride],
-                                                   float (*dev)[kTileStride], double (*eta)[kEtaStride], int nloc, int b,
-                                                   int32_t* status, const FilterIOs& io, const Pdf2& pdf,
-                                                   const SigmaWeights& sw) {
-    gsukf_factor_block(src, fac, nloc, status);
-    // B. one sigma point per lane: outputs and deviations
-    const int j = threadIdx.x & (kGroup - 1), gl = threadIdx.x / kGroup;
-    if (gl < nloc && j < GSE_NSIGMA) {
-        float m[5], L[15], s[5];
-        read_factor(fac[gl], m, L);
-        sigma_point(m, L, j, s);
-        float y0, y1;
-        bioreactor_output(s[0], s[2], y0, y1);
-        eta[gl][j * 2 + 0] = (double)y0;
-        eta[gl][j * 2 + 1] = (double)y1;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) dev[gl][j * 5 + k] = s[k] - m[k];
-    }
-    __syncthreads();
-    // C. one Gaussian per lane
-    const int t = threadIdx.x;
-    if (t >= nloc) return;
-    const double* eta_g = eta[t];
-    const float* dev_g = dev[t];
-    const float *mu_g, *P_g;
-    src(t, mu_g, P_g);
-    float *mu_o, *P_o;
-    dst(t, mu_o, P_o);
-    gsukf_update_gaussian<false>([&](int q, int c) { return eta_g[q * 2 + c]; }, [&](int q, int k) { return dev_g[q * 5 + k]; },
-                                 fac[t], P_g, mu_o, P_o, w_in(t), w_out(t), io.f[b].z0, io.f[b].z1, pdf, sw);
-}
-
-template <int kBankT>
-__global__ __launch_bounds__(kBankT * kGroup) void gsukf_update_kernel(float* __restrict__ mu, float* __restrict__ P,
-                                                                       float* __restrict__ w, int64_t N,
-                                                                       int32_t* __restrict__ status,
-                                                                       const GsukfUpdateArgs a) {
-    __shared__ float fac[kBankT][kFacStride];
-    __shared__ float dev[kBankT][kTileStride];       // sigma_j - mu
-    __shared__ double eta[kBankT][kEtaStride];       // g(sigma_j)
-    const int b = blockIdx.y;
-    const int64_t g0 = (int64_t)blockIdx.x * kBankT;
-    const int nloc = (int)min((int64_t)kBankT, N - g0);
-    float* mu_b = mu + ((int64_t)b * N + g0) * 5;
-    float* P_b = P + ((int64_t)b * N + g0) * 25;
-    float* w_b = w + (int64_t)b * N + g0;
-    auto src = [&](int t, const float*& m_, const float*& p_) { m_ = mu_b + t * 5; p_ = P_b + t * 25; };
-    auto dst = [&](int t, float*& m_, float*& p_) { m_ = mu_b + t * 5; p_ = P_b + t * 25; };
-    gsukf_update_block(src, dst, [&](int t) { return (const float*)(w_b + t); }, [&](int t) { return w_b + t; }, fac, dev, eta,
-                       nloc, b, status, a.io, a.pdf, a.sw);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Large banks: ONE LANE PER GAUSSIAN.  The kernels above give a Gaussian 16 lanes for its 11 sigma points and one lane for
-// its algebra, handing over through LDS -- right for a few hundred Gaussians (parallelism is scarce, latency rules), wrong
-// for 2^18: the single-lane phases run in one wavefront of sixteen while the workgroup holds a whole CU (round 1: 143 us
-// per cycle, 0.17 of the HBM roofline).  Here a workgroup of 256 threads takes 256 Gaussians and a lane does everything for
-// its own: factorisation, the 11 sigma points one after the other (model step + noise draw, or output function), the
-// contractions -- all in registers, no hand-off, no barrier inside, every lane busy in every phase.  (mu, P) travel through
-// LDS only to make the global traffic coalesced: the workgroup's rows are one contiguous block of 256 x 120 bytes, staged
-// with stride 31 floats (conflict-free when a lane walks its row).  Same device functions, same sigma-point order and the
-// same random-number elements as the kernels above: results agree bit for bit.
-constexpr int kLaneBank = 256;
-constexpr int kStageStride = 31;                 // 5 + 25 floats per Gaussian, padded to an odd stride
-
-__device__ __forceinline__ void stage_bank_in(float* stage, const float* mu_b, const float* P_b, int nloc) {
-    for (int i = threadIdx.x; i < nloc * 5; i += kLaneBank) {
-        const int g = i / 5;
-        stage[g * kStageStride + (i - g * 5)] = mu_b[i];
-    }
-    for (int i = threadIdx.x; i < nloc * 25; i += kLaneBank) {
-        const int g = i / 25;
-        stage[g * kStageStride + 5 + (i - g * 25)] = P_b[i];
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ void stage_bank_out(const float* stage, float* mu_b, float* P_b, int nloc) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < nloc * 5; i += kLaneBank) {
-        const int g = i / 5;
-        mu_b[i] = stage[g * kStageStride + (i - g * 5)];
-    }
-    for (int i = threadIdx.x; i < nloc * 25; i += kLaneBank) {
-        const int g = i / 25;
-        P_b[i] = stage[g * kStageStride + 5 + (i - g * 25)];
-    }
-}
-
-#ifndef GSE_GSUKF_PRED_WAVES
-#define GSE_GSUKF_PRED_WAVES 1   // waves per SIMD the register allocator must leave room for (tuning knob)
-#endif
-#ifndef GSE_GSUKF_PRED_SERIAL
-#define GSE_GSUKF_PRED_SERIAL 0  // 1: a scheduling barrier between the sigma points of a lane (tuning knob)
-#endif
-// predict of ONE Gaussian held in `mine` (mu[5], P[25]); g: its index in the filter (random-number element)
-template <bool kInjected>
-__device__ __forceinline__ void gsukf_predict_lane(float* mine, int b, int64_t g, int64_t N, const float* noise,
-                                                   const DrawParams& dp, int32_t* status, const GsukfPredictArgs& a) {
-    float m[5], L[15];
-    bool ok;
-    load_and_factor(mine, mine + 5, m, L, ok);
-    if (!ok && status) atomicAdd(status, 1);
-    float sg[GSE_NSIGMA * 5];
-#pragma unroll
-    for (int j = 0; j < GSE_NSIGMA; ++j) {
-        float s[5], e[5];
-        sigma_point(m, L, j, s);
-        bioreactor_step(s, a.io.f[b].u0, a.io.f[b].u1, a.dt);
-        if (kInjected) {
-            const float* nz = noise + (((int64_t)b * N + g) * GSE_NSIGMA + j) * 5;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) e[k] = nz[k];
-        } else {
-            uint32_t wd[8];
-            rng_words8(a.rng, (uint64_t)(g * GSE_NSIGMA + j), (uint32_t)b, wd);
-            mixture_draw5(dp, wd, e);
-        }
-#pragma unroll
-        for (int k = 0; k < 5; ++k) sg[j * 5 + k] = s[k] + e[k];
-#if GSE_GSUKF_PRED_SERIAL
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-    float mean[5];
-    sigma_mean_cov(sg, a.sw, mean, mine + 5);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) mine[k] = mean[k];
-}
-
-// update of ONE Gaussian held in `mine`; its weight at *w
-__device__ __forceinline__ void gsukf_update_lane(float* mine, float* w, double z0, double z1, int32_t* status, const Pdf2& pdf,
-                                                  const SigmaWeights& sw) {
-    float m[5], L[15];
-    bool ok;
-    load_and_factor(mine, mine + 5, m, L, ok);
-    if (!ok && status) atomicAdd(status, 1);
-    // outputs of the 11 sigma points (fp64, as the kernels above keep them); the deviations sigma_j - mu are re-formed
-    // from the factor where the contraction needs them (a select and a subtraction) instead of being kept
-    double eta[GSE_NSIGMA][2];
-#pragma unroll
-    for (int j = 0; j < GSE_NSIGMA; ++j) {
-        float s[5], y0, y1;
-        sigma_point(m, L, j, s);
-        bioreactor_output(s[0], s[2], y0, y1);
-        eta[j][0] = (double)y0;
-        eta[j][1] = (double)y1;
-    }
-    float prior[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) prior[k] = m[k];
-    gsukf_update_gaussian<true>([&](int q, int c) { return eta[q][c]; },
-                                [&](int q, int k) {
-                                    float s[5];
-                                    sigma_point(m, L, q, s);
-                                    return s[k] - m[k];
-                                },
-                                prior, mine + 5, mine, mine + 5, w, w, z0, z1, pdf, sw);
-}
-
-#ifndef GSE_GSUKF_PRED_WAVES
-#define GSE_GSUKF_PRED_WAVES 1   // waves per SIMD the register allocator must leave room for (tuning knob)
-#endif
-#ifndef GSE_GSUKF_PRED_SERIAL
-#define GSE_GSUKF_PRED_SERIAL 0  // 1: a scheduling barrier between the sigma points of a lane (tuning knob)
-#endif
-template <bool kInjected>
-__global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict_lanes_kernel(
-    float* __restrict__ mu, float* __restrict__ P, const float* __restrict__ noise, int64_t N, int32_t* __restrict__ status,
-    const GsukfPredictArgs a) {
-    __shared__ DrawParams dp;
-    __shared__ float stage[kLaneBank * kStageStride];
-    const int t = threadIdx.x, b = blockIdx.y;
-    const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
-    const int nloc = (int)min((int64_t)kLaneBank, N - g0);
-    float* mu_b = mu + ((int64_t)b * N + g0) * 5;
-    float* P_b = P + ((int64_t)b * N + g0) * 25;
-    if (!kInjected) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.draw);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
-        for (int i = t; i < (int)(sizeof(DrawParams) / 4); i += kLaneBank) dst[i] = src[i];
-    }
-    stage_bank_in(stage, mu_b, P_b, nloc);
-    if (t < nloc) gsukf_predict_lane<kInjected>(stage + t * kStageStride, b, g0 + t, N, noise, dp, status, a);
-    stage_bank_out(stage, mu_b, P_b, nloc);
-}
-
-__global__ __launch_bounds__(kLaneBank) void gsukf_update_lanes_kernel(float* __restrict__ mu, float* __restrict__ P,
-                                                                       float* __restrict__ w, int64_t N,
-                                                                       int32_t* __restrict__ status, const GsukfUpdateArgs a) {
-    __shared__ float stage[kLaneBank * kStageStride];
-    const int t = threadIdx.x, b = blockIdx.y;
-    const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
-    const int nloc = (int)min((int64_t)kLaneBank, N - g0);
-    float* mu_b = mu + ((int64_t)b * N + g0) * 5;
-    float* P_b = P + ((int64_t)b * N + g0) * 25;
-    stage_bank_in(stage, mu_b, P_b, nloc);
-    if (t < nloc)
-        gsukf_update_lane(stage + t * kStageStride, w + (int64_t)b * N + g0 + t, a.io.f[b].z0, a.io.f[b].z1, status, a.pdf, a.sw);
-    stage_bank_out(stage, mu_b, P_b, nloc);
-}
-
-// predict and update of a large bank in ONE launch (the class defers predict() until update()): what predict leaves in
-// the staged rows is what update picks up -- the same fp32 values the separate launches pass through memory, so the same
-// bits, without writing 120 bytes per Gaussian and reading them back, and one launch less.
-struct GsukfPredictUpdateArgs {
-    GsukfPredictArgs pred;      // (its io carries u and z)
-    Pdf2 pdf;
-};
-template <bool kInjected>
-__global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict_update_lanes_kernel(
-    float* __restrict__ mu, float* __restrict__ P, float* __restrict__ w, const float* __restrict__ noise, int64_t N,
-    int32_t* __restrict__ status, const GsukfPredictUpdateArgs a) {
-    __shared__ DrawParams dp;
-    __shared__ float stage[kLaneBank * kStageStride];
-    const int t = threadIdx.x, b = blockIdx.y;
-    const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
-    const int nloc = (int)min((int64_t)kLaneBank, N - g0);
-    float* mu_b = mu + ((int64_t)b * N + g0) * 5;
-    float* P_b = P + ((int64_t)b * N + g0) * 25;
-    if (!kInjected) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.pred.draw);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
-        for (int i = t; i < (int)(sizeof(DrawParams) / 4); i += kLaneBank) dst[i] = src[i];
-    }
-    stage_bank_in(stage, mu_b, P_b, nloc);
-    if (t < nloc) {
-        float* mine = stage + t * kStageStride;
-        gsukf_predict_lane<kInjected>(mine, b, g0 + t, N, noise, dp, status, a.pred);
-        gsukf_update_lane(mine, w + (int64_t)b * N + g0 + t, a.pred.io.f[b].z0, a.pred.io.f[b].z1, status, a.pdf, a.pred.sw);
-    }
-    stage_bank_out(stage, mu_b, P_b, nloc);
-}
-
-// ------------------------------------------------------------------------------------------------
-// The whole cycle predict -> update -> resample of a bank of at most 64 Gaussians in ONE workgroup of 1024 threads
-// (64 groups of 16 lanes): BASELINE config 3 is launch-latency-bound, so one launch instead of five is the lever.
-// mu, P live in LDS between the phases; the resample is the arithmetic of cumsum_kernel + the gather for a single
-// tile (all per-thread sums sit in wavefront 0), so the result is bit-identical to the separate launches.
-constexpr int kSmallBank = 64;
-constexpr int kSmallBlock = kSmallBank * kGroup;      // 1024
-
-struct GsukfCycleArgs {
-    GsukfPredictArgs pred;
-    Pdf2 pdf;
-    double r[GSE_MAX_B];
-};
-
-template <bool kInjected>
-__global__ __launch_bounds__(kSmallBlock) void gsukf_cycle_kernel(float* __restrict__ mu, float* __restrict__ P,
-                                                                  float* __restrict__ w, const float* __restrict__ noise,
-                                                                  int32_t* __restrict__ idx_out, int N,
-                                                                  int32_t* __restrict__ status, const GsukfCycleArgs a) {
-    __shared__ DrawParams dp;
-    __shared__ float fac[kBank][kFacStride];
-    __shared__ float tile[kBank][kTileStride];                   // predict: sigma points; update: deviations
-    __shared__ double eta[kBank][kEtaStride];
-    __shared__ float mu_s[kSmallBank][5];
-    __shared__ float P_s[kSmallBank][25];
-    __shared__ float w_s[kSmallBank];
-    __shared__ double c_s[kSmallBank];
-    __shared__ int anc_s[kSmallBank];
-    static_assert(kSmallBank == kBank, "the cycle kernel is one bank");
-    const int tid = threadIdx.x, b = blockIdx.y;
-    const int j = tid & (kGroup - 1), gl = tid / kGroup;
-    const bool live = gl < N;
-    const int64_t gi = (int64_t)b * N + (live ? gl : 0);
-    if (!kInjected) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.pred.draw);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
-        for (int i = tid; i < (int)(sizeof(DrawParams) / 4); i += kSmallBlock) dst[i] = src[i];
-        __syncthreads();
-    }
-    float* mu_b = mu + (int64_t)b * N * 5;
-    float* P_b = P + (int64_t)b * N * 25;
-    float* w_b = w + (int64_t)b * N;
-    auto from_global = [&](int t, const float*& m_, const float*& p_) { m_ = mu_b + t * 5; p_ = P_b + t * 25; };
-    auto from_lds = [&](int t, const float*& m_, const float*& p_) { m_ = mu_s[t]; p_ = P_s[t]; };
-    auto to_lds = [&](int t, float*& m_, float*& p_) { m_ = mu_s[t]; p_ = P_s[t]; };
-    // 1. predict: global -> LDS
-    gsukf_predict_block<kInjected>(from_global, to_lds, fac, tile, N, b, 0,
-                                   kInjected ? noise + (int64_t)b * N * GSE_NSIGMA * 5 : nullptr, dp, status, a.pred);
-    __syncthreads();
-    // 2. update in LDS; the weight goes global -> LDS
-    gsukf_update_block(from_lds, to_lds, [&](int t) { return (const float*)(w_b + t); }, [&](int t) { return &w_s[t]; }, fac,
-                       tile, eta, N, b, status, a.pred.io, a.pdf, a.pred.sw);
-    __syncthreads();
-    // 3. resample, one tile: thread t < 16 of wavefront 0 owns weights 4t..4t+3, exactly as cumsum_kernel does
-    __shared__ double total_s;
-    if (tid < 64) {
-        const int i0 = tid * 4;
-        double sc[4];
-        sc[0] = (i0 + 0 < N) ? (double)w_s[min(i0 + 0, kSmallBank - 1)] : 0.0;
-        sc[1] = sc[0] + ((i0 + 1 < N) ? (double)w_s[min(i0 + 1, kSmallBank - 1)] : 0.0);
-        sc[2] = sc[1] + ((i0 + 2 < N) ? (double)w_s[min(i0 + 2, kSmallBank - 1)] : 0.0);
-        sc[3] = sc[2] + ((i0 + 3 < N) ? (double)w_s[min(i0 + 3, kSmallBank - 1)] : 0.0);
-        const double inc = wave_inclusive_scan(sc[3], tid);
-        const double W = __shfl(inc, 63, 64);                       // workgroup total: wavefronts 1.. hold zeros
-        double excl = wave_shift_up1(inc);
-        if (tid == 0) excl = 0.0;
-        const double top = W / W;
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            if (i0 + p < N) c_s[i0 + p] = (i0 + p == N - 1) ? top : fmin((0.0 + (excl + sc[p])) / W, top);
-        if (tid == 0) total_s = W;
-    }
-    __syncthreads();
-    if (tid < N) {                                                   // ancestor of output tid
-        const double W = total_s;
-        int k = 0;
-        if ((W > 0.0) && (W < INFINITY)) {
-            const double u = ((double)tid + a.r[b]) / (double)N;
-            int lo = 0, hi = N - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (c_s[mid] < u) lo = mid + 1; else hi = mid;
-            }
-            k = lo;
-        }
-        anc_s[tid] = k;
-        if (idx_out) idx_out[(int64_t)b * N + tid] = k;
-        w[(int64_t)b * N + tid] = (float)(1.0 / (double)N);
-    }
-    __syncthreads();
-    // 4. gather LDS -> global (in place: the source is LDS)
-    if (live) {
-        const int src = anc_s[gl];
-        for (int e = j; e < 30; e += kGroup) {
-            if (e < 5) mu[gi * 5 + e] = mu_s[src][e];
-            else P[gi * 25 + (e - 5)] = P_s[src][e - 5];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// moments: one thread per Gaussian, blocks stride; 36 fp64 sums
-__global__ __launch_bounds__(kBlock) void gsukf_moments_kernel(const float* __restrict__ mu, const float* __restrict__ P,
-                                                               const float* __restrict__ w,
-                                                               double* __restrict__ partials, int64_t N) {
-    __shared__ double red[4 * 36];
-    const int b = blockIdx.y;
-    const float* mb = mu + (int64_t)b * N * 5;
-    const float* Pb = P + (int64_t)b * N * 25;
-    const float* wb = w + (int64_t)b * N;
-    double pv[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) pv[k] = (double)mb[k];
-    double acc[36];
-#pragma unroll
-    for (int c = 0; c < 36; ++c) acc[c] = 0.0;
-    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < N; g += (int64_t)gridDim.x * kBlock) {
-        const double wp = (double)wb[g];
-        double d[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) d[k] = (double)mb[g * 5 + k] - pv[k];
-        acc[0] += wp;
-        int c = 6;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const double wd = wp * d[k];
-            acc[1 + k] += wd;
-#pragma unroll
-            for (int l = k; l < 5; ++l) acc[c++] += wd * d[l];
-        }
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-#pragma unroll
-            for (int l = k; l < 5; ++l) acc[c++] += wp * (double)Pb[g * 25 + k * 5 + l];
-    }
-    double* out = partials + ((int64_t)b * kMomentBlocks + blockIdx.x) * kMomentWidth;
-    block_sums<36>(acc, red, [&](int c, double total) { out[c] = total; });
-}
-
-static int pack_sigma_weights(SigmaWeights& sw, const float* w_sigma) {
-    float s32 = 0.0f;
-    double s64 = 0.0;
-    // numpy sums 11 contiguous values pairwise only above 8 elements per block of its unrolled loop; for n = 11
-    // its pairwise routine reduces to a plain left-to-right loop (n < 8 is the unrolled threshold... n < 128
-    // takes the simple path with 8 accumulators only when n >= 8): replicate that order.
-    // numpy pairwise_sum, n in [8, 128): r[0..7] = a[0..7]; for i = 8; i < n - n%8: r[k] += a[i+k];
-    // res = ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)); then the remaining n%8 elements are added in order.
-    {
-        float r[8];
-        for (int k = 0; k < 8; ++k) r[k] = w_sigma[k];
-        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (int i = 8; i < GSE_NSIGMA; ++i) res += w_sigma[i];
-        s32 = res;
-        double q[8];
-        for (int k = 0; k < 8; ++k) q[k] = (double)w_sigma[k];
-        double resd = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-        for (int i = 8; i < GSE_NSIGMA; ++i) resd += (double)w_sigma[i];
-        s64 = resd;
-    }
-    for (int i = 0; i < GSE_NSIGMA; ++i) sw.w[i] = w_sigma[i];
-    sw.scl32 = s32;
-    sw.scl64 = s64;
-    return 0;
+static void pack_sigma_weights(SigmaWeights& sw, const float* w_sigma, int ns) {
+    for (int i = 0; i < GSE_NSIGMA; ++i) sw.w[i] = i < ns ? w_sigma[i] : 0.0f;
+    sw.scl32 = numpy_sum<float>(w_sigma, ns);
+    sw.scl64 = numpy_sum<double>(w_sigma, ns);
 }
 
 // Which family of kernels: one lane per Gaussian once the bank fills the chip that way (256 CUs x 256 lanes = 2^16
@@ -800,54 +54,71 @@ static int check_gsukf(const char* fn, int B, int64_t N) {
     return GSE_OK;
 }
 
-}  // namespace gse
+// One launch, either way: the kernel compiled into this library, or -- model != null -- the instance `name` of the same
+// template compiled for the user's model at run time (first use: about a second), with the same argument list.
+template <class... Params, class... Args>
+static int launch(UserModel* model, const char* name, void (*kernel)(Params...), dim3 grid, dim3 block, hipStream_t st,
+                  Args... args) {
+    if (model) {
+        std::tuple<Params...> held(args...);                       // the arguments in the kernel's own parameter types
+        void* params[sizeof...(Params)];
+        int i = 0;
+        std::apply([&](auto&... p) { ((params[i++] = (void*)&p), ...); }, held);
+        return launch_user_kernel(model, name, grid, block, 0, st, params);
+    }
+    hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+    GSE_LAUNCH_CHECK(name);
+    return GSE_OK;
+}
 
-using namespace gse;
+static int states_of(UserModel* model) { return model ? user_model_nx(model) : kNx; }
 
-extern "C" {
+#define GSE_WIDE_STR_(x) #x
+#define GSE_WIDE_STR(x) GSE_WIDE_STR_(x)
+#define GSE_WIDE GSE_WIDE_STR(GSE_GSUKF_WIDE_BANK)
 
-int gse_gsukf_sigma_points(const float* mu, const float* P, float* sigmas, int B, int64_t N, int32_t* status,
-                           void* stream) {
+// ------------------------------------------------------------------------------------------------ implementations
+static int gsukf_sigma_points(UserModel* model, const float* mu, const float* P, float* sigmas, int B, int64_t N,
+                              int32_t* status, void* stream) {
     if (int rc = check_gsukf("gse_gsukf_sigma_points", B, N)) return rc;
     GSE_REQUIRE(mu && P && sigmas, "gse_gsukf_sigma_points: null argument");
     const unsigned gx = (unsigned)((N + kGaussPerBlock - 1) / kGaussPerBlock);
-    hipLaunchKernelGGL(gsukf_sigma_kernel, dim3(gx, B), dim3(kBlock), 0, (hipStream_t)stream, mu, P, sigmas, N, status);
-    GSE_LAUNCH_CHECK("gsukf_sigma_kernel");
-    return GSE_OK;
+    return launch(model, "gse::gsukf_sigma_kernel<0>", gsukf_sigma_kernel<0>, dim3(gx, B), dim3(kBlock), (hipStream_t)stream, mu, P,
+                  sigmas, N, status);
 }
 
-int gse_gsukf_predict(float* mu, float* P, int B, int64_t N, const double* u, double dt, const float* w_sigma,
-                      const gse_mixture* state_pdf, const gse_rng* rng, const float* noise, int32_t* status,
-                      void* stream) {
+static int gsukf_predict(UserModel* model, float* mu, float* P, int B, int64_t N, const double* u, double dt,
+                         const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng, const float* noise,
+                         int32_t* status, void* stream) {
     if (int rc = check_gsukf("gse_gsukf_predict", B, N)) return rc;
     GSE_REQUIRE(mu && P && u && w_sigma, "gse_gsukf_predict: null argument");
     GSE_REQUIRE(noise || (state_pdf && rng), "gse_gsukf_predict: need either noise or (state_pdf, rng)");
+    const int nx = states_of(model);
     GsukfPredictArgs a;
     pack_io(a.io, B, u, nullptr);
-    pack_sigma_weights(a.sw, w_sigma);
+    pack_sigma_weights(a.sw, w_sigma, 2 * nx + 1);
     a.dt = dt;
     const bool lanes = lane_per_gaussian(B, N);
     const unsigned gx = lanes ? (unsigned)((N + kLaneBank - 1) / kLaneBank) : (unsigned)((N + kWideBank - 1) / kWideBank);
-    const dim3 block(lanes ? kLaneBank : kWideBank * kGroup);
+    const dim3 grid(gx, B), block(lanes ? kLaneBank : kWideBank * kGroup);
+    hipStream_t st = (hipStream_t)stream;
     if (noise) {
         a.draw = DrawParams{};
         a.rng = RngKey{};
-        if (lanes) hipLaunchKernelGGL(gsukf_predict_lanes_kernel<true>, dim3(gx, B), block, 0, (hipStream_t)stream, mu, P, noise, N, status, a);
-        else hipLaunchKernelGGL((gsukf_predict_kernel<true, kWideBank>), dim3(gx, B), block, 0, (hipStream_t)stream, mu, P, noise, N, status, a);
-    } else {
-        if (int rc = check_mixture("gse_gsukf_predict", state_pdf, GSE_NX)) return rc;
-        pack_draw(a.draw, *state_pdf);
-        a.rng = make_rng_key(*rng, kPurposeGsukf);
-        if (lanes) hipLaunchKernelGGL(gsukf_predict_lanes_kernel<false>, dim3(gx, B), block, 0, (hipStream_t)stream, mu, P, (const float*)nullptr, N, status, a);
-        else hipLaunchKernelGGL((gsukf_predict_kernel<false, kWideBank>), dim3(gx, B), block, 0, (hipStream_t)stream, mu, P, (const float*)nullptr, N, status, a);
+        if (lanes) return launch(model, "gse::gsukf_predict_lanes_kernel<true>", gsukf_predict_lanes_kernel<true>, grid, block, st, mu, P, noise, N, status, a);
+        return launch(model, "gse::gsukf_predict_kernel<true, " GSE_WIDE ">", gsukf_predict_kernel<true, kWideBank>, grid, block, st, mu, P, noise, N, status, a);
     }
-    GSE_LAUNCH_CHECK("gsukf_predict_kernel");
-    return GSE_OK;
+    if (int rc = check_mixture("gse_gsukf_predict", state_pdf, nx)) return rc;
+    pack_draw(a.draw, *state_pdf);
+    a.rng = make_rng_key(*rng, kPurposeGsukf);
+    const float* none = nullptr;
+    if (lanes) return launch(model, "gse::gsukf_predict_lanes_kernel<false>", gsukf_predict_lanes_kernel<false>, grid, block, st, mu, P, none, N, status, a);
+    return launch(model, "gse::gsukf_predict_kernel<false, " GSE_WIDE ">", gsukf_predict_kernel<false, kWideBank>, grid, block, st, mu, P, none, N, status, a);
 }
 
-int gse_gsukf_update(float* mu, float* P, float* w, int B, int64_t N, const double* u, const double* z,
-                     const float* w_sigma, const gse_mixture* measurement_pdf, int32_t* status, void* workspace,
-                     void* stream) {
+static int gsukf_update(UserModel* model, float* mu, float* P, float* w, int B, int64_t N, const double* u, const double* z,
+                        const float* w_sigma, const gse_mixture* measurement_pdf, int32_t* status, void* workspace,
+                        void* stream) {
     if (int rc = check_gsukf("gse_gsukf_update", B, N)) return rc;
     GSE_REQUIRE(mu && P && w && u && z && w_sigma && measurement_pdf, "gse_gsukf_update: null argument");
     if (int rc = check_mixture("gse_gsukf_update", measurement_pdf, GSE_NY)) return rc;
@@ -855,82 +126,83 @@ int gse_gsukf_update(float* mu, float* P, float* w, int B, int64_t N, const doub
     GsukfUpdateArgs a;
     pack_io(a.io, B, u, z);
     pack_pdf2(a.pdf, *measurement_pdf);
-    pack_sigma_weights(a.sw, w_sigma);
-    if (lane_per_gaussian(B, N)) {
-        hipLaunchKernelGGL(gsukf_update_lanes_kernel, dim3((unsigned)((N + kLaneBank - 1) / kLaneBank), B), dim3(kLaneBank), 0,
-                           (hipStream_t)stream, mu, P, w, N, status, a);
-    } else {
-        hipLaunchKernelGGL(gsukf_update_kernel<kWideBank>, dim3((unsigned)((N + kWideBank - 1) / kWideBank), B),
-                           dim3(kWideBank * kGroup), 0, (hipStream_t)stream, mu, P, w, N, status, a);
-    }
-    GSE_LAUNCH_CHECK("gsukf_update_kernel");
-    return GSE_OK;
+    pack_sigma_weights(a.sw, w_sigma, 2 * states_of(model) + 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (lane_per_gaussian(B, N))
+        return launch(model, "gse::gsukf_update_lanes_kernel<0>", gsukf_update_lanes_kernel<0>,
+                      dim3((unsigned)((N + kLaneBank - 1) / kLaneBank), B), dim3(kLaneBank), st, mu, P, w, N, status, a);
+    return launch(model, "gse::gsukf_update_kernel<" GSE_WIDE ">", gsukf_update_kernel<kWideBank>,
+                  dim3((unsigned)((N + kWideBank - 1) / kWideBank), B), dim3(kWideBank * kGroup), st, mu, P, w, N, status, a);
 }
 
-int gse_gsukf_predict_update(float* mu, float* P, float* w, int B, int64_t N, const double* u, double dt, const double* z,
-                             const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng, const float* noise,
-                             const gse_mixture* measurement_pdf, int32_t* status, void* stream) {
+static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w, int B, int64_t N, const double* u, double dt,
+                                const double* z, const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng,
+                                const float* noise, const gse_mixture* measurement_pdf, int32_t* status, void* stream) {
     if (int rc = check_gsukf("gse_gsukf_predict_update", B, N)) return rc;
     GSE_REQUIRE(mu && P && w && u && z && w_sigma && measurement_pdf, "gse_gsukf_predict_update: null argument");
     GSE_REQUIRE(noise || (state_pdf && rng), "gse_gsukf_predict_update: need either noise or (state_pdf, rng)");
     if (int rc = check_mixture("gse_gsukf_predict_update", measurement_pdf, GSE_NY)) return rc;
+    const int nx = states_of(model);
     GsukfPredictUpdateArgs a;
     pack_io(a.pred.io, B, u, z);
-    pack_sigma_weights(a.pred.sw, w_sigma);
+    pack_sigma_weights(a.pred.sw, w_sigma, 2 * nx + 1);
     a.pred.dt = dt;
     pack_pdf2(a.pdf, *measurement_pdf);
     const dim3 grid((unsigned)((N + kLaneBank - 1) / kLaneBank), B), block(kLaneBank);
+    hipStream_t st = (hipStream_t)stream;
     if (noise) {
         a.pred.draw = DrawParams{};
         a.pred.rng = RngKey{};
-        hipLaunchKernelGGL(gsukf_predict_update_lanes_kernel<true>, grid, block, 0, (hipStream_t)stream, mu, P, w, noise, N, status, a);
-    } else {
-        if (int rc = check_mixture("gse_gsukf_predict_update", state_pdf, GSE_NX)) return rc;
-        pack_draw(a.pred.draw, *state_pdf);
-        a.pred.rng = make_rng_key(*rng, kPurposeGsukf);
-        hipLaunchKernelGGL(gsukf_predict_update_lanes_kernel<false>, grid, block, 0, (hipStream_t)stream, mu, P, w,
-                           (const float*)nullptr, N, status, a);
+        return launch(model, "gse::gsukf_predict_update_lanes_kernel<true>", gsukf_predict_update_lanes_kernel<true>, grid, block, st,
+                      mu, P, w, noise, N, status, a);
     }
-    GSE_LAUNCH_CHECK("gsukf_predict_update_lanes_kernel");
-    return GSE_OK;
+    if (int rc = check_mixture("gse_gsukf_predict_update", state_pdf, nx)) return rc;
+    pack_draw(a.pred.draw, *state_pdf);
+    a.pred.rng = make_rng_key(*rng, kPurposeGsukf);
+    const float* none = nullptr;
+    return launch(model, "gse::gsukf_predict_update_lanes_kernel<false>", gsukf_predict_update_lanes_kernel<false>, grid, block, st,
+                  mu, P, w, none, N, status, a);
 }
 
-int gse_gsukf_cycle(float* mu, float* P, float* w, int32_t* idx, int B, int64_t N, const double* u, double dt, const double* z,
-                    const double* r, const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng,
-                    const float* noise, const gse_mixture* measurement_pdf, int32_t* status, void* stream) {
+static int gsukf_cycle(UserModel* model, float* mu, float* P, float* w, int32_t* idx, int B, int64_t N, const double* u,
+                       double dt, const double* z, const double* r, const float* w_sigma, const gse_mixture* state_pdf,
+                       const gse_rng* rng, const float* noise, const gse_mixture* measurement_pdf, int32_t* status,
+                       void* stream) {
     if (int rc = check_gsukf("gse_gsukf_cycle", B, N)) return rc;
     GSE_REQUIRE(N <= kSmallBank, "gse_gsukf_cycle: at most %d Gaussians (got %lld); use the separate calls", kSmallBank,
                 (long long)N);
     GSE_REQUIRE(mu && P && w && u && z && r && w_sigma && measurement_pdf, "gse_gsukf_cycle: null argument");
     GSE_REQUIRE(noise || (state_pdf && rng), "gse_gsukf_cycle: need either noise or (state_pdf, rng)");
     if (int rc = check_mixture("gse_gsukf_cycle", measurement_pdf, GSE_NY)) return rc;
+    const int nx = states_of(model);
     GsukfCycleArgs a;
     pack_io(a.pred.io, B, u, z);
-    pack_sigma_weights(a.pred.sw, w_sigma);
+    pack_sigma_weights(a.pred.sw, w_sigma, 2 * nx + 1);
     a.pred.dt = dt;
     pack_pdf2(a.pdf, *measurement_pdf);
     for (int b = 0; b < B; ++b) {
         GSE_REQUIRE(r[b] >= 0.0 && r[b] < 1.0, "gse_gsukf_cycle: r[%d] = %g is outside [0, 1)", b, r[b]);
         a.r[b] = r[b];
     }
+    hipStream_t st = (hipStream_t)stream;
+    const int n32 = (int)N;
     if (noise) {
         a.pred.draw = DrawParams{};
         a.pred.rng = RngKey{};
-        hipLaunchKernelGGL(gsukf_cycle_kernel<true>, dim3(1, B), dim3(kSmallBlock), 0, (hipStream_t)stream, mu, P, w, noise,
-                           idx, (int)N, status, a);
-    } else {
-        if (int rc = check_mixture("gse_gsukf_cycle", state_pdf, GSE_NX)) return rc;
-        pack_draw(a.pred.draw, *state_pdf);
-        a.pred.rng = make_rng_key(*rng, kPurposeGsukf);
-        hipLaunchKernelGGL(gsukf_cycle_kernel<false>, dim3(1, B), dim3(kSmallBlock), 0, (hipStream_t)stream, mu, P, w,
-                           (const float*)nullptr, idx, (int)N, status, a);
+        return launch(model, "gse::gsukf_cycle_kernel<true>", gsukf_cycle_kernel<true>, dim3(1, B), dim3(kSmallBlock), st, mu, P, w,
+                      noise, idx, n32, status, a);
     }
-    GSE_LAUNCH_CHECK("gsukf_cycle_kernel");
-    return GSE_OK;
+    if (int rc = check_mixture("gse_gsukf_cycle", state_pdf, nx)) return rc;
+    pack_draw(a.pred.draw, *state_pdf);
+    a.pred.rng = make_rng_key(*rng, kPurposeGsukf);
+    const float* none = nullptr;
+    return launch(model, "gse::gsukf_cycle_kernel<false>", gsukf_cycle_kernel<false>, dim3(1, B), dim3(kSmallBlock), st, mu, P, w,
+                  none, idx, n32, status, a);
 }
 
-int gse_gsukf_resample(const float* mu_in, const float* P_in, const float* w, float* mu_out, float* P_out, float* w_out,
-                       int32_t* idx, int B, int64_t N, const double* r, uint32_t flags, void* workspace, void* stream) {
+static int gsukf_resample(UserModel* model, const float* mu_in, const float* P_in, const float* w, float* mu_out, float* P_out,
+                          float* w_out, int32_t* idx, int B, int64_t N, const double* r, uint32_t flags, void* workspace,
+                          void* stream) {
     if (int rc = check_gsukf("gse_gsukf_resample", B, N)) return rc;
     GSE_REQUIRE(mu_in && P_in && w && mu_out && P_out && w_out && r && workspace, "gse_gsukf_resample: null argument");
     GSE_REQUIRE(mu_in != mu_out && P_in != P_out && w != w_out, "gse_gsukf_resample: outputs must not alias inputs");
@@ -944,22 +216,108 @@ int gse_gsukf_resample(const float* mu_in, const float* P_in, const float* w, fl
     hipStream_t st = (hipStream_t)stream;
     if (int rc = launch_cumsum(w, N, B, N, flags & ~GSE_RESAMPLE_TILES_VALID, nullptr, ws, ws.cumsum, st)) return rc;
     GsukfPayload pl{mu_in, P_in, mu_out, P_out, N};
-    return launch_gsukf_gather(pl, w_out, idx, B, N, ra, ws, st);
+    return launch_gsukf_gather(pl, w_out, idx, B, N, ra, ws, st, model);
 }
 
-int gse_gsukf_moments(const float* mu, const float* P, const float* w, int B, int64_t N, double* out, void* workspace,
-                      void* stream) {
+static int gsukf_moments(UserModel* model, const float* mu, const float* P, const float* w, int B, int64_t N, double* out,
+                         void* workspace, void* stream) {
     if (int rc = check_gsukf("gse_gsukf_moments", B, N)) return rc;
     GSE_REQUIRE(mu && P && w && out && workspace, "gse_gsukf_moments: null argument");
     Workspace ws = carve_workspace(workspace, B, N);
     const int nblk = (int)std::min<int64_t>(kMomentBlocks, (N + kBlock - 1) / kBlock);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gsukf_moments_kernel, dim3(nblk, B), dim3(kBlock), 0, st, mu, P, w, ws.partials, N);
-    GSE_LAUNCH_CHECK("gsukf_moments_kernel");
-    // out: S0, S1[5], S2[15], pivot[5] at 21, C[15] at 26  (the kernel's order is S0,S1,S2,C -> remapped below)
-    launch_moments_finish(ws.partials, nblk, 36, out, 46, B, mu, N * 5, 1, 36, st);
+    const int nx = states_of(model), width = 1 + nx + nx * (nx + 1);        // S0, S1[nx], S2[tri], C[tri]
+    if (int rc = launch(model, "gse::gsukf_moments_kernel<0>", gsukf_moments_kernel<0>, dim3(nblk, B), dim3(kBlock), st, mu, P, w,
+                        ws.partials, N))
+        return rc;
+    // out[b]: the sums, then the pivot (mu of Gaussian 0) at [width, width + nx); rows are GSE_GSUKF_MOMENTS doubles apart
+    launch_moments_finish(ws.partials, nblk, width, out, GSE_GSUKF_MOMENTS, B, mu, N * nx, 1, width, nx, st);
     GSE_LAUNCH_CHECK("moments_finish_kernel");
     return GSE_OK;
+}
+
+}  // namespace gse
+
+using namespace gse;
+
+extern "C" {
+
+int gse_gsukf_sigma_points(const float* mu, const float* P, float* sigmas, int B, int64_t N, int32_t* status, void* stream) {
+    return gsukf_sigma_points(nullptr, mu, P, sigmas, B, N, status, stream);
+}
+int gse_gsukf_predict(float* mu, float* P, int B, int64_t N, const double* u, double dt, const float* w_sigma,
+                      const gse_mixture* state_pdf, const gse_rng* rng, const float* noise, int32_t* status, void* stream) {
+    return gsukf_predict(nullptr, mu, P, B, N, u, dt, w_sigma, state_pdf, rng, noise, status, stream);
+}
+int gse_gsukf_update(float* mu, float* P, float* w, int B, int64_t N, const double* u, const double* z, const float* w_sigma,
+                     const gse_mixture* measurement_pdf, int32_t* status, void* workspace, void* stream) {
+    return gsukf_update(nullptr, mu, P, w, B, N, u, z, w_sigma, measurement_pdf, status, workspace, stream);
+}
+int gse_gsukf_predict_update(float* mu, float* P, float* w, int B, int64_t N, const double* u, double dt, const double* z,
+                             const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng, const float* noise,
+                             const gse_mixture* measurement_pdf, int32_t* status, void* stream) {
+    return gsukf_predict_update(nullptr, mu, P, w, B, N, u, dt, z, w_sigma, state_pdf, rng, noise, measurement_pdf, status, stream);
+}
+int gse_gsukf_cycle(float* mu, float* P, float* w, int32_t* idx, int B, int64_t N, const double* u, double dt, const double* z,
+                    const double* r, const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng,
+                    const float* noise, const gse_mixture* measurement_pdf, int32_t* status, void* stream) {
+    return gsukf_cycle(nullptr, mu, P, w, idx, B, N, u, dt, z, r, w_sigma, state_pdf, rng, noise, measurement_pdf, status, stream);
+}
+int gse_gsukf_resample(const float* mu_in, const float* P_in, const float* w, float* mu_out, float* P_out, float* w_out,
+                       int32_t* idx, int B, int64_t N, const double* r, uint32_t flags, void* workspace, void* stream) {
+    return gsukf_resample(nullptr, mu_in, P_in, w, mu_out, P_out, w_out, idx, B, N, r, flags, workspace, stream);
+}
+int gse_gsukf_moments(const float* mu, const float* P, const float* w, int B, int64_t N, double* out, void* workspace,
+                      void* stream) {
+    return gsukf_moments(nullptr, mu, P, w, B, N, out, workspace, stream);
+}
+
+// ---- the same calls for a user model compiled at run time (handle from gse_model_create); shapes follow the model's
+//      number of states nx: mu [B][N][nx], P [B][N][nx][nx], sigma points [B][N][2 nx + 1][nx], w_sigma [2 nx + 1]
+#define GSE_MODEL_ARG(model) \
+    GSE_REQUIRE(model, "%s: null model handle", __func__); \
+    UserModel* m_ = static_cast<UserModel*>(model)
+
+int gse_gsukf_sigma_points_model(void* model, const float* mu, const float* P, float* sigmas, int B, int64_t N, int32_t* status,
+                                 void* stream) {
+    GSE_MODEL_ARG(model);
+    return gsukf_sigma_points(m_, mu, P, sigmas, B, N, status, stream);
+}
+int gse_gsukf_predict_model(void* model, float* mu, float* P, int B, int64_t N, const double* u, double dt, const float* w_sigma,
+                            const gse_mixture* state_pdf, const gse_rng* rng, const float* noise, int32_t* status,
+                            void* stream) {
+    GSE_MODEL_ARG(model);
+    return gsukf_predict(m_, mu, P, B, N, u, dt, w_sigma, state_pdf, rng, noise, status, stream);
+}
+int gse_gsukf_update_model(void* model, float* mu, float* P, float* w, int B, int64_t N, const double* u, const double* z,
+                           const float* w_sigma, const gse_mixture* measurement_pdf, int32_t* status, void* workspace,
+                           void* stream) {
+    GSE_MODEL_ARG(model);
+    return gsukf_update(m_, mu, P, w, B, N, u, z, w_sigma, measurement_pdf, status, workspace, stream);
+}
+int gse_gsukf_predict_update_model(void* model, float* mu, float* P, float* w, int B, int64_t N, const double* u, double dt,
+                                   const double* z, const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng,
+                                   const float* noise, const gse_mixture* measurement_pdf, int32_t* status, void* stream) {
+    GSE_MODEL_ARG(model);
+    return gsukf_predict_update(m_, mu, P, w, B, N, u, dt, z, w_sigma, state_pdf, rng, noise, measurement_pdf, status, stream);
+}
+int gse_gsukf_cycle_model(void* model, float* mu, float* P, float* w, int32_t* idx, int B, int64_t N, const double* u, double dt,
+                          const double* z, const double* r, const float* w_sigma, const gse_mixture* state_pdf,
+                          const gse_rng* rng, const float* noise, const gse_mixture* measurement_pdf, int32_t* status,
+                          void* stream) {
+    GSE_MODEL_ARG(model);
+    return gsukf_cycle(m_, mu, P, w, idx, B, N, u, dt, z, r, w_sigma, state_pdf, rng, noise, measurement_pdf, status, stream);
+}
+int gse_gsukf_resample_model(void* model, const float* mu_in, const float* P_in, const float* w, float* mu_out, float* P_out,
+                             float* w_out, int32_t* idx, int B, int64_t N, const double* r, uint32_t flags, void* workspace,
+                             void* stream) {
+    GSE_MODEL_ARG(model);
+    return gsukf_resample(m_, mu_in, P_in, w, mu_out, P_out, w_out, idx, B, N, r, flags, workspace, stream);
+}
+int gse_gsukf_moments_model(void* model, const float* mu, const float* P, const float* w, int B, int64_t N, double* out,
+                            void* workspace, void* stream) {
+    GSE_MODEL_ARG(model);
+    return gsukf_moments(m_, mu, P, w, B, N, out, workspace, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,769 @@
+// gse_gsukf_kernels.h -- the Gaussian-sum unscented Kalman filter kernels (device code only), in a header of their own
+// for the same reason as gse_pf_kernels.h: gse_gsukf.hip compiles them for the built-in bioreactor model, gse_rtc.hip
+// compiles them at run time for a user model (what Numba's JIT does for the reference's GS-UKF, filter/gs_ukf.py:243-275).
+// Every kernel is a template so that a run-time compilation instantiates the one it was asked for and nothing else.
+//
+// A bank of N Gaussians (mu_i, P_i, w_i); each is a UKF with 2*kNx+1 unscaled sigma points (11 for the bioreactor's 5
+// states; filter/gs_ukf.py).
+// A workgroup of 1024 threads takes 64 Gaussians and every phase alternates between two mappings:
+//   * per SIGMA POINT, 16 lanes per Gaussian (lane j < 11 owns sigma point j): the model step with its noise draw
+//     (predict) and the output function (update) -- the part with 11-fold parallelism per Gaussian;
+//   * per GAUSSIAN, one lane each (the 64 lanes of wavefront 0): the 5x5 Cholesky, the 11-term contractions (mean, P,
+//     P_xy, P_yy), the 2x2 pseudo-inverse, the gain and the covariance update.  A wavefront issues an instruction once
+//     whatever the number of lanes that need it, so doing this per-Gaussian algebra in all 16 lanes of every Gaussian
+//     (the first version) cost 16 wavefronts' worth of issue slots per 64 Gaussians instead of one.
+// Large banks take the one-lane-per-Gaussian kernels further down; banks of at most 64 the one-launch cycle kernel.
+// Hand-offs go through LDS (rows padded to odd strides: a lane per Gaussian walks rows).  Sums run in the reference's
+// order (j = 0..10) so that results track the NumPy class closely.  These contractions are 5x11x5 at most: far too small
+// to feed the matrix cores (a 16x16x4 fp32 MFMA tile would be >90 % padding) and nowhere near a bound.
+#pragma once
+
+#include "gse_host.h"
+
+namespace gse {
+
+// States of the model the kernels are compiled for: 5 for the built-in bioreactor; a user model brings its own count
+// (GSE_USER_NX, 1..5) and every shape below follows -- the storage is (mu[kNx], P[kNx][kNx]) per Gaussian, row-major.
+constexpr int kNx = kModelNx;
+constexpr int kNs = 2 * kNx + 1;                 // sigma points per Gaussian
+constexpr int kTri = kNx * (kNx + 1) / 2;        // packed triangle of a kNx x kNx matrix
+constexpr int kNxx = kNx * kNx;
+constexpr int kRow = kNx + kNxx;                 // floats per Gaussian (30 for the bioreactor)
+static_assert(kNs <= GSE_NSIGMA, "at most 11 sigma points (5 states)");
+constexpr int kGroup = 16;                       // lanes per Gaussian in the per-sigma-point parts
+constexpr int kGaussPerBlock = kBlock / kGroup;  // 16 (gsukf_sigma_kernel only)
+#ifndef GSE_GSUKF_WIDE_BANK
+#define GSE_GSUKF_WIDE_BANK 64   // (16 / 32 / 64 Gaussians per workgroup, 2^18 Gaussians: 64 is 15 % faster than 16 or 32)
+#endif
+constexpr int kWideBank = GSE_GSUKF_WIDE_BANK;   // Gaussians per workgroup of the separate predict / update kernels
+constexpr int kBank = 64;                        // Gaussians per workgroup of the one-launch cycle kernel
+constexpr int kFacStride = (kNx + kTri) | 1;     // LDS row: m[kNx], L[kTri] (odd stride; 21 for 5 states)
+constexpr int kTileStride = (kNs * kNx + 2) | 1; // odd; 57 floats for 5 states
+constexpr int kEtaStride = kNs * 2 + 1;          // 23 doubles for 5 states
+
+// Packed lower-triangular index helpers: entry (i, j), j <= i, lives at i*(i+1)/2 + j.
+__device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// Cholesky factor of a symmetric 5x5 matrix given by its packed lower triangle (fp32, like LAPACK spotrf on
+// the fp32 covariances).  Returns false when a pivot is not positive.
+__device__ __forceinline__ bool chol5(const float (&A)[kTri], float (&L)[kTri]) {
+    // (no contraction into FMAs left to the compiler: the same source inlined into different kernels must give the same
+    //  bits, and whether `s - a * b` is fused depends on the surrounding code)
+#pragma clang fp contract(off)
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < kNx; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            float s = A[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[tri(i, k)] * L[tri(j, k)];
+            if (i == j) {
+                ok = ok && (s > 0.0f);
+                L[tri(i, i)] = sqrtf(s);
+            } else {
+                L[tri(i, j)] = s / L[tri(j, j)];
+            }
+        }
+    }
+    return ok;
+}
+
+// Loads (mu, lower triangle of P) of one Gaussian and factorises P, retrying once with 1e-10 on the diagonal
+// (filter/gs_ukf.py:72-75).  ok = false if the matrix is still not positive definite.
+__device__ __forceinline__ void load_and_factor(const float* __restrict__ mu_g, const float* __restrict__ P_g,
+                                                float (&mu)[kNx], float (&L)[kTri], bool& ok) {
+    float A[kTri];
+#pragma unroll
+    for (int k = 0; k < kNx; ++k) mu[k] = mu_g[k];
+#pragma unroll
+    for (int i = 0; i < kNx; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) A[tri(i, j)] = P_g[i * kNx + j];
+    ok = chol5(A, L);
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < kNx; ++i) A[tri(i, i)] += 1e-10f;
+        ok = chol5(A, L);
+    }
+}
+
+// Sigma point j (0..2 kNx) of N(mu, L L^T): mu, mu + L[:, c], mu - L[:, c]   (filter/gs_ukf.py:76-80).  s is a row as the
+// model functions take it: GSE_NX wide, states the model does not have stay zero.
+__device__ __forceinline__ void sigma_point(const float (&mu)[kNx], const float (&L)[kTri], int j, float (&s)[GSE_NX]) {
+    const int c = (j == 0) ? -1 : (j - 1) % kNx;
+    const float sign = (j <= kNx) ? 1.0f : -1.0f;
+#pragma unroll
+    for (int k = kNx; k < GSE_NX; ++k) s[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kNx; ++k) {
+        float col = 0.0f;
+#pragma unroll
+        for (int cc = 0; cc <= k; ++cc) col = (c == cc) ? L[tri(k, cc)] : col;
+        s[k] = (c < 0) ? mu[k] : mu[k] + sign * col;
+    }
+}
+
+struct SigmaWeights {
+    float w[GSE_NSIGMA];
+    float scl32;          // sum(w) in fp32  -- the divisor numpy.average uses for fp32 data
+    double scl64;         // sum(w) accumulated in fp64 -- its divisor for fp64 data
+};
+
+// ------------------------------------------------------------------------------------------------
+template <int kUnused>
+__global__ __launch_bounds__(kBlock) void gsukf_sigma_kernel(const float* __restrict__ mu, const float* __restrict__ P,
+                                                             float* __restrict__ sigmas, int64_t N,
+                                                             int32_t* __restrict__ status) {
+    const int b = blockIdx.y;
+    const int j = threadIdx.x & (kGroup - 1);
+    const int64_t g = (int64_t)blockIdx.x * kGaussPerBlock + (threadIdx.x / kGroup);
+    if (g >= N) return;
+    const int64_t gi = (int64_t)b * N + g;
+    float m[kNx], L[kTri], s[GSE_NX];
+    bool ok;
+    load_and_factor(mu + gi * kNx, P + gi * kNxx, m, L, ok);
+    if (j >= kNs) return;
+    sigma_point(m, L, j, s);
+    if (!ok && j == 0 && status) atomicAdd(status, 1);
+    float* out = sigmas + (gi * kNs + j) * kNx;
+#pragma unroll
+    for (int k = 0; k < kNx; ++k) out[k] = s[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+struct GsukfPredictArgs {
+    FilterIOs io;
+    DrawParams draw;
+    RngKey rng;
+    SigmaWeights sw;
+    double dt;
+};
+
+// Mean and covariance of the 11 propagated sigma points of one Gaussian (filter/gs_ukf.py:96-103), shared by every
+// kernel that predicts: mean = (sum_j sigma_j w_j) / sum(w) in fp32, j in order, no FMA contraction (numpy.average);
+// P = sum_j d_j (d_j w_j)^T entry by entry of the upper triangle, mirrored.  P_o: kNx x kNx floats, row-major.
+__device__ __forceinline__ void sigma_mean_cov(const float (&sg)[kNs * kNx], const SigmaWeights& sw, float (&mean)[kNx],
+                                               float* P_o) {
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int k = 0; k < kNx; ++k) {
+            float acc = sg[k] * sw.w[0];
+#pragma unroll
+            for (int q = 1; q < kNs; ++q) acc = acc + sg[q * kNx + k] * sw.w[q];
+            mean[k] = acc / sw.scl32;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kNx; ++r)
+#pragma unroll
+        for (int c = r; c < kNx; ++c) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kNs; ++q) {
+                const float dr = sg[q * kNx + r] - mean[r];
+                const float dc = sg[q * kNx + c] - mean[c];
+                acc = fmaf(dr, dc * sw.w[q], acc);
+            }
+            P_o[r * kNx + c] = acc;
+            P_o[c * kNx + r] = acc;
+        }
+}
+
+// Phase A of predict and update: lane t < nloc of the workgroup factorises local Gaussian t and leaves (m, L) in fac[t].
+// Src: t -> (mu pointer, P pointer); global memory or LDS.  Ends with a workgroup barrier.
+template <class Src>
+__device__ __forceinline__ void gsukf_factor_block(Src src, float (*fac)[kFacStride], int nloc, int32_t* status) {
+    const int t = threadIdx.x;
+    if (t < nloc) {
+        float m[kNx], L[kTri];
+        bool ok;
+        const float *mu_g, *P_g;
+        src(t, mu_g, P_g);
+        load_and_factor(mu_g, P_g, m, L, ok);
+        if (!ok && status) atomicAdd(status, 1);
+#pragma unroll
+        for (int k = 0; k < kNx; ++k) fac[t][k] = m[k];
+#pragma unroll
+        for (int k = 0; k < kTri; ++k) fac[t][kNx + k] = L[k];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void read_factor(const float* fac_g, float (&m)[kNx], float (&L)[kTri]) {
+#pragma unroll
+    for (int k = 0; k < kNx; ++k) m[k] = fac_g[k];
+#pragma unroll
+    for (int k = 0; k < kTri; ++k) L[k] = fac_g[kNx + k];
+}
+
+// Predict of the workgroup's nloc Gaussians (local index gl = tid / 16, lane j = tid % 16).  src / dst: local index ->
+// where (mu, P) are read / written (may be the same memory: every read precedes a barrier that every write follows).
+// g0: filter index of local Gaussian 0 (RNG element), noise: injected rows [N][11][5] of this filter or null.
+// Must be called by every thread of the workgroup.
+template <bool kInjected, class Src, class Dst>
+__device__ __forceinline__ void gsukf_predict_block(Src src, Dst dst, float (*fac)[kFacStride], float (*tile)[kTileStride],
+                                                    int nloc, int b, int64_t g0, const float* noise, const DrawParams& dp,
+                                                    int32_t* status, const GsukfPredictArgs& a) {
+    gsukf_factor_block(src, fac, nloc, status);
+    // B. one sigma point per lane, packed densely (11 per Gaussian: 704 points keep 11 of the 16 wavefronts busy, the
+    //    other five skip the model step and the noise draw altogether)
+    const int gl = (int)threadIdx.x / kNs, j = (int)threadIdx.x - gl * kNs;
+    if (gl < nloc) {
+        float m[kNx], L[kTri], s[GSE_NX];
+        read_factor(fac[gl], m, L);
+        sigma_point(m, L, j, s);
+        model_step(s, a.io.f[b].u0, a.io.f[b].u1, a.dt);
+        float e[GSE_NX];
+        if (kInjected) {
+            const float* nz = noise + (g0 + gl) * kNs * kNx;
+#pragma unroll
+            for (int k = 0; k < kNx; ++k) e[k] = nz[j * kNx + k];
+        } else {
+            uint32_t wd[8];
+            rng_words8(a.rng, (uint64_t)((g0 + gl) * kNs + j), (uint32_t)b, wd);
+            mixture_draw5(dp, wd, e);
+        }
+#pragma unroll
+        for (int k = 0; k < kNx; ++k) tile[gl][j * kNx + k] = s[k] + e[k];
+    }
+    __syncthreads();
+    // C. one Gaussian per lane: mean and covariance of its sigma points
+    const int t = threadIdx.x;
+    if (t < nloc) {
+        float sg[kNs * kNx];
+#pragma unroll
+        for (int i = 0; i < kNs * kNx; ++i) sg[i] = tile[t][i];
+        float mean[kNx];
+        float *mu_o, *P_o;
+        dst(t, mu_o, P_o);
+        sigma_mean_cov(sg, a.sw, mean, P_o);
+#pragma unroll
+        for (int k = 0; k < kNx; ++k) mu_o[k] = mean[k];
+    }
+}
+
+template <bool kInjected, int kBankT>
+__global__ __launch_bounds__(kBankT * kGroup) void gsukf_predict_kernel(float* __restrict__ mu, float* __restrict__ P,
+                                                                        const float* __restrict__ noise, int64_t N,
+                                                                        int32_t* __restrict__ status,
+                                                                        const GsukfPredictArgs a) {
+    __shared__ DrawParams dp;
+    __shared__ float fac[kBankT][kFacStride];
+    __shared__ float tile[kBankT][kTileStride];
+    if (!kInjected) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.draw);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
+        for (int i = threadIdx.x; i < (int)(sizeof(DrawParams) / 4); i += kBankT * kGroup) dst[i] = src[i];
+        __syncthreads();
+    }
+    const int b = blockIdx.y;
+    const int64_t g0 = (int64_t)blockIdx.x * kBankT;
+    const int nloc = (int)min((int64_t)kBankT, N - g0);
+    float* mu_b = mu + ((int64_t)b * N + g0) * kNx;
+    float* P_b = P + ((int64_t)b * N + g0) * kNxx;
+    auto src = [&](int t, const float*& m_, const float*& p_) { m_ = mu_b + t * kNx; p_ = P_b + t * kNxx; };
+    auto dst = [&](int t, float*& m_, float*& p_) { m_ = mu_b + t * kNx; p_ = P_b + t * kNxx; };
+    gsukf_predict_block<kInjected>(src, dst, fac, tile, nloc, b, g0, kInjected ? noise + (int64_t)b * N * kNs * kNx : nullptr,
+                                   dp, status, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct GsukfUpdateArgs {
+    FilterIOs io;
+    Pdf2 pdf;
+    SigmaWeights sw;
+};
+
+// Pseudo-inverse of a symmetric 2x2 matrix with numpy.linalg.pinv's default cut-off (singular values
+// <= 1e-15 * largest are dropped; filter/gs_ukf.py:132).
+__device__ __forceinline__ void pinv_sym2(double a, double s, double d, double (&X)[2][2]) {
+#pragma clang fp contract(off)
+    const double half_tr = 0.5 * (a + d);
+    const double disc = sqrt(0.25 * (a - d) * (a - d) + s * s);
+    const double big = (fabs(half_tr + disc) >= fabs(half_tr - disc)) ? half_tr + disc : half_tr - disc;
+    const double det = a * d - s * s;
+    const double small = (big != 0.0) ? det / big : 0.0;
+    const double cut = 1e-15 * fabs(big);
+    if (!(fabs(big) > 0.0)) {
+        X[0][0] = X[0][1] = X[1][0] = X[1][1] = 0.0;
+    } else if (fabs(small) > cut) {
+        const double inv = 1.0 / det;
+        X[0][0] = d * inv; X[0][1] = -s * inv; X[1][0] = -s * inv; X[1][1] = a * inv;
+    } else {                                   // rank one: v v^T / big
+        double v0 = s, v1 = big - a;
+        const double w0 = big - d, w1 = s;
+        if (w0 * w0 + w1 * w1 > v0 * v0 + v1 * v1) { v0 = w0; v1 = w1; }
+        const double n2 = v0 * v0 + v1 * v1;
+        const double sc = (n2 > 0.0) ? 1.0 / (n2 * big) : 0.0;
+        X[0][0] = v0 * v0 * sc; X[0][1] = v0 * v1 * sc; X[1][0] = X[0][1]; X[1][1] = v1 * v1 * sc;
+    }
+}
+
+// The per-Gaussian algebra of the update (filter/gs_ukf.py:116-149): eta_mean, P_yy, P_xy in fp64 with j in order (the CPU
+// class keeps the etas in fp64), K = P_xy pinv(P_yy), mu += K (z - eta_mean), P -= (K P_yy) K^T, w *= pdf(z - g(mu_new)).
+// eta(q, c): output c of sigma point q (fp64); dev(q, k): sigma_q[k] - mu[k] (fp32); m: the prior mean; P_in / P_o: kNx x kNx
+// floats row-major (may be the same memory: every entry is read before it is written).  kUnrolled: the 11-term loop is unrolled
+// (operands in registers) or kept as a loop (operands in LDS: unrolled, the compiler hoists all 77 reads and spills).
+// One definition for every kernel that updates, so they agree to the bit.
+template <bool kUnrolled, class Eta, class Dev>
+__device__ __forceinline__ void gsukf_update_gaussian(Eta eta, Dev dev, const float* m, const float* P_in, float* mu_o,
+                                                      float* P_o, const float* w_in, float* w_out, double u0, double u1,
+                                                      double z0, double z1, const Pdf2& pdf, const SigmaWeights& sw) {
+    // (only the fma() calls written out below are fused: see chol5)
+#pragma clang fp contract(off)
+    double em[2];
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+#pragma clang fp contract(off)
+        double acc = eta(0, q2) * (double)sw.w[0];
+#pragma unroll
+        for (int q = 1; q < kNs; ++q) acc = acc + eta(q, q2) * (double)sw.w[q];
+        em[q2] = acc / sw.scl64;
+    }
+    double pyy[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    double pxy[kNx][2];
+#pragma unroll
+    for (int k = 0; k < kNx; ++k) pxy[k][0] = pxy[k][1] = 0.0;
+    auto term = [&](int q) {
+        const double wq = (double)sw.w[q];
+        const double e0 = eta(q, 0) - em[0], e1 = eta(q, 1) - em[1];
+        const double ew0 = e0 * wq, ew1 = e1 * wq;
+        pyy[0][0] = fma(e0, ew0, pyy[0][0]);
+        pyy[0][1] = fma(e0, ew1, pyy[0][1]);
+        pyy[1][0] = fma(e1, ew0, pyy[1][0]);
+        pyy[1][1] = fma(e1, ew1, pyy[1][1]);
+#pragma unroll
+        for (int k = 0; k < kNx; ++k) {
+            const double dk = (double)dev(q, k);
+            pxy[k][0] = fma(dk, ew0, pxy[k][0]);
+            pxy[k][1] = fma(dk, ew1, pxy[k][1]);
+        }
+    };
+    if constexpr (kUnrolled) {
+#pragma unroll
+        for (int q = 0; q < kNs; ++q) term(q);
+    } else {
+#pragma unroll 1
+        for (int q = 0; q < kNs; ++q) term(q);
+    }
+    double X[2][2];
+    pinv_sym2(pyy[0][0], 0.5 * (pyy[0][1] + pyy[1][0]), pyy[1][1], X);
+    double K[kNx][2];
+#pragma unroll
+    for (int k = 0; k < kNx; ++k) {
+        K[k][0] = pxy[k][0] * X[0][0] + pxy[k][1] * X[1][0];
+        K[k][1] = pxy[k][0] * X[0][1] + pxy[k][1] * X[1][1];
+    }
+    const double i0 = z0 - em[0], i1 = z1 - em[1];
+    float mnew[GSE_NX];                       // (a row as the model's g takes it: states it does not have stay zero)
+#pragma unroll
+    for (int k = kNx; k < GSE_NX; ++k) mnew[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kNx; ++k) mnew[k] = (float)((double)m[k] + (K[k][0] * i0 + K[k][1] * i1));
+    // P -= (K P_yy) K^T, entry (r, c) and its mirror (which uses (K P_yy)[c] . K[r]; identical when P_yy is symmetric to
+    // rounding).  Every entry is read before it is written, and by this lane only.
+#pragma unroll
+    for (int r = 0; r < kNx; ++r) {
+        const double t0 = K[r][0] * pyy[0][0] + K[r][1] * pyy[1][0];     // row r of K P_yy
+        const double t1 = K[r][0] * pyy[0][1] + K[r][1] * pyy[1][1];
+#pragma unroll
+        for (int c = r; c < kNx; ++c) {
+            const float prc = (float)((double)P_in[r * kNx + c] - (t0 * K[c][0] + t1 * K[c][1]));
+            float pcr = prc;
+            if (r != c) {
+                const double v0 = K[c][0] * pyy[0][0] + K[c][1] * pyy[1][0];
+                const double v1 = K[c][0] * pyy[0][1] + K[c][1] * pyy[1][1];
+                pcr = (float)((double)P_in[c * kNx + r] - (v0 * K[r][0] + v1 * K[r][1]));
+            }
+            P_o[r * kNx + c] = prc;
+            if (r != c) P_o[c * kNx + r] = pcr;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kNx; ++k) mu_o[k] = mnew[k];
+    // global update: w *= pdf(z - g(mu_new))
+    float y0, y1;
+    model_output(mnew, u0, u1, y0, y1);
+    const double lik = mixture_pdf2<0>(pdf, z0 - (double)y0, z1 - (double)y1);
+    *w_out = (float)((double)(*w_in) * lik);
+}
+
+// Update of the workgroup's nloc Gaussians, in place where src / dst point (global memory or LDS); weights are read
+// through w_in(t) and written through w_out(t).  Must be called by every thread of the workgroup.
+template <class Src, class Dst, class Win, class Wout>
+__device__ __forceinline__ void gsukf_update_block(Src src, Dst dst, Win w_in, Wout w_out, float (*fac)[kFacStride],
+                                                   float (*dev)[kTileStride], double (*eta)[kEtaStride], int nloc, int b,
+                                                   int32_t* status, const FilterIOs& io, const Pdf2& pdf,
+                                                   const SigmaWeights& sw) {
+    gsukf_factor_block(src, fac, nloc, status);
+    // B. one sigma point per lane: outputs and deviations
+    const int j = threadIdx.x & (kGroup - 1), gl = threadIdx.x / kGroup;
+    if (gl < nloc && j < kNs) {
+        float m[kNx], L[kTri], s[GSE_NX];
+        read_factor(fac[gl], m, L);
+        sigma_point(m, L, j, s);
+        float y0, y1;
+        model_output(s, io.f[b].u0, io.f[b].u1, y0, y1);
+        eta[gl][j * 2 + 0] = (double)y0;
+        eta[gl][j * 2 + 1] = (double)y1;
+#pragma unroll
+        for (int k = 0; k < kNx; ++k) dev[gl][j * kNx + k] = s[k] - m[k];
+    }
+    __syncthreads();
+    // C. one Gaussian per lane
+    const int t = threadIdx.x;
+    if (t >= nloc) return;
+    const double* eta_g = eta[t];
+    const float* dev_g = dev[t];
+    const float *mu_g, *P_g;
+    src(t, mu_g, P_g);
+    float *mu_o, *P_o;
+    dst(t, mu_o, P_o);
+    gsukf_update_gaussian<false>([&](int q, int c) { return eta_g[q * 2 + c]; }, [&](int q, int k) { return dev_g[q * kNx + k]; },
+                                 fac[t], P_g, mu_o, P_o, w_in(t), w_out(t), io.f[b].u0, io.f[b].u1, io.f[b].z0, io.f[b].z1, pdf,
+                                 sw);
+}
+
+template <int kBankT>
+__global__ __launch_bounds__(kBankT * kGroup) void gsukf_update_kernel(float* __restrict__ mu, float* __restrict__ P,
+                                                                       float* __restrict__ w, int64_t N,
+                                                                       int32_t* __restrict__ status,
+                                                                       const GsukfUpdateArgs a) {
+    __shared__ float fac[kBankT][kFacStride];
+    __shared__ float dev[kBankT][kTileStride];       // sigma_j - mu
+    __shared__ double eta[kBankT][kEtaStride];       // g(sigma_j)
+    const int b = blockIdx.y;
+    const int64_t g0 = (int64_t)blockIdx.x * kBankT;
+    const int nloc = (int)min((int64_t)kBankT, N - g0);
+    float* mu_b = mu + ((int64_t)b * N + g0) * kNx;
+    float* P_b = P + ((int64_t)b * N + g0) * kNxx;
+    float* w_b = w + (int64_t)b * N + g0;
+    auto src = [&](int t, const float*& m_, const float*& p_) { m_ = mu_b + t * kNx; p_ = P_b + t * kNxx; };
+    auto dst = [&](int t, float*& m_, float*& p_) { m_ = mu_b + t * kNx; p_ = P_b + t * kNxx; };
+    gsukf_update_block(src, dst, [&](int t) { return (const float*)(w_b + t); }, [&](int t) { return w_b + t; }, fac, dev, eta,
+                       nloc, b, status, a.io, a.pdf, a.sw);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large banks: ONE LANE PER GAUSSIAN.  The kernels above give a Gaussian 16 lanes for its 11 sigma points and one lane for
+// its algebra, handing over through LDS -- right for a few hundred Gaussians (parallelism is scarce, latency rules), wrong
+// for 2^18: the single-lane phases run in one wavefront of sixteen while the workgroup holds a whole CU (round 1: 143 us
+// per cycle, 0.17 of the HBM roofline).  Here a workgroup of 256 threads takes 256 Gaussians and a lane does everything for
+// its own: factorisation, the 11 sigma points one after the other (model step + noise draw, or output function), the
+// contractions -- all in registers, no hand-off, no barrier inside, every lane busy in every phase.  (mu, P) travel through
+// LDS only to make the global traffic coalesced: the workgroup's rows are one contiguous block of 256 x 120 bytes, staged
+// with stride 31 floats (conflict-free when a lane walks its row).  Same device functions, same sigma-point order and the
+// same random-number elements as the kernels above: results agree bit for bit.
+constexpr int kLaneBank = 256;
+constexpr int kStageStride = kRow | 1;           // mu + P of a Gaussian, padded to an odd stride (31 floats for 5 states)
+
+__device__ __forceinline__ void stage_bank_in(float* stage, const float* mu_b, const float* P_b, int nloc) {
+    for (int i = threadIdx.x; i < nloc * kNx; i += kLaneBank) {
+        const int g = i / kNx;
+        stage[g * kStageStride + (i - g * kNx)] = mu_b[i];
+    }
+    for (int i = threadIdx.x; i < nloc * kNxx; i += kLaneBank) {
+        const int g = i / kNxx;
+        stage[g * kStageStride + kNx + (i - g * kNxx)] = P_b[i];
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void stage_bank_out(const float* stage, float* mu_b, float* P_b, int nloc) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nloc * kNx; i += kLaneBank) {
+        const int g = i / kNx;
+        mu_b[i] = stage[g * kStageStride + (i - g * kNx)];
+    }
+    for (int i = threadIdx.x; i < nloc * kNxx; i += kLaneBank) {
+        const int g = i / kNxx;
+        P_b[i] = stage[g * kStageStride + kNx + (i - g * kNxx)];
+    }
+}
+
+#ifndef GSE_GSUKF_PRED_WAVES
+#define GSE_GSUKF_PRED_WAVES 1   // waves per SIMD the register allocator must leave room for (tuning knob)
+#endif
+#ifndef GSE_GSUKF_PRED_SERIAL
+#define GSE_GSUKF_PRED_SERIAL 0  // 1: a scheduling barrier between the sigma points of a lane (tuning knob)
+#endif
+// predict of ONE Gaussian held in `mine` (mu[kNx], P[kNx][kNx]); g: its index in the filter (random-number element)
+template <bool kInjected>
+__device__ __forceinline__ void gsukf_predict_lane(float* mine, int b, int64_t g, int64_t N, const float* noise,
+                                                   const DrawParams& dp, int32_t* status, const GsukfPredictArgs& a) {
+    float m[kNx], L[kTri];
+    bool ok;
+    load_and_factor(mine, mine + kNx, m, L, ok);
+    if (!ok && status) atomicAdd(status, 1);
+    float sg[kNs * kNx];
+#pragma unroll
+    for (int j = 0; j < kNs; ++j) {
+        float s[GSE_NX], e[GSE_NX];
+        sigma_point(m, L, j, s);
+        model_step(s, a.io.f[b].u0, a.io.f[b].u1, a.dt);
+        if (kInjected) {
+            const float* nz = noise + (((int64_t)b * N + g) * kNs + j) * kNx;
+#pragma unroll
+            for (int k = 0; k < kNx; ++k) e[k] = nz[k];
+        } else {
+            uint32_t wd[8];
+            rng_words8(a.rng, (uint64_t)(g * kNs + j), (uint32_t)b, wd);
+            mixture_draw5(dp, wd, e);
+        }
+#pragma unroll
+        for (int k = 0; k < kNx; ++k) sg[j * kNx + k] = s[k] + e[k];
+#if GSE_GSUKF_PRED_SERIAL
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    float mean[kNx];
+    sigma_mean_cov(sg, a.sw, mean, mine + kNx);
+#pragma unroll
+    for (int k = 0; k < kNx; ++k) mine[k] = mean[k];
+}
+
+// update of ONE Gaussian held in `mine`; its weight at *w
+__device__ __forceinline__ void gsukf_update_lane(float* mine, float* w, double u0, double u1, double z0, double z1,
+                                                  int32_t* status, const Pdf2& pdf, const SigmaWeights& sw) {
+    float m[kNx], L[kTri];
+    bool ok;
+    load_and_factor(mine, mine + kNx, m, L, ok);
+    if (!ok && status) atomicAdd(status, 1);
+    // outputs of the 11 sigma points (fp64, as the kernels above keep them); the deviations sigma_j - mu are re-formed
+    // from the factor where the contraction needs them (a select and a subtraction) instead of being kept
+    double eta[kNs][2];
+#pragma unroll
+    for (int j = 0; j < kNs; ++j) {
+        float s[GSE_NX], y0, y1;
+        sigma_point(m, L, j, s);
+        model_output(s, u0, u1, y0, y1);
+        eta[j][0] = (double)y0;
+        eta[j][1] = (double)y1;
+    }
+    float prior[kNx];
+#pragma unroll
+    for (int k = 0; k < kNx; ++k) prior[k] = m[k];
+    gsukf_update_gaussian<true>([&](int q, int c) { return eta[q][c]; },
+                                [&](int q, int k) {
+                                    float s[GSE_NX];
+                                    sigma_point(m, L, q, s);
+                                    return s[k] - m[k];
+                                },
+                                prior, mine + kNx, mine, mine + kNx, w, w, u0, u1, z0, z1, pdf, sw);
+}
+
+template <bool kInjected>
+__global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict_lanes_kernel(
+    float* __restrict__ mu, float* __restrict__ P, const float* __restrict__ noise, int64_t N, int32_t* __restrict__ status,
+    const GsukfPredictArgs a) {
+    __shared__ DrawParams dp;
+    __shared__ float stage[kLaneBank * kStageStride];
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
+    const int nloc = (int)min((int64_t)kLaneBank, N - g0);
+    float* mu_b = mu + ((int64_t)b * N + g0) * kNx;
+    float* P_b = P + ((int64_t)b * N + g0) * kNxx;
+    if (!kInjected) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.draw);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
+        for (int i = t; i < (int)(sizeof(DrawParams) / 4); i += kLaneBank) dst[i] = src[i];
+    }
+    stage_bank_in(stage, mu_b, P_b, nloc);
+    if (t < nloc) gsukf_predict_lane<kInjected>(stage + t * kStageStride, b, g0 + t, N, noise, dp, status, a);
+    stage_bank_out(stage, mu_b, P_b, nloc);
+}
+
+template <int kUnused>
+__global__ __launch_bounds__(kLaneBank) void gsukf_update_lanes_kernel(float* __restrict__ mu, float* __restrict__ P,
+                                                                       float* __restrict__ w, int64_t N,
+                                                                       int32_t* __restrict__ status, const GsukfUpdateArgs a) {
+    __shared__ float stage[kLaneBank * kStageStride];
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
+    const int nloc = (int)min((int64_t)kLaneBank, N - g0);
+    float* mu_b = mu + ((int64_t)b * N + g0) * kNx;
+    float* P_b = P + ((int64_t)b * N + g0) * kNxx;
+    stage_bank_in(stage, mu_b, P_b, nloc);
+    if (t < nloc)
+        gsukf_update_lane(stage + t * kStageStride, w + (int64_t)b * N + g0 + t, a.io.f[b].u0, a.io.f[b].u1, a.io.f[b].z0,
+                          a.io.f[b].z1, status, a.pdf, a.sw);
+    stage_bank_out(stage, mu_b, P_b, nloc);
+}
+
+// predict and update of a large bank in ONE launch (the class defers predict() until update()): what predict leaves in
+// the staged rows is what update picks up -- the same fp32 values the separate launches pass through memory, so the same
+// bits, without writing 120 bytes per Gaussian and reading them back, and one launch less.
+struct GsukfPredictUpdateArgs {
+    GsukfPredictArgs pred;      // (its io carries u and z)
+    Pdf2 pdf;
+};
+template <bool kInjected>
+__global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict_update_lanes_kernel(
+    float* __restrict__ mu, float* __restrict__ P, float* __restrict__ w, const float* __restrict__ noise, int64_t N,
+    int32_t* __restrict__ status, const GsukfPredictUpdateArgs a) {
+    __shared__ DrawParams dp;
+    __shared__ float stage[kLaneBank * kStageStride];
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
+    const int nloc = (int)min((int64_t)kLaneBank, N - g0);
+    float* mu_b = mu + ((int64_t)b * N + g0) * kNx;
+    float* P_b = P + ((int64_t)b * N + g0) * kNxx;
+    if (!kInjected) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.pred.draw);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
+        for (int i = t; i < (int)(sizeof(DrawParams) / 4); i += kLaneBank) dst[i] = src[i];
+    }
+    stage_bank_in(stage, mu_b, P_b, nloc);
+    if (t < nloc) {
+        float* mine = stage + t * kStageStride;
+        gsukf_predict_lane<kInjected>(mine, b, g0 + t, N, noise, dp, status, a.pred);
+        gsukf_update_lane(mine, w + (int64_t)b * N + g0 + t, a.pred.io.f[b].u0, a.pred.io.f[b].u1, a.pred.io.f[b].z0,
+                          a.pred.io.f[b].z1, status, a.pdf, a.pred.sw);
+    }
+    stage_bank_out(stage, mu_b, P_b, nloc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole cycle predict -> update -> resample of a bank of at most 64 Gaussians in ONE workgroup of 1024 threads
+// (64 groups of 16 lanes): BASELINE config 3 is launch-latency-bound, so one launch instead of five is the lever.
+// mu, P live in LDS between the phases; the resample is the arithmetic of cumsum_kernel + the gather for a single
+// tile (all per-thread sums sit in wavefront 0), so the result is bit-identical to the separate launches.
+constexpr int kSmallBank = 64;
+constexpr int kSmallBlock = kSmallBank * kGroup;      // 1024
+
+struct GsukfCycleArgs {
+    GsukfPredictArgs pred;
+    Pdf2 pdf;
+    double r[GSE_MAX_B];
+};
+
+template <bool kInjected>
+__global__ __launch_bounds__(kSmallBlock) void gsukf_cycle_kernel(float* __restrict__ mu, float* __restrict__ P,
+                                                                  float* __restrict__ w, const float* __restrict__ noise,
+                                                                  int32_t* __restrict__ idx_out, int N,
+                                                                  int32_t* __restrict__ status, const GsukfCycleArgs a) {
+    __shared__ DrawParams dp;
+    __shared__ float fac[kBank][kFacStride];
+    __shared__ float tile[kBank][kTileStride];                   // predict: sigma points; update: deviations
+    __shared__ double eta[kBank][kEtaStride];
+    __shared__ float mu_s[kSmallBank][kNx];
+    __shared__ float P_s[kSmallBank][kNxx];
+    __shared__ float w_s[kSmallBank];
+    __shared__ double c_s[kSmallBank];
+    __shared__ int anc_s[kSmallBank];
+    static_assert(kSmallBank == kBank, "the cycle kernel is one bank");
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int j = tid & (kGroup - 1), gl = tid / kGroup;
+    const bool live = gl < N;
+    const int64_t gi = (int64_t)b * N + (live ? gl : 0);
+    if (!kInjected) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&a.pred.draw);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
+        for (int i = tid; i < (int)(sizeof(DrawParams) / 4); i += kSmallBlock) dst[i] = src[i];
+        __syncthreads();
+    }
+    float* mu_b = mu + (int64_t)b * N * kNx;
+    float* P_b = P + (int64_t)b * N * kNxx;
+    float* w_b = w + (int64_t)b * N;
+    auto from_global = [&](int t, const float*& m_, const float*& p_) { m_ = mu_b + t * kNx; p_ = P_b + t * kNxx; };
+    auto from_lds = [&](int t, const float*& m_, const float*& p_) { m_ = mu_s[t]; p_ = P_s[t]; };
+    auto to_lds = [&](int t, float*& m_, float*& p_) { m_ = mu_s[t]; p_ = P_s[t]; };
+    // 1. predict: global -> LDS
+    gsukf_predict_block<kInjected>(from_global, to_lds, fac, tile, N, b, 0,
+                                   kInjected ? noise + (int64_t)b * N * kNs * kNx : nullptr, dp, status, a.pred);
+    __syncthreads();
+    // 2. update in LDS; the weight goes global -> LDS
+    gsukf_update_block(from_lds, to_lds, [&](int t) { return (const float*)(w_b + t); }, [&](int t) { return &w_s[t]; }, fac,
+                       tile, eta, N, b, status, a.pred.io, a.pdf, a.pred.sw);
+    __syncthreads();
+    // 3. resample, one tile: thread t < 16 of wavefront 0 owns weights 4t..4t+3, exactly as cumsum_kernel does
+    __shared__ double total_s;
+    if (tid < 64) {
+        const int i0 = tid * 4;
+        double sc[4];
+        sc[0] = (i0 + 0 < N) ? (double)w_s[min(i0 + 0, kSmallBank - 1)] : 0.0;
+        sc[1] = sc[0] + ((i0 + 1 < N) ? (double)w_s[min(i0 + 1, kSmallBank - 1)] : 0.0);
+        sc[2] = sc[1] + ((i0 + 2 < N) ? (double)w_s[min(i0 + 2, kSmallBank - 1)] : 0.0);
+        sc[3] = sc[2] + ((i0 + 3 < N) ? (double)w_s[min(i0 + 3, kSmallBank - 1)] : 0.0);
+        const double inc = wave_inclusive_scan(sc[3], tid);
+        const double W = __shfl(inc, 63, 64);                       // workgroup total: wavefronts 1.. hold zeros
+        double excl = wave_shift_up1(inc);
+        if (tid == 0) excl = 0.0;
+        const double top = W / W;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (i0 + p < N) c_s[i0 + p] = (i0 + p == N - 1) ? top : fmin((0.0 + (excl + sc[p])) / W, top);
+        if (tid == 0) total_s = W;
+    }
+    __syncthreads();
+    if (tid < N) {                                                   // ancestor of output tid
+        const double W = total_s;
+        int k = 0;
+        if ((W > 0.0) && (W < INFINITY)) {
+            const double u = ((double)tid + a.r[b]) / (double)N;
+            int lo = 0, hi = N - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (c_s[mid] < u) lo = mid + 1; else hi = mid;
+            }
+            k = lo;
+        }
+        anc_s[tid] = k;
+        if (idx_out) idx_out[(int64_t)b * N + tid] = k;
+        w[(int64_t)b * N + tid] = (float)(1.0 / (double)N);
+    }
+    __syncthreads();
+    // 4. gather LDS -> global (in place: the source is LDS)
+    if (live) {
+        const int src = anc_s[gl];
+        for (int e = j; e < kRow; e += kGroup) {
+            if (e < kNx) mu[gi * kNx + e] = mu_s[src][e];
+            else P[gi * kNxx + (e - kNx)] = P_s[src][e - kNx];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// moments: one thread per Gaussian, blocks stride; 1 + kNx + 2 kTri fp64 sums (36 for 5 states): sum w, sum w d,
+// sum w d d^T (upper triangle) with d = mu - pivot, sum w P (upper triangle)
+constexpr int kGsukfMoments = 1 + kNx + 2 * kTri;
+template <int kUnused>
+__global__ __launch_bounds__(kBlock) void gsukf_moments_kernel(const float* __restrict__ mu, const float* __restrict__ P,
+                                                               const float* __restrict__ w,
+                                                               double* __restrict__ partials, int64_t N) {
+    __shared__ double red[4 * kGsukfMoments];
+    const int b = blockIdx.y;
+    const float* mb = mu + (int64_t)b * N * kNx;
+    const float* Pb = P + (int64_t)b * N * kNxx;
+    const float* wb = w + (int64_t)b * N;
+    double pv[kNx];
+#pragma unroll
+    for (int k = 0; k < kNx; ++k) pv[k] = (double)mb[k];
+    double acc[kGsukfMoments];
+#pragma unroll
+    for (int c = 0; c < kGsukfMoments; ++c) acc[c] = 0.0;
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < N; g += (int64_t)gridDim.x * kBlock) {
+        const double wp = (double)wb[g];
+        double d[kNx];
+#pragma unroll
+        for (int k = 0; k < kNx; ++k) d[k] = (double)mb[g * kNx + k] - pv[k];
+        acc[0] += wp;
+        int c = 1 + kNx;
+#pragma unroll
+        for (int k = 0; k < kNx; ++k) {
+            const double wd = wp * d[k];
+            acc[1 + k] += wd;
+#pragma unroll
+            for (int l = k; l < kNx; ++l) acc[c++] += wd * d[l];
+        }
+#pragma unroll
+        for (int k = 0; k < kNx; ++k)
+#pragma unroll
+            for (int l = k; l < kNx; ++l) acc[c++] += wp * (double)Pb[g * kNxx + k * kNx + l];
+    }
+    double* out = partials + ((int64_t)b * kMomentBlocks + blockIdx.x) * kMomentWidth;
+    block_sums<kGsukfMoments>(acc, red, [&](int c, double total) { out[c] = total; });
+}
+
+}  // namespace gse

@@ -104,36 +104,38 @@ struct RowsPayload {                  // state-major particles in, row-major off
     }
 };
 
-struct GsukfPayload {                 // row-major (mu[5], P[25]) per Gaussian
+struct GsukfPayload {                 // row-major (mu[nx], P[nx][nx]) per Gaussian, nx = states of the model
     const float* __restrict__ mu_in;
     const float* __restrict__ P_in;
     float* __restrict__ mu_out;
     float* __restrict__ P_out;
     int64_t N;
     __device__ __forceinline__ void copy(int b, int64_t anc, int64_t j) const {
-        const float* sm = mu_in + ((int64_t)b * N + anc) * 5;
-        const float* sp = P_in + ((int64_t)b * N + anc) * 25;
-        float* dm = mu_out + ((int64_t)b * N + j) * 5;
-        float* dp = P_out + ((int64_t)b * N + j) * 25;
-        float v[30];
+        constexpr int nx = kModelNx, nxx = nx * nx;
+        const float* sm = mu_in + ((int64_t)b * N + anc) * nx;
+        const float* sp = P_in + ((int64_t)b * N + anc) * nxx;
+        float* dm = mu_out + ((int64_t)b * N + j) * nx;
+        float* dp = P_out + ((int64_t)b * N + j) * nxx;
+        float v[nx + nxx];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) v[k] = sm[k];
+        for (int k = 0; k < nx; ++k) v[k] = sm[k];
 #pragma unroll
-        for (int k = 0; k < 25; ++k) v[5 + k] = sp[k];
+        for (int k = 0; k < nxx; ++k) v[nx + k] = sp[k];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) dm[k] = v[k];
+        for (int k = 0; k < nx; ++k) dm[k] = v[k];
 #pragma unroll
-        for (int k = 0; k < 25; ++k) dp[k] = v[5 + k];
+        for (int k = 0; k < nxx; ++k) dp[k] = v[nx + k];
     }
 };
 
 #ifndef __HIPCC_RTC__
 int launch_cumsum(const float* w, int64_t ldw, int B, int64_t N, uint32_t flags, double* island, const Workspace& ws,
                   double* c_out, hipStream_t st);
+struct UserModel;
 int launch_gsukf_gather(const GsukfPayload& pl, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra,
-                        const Workspace& ws, hipStream_t st);
+                        const Workspace& ws, hipStream_t st, UserModel* model = nullptr);
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
-                           const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, hipStream_t st);
+                           const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, int pivot_count, hipStream_t st);
 
 #endif  // !__HIPCC_RTC__
 

@@ -29,17 +29,24 @@ int launch_cumsum(const float* w, int64_t ldw, int B, int64_t N, uint32_t flags,
 }
 
 int launch_gsukf_gather(const GsukfPayload& pl, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra,
-                        const Workspace& ws, hipStream_t st) {
+                        const Workspace& ws, hipStream_t st, UserModel* model) {
+    const int64_t zero = 0;
+    if (model) {                                     // the payload's row length is the model's: compiled with it
+        void* params[] = {(void*)&pl, (void*)&ws.cumsum, (void*)&ws.totals, (void*)&w_out, (void*)&idx, (void*)&N, (void*)&N,
+                          (void*)&ra, (void*)&zero, (void*)&N, (void*)&N};
+        return launch_user_kernel(model, "gse::gather_kernel<gse::GsukfPayload>", dim3((unsigned)tiles_of(N), B), dim3(kBlock), 0,
+                                  st, params);
+    }
     hipLaunchKernelGGL(gather_kernel<GsukfPayload>, dim3((unsigned)tiles_of(N), B), dim3(kBlock), 0, st, pl, ws.cumsum,
-                       ws.totals, w_out, idx, N, N, ra, (int64_t)0, N, N);
+                       ws.totals, w_out, idx, N, N, ra, zero, N, N);
     GSE_LAUNCH_CHECK("gather_kernel<gsukf>");
     return GSE_OK;
 }
 
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
-                           const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, hipStream_t st) {
+                           const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, int pivot_count, hipStream_t st) {
     hipLaunchKernelGGL(moments_finish_kernel, dim3(B), dim3(64 * kFinishGroups), 0, st, partials, nblk, width, out,
-                       out_stride, pivot_src, pfs, pes, pivot_at);
+                       out_stride, pivot_src, pfs, pes, pivot_at, pivot_count);
 }
 
 }  // namespace gse
@@ -366,7 +373,7 @@ int gse_pf_moments(const float* x, const float* w, int64_t ld, int B, int64_t N,
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pf_moments_kernel, dim3(nblk, B), dim3(kBlock), 0, st, x, w, ws.partials, N, ld);
     GSE_LAUNCH_CHECK("pf_moments_kernel");
-    launch_moments_finish(ws.partials, nblk, 21, out, 26, B, x, GSE_NX * ld, ld, 21, st);
+    launch_moments_finish(ws.partials, nblk, 21, out, 26, B, x, GSE_NX * ld, ld, 21, GSE_NX, st);
     GSE_LAUNCH_CHECK("moments_finish_kernel");
     return GSE_OK;
 }
@@ -390,7 +397,7 @@ int gse_pf_moments_resampled(const float* x, const float* w, int64_t ld, int B, 
     hipLaunchKernelGGL(pf_moments_resampled_kernel, dim3(nblk, B), dim3(kBlock), (size_t)(T + 1) * sizeof(double), st, x, w,
                        ws.scan_sums[slot], ws.scan[slot], ws.partials, N, ld, T, ra);
     GSE_LAUNCH_CHECK("pf_moments_resampled_kernel");
-    launch_moments_finish(ws.partials, nblk, 21, out, 26, B, x, GSE_NX * ld, ld, 21, st);
+    launch_moments_finish(ws.partials, nblk, 21, out, 26, B, x, GSE_NX * ld, ld, 21, GSE_NX, st);
     GSE_LAUNCH_CHECK("moments_finish_kernel");
     return GSE_OK;
 }

@@ -1217,14 +1217,15 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
     block_sums<21>(acc, red, [&](int c, double total) { out[c] = total; });
 }
 
-// Fixed-order reduction of the per-workgroup partials -> out[b][0..width); appends `tail` pivot values.
+// Fixed-order reduction of the per-workgroup partials -> out[b][0..width); appends pivot_count pivot values.
 constexpr int kFinishGroups = 16;        // 1024 threads: (group, column) = (tid / 64, tid % 64)
 __global__ __launch_bounds__(64 * kFinishGroups) void moments_finish_kernel(const double* __restrict__ partials, int nblk,
                                                                            int width, double* __restrict__ out,
                                                                            int out_stride,
                                                                            const float* __restrict__ pivot_src,
                                                                            int64_t pivot_filter_stride,
-                                                                           int64_t pivot_elem_stride, int pivot_at) {
+                                                                           int64_t pivot_elem_stride, int pivot_at,
+                                                                           int pivot_count) {
     // Thread (g, c) adds the partials q = g, g + 16, ... of column c into 8 interleaved accumulators (8 loads in flight),
     // folds them pairwise, and the 16 group totals are folded pairwise after one barrier: a fixed order, so the result
     // does not depend on timing; <= 4 dependent load rounds for 512 partials.
@@ -1253,7 +1254,7 @@ __global__ __launch_bounds__(64 * kFinishGroups) void moments_finish_kernel(cons
             for (int k = 0; k < kFinishGroups; k += 2 * span) t[k] += t[k + span];
         out[(int64_t)b * out_stride + c] = t[0];
     }
-    if (threadIdx.x < GSE_NX)
+    if ((int)threadIdx.x < pivot_count)
         out[(int64_t)b * out_stride + pivot_at + threadIdx.x] =
             (double)pivot_src[(int64_t)b * pivot_filter_stride + threadIdx.x * pivot_elem_stride];
 }

@@ -79,10 +79,11 @@ int user_model_nx(const UserModel* model) { return model->nx; }
 // hiprtc: source -> code object (+ the mangled name of the instance).  No device needed.
 static int compile_instance(UserModel* m, const char* name_expression, std::vector<char>& code, std::string& lowered_name) {
     // one translation unit per kernel instance: the model header (registered as an in-memory include), then the kernels
-    const std::string source =
-        "#define GSE_USER_MODEL \"gse_user_model.h\"\n"
-        "#include \"gse_pf_kernels.h\"\n"
-        "#include \"gse_rows_kernels.h\"\n";
+    // (the GS-UKF kernels are a translation unit of their own: a particle-filter instance does not pay for parsing them)
+    const bool gsukf = strstr(name_expression, "gse::gsukf_") != nullptr;
+    const std::string source = std::string("#define GSE_USER_MODEL \"gse_user_model.h\"\n") +
+                               (gsukf ? "#include \"gse_gsukf_kernels.h\"\n"
+                                      : "#include \"gse_pf_kernels.h\"\n#include \"gse_rows_kernels.h\"\n");
     const char* header_names[] = {"gse_user_model.h"};
     const char* header_texts[] = {m->header.c_str()};
     rtc_program prog = nullptr;

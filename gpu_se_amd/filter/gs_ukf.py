@@ -8,7 +8,7 @@ import torch
 import gpu_se_amd
 from gpu_se_amd import _lib
 from gpu_se_amd.devarray import DevArray, as_device, device, stream_ptr
-from gpu_se_amd.filter.particle import _KernelLauncher, _parallel_resample, _require_builtin_model, rows_f, rows_g
+from gpu_se_amd.filter.particle import _KernelLauncher, _model_library, _parallel_resample, rows_f, rows_g
 from gpu_se_amd.gaussian_sum_dist import DeterministicGaussianSum
 
 
@@ -27,8 +27,14 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     _parallel_resample = _KernelLauncher(_parallel_resample)
 
     def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, _batch=1):
-        _require_builtin_model(f, g)
-        _lib.load()
+        # the bioreactor functions run the kernels shipped in the library; any other (f, g) is translated and its kernels
+        # are compiled for the device at run time (gs_ukf.py:243-275 hands them to Numba)
+        self._lib, self._model = _model_library(f, g)
+        self._Nx = self._model.nx if self._model else _lib.GSE_NX
+        for name, pdf, want in (("x0", x0, self._Nx), ("state_pdf", state_pdf, self._Nx),
+                                ("measurement_pdf", measurement_pdf, _lib.GSE_NY)):
+            if pdf._Nx != want:
+                raise ValueError("%s is %d-dimensional, the model needs %d" % (name, pdf._Nx, want))
         self.f = f
         self.g = g
         self.N_particles = int(N_particles)
@@ -40,7 +46,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
             raise ValueError("batch size must be in 1..%d" % _lib.GSE_MAX_B)
         dev = device()
 
-        self._means = x0.draw((B, n)).as_subclass(torch.Tensor).reshape(B, n, _lib.GSE_NX).contiguous()  # (gs_ukf.py:50)
+        self._means = x0.draw((B, n)).as_subclass(torch.Tensor).reshape(B, n, self._Nx).contiguous()     # (gs_ukf.py:50)
         cov0 = torch.as_tensor(numpy.asarray(state_pdf.covariances[0], dtype=numpy.float32), device=dev)
         self._covs = cov0[None, None, :, :].repeat(B, n, 1, 1).contiguous()                               # (:52)
         self._w = torch.full((B, n), 1.0 / n, dtype=torch.float32, device=dev)                            # (:54)
@@ -48,7 +54,6 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._covs_alt = torch.empty_like(self._covs)
         self._w_alt = torch.empty_like(self._w)
 
-        self._Nx = _lib.GSE_NX
         self._Ny = _lib.GSE_NY
         self._N_sigmas = 2 * self._Nx + 1
         # sigma weights: w_mu + 2 n w_sigma = 1 and w_mu / w_sigma = 0.4 / 0.25  (gs_ukf.py:62-67)
@@ -59,7 +64,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._w_sigma = DevArray.wrap(torch.as_tensor(w_sigma, device=dev))
 
         self._ws = torch.empty(_lib.load().gse_workspace_bytes(B, n), dtype=torch.uint8, device=dev)
-        self._moments = torch.empty((B, 46), dtype=torch.float64, device=dev)
+        self._moments = torch.empty((B, _lib.GSE_GSUKF_MOMENTS), dtype=torch.float64, device=dev)
         self._status = torch.zeros(1, dtype=torch.int32, device=dev)
         self._seed = gpu_se_amd._new_stream_seed()
         self._step = 0
@@ -76,6 +81,11 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._threads_per_block = self._tpb = 1024
         self._blocks_per_grid = self._bpg = (n - 1) // 1024 + 1
         self._y_dummy = DevArray.wrap(torch.zeros(self._Ny, dtype=torch.float32, device=dev))
+
+    def _call(self, name, *args):
+        rc = getattr(self._lib, name)(*args)
+        if rc:
+            (self._model.check if self._model else _lib.check)(rc)
 
     # ------------------------------------------------------------------ attributes
     def _flush(self):
@@ -119,6 +129,15 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._flush()
         self._w.copy_(as_device(value, torch.float32).reshape(self._B, self.N_particles))
 
+    def _inputs(self, u):
+        """Inputs as the kernels take them: two per bank (a user model with one input gets a zero for the other)."""
+        a = numpy.asarray(u, dtype=numpy.float64)
+        nu = self._model.nu if self._model is not None else _lib.GSE_NU
+        a = a.reshape(-1, nu)
+        if nu < _lib.GSE_NU:
+            a = numpy.concatenate([a, numpy.zeros((a.shape[0], _lib.GSE_NU - nu))], axis=1)
+        return self._per_bank(a, _lib.GSE_NU)
+
     def _per_bank(self, values, width):
         """Host values for every bank as the C ABI takes them ([B][width] doubles; one row is broadcast to all banks)."""
         a = numpy.asarray(values, dtype=numpy.float64)
@@ -143,7 +162,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._flush()
         n, B = self.N_particles, self._B
         out = torch.empty((B, n, self._N_sigmas, self._Nx), dtype=torch.float32, device=self._means.device)
-        _lib.call("gse_gsukf_sigma_points", self._means.data_ptr(), self._covs.data_ptr(), out.data_ptr(), B, n,
+        self._call("gse_gsukf_sigma_points", self._means.data_ptr(), self._covs.data_ptr(), out.data_ptr(), B, n,
                   self._status.data_ptr(), stream_ptr())
         return DevArray.wrap(out[0] if B == 1 else out)
 
@@ -167,8 +186,8 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     def _predict_now(self, u, dt):
         pod, rng, noise = self._draw_args()
-        _lib.call("gse_gsukf_predict", self._means.data_ptr(), self._covs.data_ptr(), self._B, self.N_particles,
-                  self._per_bank(u, _lib.GSE_NU), float(dt), self._w_sigma_c, pod, rng, noise, self._status.data_ptr(),
+        self._call("gse_gsukf_predict", self._means.data_ptr(), self._covs.data_ptr(), self._B, self.N_particles,
+                  self._inputs(u), float(dt), self._w_sigma_c, pod, rng, noise, self._status.data_ptr(),
                   stream_ptr())
 
     def update(self, u, z):
@@ -186,14 +205,14 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     def _predict_update_now(self, u, dt, z):
         """predict(u, dt) and update(., z) of a large bank in one launch (gse_gsukf_predict_update): same bits as the two."""
         pod, rng, noise = self._draw_args()
-        _lib.call("gse_gsukf_predict_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B,
-                  self.N_particles, self._per_bank(u, _lib.GSE_NU), float(dt), self._per_bank(z, _lib.GSE_NY),
+        self._call("gse_gsukf_predict_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B,
+                  self.N_particles, self._inputs(u), float(dt), self._per_bank(z, _lib.GSE_NY),
                   self._w_sigma_c, pod, rng, noise, ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(),
                   stream_ptr())
 
     def _update_now(self, u, z):
-        _lib.call("gse_gsukf_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B,
-                  self.N_particles, self._per_bank(u, _lib.GSE_NU), self._per_bank(z, _lib.GSE_NY), self._w_sigma_c,
+        self._call("gse_gsukf_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B,
+                  self.N_particles, self._inputs(u), self._per_bank(z, _lib.GSE_NY), self._w_sigma_c,
                   ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(), self._ws.data_ptr(), stream_ptr())
 
     def resample(self, r=None, return_index=False):
@@ -206,13 +225,13 @@ class ParallelGaussianSumUnscentedKalmanFilter:
             (u, dt), (_, z) = self._pend_predict, self._pend_update
             self._pend_predict = self._pend_update = None
             pod, rng, noise = self._draw_args()
-            _lib.call("gse_gsukf_cycle", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
-                      idx.data_ptr() if return_index else None, B, n, self._per_bank(u, _lib.GSE_NU), dt,
+            self._call("gse_gsukf_cycle", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
+                      idx.data_ptr() if return_index else None, B, n, self._inputs(u), dt,
                       self._per_bank(z, _lib.GSE_NY), rr, self._w_sigma_c, pod, rng, noise,
                       ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(), stream_ptr())
         else:
             self._flush()
-            _lib.call("gse_gsukf_resample", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
+            self._call("gse_gsukf_resample", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
                       self._means_alt.data_ptr(), self._covs_alt.data_ptr(), self._w_alt.data_ptr(),
                       idx.data_ptr() if return_index else None, B, n, rr, 0, self._ws.data_ptr(), stream_ptr())
             self._means, self._means_alt = self._means_alt, self._means
@@ -225,16 +244,19 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     def _moment_sums_all(self):
         """Per bank (sum w, w @ mu, sum w P + sum w (mu - mean)(mu - mean)^T) from one device pass (synchronises)."""
         self._flush()
-        _lib.call("gse_gsukf_moments", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B,
+        self._call("gse_gsukf_moments", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B,
                   self.N_particles, self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
         mm = self._moments.cpu().numpy()
         self._check_status()
         from gpu_se_amd.filter.particle import moments_to_mean_cov
         out = []
+        nx = self._Nx
+        tri = nx * (nx + 1) // 2
+        at = numpy.cumsum([0, 1, nx, tri, tri, nx])                     # S0 | S1 | S2 | C | pivot
         for m in mm:
-            s0, mean, cov_mean = moments_to_mean_cov(m[0], m[1:6], m[6:21], m[36:41])
-            cc = numpy.zeros((self._Nx, self._Nx))
-            cc[numpy.triu_indices(self._Nx)] = m[21:36]
+            s0, mean, cov_mean = moments_to_mean_cov(m[0], m[at[1]:at[2]], m[at[2]:at[3]], m[at[4]:at[5]])
+            cc = numpy.zeros((nx, nx))
+            cc[numpy.triu_indices(nx)] = m[at[3]:at[4]]
             out.append((s0, mean, cc + cc.T - numpy.diag(numpy.diag(cc)) + cov_mean))
         return out
 
@@ -252,11 +274,11 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     # ------------------------------------------------------------------ pieces the benchmark scripts call
     def f_vectorize(self, particles, u, dt):
         """out[..., :] = f(particles[..., :], u, dt), device array fp32 (gs_ukf.py:243-258; gsf_run_seq.py:220)."""
-        return rows_f(_lib.call, self._Nx, particles, [float(v) for v in numpy.asarray(u, dtype=numpy.float64).reshape(-1)], dt)
+        return rows_f(self._call, self._Nx, particles, list(self._inputs(u))[:_lib.GSE_NU], dt)
 
     def g_vectorize(self, particles, u, _y_dummy=None):
         """out[..., :] = g(particles[..., :], u), device array (.. x Ny) fp32 (gs_ukf.py:260-275; gsf_run_seq.py:285)."""
-        return rows_g(_lib.call, self._Nx, particles, [float(v) for v in numpy.asarray(u, dtype=numpy.float64).reshape(-1)])
+        return rows_g(self._call, self._Nx, particles, list(self._inputs(u))[:_lib.GSE_NU])
 
 
 class BatchedGaussianSumUnscentedKalmanFilter(ParallelGaussianSumUnscentedKalmanFilter):

@@ -24,15 +24,6 @@ def _model_library(f, g):
     return model.lib, model
 
 
-def _require_builtin_model(f, g):
-    """For the classes without run-time compiled kernels (the GS-UKF): bioreactor functions only."""
-    if f is not Bioreactor.homeostatic_DEs or g is not Bioreactor.static_outputs:
-        raise NotImplementedError(
-            "this filter runs the built-in bioreactor model only: pass "
-            "f=gpu_se_amd.model.Bioreactor.homeostatic_DEs and g=gpu_se_amd.model.Bioreactor.static_outputs "
-            "(user models are compiled for the particle filter; there is no CPU fallback)")
-
-
 class _KernelLauncher:
     """Callable that also accepts ``[blocks, threads]`` -- the shape of a Numba kernel launch, which the
     reference's benchmark scripts use (pf_run_seq.py:282-287).  The launch geometry is chosen by the

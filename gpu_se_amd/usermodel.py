@@ -230,11 +230,11 @@ def translate(f, g):
 
 
 USER_DIR = os.path.join(build.LIBDIR, "user")
-USER_SOURCES = ["gse_host.hip", "gse_pf.hip", "gse_rows.hip", "gse_rtc.hip"]          # everything the particle filter calls
+USER_SOURCES = ["gse_host.hip", "gse_pf.hip", "gse_gsukf.hip", "gse_rows.hip", "gse_rtc.hip"]     # everything the filters call
 
 
 class CompiledModel:
-    """A user model's library: the C ABI of include/gse.h restricted to the particle-filter entry points."""
+    """A user model's library: the C ABI of include/gse.h restricted to the filters' entry points."""
 
     def __init__(self, nx, nu, tag, path):
         self.nx, self.nu, self.tag, self.path = nx, nu, tag, path
@@ -254,10 +254,11 @@ class CompiledModel:
 
 
 class _ModelEntryPoints:
-    """The C ABI as a particle filter with a run-time compiled model sees it: the step and the row helpers go to their
+    """The C ABI as a filter with a run-time compiled model sees it: the step, the GS-UKF calls and the row helpers go to their
     ``*_model`` forms with the model handle in front, everything else (workspace, resample_begin, moments, draws -- none of
     which contains the model) is the shipped library's."""
-    _ROUTED = ("gse_pf_step", "gse_model_f", "gse_model_g_u")
+    _ROUTED = ("gse_pf_step", "gse_model_f", "gse_model_g_u", "gse_gsukf_sigma_points", "gse_gsukf_predict", "gse_gsukf_update",
+               "gse_gsukf_predict_update", "gse_gsukf_cycle", "gse_gsukf_resample", "gse_gsukf_moments")
 
     def __init__(self, lib, handle):
         self._lib, self._handle = lib, handle

@@ -225,11 +225,39 @@ int gse_gsukf_resample(const float *mu_in, const float *P_in, const float *w, fl
                        float *w_out, int32_t *idx, int B, int64_t N, const double *r, uint32_t flags,
                        void *workspace, void *stream);
 
-/* Moments behind point_estimate / point_covariance (filter/gs_ukf.py:438-449): out [B][46] device =
+/* Moments behind point_estimate / point_covariance (filter/gs_ukf.py:438-449): out [B][GSE_GSUKF_MOMENTS] device =
  * { S0, S1[5] = sum w (mu - p), S2[15] = upper triangle of sum w (mu - p)(mu - p)^T,
  *   C[15] = upper triangle of sum w P, p[5] (= mu_0, the pivot), 5 reserved }. */
+#define GSE_GSUKF_MOMENTS 46
 int gse_gsukf_moments(const float *mu, const float *P, const float *w, int B, int64_t N, double *out,
                       void *workspace, void *stream);
+
+/* The GS-UKF for a user model compiled at run time (filter/gs_ukf.py:243-275 lets Numba JIT any f / g): the calls above
+ * with the handle of gse_model_create in front.  Shapes follow the model's number of states nx (1..5): mu [B][N][nx],
+ * P [B][N][nx][nx], sigma points and injected noise [B][N][2 nx + 1][nx], w_sigma host [2 nx + 1]; the moments row is
+ * { S0, S1[nx], S2[nx (nx + 1) / 2], C[nx (nx + 1) / 2], p[nx] } in a row of GSE_GSUKF_MOMENTS doubles.  The kernels are
+ * those of the built-in model (gse_gsukf_kernels.h) instantiated for the user's f and g on first use. */
+int gse_gsukf_sigma_points_model(void *model, const float *mu, const float *P, float *sigmas, int B, int64_t N,
+                                 int32_t *status, void *stream);
+int gse_gsukf_predict_model(void *model, float *mu, float *P, int B, int64_t N, const double *u, double dt,
+                            const float *w_sigma, const gse_mixture *state_pdf, const gse_rng *rng,
+                            const float *noise, int32_t *status, void *stream);
+int gse_gsukf_update_model(void *model, float *mu, float *P, float *w, int B, int64_t N, const double *u,
+                           const double *z, const float *w_sigma, const gse_mixture *measurement_pdf,
+                           int32_t *status, void *workspace, void *stream);
+int gse_gsukf_predict_update_model(void *model, float *mu, float *P, float *w, int B, int64_t N, const double *u,
+                                   double dt, const double *z, const float *w_sigma, const gse_mixture *state_pdf,
+                                   const gse_rng *rng, const float *noise, const gse_mixture *measurement_pdf,
+                                   int32_t *status, void *stream);
+int gse_gsukf_cycle_model(void *model, float *mu, float *P, float *w, int32_t *idx, int B, int64_t N, const double *u,
+                          double dt, const double *z, const double *r, const float *w_sigma,
+                          const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,
+                          const gse_mixture *measurement_pdf, int32_t *status, void *stream);
+int gse_gsukf_resample_model(void *model, const float *mu_in, const float *P_in, const float *w, float *mu_out,
+                             float *P_out, float *w_out, int32_t *idx, int B, int64_t N, const double *r,
+                             uint32_t flags, void *workspace, void *stream);
+int gse_gsukf_moments_model(void *model, const float *mu, const float *P, const float *w, int B, int64_t N,
+                            double *out, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------- row helpers -------------------- */
 /* The pieces the reference's benchmark scripts call one by one (results/pf_openloop/pf_run_seq.py:134-296). */

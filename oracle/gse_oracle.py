@@ -357,7 +357,12 @@ class GSUKFOracle:
     """Bank of N Gaussians, each an unscented Kalman filter with 2 Nx + 1 unscaled sigma points;
     mixture weights are updated and resampled like particle weights."""
 
-    def __init__(self, n, x0, state_pdf, measurement_pdf, rng=None, means=None, covariances=None):
+    def __init__(self, n, x0, state_pdf, measurement_pdf, rng=None, means=None, covariances=None, f_rows=None, g_rows=None):
+        # f_rows(x (..., Nx), u, dt) -> increments, g_rows(x (..., Nx), u) -> outputs (..., 2): the model evaluated on every
+        # row (default: the bioreactor; the reference calls self.f / self.g per sigma point, gs_ukf.py:91-93, :113-114)
+        self.f_rows = f_rows if f_rows is not None else bioreactor_f_vec
+        self.g_rows = g_rows if g_rows is not None else (lambda x, u: bioreactor_g_vec(x))
+        self._builtin = f_rows is None
         self.n = int(n)
         self.state_pdf = state_pdf
         self.measurement_pdf = measurement_pdf
@@ -389,12 +394,12 @@ class GSUKFOracle:
         """gs_ukf.py:82-103: propagate sigma points through f, add a noise DRAW to every sigma
         point (not Q), then mean = average_w(sigma), P = sum_j w_j d_j d_j^T."""
         sig = self.sigma_points()
-        if loop:
+        if loop and self._builtin:
             for a in range(self.n):
                 for j in range(self.n_sigma):
                     sig[a, j] += bioreactor_f(sig[a, j], u, dt)
         else:
-            sig += bioreactor_f_vec(sig, u, dt)
+            sig += self.f_rows(sig, u, dt)
         sig += self.state_pdf.draw((self.n, self.n_sigma)) if noise is None else np.asarray(noise, dtype=np.float32)
         self.means = np.average(sig, axis=1, weights=self.w_sigma)
         sig -= self.means[:, None, :]
@@ -405,7 +410,7 @@ class GSUKFOracle:
         pseudo-inverse), then the global weight update w *= pdf(z - g(mu_new))."""
         z = np.asarray(z, dtype=np.float64)
         sig = self.sigma_points()
-        eta = bioreactor_g_vec(sig).astype(np.float64)                    # (N, 11, 2)
+        eta = self.g_rows(sig, u).astype(np.float64)                      # (N, 11, 2)
         eta_mean = np.average(eta, axis=1, weights=self.w_sigma)
         sig -= self.means[:, None, :]
         eta -= eta_mean[:, None, :]
@@ -415,7 +420,7 @@ class GSUKFOracle:
         innov = z - eta_mean
         self.means += (gain @ innov[:, :, None]).squeeze(-1)
         self.covariances -= gain @ p_yy @ np.swapaxes(gain, 1, 2)
-        e = z[None, :] - bioreactor_g_vec(self.means).astype(np.float64)
+        e = z[None, :] - self.g_rows(self.means, u).astype(np.float64)
         self.weights *= self.measurement_pdf.pdf(e)
 
     def resample(self, r=None, loop=True):

@@ -146,12 +146,20 @@ def test_a_model_nobody_prebuilt_is_compiled_in_the_process_and_both_backends_ag
                 pf.update([0.8], np.array([15.0, -2.0]))
                 pf.resample(r=0.1 + 0.2 * c)
             results[backend] = (pf.particles.get().copy(), pf.weights.get().copy(), time.perf_counter() - t0)
+            gf = ParallelGaussianSumUnscentedKalmanFilter(drift_f, drift_g, 20, x0, state, meas)      # the GS-UKF on the same model
+            for c in range(3):
+                gf.predict([0.8], 0.02)
+                gf.update([0.8], np.array([15.0, -2.0]))
+                gf.resample(r=0.1 + 0.2 * c)
+            results[backend] += (gf.means.get().copy(), gf.covariances.get().copy())
         finally:
             os.environ.pop("GSE_USERMODEL_BACKEND", None) if backend == "hipcc" else None
     assert model.kernels >= 2                              # (the first cycle's launch and the single-launch cycle)
     assert results["rtc"][2] < 15.0                        # a few instances at about a second each
     np.testing.assert_array_equal(results["rtc"][0], results["hipcc"][0])
     np.testing.assert_array_equal(results["rtc"][1], results["hipcc"][1])
+    np.testing.assert_array_equal(results["rtc"][3], results["hipcc"][3])
+    np.testing.assert_array_equal(results["rtc"][4], results["hipcc"][4])
     # against the same Python functions in NumPy: one predict with injected noise
     x0, state_d, meas = _two_state_parts(deterministic=True)
     n = 2000
@@ -164,13 +172,156 @@ def test_a_model_nobody_prebuilt_is_compiled_in_the_process_and_both_backends_ag
     np.testing.assert_array_equal(pf.particles.get(), want)
 
 
-def test_other_classes_refuse_user_models_loudly():
+def _gsukf_oracle(f, g, n, means, state, meas):
+    """The NumPy GS-UKF of the oracle with the user's Python functions evaluated row by row in float64."""
+    sp = orc.MixtureOracle(state.means, state.covariances, state.weights)
+    mp = orc.MixtureOracle(meas.means, meas.covariances, meas.weights)
+
+    def f_rows(x, u, dt):
+        flat = x.reshape(-1, x.shape[-1])
+        inc = _python_rows(f, flat, u, dt)
+        return ((flat.astype(np.float64) + inc).astype(np.float32) - flat).reshape(x.shape)   # "row_f32 += tuple_f64"
+
+    def g_rows(x, u):
+        flat = x.reshape(-1, x.shape[-1])
+        return _python_rows(g, flat, u).astype(np.float32).reshape(x.shape[:-1] + (2,))
+
+    return orc.GSUKFOracle(n, None, sp, mp, means=means, f_rows=f_rows, g_rows=g_rows)
+
+
+def _close(dev, ref, cov, rel_sigma=2e-4, rtol=1e-6):
+    sd = np.sqrt(np.abs(np.einsum("...ii->...i", np.asarray(cov, dtype=np.float64))))
+    err = np.abs(np.asarray(dev, dtype=np.float64) - ref)
+    assert np.all(err <= rel_sigma * sd + rtol * np.abs(ref) + 1e-12), float(np.max(err / (rel_sigma * sd + rtol * np.abs(ref) + 1e-12)))
+
+
+@pytest.mark.parametrize("n", [9, 200])
+def test_gsukf_with_a_three_state_model_against_the_numpy_class(n):
+    """The GS-UKF with a user model (gs_ukf.py:243-275: Numba JITs any f / g): 3 states -> 7 sigma points, shapes and
+    sigma weights follow; kernels compiled in the process.  Injected noise, given r: means, covariances, weights and
+    ancestors against the oracle's NumPy class calling the same Python functions.  n = 9: the one-launch cycle (and, eagerly,
+    the same calls one kernel each: bit-identical); n = 200: the group kernels."""
+    gpu_se_amd.seed(6)
+    x0 = gsd.MultivariateGaussianSum(means=np.array([[2.0, 1.0, 3.0]]), covariances=np.array([np.diag([0.05, 0.01, 0.08])]),
+                                     weights=np.array([1.0]))
+    state = gsd.DeterministicGaussianSum(means=np.zeros((1, 3)), covariances=np.array([np.diag([1e-3, 2e-3, 1e-3])]),
+                                         weights=np.array([1.0]))
+    meas = gsd.MultivariateGaussianSum(means=np.zeros((2, 2)), covariances=np.array([np.diag([4.0, 1.0]), np.diag([40.0, 9.0])]),
+                                       weights=np.array([0.8, 0.2]))
+    banks = []
+    for lazy in (True, False):
+        gf = ParallelGaussianSumUnscentedKalmanFilter(um.three_state_f, um.three_state_g, n, x0, state, meas)
+        gf.lazy = lazy
+        banks.append(gf)
+    gf = banks[0]
+    assert gf._Nx == 3 and gf._N_sigmas == 7 and tuple(gf.means.shape) == (n, 3) and tuple(gf.covariances.shape) == (n, 3, 3)
+    np.testing.assert_array_equal(gf._w_sigma.get(), orc.sigma_weights(3))
+    banks[1].means = gf.means.get()
+    o = _gsukf_oracle(um.three_state_f, um.three_state_g, n, gf.means.get(), state, meas)
+    o.covariances = gf.covariances.get().copy()
+    sig = gf._get_sigma_points().get()
+    assert sig.shape == (n, 7, 3)
+    np.testing.assert_allclose(sig, o.sigma_points(), rtol=2e-6)
+    rng = np.random.default_rng(2)
+    for c in range(3):
+        u, z, r = [0.3 + 0.1 * c, 0.5], np.array([21.0 + c, 2.5]), 0.15 + 0.2 * c
+        noise = (rng.standard_normal((n, 7, 3)) * 0.03).astype(np.float32)
+        idx = []
+        for b in banks:
+            gsd.DeterministicGaussianSum.preload(noise)
+            b.predict(u, 0.2)
+            b.update(u, z)
+            idx.append(b.resample(r=r, return_index=True).get())
+        np.testing.assert_array_equal(idx[0], idx[1])
+        np.testing.assert_array_equal(banks[0].means.get(), banks[1].means.get())
+        np.testing.assert_array_equal(banks[0].covariances.get(), banks[1].covariances.get())
+        o.predict(u, 0.2, noise=noise, loop=False)
+        prior = o.covariances.copy()
+        o.update(u, z)
+        want = o.resample(r=r, loop=False)
+        assert np.mean(idx[0] != want) <= 2.0 / n
+        if np.array_equal(idx[0], want):
+            _close(gf.means.get(), o.means, prior[want])
+            np.testing.assert_allclose(gf.covariances.get(), o.covariances, rtol=2e-3, atol=1e-7)
+        else:                                   # (a tie fell the other way: carry on from the device's ancestors)
+            o.means, o.covariances = gf.means.get().copy(), gf.covariances.get().copy()
+    est = gf.point_estimate()
+    assert est.shape == (3,)
+    np.testing.assert_allclose(est, o.point_estimate(), rtol=1e-5)
+    np.testing.assert_allclose(gf.point_covariance(), o.point_covariance(), rtol=1e-4)
+    # the pieces the reference's scripts call on the GS-UKF object (gsf_run_seq.py:220, :285)
+    rows = gf.means.get()[:5]
+    inc = _python_rows(um.three_state_f, rows, [0.3, 0.5], 0.2)
+    np.testing.assert_array_equal(gf.f_vectorize(rows, [0.3, 0.5], 0.2).get(), inc.astype(np.float32))
+    np.testing.assert_array_equal(gf.g_vectorize(rows, [0.3, 0.5]).get(), _python_rows(um.three_state_g, rows, [0.3, 0.5]).astype(np.float32))
+
+
+def test_gsukf_with_a_two_state_model_philox_noise_large_and_batched():
+    """Two states, one input, Philox noise: a large bank takes the lane kernels (predict + update in one launch) and gives
+    the bits of the same calls one kernel each; a batch of banks equals the single banks; the estimate follows the
+    measurements."""
+    from gpu_se_amd.filter import BatchedGaussianSumUnscentedKalmanFilter
+    gpu_se_amd.seed(7)
     x0, state, meas = _two_state_parts()
-    with pytest.raises(NotImplementedError):
-        ParallelGaussianSumUnscentedKalmanFilter(um.two_state_f, um.two_state_g, 8, x0, state, meas)
+    x0 = gsd.MultivariateGaussianSum(means=np.array([[9.0, 0.5]]), covariances=np.array([[[0.3, 0], [0, 0.05]]]), weights=np.array([1.0]))
+    n = 1 << 16
+    banks = []
+    for lazy in (True, False):
+        gf = ParallelGaussianSumUnscentedKalmanFilter(um.two_state_f, um.two_state_g, n, x0, state, meas)
+        gf.lazy = lazy
+        banks.append(gf)
+    banks[1].means = banks[0].means.get()
+    banks[1]._seed = banks[0]._seed
+    truth = np.array([9.0, 0.5])
+    for c in range(6):
+        truth = truth + np.array(um.two_state_f(truth, [1.0], 0.01))
+        z = np.array(um.two_state_g(truth, [1.0])) + [0.7, -0.3]
+        for gf in banks:
+            gf.predict([1.0], 0.01)
+            gf.update([1.0], z)
+        np.testing.assert_array_equal(banks[0].means.get(), banks[1].means.get())
+        np.testing.assert_array_equal(banks[0].covariances.get(), banks[1].covariances.get())
+        np.testing.assert_array_equal(banks[0].weights.get(), banks[1].weights.get())
+        r = 0.1 + 0.15 * c
+        np.testing.assert_array_equal(banks[0].resample(r=r, return_index=True).get(), banks[1].resample(r=r, return_index=True).get())
+    est = banks[0].point_estimate()
+    assert est.shape == (2,) and abs(est[1] - truth[1]) < 0.6 and abs(est[0] * est[1] - truth[0] * truth[1]) < 2.5
+    # a batch of small banks
+    B, m = 3, 50
+    batch = BatchedGaussianSumUnscentedKalmanFilter(um.two_state_f, um.two_state_g, m, x0, state, meas, batch=B)
+    assert tuple(batch.means.shape) == (B, m, 2) and tuple(batch.covariances.shape) == (B, m, 2, 2)
+    singles = []
+    for b in range(B):
+        gf = ParallelGaussianSumUnscentedKalmanFilter(um.two_state_f, um.two_state_g, m, x0, state, meas)
+        gf.means = batch.means.get()[b]
+        gf._seed, gf._filter_offset = batch._seed, b
+        singles.append(gf)
+    u = np.array([[1.0], [0.9], [1.1]])
+    z = np.array(um.two_state_g(truth, [1.0]))[None, :] + np.array([[0.7, -0.3], [0.2, 0.1], [-0.4, 0.3]])
+    for c in range(2):
+        batch.predict(u, 0.01)
+        batch.update(u, z)
+        batch.resample(r=[0.2, 0.5, 0.8])
+        for b, gf in enumerate(singles):
+            gf.predict(u[b], 0.01)
+            gf.update(u[b], z[b])
+            gf.resample(r=[0.2, 0.5, 0.8][b])
+            np.testing.assert_array_equal(batch.means.get()[b], gf.means.get())
+            np.testing.assert_array_equal(batch.covariances.get()[b], gf.covariances.get())
+    est, cov = batch.estimates()
+    assert est.shape == (B, 2) and cov.shape == (B,)
+    np.testing.assert_array_equal(est[2], singles[2].point_estimate())
+
+
+def test_dimension_mismatches_are_refused_loudly():
+    x0, state, meas = _two_state_parts()
+    with pytest.raises(ValueError, match="dimensional"):
+        ParallelGaussianSumUnscentedKalmanFilter(um.three_state_f, um.three_state_g, 8, x0, state, meas)
     with pytest.raises(ValueError, match="dimensional"):
         ParallelParticleFilter(um.three_state_f, um.three_state_g, 16, x0, state, meas)
     # and the shipped library still serves the bioreactor
     from gpu_se_amd import sim_base
     _, _, _, pf = sim_base.get_parts(N_particles=256)
     assert pf._model is None and tuple(pf.particles.shape) == (256, 5)
+    _, _, _, gf = sim_base.get_parts(N_particles=16, pf=False)
+    assert gf._model is None and tuple(gf.means.shape) == (16, 5)

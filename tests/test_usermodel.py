@@ -46,7 +46,13 @@ def test_kernels_compile_at_run_time_for_a_user_model():
     with pytest.raises(Exception, match="failed"):
         model.compile_check("gse::no_such_kernel")
     assert usermodel.compile_model(um.two_state_f, um.two_state_g) is model          # cached
-    assert usermodel.compile_model(um.three_state_f, um.three_state_g).nx == 3
+    three = usermodel.compile_model(um.three_state_f, um.three_state_g)
+    assert three.nx == 3
+    # the GS-UKF kernels (a translation unit of their own) for a model with 3 states: 7 sigma points, 3 x 3 covariances
+    for name in ("gse::gsukf_cycle_kernel<false>", "gse::gsukf_predict_kernel<true, 64>", "gse::gsukf_update_kernel<64>",
+                 "gse::gsukf_predict_update_lanes_kernel<false>", "gse::gsukf_sigma_kernel<0>", "gse::gsukf_moments_kernel<0>",
+                 "gse::gather_kernel<gse::GsukfPayload>"):
+        assert three.compile_check(name) > 5000
 
 
 def test_library_builds_for_a_user_model():
@@ -54,7 +60,8 @@ def test_library_builds_for_a_user_model():
     model = usermodel.compile_model(um.two_state_f, um.two_state_g, backend="hipcc")
     assert os.path.exists(model.path) and (model.nx, model.nu) == (2, 1)
     assert int(model.lib.gse_model_tag()) == model.tag != 0
-    for name in ("gse_pf_step", "gse_pf_resample_begin", "gse_pf_moments", "gse_model_f", "gse_model_g_u", "gse_last_error"):
+    for name in ("gse_pf_step", "gse_pf_resample_begin", "gse_pf_moments", "gse_model_f", "gse_model_g_u", "gse_last_error",
+                 "gse_gsukf_cycle", "gse_gsukf_predict_update", "gse_gsukf_moments"):
         assert hasattr(model.lib, name), name
     # argument checking works in the model's library too, without a GPU
     assert model.lib.gse_pf_step(512, 16, 16, None, None, None, 8, 1, 8, None, 0.0, None, None, None, None, None, None,
