@@ -378,6 +378,12 @@ int gse_pf_moments(const float* x, const float* w, int64_t ld, int B, int64_t N,
     return GSE_OK;
 }
 
+#ifndef GSE_MOMRES_TOTAL_BLOCKS
+#define GSE_MOMRES_TOTAL_BLOCKS 1024   // workgroups of the resampled-moments pass over all filters (4 per CU: one resident generation)
+#endif
+#ifndef GSE_MOMRES_MIN_BLOCKS
+#define GSE_MOMRES_MIN_BLOCKS 32
+#endif
 int gse_pf_moments_resampled(const float* x, const float* w, int64_t ld, int B, int64_t N, const double* r, int slot,
                              double* out, void* workspace, void* stream) {
     if (int rc = check_pf_geometry("gse_pf_moments_resampled", B, N, ld)) return rc;
@@ -392,7 +398,7 @@ int gse_pf_moments_resampled(const float* x, const float* w, int64_t ld, int B, 
         ra.r[b] = r[b];
     }
     Workspace ws = carve_workspace(workspace, B, N);
-    const int nblk = (int)std::min<int64_t>(std::min<int64_t>(kMomentBlocks, T), std::max<int64_t>(GSE_MOMENT_TOTAL_BLOCKS / B, 32));
+    const int nblk = (int)std::min<int64_t>(std::min<int64_t>(kMomentBlocks, T), std::max<int64_t>(GSE_MOMRES_TOTAL_BLOCKS / B, GSE_MOMRES_MIN_BLOCKS));
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pf_moments_resampled_kernel, dim3(nblk, B), dim3(kBlock), (size_t)(T + 1) * sizeof(double), st, x, w,
                        ws.scan_sums[slot], ws.scan[slot], ws.partials, N, ld, T, ra);

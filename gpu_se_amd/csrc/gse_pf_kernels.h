@@ -1098,6 +1098,12 @@ __global__ __launch_bounds__(kBlock) void pf_moments_kernel(const float* __restr
 // weighs n_k * fp32(1 / N) with n_k = F(k) - F(k-1) its offspring count under the systematic resample with this r -- the
 // inverse map of the gather stage (OffspringCount; keys re-formed from weights + per-thread tile prefixes exactly as there).
 // A workgroup builds the tile prefix of its filter in LDS, then its wavefronts stride over the tiles.
+// Round 2 tried to get this pass off its 188 vector registers (21 fp64 accumulators per lane: two wavefronts per SIMD) by
+// COLLECTING the particles with offspring in a per-wavefront LDS list and working them off term-parallel (one accumulator
+// per lane, 116 registers, four wavefronts per SIMD): 32 us against 40 when 5 % of the particles have offspring, but inside
+// the closed loop -- where 3 % to 70 % of them do, 16 % on average -- 59 us against 53: pushing and flushing cost what the
+// occupancy wins.  Fetching a step's state rows whole and coalesced instead of each such particle's own 20 bytes, and a
+// software pipeline over the steps (inputs requested one step ahead, states used one step late) changed nothing either way.
 __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                       const double* __restrict__ tile_sums,
                                                                       const double* __restrict__ qx_all,

@@ -623,9 +623,15 @@ def test_resampled_moments_equal_the_moments_after_the_copy():
     from gpu_se_amd.filter import BatchedParticleFilter
     from gpu_se_amd.filter.particle import moments_to_mean_cov
     xss = orc.steady_state()
-    for n, B in ((5003, 1), (1 << 18, 1), (40000, 3)):
+    from gpu_se_amd.gaussian_sum_dist import MultivariateGaussianSum
+    # (the last four: measurement noise so wide that the weights stay near uniform -- from "every particle has its one
+    #  offspring" to "a third of them have": the kernel's list of particles with offspring overflows into repeated flushes)
+    for n, B, wide in ((5003, 1, 0), (1 << 18, 1, 0), (40000, 3, 0), (70001, 2, 1e6), (1 << 16, 1, 30.0), (50000, 2, 3.0), (30000, 1, 0.5)):
         gpu_se_amd.seed(11)
         sp, mp = sim_base.get_noise()
+        if wide:
+            mp = MultivariateGaussianSum(means=np.zeros((2, 2)), covariances=np.array([np.eye(2) * wide, np.eye(2) * 2 * wide]),
+                                         weights=np.array([0.5, 0.5]))
         x0, _ = sim_base.get_noise()
         x0.means += xss[None, :].astype(np.float32)
         pf = BatchedParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, sp, mp, batch=B)
