@@ -266,15 +266,16 @@ def gsukf_block(torch, sizes=(64, 1 << 18)):
     return out
 
 
-def closed_loop_block(torch, B=32, log2n=18, end_time=50):
+def closed_loop_block(torch, B=32, log2n=18, end_time=50, pf=True):
     """BASELINE config 5 per GPU: 32 closed-loop rollouts x 2^18 particles, 499 ticks, MPC every tick, everything
-    resident on the device (sim_base.BatchedSimulation(resident=True))."""
+    resident on the device (sim_base.BatchedSimulation(resident=True)).  pf=False: the same loop with banks of 2^log2n
+    Gaussians (GS-UKF) as the estimator (results/gsf_closedloop/bioreactor_performance_gsf.py)."""
     from gpu_se_amd import sim_base
     sim = sim_base.BatchedSimulation(batch=B, N_particles=1 << log2n, dt_control=0.1, dt_predict=0.1, end_time=end_time,
-                                     seed=1, resident=True)
+                                     seed=1, resident=True, pf=pf)
     sim.K._device_law()
-    warm = sim_base.BatchedSimulation(batch=B, N_particles=1 << 10, dt_control=0.1, dt_predict=0.1, end_time=2, seed=2,
-                                      resident=True)
+    warm = sim_base.BatchedSimulation(batch=B, N_particles=(1 << 10) if pf else (1 << log2n), dt_control=0.1, dt_predict=0.1,
+                                      end_time=2, seed=2, resident=True, pf=pf)
     warm.K = sim.K
     warm.simulate()
     torch.cuda.synchronize()
@@ -284,7 +285,8 @@ def closed_loop_block(torch, B=32, log2n=18, end_time=50):
     wall = time.perf_counter() - t0
     ticks = len(sim.ts) - 1
     dev_s = float(sim.timing["device_loop"])          # HIP events around the ticks' launches (excludes the host's final statistics)
-    return {"rollouts": B, "particles_per_rollout": 1 << log2n, "ticks": ticks, "device_s": round(dev_s, 4),
+    return {"rollouts": B, "particles_per_rollout" if pf else "gaussians_per_rollout": 1 << log2n, "ticks": ticks,
+            "device_s": round(dev_s, 4),
             "wall_s": round(wall, 4), "host_enqueue_s": round(float(sim.timing["enqueue"]), 4),
             "ticks_per_s_device": round(ticks / dev_s, 1),
             "particle_cycles_per_s_device": round(ticks * B * (1 << log2n) / dev_s, 1),
@@ -423,6 +425,7 @@ def main():
             result["protocol_sum_us"] = protocol_sum(torch, n, io, dt)
             result["gsukf"] = gsukf_block(torch)
             result["closed_loop"] = closed_loop_block(torch)
+            result["closed_loop_gsukf"] = closed_loop_block(torch, log2n=6, pf=False)     # 32 rollouts x 64 Gaussians (config 3's bank)
         if world == 1 and not args.no_cpu_baseline:
             full, small, vec = cpu_baseline(n, dt)
             result["cpu_baseline"] = {

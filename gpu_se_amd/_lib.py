@@ -15,6 +15,7 @@ GSE_RESAMPLE_SEPARATE_SCAN = 2
 GSE_OP_GATHER, GSE_OP_PREDICT, GSE_OP_UPDATE = 1, 2, 4
 GSE_OP_SCAN_IN, GSE_OP_SCAN_OUT, GSE_OP_SCAN_IN_SLOT1, GSE_OP_SCAN_OUT_SLOT1 = 8, 16, 32, 64
 GSE_OP_U_DEVICE, GSE_OP_Z_DEVICE = 128, 256
+GSE_IO_U_DEVICE, GSE_IO_Z_DEVICE = 1, 2
 GSE_SCAN_MAX_TILES = 2048      # policy: beyond 2^21 particles the two-kernel resample is faster (every workgroup
                                # builds the whole tile prefix: at 4096 tiles the single launch takes 131 us against 102)
 GSE_GSUKF_CYCLE_MAX = 64
@@ -84,6 +85,13 @@ PROTOTYPES = {
                                        c_vp, P_MIX, c_vp, c_vp]),
     "gse_gsukf_resample": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_u32, c_vp, c_vp]),
     "gse_gsukf_moments": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
+    "gse_gsukf_predict_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d, P_F, P_MIX, P_RNG, c_vp, c_vp, c_u32, c_vp]),
+    "gse_gsukf_update_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp, P_F, P_MIX, c_vp, c_vp, c_u32, c_vp]),
+    "gse_gsukf_predict_update_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d, c_vp, P_F, P_MIX, P_RNG, c_vp,
+                                                    P_MIX, c_vp, c_u32, c_vp]),
+    "gse_gsukf_cycle_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d, c_vp, P_D, P_F, P_MIX, P_RNG,
+                                           c_vp, P_MIX, c_vp, c_u32, c_vp]),
+    "gse_gsukf_moments26": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
     "gse_gsukf_sigma_points_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
     "gse_gsukf_predict_model": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_F, P_MIX, P_RNG, c_vp, c_vp, c_vp]),
     "gse_gsukf_update_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, P_D, P_F, P_MIX, c_vp, c_vp, c_vp]),

@@ -73,6 +73,15 @@ static int launch(UserModel* model, const char* name, void (*kernel)(Params...),
 
 static int states_of(UserModel* model) { return model ? user_model_nx(model) : kNx; }
 
+// Where u and z live: host arrays (copied into the kernel arguments) or, bit by bit, DEVICE arrays [B][2] fp64 that the
+// kernel reads when it runs (GSE_IO_U_DEVICE / GSE_IO_Z_DEVICE: the `_dev` entry points, a closed loop on the device).
+static void pack_bank_io(FilterIOs& io, const double*& u_dev, const double*& z_dev, int B, const double* u, const double* z,
+                         uint32_t where) {
+    u_dev = (where & GSE_IO_U_DEVICE) ? u : nullptr;
+    z_dev = (where & GSE_IO_Z_DEVICE) ? z : nullptr;
+    pack_io(io, B, u_dev ? nullptr : u, z_dev ? nullptr : z);
+}
+
 #define GSE_WIDE_STR_(x) #x
 #define GSE_WIDE_STR(x) GSE_WIDE_STR_(x)
 #define GSE_WIDE GSE_WIDE_STR(GSE_GSUKF_WIDE_BANK)
@@ -89,13 +98,13 @@ static int gsukf_sigma_points(UserModel* model, const float* mu, const float* P,
 
 static int gsukf_predict(UserModel* model, float* mu, float* P, int B, int64_t N, const double* u, double dt,
                          const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng, const float* noise,
-                         int32_t* status, void* stream) {
+                         int32_t* status, void* stream, uint32_t where = 0) {
     if (int rc = check_gsukf("gse_gsukf_predict", B, N)) return rc;
     GSE_REQUIRE(mu && P && u && w_sigma, "gse_gsukf_predict: null argument");
     GSE_REQUIRE(noise || (state_pdf && rng), "gse_gsukf_predict: need either noise or (state_pdf, rng)");
     const int nx = states_of(model);
     GsukfPredictArgs a;
-    pack_io(a.io, B, u, nullptr);
+    pack_bank_io(a.io, a.u_dev, a.z_dev, B, u, nullptr, where & GSE_IO_U_DEVICE);
     pack_sigma_weights(a.sw, w_sigma, 2 * nx + 1);
     a.dt = dt;
     const bool lanes = lane_per_gaussian(B, N);
@@ -118,13 +127,13 @@ static int gsukf_predict(UserModel* model, float* mu, float* P, int B, int64_t N
 
 static int gsukf_update(UserModel* model, float* mu, float* P, float* w, int B, int64_t N, const double* u, const double* z,
                         const float* w_sigma, const gse_mixture* measurement_pdf, int32_t* status, void* workspace,
-                        void* stream) {
+                        void* stream, uint32_t where = 0) {
     if (int rc = check_gsukf("gse_gsukf_update", B, N)) return rc;
     GSE_REQUIRE(mu && P && w && u && z && w_sigma && measurement_pdf, "gse_gsukf_update: null argument");
     if (int rc = check_mixture("gse_gsukf_update", measurement_pdf, GSE_NY)) return rc;
     (void)workspace;
     GsukfUpdateArgs a;
-    pack_io(a.io, B, u, z);
+    pack_bank_io(a.io, a.u_dev, a.z_dev, B, u, z, where);
     pack_pdf2(a.pdf, *measurement_pdf);
     pack_sigma_weights(a.sw, w_sigma, 2 * states_of(model) + 1);
     hipStream_t st = (hipStream_t)stream;
@@ -137,14 +146,15 @@ static int gsukf_update(UserModel* model, float* mu, float* P, float* w, int B, 
 
 static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w, int B, int64_t N, const double* u, double dt,
                                 const double* z, const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng,
-                                const float* noise, const gse_mixture* measurement_pdf, int32_t* status, void* stream) {
+                                const float* noise, const gse_mixture* measurement_pdf, int32_t* status, void* stream,
+                                uint32_t where = 0) {
     if (int rc = check_gsukf("gse_gsukf_predict_update", B, N)) return rc;
     GSE_REQUIRE(mu && P && w && u && z && w_sigma && measurement_pdf, "gse_gsukf_predict_update: null argument");
     GSE_REQUIRE(noise || (state_pdf && rng), "gse_gsukf_predict_update: need either noise or (state_pdf, rng)");
     if (int rc = check_mixture("gse_gsukf_predict_update", measurement_pdf, GSE_NY)) return rc;
     const int nx = states_of(model);
     GsukfPredictUpdateArgs a;
-    pack_io(a.pred.io, B, u, z);
+    pack_bank_io(a.pred.io, a.pred.u_dev, a.pred.z_dev, B, u, z, where);
     pack_sigma_weights(a.pred.sw, w_sigma, 2 * nx + 1);
     a.pred.dt = dt;
     pack_pdf2(a.pdf, *measurement_pdf);
@@ -167,7 +177,7 @@ static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w,
 static int gsukf_cycle(UserModel* model, float* mu, float* P, float* w, int32_t* idx, int B, int64_t N, const double* u,
                        double dt, const double* z, const double* r, const float* w_sigma, const gse_mixture* state_pdf,
                        const gse_rng* rng, const float* noise, const gse_mixture* measurement_pdf, int32_t* status,
-                       void* stream) {
+                       void* stream, uint32_t where = 0) {
     if (int rc = check_gsukf("gse_gsukf_cycle", B, N)) return rc;
     GSE_REQUIRE(N <= kSmallBank, "gse_gsukf_cycle: at most %d Gaussians (got %lld); use the separate calls", kSmallBank,
                 (long long)N);
@@ -176,7 +186,7 @@ static int gsukf_cycle(UserModel* model, float* mu, float* P, float* w, int32_t*
     if (int rc = check_mixture("gse_gsukf_cycle", measurement_pdf, GSE_NY)) return rc;
     const int nx = states_of(model);
     GsukfCycleArgs a;
-    pack_io(a.pred.io, B, u, z);
+    pack_bank_io(a.pred.io, a.pred.u_dev, a.pred.z_dev, B, u, z, where);
     pack_sigma_weights(a.pred.sw, w_sigma, 2 * nx + 1);
     a.pred.dt = dt;
     pack_pdf2(a.pdf, *measurement_pdf);
@@ -220,13 +230,23 @@ static int gsukf_resample(UserModel* model, const float* mu_in, const float* P_i
 }
 
 static int gsukf_moments(UserModel* model, const float* mu, const float* P, const float* w, int B, int64_t N, double* out,
-                         void* workspace, void* stream) {
+                         void* workspace, void* stream, bool as_particles = false) {
     if (int rc = check_gsukf("gse_gsukf_moments", B, N)) return rc;
     GSE_REQUIRE(mu && P && w && out && workspace, "gse_gsukf_moments: null argument");
     Workspace ws = carve_workspace(workspace, B, N);
     const int nblk = (int)std::min<int64_t>(kMomentBlocks, (N + kBlock - 1) / kBlock);
     hipStream_t st = (hipStream_t)stream;
     const int nx = states_of(model), width = 1 + nx + nx * (nx + 1);        // S0, S1[nx], S2[tri], C[tri]
+    if (as_particles) {
+        // the particle filter's row (gse_pf_moments): S0, S1, S2 + C, pivot -- 1 + nx + tri + nx doubles in a row of 26
+        const int w26 = 1 + nx + nx * (nx + 1) / 2;
+        if (int rc = launch(model, "gse::gsukf_moments_kernel<1>", gsukf_moments_kernel<1>, dim3(nblk, B), dim3(kBlock), st, mu, P,
+                            w, ws.partials, N))
+            return rc;
+        launch_moments_finish(ws.partials, nblk, w26, out, 26, B, mu, N * nx, 1, w26, nx, st);
+        GSE_LAUNCH_CHECK("moments_finish_kernel");
+        return GSE_OK;
+    }
     if (int rc = launch(model, "gse::gsukf_moments_kernel<0>", gsukf_moments_kernel<0>, dim3(nblk, B), dim3(kBlock), st, mu, P, w,
                         ws.partials, N))
         return rc;
@@ -270,6 +290,36 @@ int gse_gsukf_resample(const float* mu_in, const float* P_in, const float* w, fl
 int gse_gsukf_moments(const float* mu, const float* P, const float* w, int B, int64_t N, double* out, void* workspace,
                       void* stream) {
     return gsukf_moments(nullptr, mu, P, w, B, N, out, workspace, stream);
+}
+
+// ---- inputs and measurements in DEVICE memory (`where`: GSE_IO_U_DEVICE | GSE_IO_Z_DEVICE says which of u, z are device
+//      pointers [B][2] fp64, read when the kernel runs): a closed loop whose controller and plant are kernels too
+int gse_gsukf_predict_dev(float* mu, float* P, int B, int64_t N, const double* u, double dt, const float* w_sigma,
+                          const gse_mixture* state_pdf, const gse_rng* rng, const float* noise, int32_t* status, uint32_t where,
+                          void* stream) {
+    return gsukf_predict(nullptr, mu, P, B, N, u, dt, w_sigma, state_pdf, rng, noise, status, stream, where);
+}
+int gse_gsukf_update_dev(float* mu, float* P, float* w, int B, int64_t N, const double* u, const double* z, const float* w_sigma,
+                         const gse_mixture* measurement_pdf, int32_t* status, void* workspace, uint32_t where, void* stream) {
+    return gsukf_update(nullptr, mu, P, w, B, N, u, z, w_sigma, measurement_pdf, status, workspace, stream, where);
+}
+int gse_gsukf_predict_update_dev(float* mu, float* P, float* w, int B, int64_t N, const double* u, double dt, const double* z,
+                                 const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng, const float* noise,
+                                 const gse_mixture* measurement_pdf, int32_t* status, uint32_t where, void* stream) {
+    return gsukf_predict_update(nullptr, mu, P, w, B, N, u, dt, z, w_sigma, state_pdf, rng, noise, measurement_pdf, status, stream,
+                                where);
+}
+int gse_gsukf_cycle_dev(float* mu, float* P, float* w, int32_t* idx, int B, int64_t N, const double* u, double dt, const double* z,
+                        const double* r, const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng,
+                        const float* noise, const gse_mixture* measurement_pdf, int32_t* status, uint32_t where, void* stream) {
+    return gsukf_cycle(nullptr, mu, P, w, idx, B, N, u, dt, z, r, w_sigma, state_pdf, rng, noise, measurement_pdf, status, stream,
+                       where);
+}
+// gse_gsukf_moments in the particle filter's layout (rows of 26 doubles: S0, S1[5], S2[15] + C[15], pivot[5]): what
+// gse_loop_control and the host post-processing of a closed loop take from either estimator
+int gse_gsukf_moments26(const float* mu, const float* P, const float* w, int B, int64_t N, double* out, void* workspace,
+                        void* stream) {
+    return gsukf_moments(nullptr, mu, P, w, B, N, out, workspace, stream, true);
 }
 
 // ---- the same calls for a user model compiled at run time (handle from gse_model_create); shapes follow the model's

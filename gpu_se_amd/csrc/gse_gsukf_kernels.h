@@ -132,8 +132,19 @@ __global__ __launch_bounds__(kBlock) void gsukf_sigma_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// Inputs and measurements of the banks: host values carried in the kernel arguments (io), or -- for a closed loop whose
+// controller and plant run on the device -- [B][2] fp64 arrays in device memory, read when the kernel runs.
+__device__ __forceinline__ FilterIO bank_inputs(const FilterIOs& io, const double* u_dev, const double* z_dev, int b) {
+    FilterIO f = io.f[b];
+    if (u_dev) { f.u0 = u_dev[2 * b]; f.u1 = u_dev[2 * b + 1]; }
+    if (z_dev) { f.z0 = z_dev[2 * b]; f.z1 = z_dev[2 * b + 1]; }
+    return f;
+}
+
 struct GsukfPredictArgs {
     FilterIOs io;
+    const double* u_dev;        // null: io
+    const double* z_dev;        // (kernels that also update)
     DrawParams draw;
     RngKey rng;
     SigmaWeights sw;
@@ -205,7 +216,7 @@ __device__ __forceinline__ void read_factor(const float* fac_g, float (&m)[kNx],
 template <bool kInjected, class Src, class Dst>
 __device__ __forceinline__ void gsukf_predict_block(Src src, Dst dst, float (*fac)[kFacStride], float (*tile)[kTileStride],
                                                     int nloc, int b, int64_t g0, const float* noise, const DrawParams& dp,
-                                                    int32_t* status, const GsukfPredictArgs& a) {
+                                                    int32_t* status, const GsukfPredictArgs& a, const FilterIO& bio) {
     gsukf_factor_block(src, fac, nloc, status);
     // B. one sigma point per lane, packed densely (11 per Gaussian: 704 points keep 11 of the 16 wavefronts busy, the
     //    other five skip the model step and the noise draw altogether)
@@ -214,7 +225,7 @@ __device__ __forceinline__ void gsukf_predict_block(Src src, Dst dst, float (*fa
         float m[kNx], L[kTri], s[GSE_NX];
         read_factor(fac[gl], m, L);
         sigma_point(m, L, j, s);
-        model_step(s, a.io.f[b].u0, a.io.f[b].u1, a.dt);
+        model_step(s, bio.u0, bio.u1, a.dt);
         float e[GSE_NX];
         if (kInjected) {
             const float* nz = noise + (g0 + gl) * kNs * kNx;
@@ -266,12 +277,14 @@ __global__ __launch_bounds__(kBankT * kGroup) void gsukf_predict_kernel(float* _
     auto src = [&](int t, const float*& m_, const float*& p_) { m_ = mu_b + t * kNx; p_ = P_b + t * kNxx; };
     auto dst = [&](int t, float*& m_, float*& p_) { m_ = mu_b + t * kNx; p_ = P_b + t * kNxx; };
     gsukf_predict_block<kInjected>(src, dst, fac, tile, nloc, b, g0, kInjected ? noise + (int64_t)b * N * kNs * kNx : nullptr,
-                                   dp, status, a);
+                                   dp, status, a, bank_inputs(a.io, a.u_dev, a.z_dev, b));
 }
 
 // ------------------------------------------------------------------------------------------------
 struct GsukfUpdateArgs {
     FilterIOs io;
+    const double* u_dev;
+    const double* z_dev;
     Pdf2 pdf;
     SigmaWeights sw;
 };
@@ -395,7 +408,7 @@ __device__ __forceinline__ void gsukf_update_gaussian(Eta eta, Dev dev, const fl
 template <class Src, class Dst, class Win, class Wout>
 __device__ __forceinline__ void gsukf_update_block(Src src, Dst dst, Win w_in, Wout w_out, float (*fac)[kFacStride],
                                                    float (*dev)[kTileStride], double (*eta)[kEtaStride], int nloc, int b,
-                                                   int32_t* status, const FilterIOs& io, const Pdf2& pdf,
+                                                   int32_t* status, const FilterIO& bio, const Pdf2& pdf,
                                                    const SigmaWeights& sw) {
     gsukf_factor_block(src, fac, nloc, status);
     // B. one sigma point per lane: outputs and deviations
@@ -405,7 +418,7 @@ __device__ __forceinline__ void gsukf_update_block(Src src, Dst dst, Win w_in, W
         read_factor(fac[gl], m, L);
         sigma_point(m, L, j, s);
         float y0, y1;
-        model_output(s, io.f[b].u0, io.f[b].u1, y0, y1);
+        model_output(s, bio.u0, bio.u1, y0, y1);
         eta[gl][j * 2 + 0] = (double)y0;
         eta[gl][j * 2 + 1] = (double)y1;
 #pragma unroll
@@ -422,7 +435,7 @@ __device__ __forceinline__ void gsukf_update_block(Src src, Dst dst, Win w_in, W
     float *mu_o, *P_o;
     dst(t, mu_o, P_o);
     gsukf_update_gaussian<false>([&](int q, int c) { return eta_g[q * 2 + c]; }, [&](int q, int k) { return dev_g[q * kNx + k]; },
-                                 fac[t], P_g, mu_o, P_o, w_in(t), w_out(t), io.f[b].u0, io.f[b].u1, io.f[b].z0, io.f[b].z1, pdf,
+                                 fac[t], P_g, mu_o, P_o, w_in(t), w_out(t), bio.u0, bio.u1, bio.z0, bio.z1, pdf,
                                  sw);
 }
 
@@ -443,7 +456,7 @@ __global__ __launch_bounds__(kBankT * kGroup) void gsukf_update_kernel(float* __
     auto src = [&](int t, const float*& m_, const float*& p_) { m_ = mu_b + t * kNx; p_ = P_b + t * kNxx; };
     auto dst = [&](int t, float*& m_, float*& p_) { m_ = mu_b + t * kNx; p_ = P_b + t * kNxx; };
     gsukf_update_block(src, dst, [&](int t) { return (const float*)(w_b + t); }, [&](int t) { return w_b + t; }, fac, dev, eta,
-                       nloc, b, status, a.io, a.pdf, a.sw);
+                       nloc, b, status, bank_inputs(a.io, a.u_dev, a.z_dev, b), a.pdf, a.sw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -491,7 +504,8 @@ __device__ __forceinline__ void stage_bank_out(const float* stage, float* mu_b, 
 // predict of ONE Gaussian held in `mine` (mu[kNx], P[kNx][kNx]); g: its index in the filter (random-number element)
 template <bool kInjected>
 __device__ __forceinline__ void gsukf_predict_lane(float* mine, int b, int64_t g, int64_t N, const float* noise,
-                                                   const DrawParams& dp, int32_t* status, const GsukfPredictArgs& a) {
+                                                   const DrawParams& dp, int32_t* status, const GsukfPredictArgs& a,
+                                                   const FilterIO& bio) {
     float m[kNx], L[kTri];
     bool ok;
     load_and_factor(mine, mine + kNx, m, L, ok);
@@ -501,7 +515,7 @@ __device__ __forceinline__ void gsukf_predict_lane(float* mine, int b, int64_t g
     for (int j = 0; j < kNs; ++j) {
         float s[GSE_NX], e[GSE_NX];
         sigma_point(m, L, j, s);
-        model_step(s, a.io.f[b].u0, a.io.f[b].u1, a.dt);
+        model_step(s, bio.u0, bio.u1, a.dt);
         if (kInjected) {
             const float* nz = noise + (((int64_t)b * N + g) * kNs + j) * kNx;
 #pragma unroll
@@ -570,7 +584,8 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
         for (int i = t; i < (int)(sizeof(DrawParams) / 4); i += kLaneBank) dst[i] = src[i];
     }
     stage_bank_in(stage, mu_b, P_b, nloc);
-    if (t < nloc) gsukf_predict_lane<kInjected>(stage + t * kStageStride, b, g0 + t, N, noise, dp, status, a);
+    const FilterIO bio = bank_inputs(a.io, a.u_dev, a.z_dev, b);
+    if (t < nloc) gsukf_predict_lane<kInjected>(stage + t * kStageStride, b, g0 + t, N, noise, dp, status, a, bio);
     stage_bank_out(stage, mu_b, P_b, nloc);
 }
 
@@ -585,9 +600,10 @@ __global__ __launch_bounds__(kLaneBank) void gsukf_update_lanes_kernel(float* __
     float* mu_b = mu + ((int64_t)b * N + g0) * kNx;
     float* P_b = P + ((int64_t)b * N + g0) * kNxx;
     stage_bank_in(stage, mu_b, P_b, nloc);
+    const FilterIO bio = bank_inputs(a.io, a.u_dev, a.z_dev, b);
     if (t < nloc)
-        gsukf_update_lane(stage + t * kStageStride, w + (int64_t)b * N + g0 + t, a.io.f[b].u0, a.io.f[b].u1, a.io.f[b].z0,
-                          a.io.f[b].z1, status, a.pdf, a.sw);
+        gsukf_update_lane(stage + t * kStageStride, w + (int64_t)b * N + g0 + t, bio.u0, bio.u1, bio.z0, bio.z1, status, a.pdf,
+                          a.sw);
     stage_bank_out(stage, mu_b, P_b, nloc);
 }
 
@@ -615,11 +631,11 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
         for (int i = t; i < (int)(sizeof(DrawParams) / 4); i += kLaneBank) dst[i] = src[i];
     }
     stage_bank_in(stage, mu_b, P_b, nloc);
+    const FilterIO bio = bank_inputs(a.pred.io, a.pred.u_dev, a.pred.z_dev, b);
     if (t < nloc) {
         float* mine = stage + t * kStageStride;
-        gsukf_predict_lane<kInjected>(mine, b, g0 + t, N, noise, dp, status, a.pred);
-        gsukf_update_lane(mine, w + (int64_t)b * N + g0 + t, a.pred.io.f[b].u0, a.pred.io.f[b].u1, a.pred.io.f[b].z0,
-                          a.pred.io.f[b].z1, status, a.pdf, a.pred.sw);
+        gsukf_predict_lane<kInjected>(mine, b, g0 + t, N, noise, dp, status, a.pred, bio);
+        gsukf_update_lane(mine, w + (int64_t)b * N + g0 + t, bio.u0, bio.u1, bio.z0, bio.z1, status, a.pdf, a.pred.sw);
     }
     stage_bank_out(stage, mu_b, P_b, nloc);
 }
@@ -670,12 +686,13 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_cycle_kernel(float* __restr
     auto from_lds = [&](int t, const float*& m_, const float*& p_) { m_ = mu_s[t]; p_ = P_s[t]; };
     auto to_lds = [&](int t, float*& m_, float*& p_) { m_ = mu_s[t]; p_ = P_s[t]; };
     // 1. predict: global -> LDS
+    const FilterIO bio = bank_inputs(a.pred.io, a.pred.u_dev, a.pred.z_dev, b);
     gsukf_predict_block<kInjected>(from_global, to_lds, fac, tile, N, b, 0,
-                                   kInjected ? noise + (int64_t)b * N * kNs * kNx : nullptr, dp, status, a.pred);
+                                   kInjected ? noise + (int64_t)b * N * kNs * kNx : nullptr, dp, status, a.pred, bio);
     __syncthreads();
     // 2. update in LDS; the weight goes global -> LDS
     gsukf_update_block(from_lds, to_lds, [&](int t) { return (const float*)(w_b + t); }, [&](int t) { return &w_s[t]; }, fac,
-                       tile, eta, N, b, status, a.pred.io, a.pdf, a.pred.sw);
+                       tile, eta, N, b, status, bio, a.pdf, a.pred.sw);
     __syncthreads();
     // 3. resample, one tile: thread t < 16 of wavefront 0 owns weights 4t..4t+3, exactly as cumsum_kernel does
     __shared__ double total_s;
@@ -728,7 +745,9 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_cycle_kernel(float* __restr
 // moments: one thread per Gaussian, blocks stride; 1 + kNx + 2 kTri fp64 sums (36 for 5 states): sum w, sum w d,
 // sum w d d^T (upper triangle) with d = mu - pivot, sum w P (upper triangle)
 constexpr int kGsukfMoments = 1 + kNx + 2 * kTri;
-template <int kUnused>
+// kFold: sum w P is added into sum w d d^T, which gives the first 1 + kNx + kTri sums the meaning they have for a particle
+// filter (gse_pf_moments): whoever consumes those -- the closed loop's controller kernel -- takes either estimator.
+template <int kFold>
 __global__ __launch_bounds__(kBlock) void gsukf_moments_kernel(const float* __restrict__ mu, const float* __restrict__ P,
                                                                const float* __restrict__ w,
                                                                double* __restrict__ partials, int64_t N) {
@@ -761,6 +780,10 @@ __global__ __launch_bounds__(kBlock) void gsukf_moments_kernel(const float* __re
         for (int k = 0; k < kNx; ++k)
 #pragma unroll
             for (int l = k; l < kNx; ++l) acc[c++] += wp * (double)Pb[g * kNxx + k * kNx + l];
+    }
+    if (kFold) {
+#pragma unroll
+        for (int i = 0; i < kTri; ++i) acc[1 + kNx + i] += acc[1 + kNx + kTri + i];
     }
     double* out = partials + ((int64_t)b * kMomentBlocks + blockIdx.x) * kMomentWidth;
     block_sums<kGsukfMoments>(acc, red, [&](int c, double total) { out[c] = total; });

@@ -138,6 +138,34 @@ class ParallelGaussianSumUnscentedKalmanFilter:
             a = numpy.concatenate([a, numpy.zeros((a.shape[0], _lib.GSE_NU - nu))], axis=1)
         return self._per_bank(a, _lib.GSE_NU)
 
+    def _io(self, u, z=None):
+        """(u argument, z argument, `where` flags) of a launch: host values packed for the C ABI, or -- torch tensors
+        (B, 2) float64 on the device -- their pointers, read when the kernel runs (a closed loop on the device)."""
+        where = 0
+        if torch.is_tensor(u):
+            u_arg, where = self._device_io(u, _lib.GSE_NU).data_ptr(), where | _lib.GSE_IO_U_DEVICE
+        else:
+            u_arg = self._inputs(u)
+        if z is None:
+            z_arg = None
+        elif torch.is_tensor(z):
+            z_arg, where = self._device_io(z, _lib.GSE_NY).data_ptr(), where | _lib.GSE_IO_Z_DEVICE
+        else:
+            z_arg = self._per_bank(z, _lib.GSE_NY)
+        if where and self._model is not None:
+            raise NotImplementedError("inputs in device memory are read by the built-in model's kernels only")
+        return u_arg, z_arg, where
+
+    def _device_io(self, t, width):
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == self._B * width):
+            raise ValueError("device inputs must be contiguous float64 CUDA tensors of shape (%d, %d)" % (self._B, width))
+        return t
+
+    @staticmethod
+    def _keep(v):
+        """What a deferred stage remembers of an argument: the tensor itself (read when the kernel runs) or a host copy."""
+        return v if torch.is_tensor(v) else numpy.array(v, dtype=numpy.float64)
+
     def _per_bank(self, values, width):
         """Host values for every bank as the C ABI takes them ([B][width] doubles; one row is broadcast to all banks)."""
         a = numpy.asarray(values, dtype=numpy.float64)
@@ -170,7 +198,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         """Prediction step (gs_ukf.py:348-367).  With at most 64 Gaussians the step is deferred so that resample() can
         run predict + update + resample as one launch (the bank is launch-latency-bound)."""
         if self.lazy and (self._fusable or self._fuse_pu) and self._pend_predict is None and self._pend_update is None:
-            self._pend_predict = (numpy.array(u, dtype=numpy.float64), float(dt))
+            self._pend_predict = (self._keep(u), float(dt))
             return
         self._flush()
         self._predict_now(u, dt)
@@ -186,14 +214,17 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     def _predict_now(self, u, dt):
         pod, rng, noise = self._draw_args()
+        u_arg, _, where = self._io(u)
+        if where:
+            return self._call("gse_gsukf_predict_dev", self._means.data_ptr(), self._covs.data_ptr(), self._B, self.N_particles,
+                              u_arg, float(dt), self._w_sigma_c, pod, rng, noise, self._status.data_ptr(), where, stream_ptr())
         self._call("gse_gsukf_predict", self._means.data_ptr(), self._covs.data_ptr(), self._B, self.N_particles,
-                  self._inputs(u), float(dt), self._w_sigma_c, pod, rng, noise, self._status.data_ptr(),
-                  stream_ptr())
+                   u_arg, float(dt), self._w_sigma_c, pod, rng, noise, self._status.data_ptr(), stream_ptr())
 
     def update(self, u, z):
         """Update step: local UKF update of every Gaussian, then the global weight update (gs_ukf.py:369-407)."""
         if self.lazy and self._fusable and self._pend_predict is not None and self._pend_update is None:
-            self._pend_update = (numpy.array(u, dtype=numpy.float64), numpy.array(z, dtype=numpy.float64))
+            self._pend_update = (self._keep(u), self._keep(z))
             return
         if self.lazy and self._fuse_pu and self._pend_predict is not None and self._pend_update is None:
             (up, dt), self._pend_predict = self._pend_predict, None
@@ -205,15 +236,20 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     def _predict_update_now(self, u, dt, z):
         """predict(u, dt) and update(., z) of a large bank in one launch (gse_gsukf_predict_update): same bits as the two."""
         pod, rng, noise = self._draw_args()
-        self._call("gse_gsukf_predict_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B,
-                  self.N_particles, self._inputs(u), float(dt), self._per_bank(z, _lib.GSE_NY),
-                  self._w_sigma_c, pod, rng, noise, ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(),
-                  stream_ptr())
+        u_arg, z_arg, where = self._io(u, z)
+        args = (self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B, self.N_particles, u_arg, float(dt),
+                z_arg, self._w_sigma_c, pod, rng, noise, ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr())
+        if where:
+            return self._call("gse_gsukf_predict_update_dev", *args, where, stream_ptr())
+        self._call("gse_gsukf_predict_update", *args, stream_ptr())
 
     def _update_now(self, u, z):
-        self._call("gse_gsukf_update", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B,
-                  self.N_particles, self._inputs(u), self._per_bank(z, _lib.GSE_NY), self._w_sigma_c,
-                  ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(), self._ws.data_ptr(), stream_ptr())
+        u_arg, z_arg, where = self._io(u, z)
+        args = (self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B, self.N_particles, u_arg, z_arg,
+                self._w_sigma_c, ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(), self._ws.data_ptr())
+        if where:
+            return self._call("gse_gsukf_update_dev", *args, where, stream_ptr())
+        self._call("gse_gsukf_update", *args, stream_ptr())
 
     def resample(self, r=None, return_index=False):
         """Systematic resample of the Gaussians based on their weights (gs_ukf.py:409-436)."""
@@ -225,10 +261,14 @@ class ParallelGaussianSumUnscentedKalmanFilter:
             (u, dt), (_, z) = self._pend_predict, self._pend_update
             self._pend_predict = self._pend_update = None
             pod, rng, noise = self._draw_args()
-            self._call("gse_gsukf_cycle", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
-                      idx.data_ptr() if return_index else None, B, n, self._inputs(u), dt,
-                      self._per_bank(z, _lib.GSE_NY), rr, self._w_sigma_c, pod, rng, noise,
-                      ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(), stream_ptr())
+            u_arg, z_arg, where = self._io(u, z)
+            args = (self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), idx.data_ptr() if return_index else None,
+                    B, n, u_arg, dt, z_arg, rr, self._w_sigma_c, pod, rng, noise, ctypes.byref(self.measurement_pdf._pod()),
+                    self._status.data_ptr())
+            if where:
+                self._call("gse_gsukf_cycle_dev", *args, where, stream_ptr())
+            else:
+                self._call("gse_gsukf_cycle", *args, stream_ptr())
         else:
             self._flush()
             self._call("gse_gsukf_resample", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
@@ -262,6 +302,15 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     def _moment_sums(self):
         return self._moment_sums_all()[0]
+
+    def _moments26_into(self, out):
+        """The moments in the particle filter's layout ([B, 26] device tensor; sum w P folded into the second moments): what the
+        closed loop on the device records per tick and hands to its controller kernel.  No synchronisation."""
+        if self._model is not None:
+            raise NotImplementedError("the 26-wide moment rows are laid out for the 5-state built-in model")
+        self._flush()
+        self._call("gse_gsukf_moments26", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B,
+                   self.N_particles, out.data_ptr(), self._ws.data_ptr(), stream_ptr())
 
     def point_estimate(self):
         """Returns the point estimate of the filter: weights @ means (gs_ukf.py:438-440)."""

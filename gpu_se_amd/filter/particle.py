@@ -391,6 +391,13 @@ class ParallelParticleFilter:
                    self._c_r, int(self._gather_slot), out.data_ptr(), self._ws.data_ptr(), stream_ptr(self._dev_index))
         return True
 
+    def _moments26_into(self, out):
+        """gse_pf_moments of the current ensemble into the device tensor ``out`` [B, 26]; no synchronisation (closed loop
+        on the device)."""
+        self._flush()
+        self._call("gse_pf_moments", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
+                   out.data_ptr(), self._ws.data_ptr(), stream_ptr(self._dev_index))
+
     def _raw_moments_all(self):
         s0, s1, s2, pv = self._raw_moments_arrays()
         return [(float(s0[b]), s1[b], s2[b], pv[b]) for b in range(self._B)]

@@ -228,9 +228,6 @@ class BatchedSimulation:
         self.resident = bool(resident)          # True: plant, controller and histories live on the device too
         if self.resident and controller is not None:
             raise ValueError("a resident loop runs the MPC on the device; host callables cannot replace it")
-        if self.resident and not pf:
-            raise NotImplementedError("the device-resident loop is written for the particle filter; the batched "
-                                      "Gaussian-sum filter runs with resident=False")
         self.ts = numpy.linspace(0, end_time, int(end_time * 10))
         self.dt = self.ts[1]
         self.dt_control, self.dt_predict = dt_control, dt_predict
@@ -243,6 +240,7 @@ class BatchedSimulation:
         self.f = batched(model.Bioreactor.homeostatic_DEs, model.Bioreactor.static_outputs, N_particles, x0, state_pdf,
                          measurement_pdf, batch=self.B)
         self.controller = controller
+        self.pf = bool(pf)
         self._rng = numpy.random.default_rng(seed)
         self.X = numpy.repeat(xss[None, :], self.B, axis=0)
         self.us = [numpy.repeat(_U_FALLBACK[None, :], self.B, axis=0)]
@@ -317,7 +315,8 @@ class BatchedSimulation:
         """The same loop with NOTHING on the host between ticks: the estimator takes its inputs and measurements from
         device memory (GSE_OP_U_DEVICE / GSE_OP_Z_DEVICE), the plant (gse_plant_step) and the controller
         (gse_loop_control) are kernels, and every per-tick record goes into device arrays that are read once, at the
-        end.  The host only enqueues -- per tick: plant + moments, and on control ticks update / resample / controller --
+        end.  Either estimator: the particle filter, or -- pf=False -- the batch of Gaussian-sum filters (one launch per
+        control tick for banks of at most 64 Gaussians, gse_gsukf_cycle_dev).  The host only enqueues -- per tick: plant + moments, and on control ticks update / resample / controller --
         and never waits.  The plant's noise comes from Philox streams of its own here (the host loop uses NumPy's); the
         bias log ``biass`` of the single-rollout class is not kept."""
         import ctypes
@@ -326,7 +325,7 @@ class BatchedSimulation:
         import gpu_se_amd
         lib = _lib.load()
         f, K, B = self.f, self.K, self.B
-        dev = f._x.device
+        dev = f._w.device
         ticks = len(self.ts)
         f64 = dict(dtype=torch.float64, device=dev)
         X = torch.as_tensor(self.X, **f64).contiguous()
@@ -353,9 +352,7 @@ class BatchedSimulation:
         stream = torch.cuda.current_stream().cuda_stream
 
         def record_moments(t):
-            f._flush()
-            _lib.check(lib.gse_pf_moments(f._x.data_ptr(), f._w.data_ptr(), f._ld, B, f.N_particles, moments[t].data_ptr(),
-                                          f._ws.data_ptr(), stream))
+            f._moments26_into(moments[t])          # (either estimator: 26 doubles per rollout, the particle filter's layout)
 
         import time
         record_moments(0)
@@ -374,7 +371,7 @@ class BatchedSimulation:
                 # the estimate the controller acts on, and this tick's record: the moments of the resampled ensemble taken
                 # from the weighted one (offspring counts), so that the resample's copy is deferred into the next tick's
                 # single launch (gather + predict + update); where that does not apply, resample now and take them after
-                if not f._resampled_moments_into(moments[t]):
+                if not (self.pf and f._resampled_moments_into(moments[t])):
                     record_moments(t)
                 K.loop_control(moments[t], ys_meas[t - 1], u, (y_pred, known, status[t]), _U_FALLBACK)
                 n_control += 1

@@ -232,6 +232,31 @@ int gse_gsukf_resample(const float *mu_in, const float *P_in, const float *w, fl
 int gse_gsukf_moments(const float *mu, const float *P, const float *w, int B, int64_t N, double *out,
                       void *workspace, void *stream);
 
+/* Inputs and measurements in DEVICE memory: `where` says which of u, z are device pointers [B][2] fp64 that the kernel
+ * reads when it runs (a closed loop whose controller and plant are kernels never brings them to the host: the counterpart
+ * of GSE_OP_U_DEVICE / GSE_OP_Z_DEVICE of gse_pf_step).  Otherwise as the calls without `_dev`. */
+#define GSE_IO_U_DEVICE 1u
+#define GSE_IO_Z_DEVICE 2u
+int gse_gsukf_predict_dev(float *mu, float *P, int B, int64_t N, const double *u, double dt, const float *w_sigma,
+                          const gse_mixture *state_pdf, const gse_rng *rng, const float *noise, int32_t *status,
+                          uint32_t where, void *stream);
+int gse_gsukf_update_dev(float *mu, float *P, float *w, int B, int64_t N, const double *u, const double *z,
+                         const float *w_sigma, const gse_mixture *measurement_pdf, int32_t *status, void *workspace,
+                         uint32_t where, void *stream);
+int gse_gsukf_predict_update_dev(float *mu, float *P, float *w, int B, int64_t N, const double *u, double dt,
+                                 const double *z, const float *w_sigma, const gse_mixture *state_pdf,
+                                 const gse_rng *rng, const float *noise, const gse_mixture *measurement_pdf,
+                                 int32_t *status, uint32_t where, void *stream);
+int gse_gsukf_cycle_dev(float *mu, float *P, float *w, int32_t *idx, int B, int64_t N, const double *u, double dt,
+                        const double *z, const double *r, const float *w_sigma, const gse_mixture *state_pdf,
+                        const gse_rng *rng, const float *noise, const gse_mixture *measurement_pdf, int32_t *status,
+                        uint32_t where, void *stream);
+/* gse_gsukf_moments in the particle filter's layout -- rows of 26 doubles { S0, S1[5], S2[15] + C[15], p[5] }, so that
+ * S2 - S1 e^T - e S1^T + S0 e e^T is the whole covariance (filter/gs_ukf.py:442-449): what gse_loop_control and the host
+ * post-processing of a closed loop (sim_base.py:243-309) take from either estimator. */
+int gse_gsukf_moments26(const float *mu, const float *P, const float *w, int B, int64_t N, double *out,
+                        void *workspace, void *stream);
+
 /* The GS-UKF for a user model compiled at run time (filter/gs_ukf.py:243-275 lets Numba JIT any f / g): the calls above
  * with the handle of gse_model_create in front.  Shapes follow the model's number of states nx (1..5): mu [B][N][nx],
  * P [B][N][nx][nx], sigma points and injected noise [B][N][2 nx + 1][nx], w_sigma host [2 nx + 1]; the moments row is

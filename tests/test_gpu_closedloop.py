@@ -103,8 +103,29 @@ def test_closed_loops_with_the_gaussian_sum_filter():
     err = np.abs(sim.ys_f[5:] - sim.ys[4:-1][:, :, [0, 2]])
     assert np.median(err[..., 0]) < 0.6 and np.median(err[..., 1]) < 0.8
     assert len(np.unique(np.round(sim.performance, 6))) == 4                      # independent rollouts
-    with pytest.raises(NotImplementedError):
-        sim_base.BatchedSimulation(batch=2, N_particles=64, dt_control=0.1, dt_predict=0.1, pf=False, resident=True)
+
+
+@pytest.mark.parametrize("n", [64, 200])
+def test_resident_loop_with_the_gaussian_sum_filter(n):
+    """pf=False, resident=True: the whole loop on the device with the batch of GS-UKFs as the estimator -- inputs and
+    measurements read from device memory (gse_gsukf_cycle_dev for 64 Gaussians, the separate _dev calls for 200), the
+    moments in the particle filter's layout for the controller kernel.  Against the host loop: same statistics."""
+    gpu_se_amd.seed(6)
+    dev = sim_base.BatchedSimulation(batch=8, N_particles=n, dt_control=0.1, dt_predict=0.1, end_time=5, pf=False, seed=3,
+                                     resident=True)
+    dev.simulate()
+    gpu_se_amd.seed(6)
+    host = sim_base.BatchedSimulation(batch=8, N_particles=n, dt_control=0.1, dt_predict=0.1, end_time=5, pf=False, seed=3)
+    host.simulate()
+    steps = len(dev.ts)
+    assert dev.xs.shape == (steps, 8, 5) and dev.ys_f.shape == (steps, 8, 2) and dev.us.shape == (steps, 8, 2)
+    assert np.all(np.isfinite(dev.performance)) and dev.mpc_frac > 0.9
+    for sim in (dev, host):
+        err = np.abs(sim.ys_f[5:] - sim.ys[4:-1][:, :, [0, 2]])
+        assert np.median(err[..., 0]) < 0.6 and np.median(err[..., 1]) < 0.8
+    # the estimate recorded on the device is the filter's own (host formulas on the moments the kernels left)
+    assert np.all(np.isfinite(dev.covariance_point_size)) and np.all(dev.covariance_point_size > 0)
+    assert abs(np.median(dev.performance) / np.median(host.performance) - 1) < 0.5
 
 
 # ------------------------------------------------------------------------------ sharded filter across two ranks
