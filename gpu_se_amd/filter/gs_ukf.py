@@ -77,6 +77,10 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._pend_update = None
         self._fusable = n <= _lib.GSE_GSUKF_CYCLE_MAX
         self._fuse_pu = B * n >= _lib.GSE_GSUKF_LANES_MIN  # large banks: predict() is deferred and rides update()'s launch
+        # persistent argument buffers: a call only rewrites a few doubles (keeps the host side of a launch short)
+        self._c_u = (_lib.c_d * (_lib.GSE_NU * B))()
+        self._c_z = (_lib.c_d * (_lib.GSE_NY * B))()
+        self._c_r = (_lib.c_d * B)()
 
         self._threads_per_block = self._tpb = 1024
         self._blocks_per_grid = self._bpg = (n - 1) // 1024 + 1
@@ -131,12 +135,12 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     def _inputs(self, u):
         """Inputs as the kernels take them: two per bank (a user model with one input gets a zero for the other)."""
-        a = numpy.asarray(u, dtype=numpy.float64)
         nu = self._model.nu if self._model is not None else _lib.GSE_NU
-        a = a.reshape(-1, nu)
-        if nu < _lib.GSE_NU:
-            a = numpy.concatenate([a, numpy.zeros((a.shape[0], _lib.GSE_NU - nu))], axis=1)
-        return self._per_bank(a, _lib.GSE_NU)
+        if nu == _lib.GSE_NU:
+            return self._per_bank(u, _lib.GSE_NU, self._c_u)
+        a = numpy.asarray(u, dtype=numpy.float64).reshape(-1, nu)
+        a = numpy.concatenate([a, numpy.zeros((a.shape[0], _lib.GSE_NU - nu))], axis=1)
+        return self._per_bank(a, _lib.GSE_NU, self._c_u)
 
     def _io(self, u, z=None):
         """(u argument, z argument, `where` flags) of a launch: host values packed for the C ABI, or -- torch tensors
@@ -151,7 +155,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         elif torch.is_tensor(z):
             z_arg, where = self._device_io(z, _lib.GSE_NY).data_ptr(), where | _lib.GSE_IO_Z_DEVICE
         else:
-            z_arg = self._per_bank(z, _lib.GSE_NY)
+            z_arg = self._per_bank(z, _lib.GSE_NY, self._c_z)
         if where and self._model is not None:
             raise NotImplementedError("inputs in device memory are read by the built-in model's kernels only")
         return u_arg, z_arg, where
@@ -161,16 +165,26 @@ class ParallelGaussianSumUnscentedKalmanFilter:
             raise ValueError("device inputs must be contiguous float64 CUDA tensors of shape (%d, %d)" % (self._B, width))
         return t
 
-    @staticmethod
-    def _keep(v):
+    def _keep(self, v):
         """What a deferred stage remembers of an argument: the tensor itself (read when the kernel runs) or a host copy."""
-        return v if torch.is_tensor(v) else numpy.array(v, dtype=numpy.float64)
+        if torch.is_tensor(v):
+            return v
+        return [float(x) for x in v] if self._B == 1 else numpy.array(v, dtype=numpy.float64)
 
-    def _per_bank(self, values, width):
-        """Host values for every bank as the C ABI takes them ([B][width] doubles; one row is broadcast to all banks)."""
-        a = numpy.asarray(values, dtype=numpy.float64)
-        a = numpy.broadcast_to(a.reshape(-1, width), (self._B, width))
-        return _lib.doubles(a.ravel(), self._B * width)
+    def _per_bank(self, values, width, buf=None):
+        """Host values for every bank as the C ABI takes them ([B][width] doubles; one row is broadcast to all banks), written
+        into the persistent buffer ``buf`` (a launch copies them into its kernel arguments before it returns)."""
+        B = self._B
+        if buf is None:
+            buf = (_lib.c_d * (B * width))()
+        if B == 1 and len(values) == width:               # the plain class: two scalars, no array round trip
+            for i in range(width):
+                buf[i] = values[i]
+            return buf
+        a = numpy.broadcast_to(numpy.asarray(values, dtype=numpy.float64).reshape(-1, width), (B, width)).ravel()
+        for i in range(B * width):
+            buf[i] = a[i]
+        return buf
 
     def _noise_rows(self):
         """Replayed noise of a DeterministicGaussianSum for every sigma point of every bank."""
@@ -254,7 +268,11 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     def resample(self, r=None, return_index=False):
         """Systematic resample of the Gaussians based on their weights (gs_ukf.py:409-436)."""
         n, B = self.N_particles, self._B
-        rr = self._per_bank(self._host_rng.random(B) if r is None else r, 1)
+        if B == 1:
+            self._c_r[0] = self._host_rng.random() if r is None else r
+            rr = self._c_r
+        else:
+            rr = self._per_bank(self._host_rng.random(B) if r is None else r, 1, self._c_r)
         idx = torch.empty((B, n), dtype=torch.int32, device=self._w.device) if return_index else None
         if self._pend_predict is not None and self._pend_update is not None:
             # the whole cycle in one launch, one workgroup per bank (gse_gsukf_cycle); in place
