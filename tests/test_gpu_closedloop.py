@@ -105,6 +105,19 @@ def test_closed_loops_with_the_gaussian_sum_filter():
     assert len(np.unique(np.round(sim.performance, 6))) == 4                      # independent rollouts
 
 
+def test_resident_loop_with_large_banks_of_gaussians():
+    """B x N >= 2^16 Gaussians: predict + update of a tick are ONE launch reading u and z from device memory
+    (gse_gsukf_predict_update_dev); the loop stays on the device and the estimate follows the plant."""
+    gpu_se_amd.seed(8)
+    sim = sim_base.BatchedSimulation(batch=2, N_particles=1 << 15, dt_control=0.1, dt_predict=0.1, end_time=3, pf=False, seed=5,
+                                     resident=True)
+    assert sim.f._fuse_pu
+    sim.simulate()
+    err = np.abs(sim.ys_f[5:] - sim.ys[4:-1][:, :, [0, 2]])
+    assert np.median(err[..., 0]) < 0.6 and np.median(err[..., 1]) < 0.8
+    assert np.all(np.isfinite(sim.performance)) and sim.mpc_frac > 0.9
+
+
 @pytest.mark.parametrize("n", [64, 200])
 def test_resident_loop_with_the_gaussian_sum_filter(n):
     """pf=False, resident=True: the whole loop on the device with the batch of GS-UKFs as the estimator -- inputs and
