@@ -91,6 +91,13 @@ PROTOTYPES = {
                                                     P_MIX, c_vp, c_u32, c_vp]),
     "gse_gsukf_cycle_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d, c_vp, P_D, P_F, P_MIX, P_RNG,
                                            c_vp, P_MIX, c_vp, c_u32, c_vp]),
+    "gse_gsukf_resample_begin": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_vp, c_vp]),
+    "gse_gsukf_gather_rows": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp]),
+    "gse_gsukf_predict_update_from": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d, c_vp, P_F,
+                                                     P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_u32, c_vp]),
+    "gse_gsukf_gather_rows_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp]),
+    "gse_gsukf_predict_update_from_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d,
+                                                           c_vp, P_F, P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_u32, c_vp]),
     "gse_gsukf_moments26": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
     "gse_gsukf_sigma_points_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
     "gse_gsukf_predict_model": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_F, P_MIX, P_RNG, c_vp, c_vp, c_vp]),

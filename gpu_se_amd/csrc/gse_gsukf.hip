@@ -131,12 +131,12 @@ static int gsukf_update(UserModel* model, float* mu, float* P, float* w, int B, 
     if (int rc = check_gsukf("gse_gsukf_update", B, N)) return rc;
     GSE_REQUIRE(mu && P && w && u && z && w_sigma && measurement_pdf, "gse_gsukf_update: null argument");
     if (int rc = check_mixture("gse_gsukf_update", measurement_pdf, GSE_NY)) return rc;
-    (void)workspace;
     GsukfUpdateArgs a;
     pack_bank_io(a.io, a.u_dev, a.z_dev, B, u, z, where);
     pack_pdf2(a.pdf, *measurement_pdf);
     pack_sigma_weights(a.sw, w_sigma, 2 * states_of(model) + 1);
     hipStream_t st = (hipStream_t)stream;
+    (void)workspace;
     if (lane_per_gaussian(B, N))
         return launch(model, "gse::gsukf_update_lanes_kernel<0>", gsukf_update_lanes_kernel<0>,
                       dim3((unsigned)((N + kLaneBank - 1) / kLaneBank), B), dim3(kLaneBank), st, mu, P, w, N, status, a);
@@ -147,9 +147,13 @@ static int gsukf_update(UserModel* model, float* mu, float* P, float* w, int B, 
 static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w, int B, int64_t N, const double* u, double dt,
                                 const double* z, const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng,
                                 const float* noise, const gse_mixture* measurement_pdf, int32_t* status, void* stream,
-                                uint32_t where = 0) {
+                                uint32_t where = 0, const float* mu_in = nullptr, const float* P_in = nullptr,
+                                const int32_t* anc = nullptr) {
     if (int rc = check_gsukf("gse_gsukf_predict_update", B, N)) return rc;
     GSE_REQUIRE(mu && P && w && u && z && w_sigma && measurement_pdf, "gse_gsukf_predict_update: null argument");
+    GSE_REQUIRE(!anc || (mu_in && P_in && mu_in != mu && P_in != P),
+                "gse_gsukf_predict_update_from: with ancestors the source arrays must be given and differ from the outputs");
+    if (!anc) { mu_in = mu; P_in = P; }
     GSE_REQUIRE(noise || (state_pdf && rng), "gse_gsukf_predict_update: need either noise or (state_pdf, rng)");
     if (int rc = check_mixture("gse_gsukf_predict_update", measurement_pdf, GSE_NY)) return rc;
     const int nx = states_of(model);
@@ -164,14 +168,14 @@ static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w,
         a.pred.draw = DrawParams{};
         a.pred.rng = RngKey{};
         return launch(model, "gse::gsukf_predict_update_lanes_kernel<true>", gsukf_predict_update_lanes_kernel<true>, grid, block, st,
-                      mu, P, w, noise, N, status, a);
+                      mu, P, w, noise, N, status, mu_in, P_in, anc, a);
     }
     if (int rc = check_mixture("gse_gsukf_predict_update", state_pdf, nx)) return rc;
     pack_draw(a.pred.draw, *state_pdf);
     a.pred.rng = make_rng_key(*rng, kPurposeGsukf);
     const float* none = nullptr;
     return launch(model, "gse::gsukf_predict_update_lanes_kernel<false>", gsukf_predict_update_lanes_kernel<false>, grid, block, st,
-                  mu, P, w, none, N, status, a);
+                  mu, P, w, none, N, status, mu_in, P_in, anc, a);
 }
 
 static int gsukf_cycle(UserModel* model, float* mu, float* P, float* w, int32_t* idx, int B, int64_t N, const double* u,
@@ -227,6 +231,33 @@ static int gsukf_resample(UserModel* model, const float* mu_in, const float* P_i
     if (int rc = launch_cumsum(w, N, B, N, flags & ~GSE_RESAMPLE_TILES_VALID, nullptr, ws, ws.cumsum, st)) return rc;
     GsukfPayload pl{mu_in, P_in, mu_out, P_out, N};
     return launch_gsukf_gather(pl, w_out, idx, B, N, ra, ws, st, model);
+}
+
+// The first half of a resample: cumulative weights and ANCESTORS (idx), weights reset to 1 / N -- no row is copied; the copy
+// rides the next gse_gsukf_predict_update_from, or gse_gsukf_gather_rows does it on its own.
+static int gsukf_resample_begin(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const double* r, void* workspace,
+                                void* stream) {
+    if (int rc = check_gsukf("gse_gsukf_resample_begin", B, N)) return rc;
+    GSE_REQUIRE(w && w_out && idx && r && workspace && w != w_out, "gse_gsukf_resample_begin: null or aliasing argument");
+    ResampleArgs ra;
+    for (int b = 0; b < B; ++b) {
+        GSE_REQUIRE(r[b] >= 0.0 && r[b] < 1.0, "gse_gsukf_resample_begin: r[%d] = %g is outside [0, 1)", b, r[b]);
+        ra.r[b] = r[b];
+    }
+    Workspace ws = carve_workspace(workspace, B, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = launch_cumsum(w, N, B, N, 0, nullptr, ws, ws.cumsum, st)) return rc;
+    return launch_index_gather(w_out, idx, B, N, ra, ws, st);
+}
+
+static int gsukf_gather_rows(UserModel* model, const float* mu_in, const float* P_in, const int32_t* idx, float* mu_out,
+                             float* P_out, int B, int64_t N, void* stream) {
+    if (int rc = check_gsukf("gse_gsukf_gather_rows", B, N)) return rc;
+    GSE_REQUIRE(mu_in && P_in && idx && mu_out && P_out && mu_in != mu_out && P_in != P_out,
+                "gse_gsukf_gather_rows: null or aliasing argument");
+    return launch(model, "gse::gsukf_gather_rows_kernel<0>", gsukf_gather_rows_kernel<0>,
+                  dim3((unsigned)((N + kLaneBank - 1) / kLaneBank), B), dim3(kLaneBank), (hipStream_t)stream, mu_in, P_in, idx, mu_out,
+                  P_out, N);
 }
 
 static int gsukf_moments(UserModel* model, const float* mu, const float* P, const float* w, int B, int64_t N, double* out,
@@ -315,6 +346,22 @@ int gse_gsukf_cycle_dev(float* mu, float* P, float* w, int32_t* idx, int B, int6
     return gsukf_cycle(nullptr, mu, P, w, idx, B, N, u, dt, z, r, w_sigma, state_pdf, rng, noise, measurement_pdf, status, stream,
                        where);
 }
+// ---- a resample whose copy is deferred (large banks): ancestors now, rows with the next predict + update
+int gse_gsukf_resample_begin(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const double* r, void* workspace,
+                             void* stream) {
+    return gsukf_resample_begin(w, w_out, idx, B, N, r, workspace, stream);
+}
+int gse_gsukf_gather_rows(const float* mu_in, const float* P_in, const int32_t* idx, float* mu_out, float* P_out, int B, int64_t N,
+                          void* stream) {
+    return gsukf_gather_rows(nullptr, mu_in, P_in, idx, mu_out, P_out, B, N, stream);
+}
+int gse_gsukf_predict_update_from(const float* mu_in, const float* P_in, const int32_t* idx, float* mu, float* P, float* w, int B,
+                                  int64_t N, const double* u, double dt, const double* z, const float* w_sigma,
+                                  const gse_mixture* state_pdf, const gse_rng* rng, const float* noise,
+                                  const gse_mixture* measurement_pdf, int32_t* status, uint32_t where, void* stream) {
+    return gsukf_predict_update(nullptr, mu, P, w, B, N, u, dt, z, w_sigma, state_pdf, rng, noise, measurement_pdf, status, stream,
+                                where, mu_in, P_in, idx);
+}
 // gse_gsukf_moments in the particle filter's layout (rows of 26 doubles: S0, S1[5], S2[15] + C[15], pivot[5]): what
 // gse_loop_control and the host post-processing of a closed loop take from either estimator
 int gse_gsukf_moments26(const float* mu, const float* P, const float* w, int B, int64_t N, double* out, void* workspace,
@@ -363,6 +410,21 @@ int gse_gsukf_resample_model(void* model, const float* mu_in, const float* P_in,
                              void* stream) {
     GSE_MODEL_ARG(model);
     return gsukf_resample(m_, mu_in, P_in, w, mu_out, P_out, w_out, idx, B, N, r, flags, workspace, stream);
+}
+int gse_gsukf_gather_rows_model(void* model, const float* mu_in, const float* P_in, const int32_t* idx, float* mu_out, float* P_out,
+                                int B, int64_t N, void* stream) {
+    GSE_MODEL_ARG(model);
+    return gsukf_gather_rows(m_, mu_in, P_in, idx, mu_out, P_out, B, N, stream);
+}
+int gse_gsukf_predict_update_from_model(void* model, const float* mu_in, const float* P_in, const int32_t* idx, float* mu, float* P,
+                                        float* w, int B, int64_t N, const double* u, double dt, const double* z,
+                                        const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng,
+                                        const float* noise, const gse_mixture* measurement_pdf, int32_t* status, uint32_t where,
+                                        void* stream) {
+    GSE_MODEL_ARG(model);
+    GSE_REQUIRE(where == 0, "gse_gsukf_predict_update_from_model: inputs in device memory are read by the built-in model only");
+    return gsukf_predict_update(m_, mu, P, w, B, N, u, dt, z, w_sigma, state_pdf, rng, noise, measurement_pdf, status, stream, 0,
+                                mu_in, P_in, idx);
 }
 int gse_gsukf_moments_model(void* model, const float* mu, const float* P, const float* w, int B, int64_t N, double* out,
                             void* workspace, void* stream) {

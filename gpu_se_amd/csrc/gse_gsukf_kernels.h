@@ -483,6 +483,22 @@ __device__ __forceinline__ void stage_bank_in(float* stage, const float* mu_b, c
     }
     __syncthreads();
 }
+// The same with the rows of the bank's ANCESTORS (a resample whose copy was deferred into this launch): local Gaussian g is
+// the row anc[g] of the filter's arrays mu_f / P_f; a row's 30 floats are still read by consecutive threads.
+__device__ __forceinline__ void stage_bank_in_gathered(float* stage, int* anc_s, const float* mu_f, const float* P_f,
+                                                       const int32_t* anc, int nloc) {
+    for (int g = threadIdx.x; g < nloc; g += kLaneBank) anc_s[g] = anc[g];
+    __syncthreads();
+    for (int i = threadIdx.x; i < nloc * kNx; i += kLaneBank) {
+        const int g = i / kNx;
+        stage[g * kStageStride + (i - g * kNx)] = mu_f[(int64_t)anc_s[g] * kNx + (i - g * kNx)];
+    }
+    for (int i = threadIdx.x; i < nloc * kNxx; i += kLaneBank) {
+        const int g = i / kNxx;
+        stage[g * kStageStride + kNx + (i - g * kNxx)] = P_f[(int64_t)anc_s[g] * kNxx + (i - g * kNxx)];
+    }
+    __syncthreads();
+}
 __device__ __forceinline__ void stage_bank_out(const float* stage, float* mu_b, float* P_b, int nloc) {
     __syncthreads();
     for (int i = threadIdx.x; i < nloc * kNx; i += kLaneBank) {
@@ -614,12 +630,16 @@ struct GsukfPredictUpdateArgs {
     GsukfPredictArgs pred;      // (its io carries u and z)
     Pdf2 pdf;
 };
+// anc != null: the bank's rows are first gathered from mu_in / P_in (the ancestors of a resample that left its copy to this
+// launch -- gse_gsukf_resample_begin) and the results go to mu / P, which must then be other arrays; anc == null: in place.
 template <bool kInjected>
 __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict_update_lanes_kernel(
     float* __restrict__ mu, float* __restrict__ P, float* __restrict__ w, const float* __restrict__ noise, int64_t N,
-    int32_t* __restrict__ status, const GsukfPredictUpdateArgs a) {
+    int32_t* __restrict__ status, const float* __restrict__ mu_in, const float* __restrict__ P_in,
+    const int32_t* __restrict__ anc, const GsukfPredictUpdateArgs a) {
     __shared__ DrawParams dp;
     __shared__ float stage[kLaneBank * kStageStride];
+    __shared__ int anc_s[kLaneBank];
     const int t = threadIdx.x, b = blockIdx.y;
     const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
     const int nloc = (int)min((int64_t)kLaneBank, N - g0);
@@ -630,7 +650,11 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
         uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
         for (int i = t; i < (int)(sizeof(DrawParams) / 4); i += kLaneBank) dst[i] = src[i];
     }
-    stage_bank_in(stage, mu_b, P_b, nloc);
+    if (anc)
+        stage_bank_in_gathered(stage, anc_s, mu_in + (int64_t)b * N * kNx, P_in + (int64_t)b * N * kNxx,
+                               anc + (int64_t)b * N + g0, nloc);
+    else
+        stage_bank_in(stage, mu_b, P_b, nloc);
     const FilterIO bio = bank_inputs(a.pred.io, a.pred.u_dev, a.pred.z_dev, b);
     if (t < nloc) {
         float* mine = stage + t * kStageStride;
@@ -638,6 +662,21 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
         gsukf_update_lane(mine, w + (int64_t)b * N + g0 + t, bio.u0, bio.u1, bio.z0, bio.z1, status, a.pdf, a.pred.sw);
     }
     stage_bank_out(stage, mu_b, P_b, nloc);
+}
+
+// The copy of a deferred resample on its own (an accessor looks at the bank before the next predict + update): rows by index.
+template <int kUnused>
+__global__ __launch_bounds__(kLaneBank) void gsukf_gather_rows_kernel(const float* __restrict__ mu_in, const float* __restrict__ P_in,
+                                                                      const int32_t* __restrict__ anc, float* __restrict__ mu,
+                                                                      float* __restrict__ P, int64_t N) {
+    __shared__ float stage[kLaneBank * kStageStride];
+    __shared__ int anc_s[kLaneBank];
+    const int b = blockIdx.y;
+    const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
+    const int nloc = (int)min((int64_t)kLaneBank, N - g0);
+    stage_bank_in_gathered(stage, anc_s, mu_in + (int64_t)b * N * kNx, P_in + (int64_t)b * N * kNxx, anc + (int64_t)b * N + g0,
+                           nloc);
+    stage_bank_out(stage, mu + ((int64_t)b * N + g0) * kNx, P + ((int64_t)b * N + g0) * kNxx, nloc);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -128,12 +128,18 @@ struct GsukfPayload {                 // row-major (mu[nx], P[nx][nx]) per Gauss
     }
 };
 
+struct NoPayload {                    // the ancestors only (idx_out of gather_kernel): a resample whose copy is deferred
+    __device__ __forceinline__ void copy(int, int64_t, int64_t) const {}
+};
+
 #ifndef __HIPCC_RTC__
 int launch_cumsum(const float* w, int64_t ldw, int B, int64_t N, uint32_t flags, double* island, const Workspace& ws,
                   double* c_out, hipStream_t st);
 struct UserModel;
 int launch_gsukf_gather(const GsukfPayload& pl, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra,
                         const Workspace& ws, hipStream_t st, UserModel* model = nullptr);
+int launch_index_gather(float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, const Workspace& ws,
+                        hipStream_t st);
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
                            const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, int pivot_count, hipStream_t st);
 

@@ -43,6 +43,15 @@ int launch_gsukf_gather(const GsukfPayload& pl, float* w_out, int32_t* idx, int 
     return GSE_OK;
 }
 
+int launch_index_gather(float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, const Workspace& ws,
+                        hipStream_t st) {
+    const int64_t zero = 0;
+    hipLaunchKernelGGL(gather_kernel<NoPayload>, dim3((unsigned)tiles_of(N), B), dim3(kBlock), 0, st, NoPayload{}, ws.cumsum,
+                       ws.totals, w_out, idx, N, N, ra, zero, N, N);
+    GSE_LAUNCH_CHECK("gather_kernel<index only>");
+    return GSE_OK;
+}
+
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
                            const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, int pivot_count, hipStream_t st) {
     hipLaunchKernelGGL(moments_finish_kernel, dim3(B), dim3(64 * kFinishGroups), 0, st, partials, nblk, width, out,

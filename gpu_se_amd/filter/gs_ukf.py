@@ -75,6 +75,8 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self.lazy = True
         self._pend_predict = None
         self._pend_update = None
+        self._pend_gather = None                      # ancestors [B, N] int32 of a resample whose row copy is still to come
+        self._idx_buf = None
         self._fusable = n <= _lib.GSE_GSUKF_CYCLE_MAX
         self._fuse_pu = B * n >= _lib.GSE_GSUKF_LANES_MIN  # large banks: predict() is deferred and rides update()'s launch
         # persistent argument buffers: a call only rewrites a few doubles (keeps the host side of a launch short)
@@ -93,7 +95,13 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     # ------------------------------------------------------------------ attributes
     def _flush(self):
-        """Run whatever predict / update is pending with the one-kernel-per-method calls."""
+        """Run whatever is pending with the one-kernel-per-method calls: the row copy of a deferred resample, predict, update."""
+        if self._pend_gather is not None:
+            idx, self._pend_gather = self._pend_gather, None
+            self._call("gse_gsukf_gather_rows", self._means.data_ptr(), self._covs.data_ptr(), idx.data_ptr(),
+                       self._means_alt.data_ptr(), self._covs_alt.data_ptr(), self._B, self.N_particles, stream_ptr())
+            self._means, self._means_alt = self._means_alt, self._means
+            self._covs, self._covs_alt = self._covs_alt, self._covs
         if self._pend_predict is not None:
             u, dt = self._pend_predict
             self._pend_predict = None
@@ -251,11 +259,17 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         """predict(u, dt) and update(., z) of a large bank in one launch (gse_gsukf_predict_update): same bits as the two."""
         pod, rng, noise = self._draw_args()
         u_arg, z_arg, where = self._io(u, z)
-        args = (self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(), self._B, self.N_particles, u_arg, float(dt),
-                z_arg, self._w_sigma_c, pod, rng, noise, ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr())
-        if where:
-            return self._call("gse_gsukf_predict_update_dev", *args, where, stream_ptr())
-        self._call("gse_gsukf_predict_update", *args, stream_ptr())
+        # ... and, if a resample left it to this launch, its row copy: every Gaussian is read from its ancestor's row, the
+        # results go to the other pair of arrays.
+        idx, self._pend_gather = self._pend_gather, None
+        out_m, out_c = (self._means_alt, self._covs_alt) if idx is not None else (self._means, self._covs)
+        self._call("gse_gsukf_predict_update_from", self._means.data_ptr(), self._covs.data_ptr(),
+                   idx.data_ptr() if idx is not None else None, out_m.data_ptr(), out_c.data_ptr(), self._w.data_ptr(), self._B,
+                   self.N_particles, u_arg, float(dt), z_arg, self._w_sigma_c, pod, rng, noise,
+                   ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(), where, stream_ptr())
+        if idx is not None:
+            self._means, self._means_alt = self._means_alt, self._means
+            self._covs, self._covs_alt = self._covs_alt, self._covs
 
     def _update_now(self, u, z):
         u_arg, z_arg, where = self._io(u, z)
@@ -287,6 +301,17 @@ class ParallelGaussianSumUnscentedKalmanFilter:
                 self._call("gse_gsukf_cycle_dev", *args, where, stream_ptr())
             else:
                 self._call("gse_gsukf_cycle", *args, stream_ptr())
+        elif self.lazy and self._fuse_pu and self._pend_predict is None and self._pend_update is None:
+            # large banks: ancestors and weights now, the rows with the next predict + update (one launch, _predict_update_now)
+            self._flush()
+            if idx is None:                          # (a buffer of the filter's own unless the caller keeps the ancestors)
+                if self._idx_buf is None:
+                    self._idx_buf = torch.empty((B, n), dtype=torch.int32, device=self._w.device)
+                idx = self._idx_buf
+            self._call("gse_gsukf_resample_begin", self._w.data_ptr(), self._w_alt.data_ptr(), idx.data_ptr(), B, n, rr,
+                       self._ws.data_ptr(), stream_ptr())
+            self._w, self._w_alt = self._w_alt, self._w
+            self._pend_gather = idx
         else:
             self._flush()
             self._call("gse_gsukf_resample", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),

@@ -258,7 +258,8 @@ class _ModelEntryPoints:
     ``*_model`` forms with the model handle in front, everything else (workspace, resample_begin, moments, draws -- none of
     which contains the model) is the shipped library's."""
     _ROUTED = ("gse_pf_step", "gse_model_f", "gse_model_g_u", "gse_gsukf_sigma_points", "gse_gsukf_predict", "gse_gsukf_update",
-               "gse_gsukf_predict_update", "gse_gsukf_cycle", "gse_gsukf_resample", "gse_gsukf_moments")
+               "gse_gsukf_predict_update", "gse_gsukf_cycle", "gse_gsukf_resample", "gse_gsukf_moments", "gse_gsukf_gather_rows",
+               "gse_gsukf_predict_update_from")
 
     def __init__(self, lib, handle):
         self._lib, self._handle = lib, handle

@@ -251,6 +251,22 @@ int gse_gsukf_cycle_dev(float *mu, float *P, float *w, int32_t *idx, int B, int6
                         const double *z, const double *r, const float *w_sigma, const gse_mixture *state_pdf,
                         const gse_rng *rng, const float *noise, const gse_mixture *measurement_pdf, int32_t *status,
                         uint32_t where, void *stream);
+/* A resample of a large bank whose row copy is deferred (what gse_pf_resample_begin is to the particle filter):
+ * gse_gsukf_resample_begin computes the cumulative weights and the ANCESTORS idx [B][N] int32 of filter/gs_ukf.py:409-436 and
+ * sets w_out to 1 / N; the rows are copied by the next gse_gsukf_predict_update_from (predict + update read every Gaussian
+ * from its ancestor's row in mu_in / P_in and write to mu / P -- the 120 bytes per Gaussian of the copy are neither written
+ * nor read back), or by gse_gsukf_gather_rows on its own.  idx == NULL in gse_gsukf_predict_update_from: no gather (mu_in, P_in
+ * ignored), i.e. gse_gsukf_predict_update_dev.  Same bits as gse_gsukf_resample followed by gse_gsukf_predict_update. */
+int gse_gsukf_resample_begin(const float *w, float *w_out, int32_t *idx, int B, int64_t N, const double *r,
+                             void *workspace, void *stream);
+int gse_gsukf_gather_rows(const float *mu_in, const float *P_in, const int32_t *idx, float *mu_out, float *P_out,
+                          int B, int64_t N, void *stream);
+int gse_gsukf_predict_update_from(const float *mu_in, const float *P_in, const int32_t *idx, float *mu, float *P,
+                                  float *w, int B, int64_t N, const double *u, double dt, const double *z,
+                                  const float *w_sigma, const gse_mixture *state_pdf, const gse_rng *rng,
+                                  const float *noise, const gse_mixture *measurement_pdf, int32_t *status,
+                                  uint32_t where, void *stream);
+
 /* gse_gsukf_moments in the particle filter's layout -- rows of 26 doubles { S0, S1[5], S2[15] + C[15], p[5] }, so that
  * S2 - S1 e^T - e S1^T + S0 e e^T is the whole covariance (filter/gs_ukf.py:442-449): what gse_loop_control and the host
  * post-processing of a closed loop (sim_base.py:243-309) take from either estimator. */
@@ -281,6 +297,13 @@ int gse_gsukf_cycle_model(void *model, float *mu, float *P, float *w, int32_t *i
 int gse_gsukf_resample_model(void *model, const float *mu_in, const float *P_in, const float *w, float *mu_out,
                              float *P_out, float *w_out, int32_t *idx, int B, int64_t N, const double *r,
                              uint32_t flags, void *workspace, void *stream);
+int gse_gsukf_gather_rows_model(void *model, const float *mu_in, const float *P_in, const int32_t *idx, float *mu_out,
+                                float *P_out, int B, int64_t N, void *stream);
+int gse_gsukf_predict_update_from_model(void *model, const float *mu_in, const float *P_in, const int32_t *idx,
+                                        float *mu, float *P, float *w, int B, int64_t N, const double *u, double dt,
+                                        const double *z, const float *w_sigma, const gse_mixture *state_pdf,
+                                        const gse_rng *rng, const float *noise, const gse_mixture *measurement_pdf,
+                                        int32_t *status, uint32_t where, void *stream);
 int gse_gsukf_moments_model(void *model, const float *mu, const float *P, const float *w, int B, int64_t N,
                             double *out, void *workspace, void *stream);
 

@@ -215,6 +215,43 @@ def test_large_bank_lane_kernels_against_the_oracle_and_the_group_kernels():
     np.testing.assert_allclose(gf.weights.get()[:m] * (n / m), o.weights, rtol=2e-3)
 
 
+def test_large_bank_deferred_resample_equals_the_eager_calls():
+    """Large banks defer the row copy of resample() into the next predict + update launch (gse_gsukf_resample_begin +
+    gse_gsukf_predict_update_from): over whole cycles bit-identical to one kernel per method (lazy = False), ancestors
+    included; accessors in between see the resampled bank (the copy then runs on its own, gse_gsukf_gather_rows)."""
+    n = (1 << 16) + 77
+    xss = orc.steady_state()
+    rng = np.random.default_rng(5)
+    means = (xss[None, :] + rng.standard_normal((n, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    banks = []
+    for lazy in (True, False):
+        gf = make(n, means)
+        gf.lazy = lazy
+        banks.append(gf)
+    banks[1]._seed = banks[0]._seed
+    z0 = np.array(orc.bioreactor_g(xss))
+    for c in range(5):
+        u = [0.05 + 0.005 * c, 0.2]
+        z = z0 + rng.normal(0, 0.3, 2)
+        r = float(rng.random())
+        idx = []
+        for gf in banks:
+            gf.predict(u, 0.1)
+            gf.update(u, z)
+            idx.append(gf.resample(r=r, return_index=(c % 2 == 0)))
+        assert banks[0]._pend_gather is not None
+        if c % 2 == 0:
+            np.testing.assert_array_equal(idx[0].get(), idx[1].get())
+        if c == 2:                                    # look at the bank between resample and predict: the copy runs now
+            np.testing.assert_array_equal(banks[0].means.get(), banks[1].means.get())
+            assert banks[0]._pend_gather is None
+        if c == 3:
+            np.testing.assert_array_equal(banks[0].point_estimate(), banks[1].point_estimate())
+    np.testing.assert_array_equal(banks[0].means.get(), banks[1].means.get())
+    np.testing.assert_array_equal(banks[0].covariances.get(), banks[1].covariances.get())
+    np.testing.assert_array_equal(banks[0].weights.get(), banks[1].weights.get())
+
+
 @pytest.mark.parametrize("n", [1, 7, 33, 64])
 def test_fused_cycle_equals_separate_launches(n):
     """predict + update + resample of a small bank in ONE launch (gse_gsukf_cycle) vs the three methods run one kernel
