@@ -172,7 +172,7 @@ def test_gsukf_philox_cycle_and_errors():
 def test_large_bank_lane_kernels_against_the_oracle_and_the_group_kernels():
     """2^16 Gaussians: the class runs one lane per Gaussian with predict + update in ONE launch.  Against the same calls
     one kernel each (lazy = False: bit-identical), against the 16-lanes-per-Gaussian kernels through the C ABI
-    (GSE_GSUKF_LANES is read once per process, so those are reached with a bank just below the threshold: same
+    (GSE_GSUKF_LANES is read once per process, so those are reached with a bank below the threshold of 1024: same
     arithmetic, same element numbers), and against the NumPy oracle on a slice."""
     n = 1 << 16
     xss = orc.steady_state()
@@ -184,7 +184,8 @@ def test_large_bank_lane_kernels_against_the_oracle_and_the_group_kernels():
         gf = make(n, means)
         gf.lazy = lazy
         banks.append(gf)
-    small = make(n - 64, means[:n - 64])                          # below the threshold: the group kernels
+    m_small = 960                                                 # below the threshold (1024): the group kernels
+    small = make(m_small, means[:m_small])
     small._seed = banks[0]._seed
     for c in range(2):
         u = [0.05 + 0.01 * c, 0.2]
@@ -194,10 +195,10 @@ def test_large_bank_lane_kernels_against_the_oracle_and_the_group_kernels():
         np.testing.assert_array_equal(banks[0].means.get(), banks[1].means.get())
         np.testing.assert_array_equal(banks[0].covariances.get(), banks[1].covariances.get())
         np.testing.assert_array_equal(banks[0].weights.get(), banks[1].weights.get())
-        np.testing.assert_array_equal(banks[0].means.get()[:n - 64], small.means.get())
-        np.testing.assert_array_equal(banks[0].covariances.get()[:n - 64], small.covariances.get())
-        # (the smaller bank starts from weights 1 / (n - 64): same likelihood factors, another scale)
-        np.testing.assert_allclose(banks[0].weights.get()[:n - 64] * (n / (n - 64.0)), small.weights.get(), rtol=3e-7)
+        np.testing.assert_array_equal(banks[0].means.get()[:m_small], small.means.get())
+        np.testing.assert_array_equal(banks[0].covariances.get()[:m_small], small.covariances.get())
+        # (the smaller bank starts from weights 1 / m_small: same likelihood factors, another scale)
+        np.testing.assert_allclose(banks[0].weights.get()[:m_small] * (n / float(m_small)), small.weights.get(), rtol=3e-7)
     # oracle: one cycle with injected noise on a fresh pair
     m = 4096
     sp, mp = orc.bioreactor_noise()
@@ -294,11 +295,12 @@ def make_batch(B, n, means, deterministic=False):
     return gf
 
 
-@pytest.mark.parametrize("n", [7, 64, 300, 1 << 15])
+@pytest.mark.parametrize("n", [7, 64, 300, 400, 1 << 15])
 def test_batch_of_banks_equals_single_banks(n):
     """B independent banks through the batch dimension of every launch (per-bank u, z, r and Philox stream) give, bank by
-    bank, bit-identical results to B separate filters: the one-launch cycle (n <= 64), the group kernels (300) and the
-    lane kernels (B * 2^15 Gaussians reach the threshold, the single banks stay below it)."""
+    bank, bit-identical results to B separate filters: the one-launch cycle (n <= 64), the group kernels (3 x 300 stay
+    below the lane kernels' threshold of 1024 Gaussians), the lane kernels against the group kernels (3 x 400 reach it,
+    the single banks do not) and the lane kernels on both sides (2^15)."""
     B = 3 if n < (1 << 15) else 2
     xss = orc.steady_state()
     rng = np.random.default_rng(n)
