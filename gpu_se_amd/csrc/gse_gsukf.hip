@@ -231,6 +231,15 @@ static int gsukf_resample(UserModel* model, const float* mu_in, const float* P_i
     }
     Workspace ws = carve_workspace(workspace, B, N);
     hipStream_t st = (hipStream_t)stream;
+    // up to 4096 Gaussians per bank: ancestors in one launch, rows in a second (the workspace's cumulative-weight array,
+    // unused on this route, holds the ancestors if the caller does not want them)
+    int32_t* anc = idx ? idx : reinterpret_cast<int32_t*>(ws.cumsum);
+    if (launch_small_resample(w, w_out, anc, B, N, ra, st)) {
+        GSE_LAUNCH_CHECK("small_resample_kernel");
+        return launch(model, "gse::gsukf_gather_rows_kernel<0>", gsukf_gather_rows_kernel<0>,
+                      dim3((unsigned)((N + kLaneBank - 1) / kLaneBank), B), dim3(kLaneBank), st, mu_in, P_in, (const int32_t*)anc,
+                      mu_out, P_out, N);
+    }
     if (int rc = launch_cumsum(w, N, B, N, flags & ~GSE_RESAMPLE_TILES_VALID, nullptr, ws, ws.cumsum, st)) return rc;
     GsukfPayload pl{mu_in, P_in, mu_out, P_out, N};
     return launch_gsukf_gather(pl, w_out, idx, B, N, ra, ws, st, model);
@@ -249,6 +258,10 @@ static int gsukf_resample_begin(const float* w, float* w_out, int32_t* idx, int 
     }
     Workspace ws = carve_workspace(workspace, B, N);
     hipStream_t st = (hipStream_t)stream;
+    if (launch_small_resample(w, w_out, idx, B, N, ra, st)) {          // up to 4096 Gaussians per bank: one launch
+        GSE_LAUNCH_CHECK("small_resample_kernel");
+        return GSE_OK;
+    }
     if (int rc = launch_cumsum(w, N, B, N, 0, nullptr, ws, ws.cumsum, st)) return rc;
     return launch_index_gather(w_out, idx, B, N, ra, ws, st);
 }

@@ -52,6 +52,12 @@ int launch_index_gather(float* w_out, int32_t* idx, int B, int64_t N, const Resa
     return GSE_OK;
 }
 
+bool launch_small_resample(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, hipStream_t st) {
+    if (tiles_of(N) > kSmallResampleTiles) return false;
+    hipLaunchKernelGGL(small_resample_kernel<0>, dim3(B), dim3(kSmallResampleBlock), 0, st, w, w_out, idx, N, ra);
+    return true;
+}
+
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
                            const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, int pivot_count, hipStream_t st) {
     hipLaunchKernelGGL(moments_finish_kernel, dim3(B), dim3(64 * kFinishGroups), 0, st, partials, nblk, width, out,

@@ -1049,6 +1049,120 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const Payload pl, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Banks small enough for ONE workgroup (N <= 4 tiles): tile sums, tile prefix, normalised cumulative weights and the
+// ancestors of every output in a single launch -- what tile_sum_kernel + cumsum_kernel<true> + gather_kernel<NoPayload> do
+// in three (each ~5 us of mostly latency at these sizes).  The cumulative weights never leave LDS (32 KB), and they
+// are formed by the SAME arithmetic, association included: a workgroup of 1024 threads works as four blocks of 256, each
+// doing for its tile what a workgroup of those kernels does (block_exclusive_scan's order of the four wavefront totals, the
+// tile prefix as the wavefront scan of the tile sums, the clamp and the pinned last entry), so the ancestors are bit for bit
+// those of the three-kernel path.  One workgroup per filter.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSmallResampleTiles = 4;       // (measured: 21-23 us per GS-UKF cycle against 25-26 up to 4096 Gaussians; at 8192 the
+                                             //  lone workgroup loses, 28 against 26.5)
+constexpr int kSmallResampleBlock = 1024;
+
+// block_exclusive_scan for a 256-thread quarter of a larger workgroup (lds: this quarter's 4 doubles)
+__device__ __forceinline__ double quarter_exclusive_scan(double v, double* lds, double& total) {
+    const int lane = threadIdx.x & 63, wq = (threadIdx.x >> 6) & 3;
+    const double inc = wave_inclusive_scan(v, lane);
+    __syncthreads();
+    if (lane == 63) lds[wq] = inc;
+    __syncthreads();
+    double base = 0.0;
+    const double w0 = lds[0], w1 = lds[1], w2 = lds[2], w3 = lds[3];
+    if (wq > 0) base = w0;
+    if (wq > 1) base += w1;
+    if (wq > 2) base += w2;
+    total = ((w0 + w1) + w2) + w3;
+    return base + wave_shift_up1(inc);
+}
+
+template <int kUnused>
+__global__ __launch_bounds__(kSmallResampleBlock) void small_resample_kernel(const float* __restrict__ w, float* __restrict__ w_out,
+                                                                            int32_t* __restrict__ idx_out, int64_t N,
+                                                                            const ResampleArgs ra) {
+    __shared__ double c_s[kSmallResampleTiles * kTile];
+    __shared__ double red[4 * 4];
+    __shared__ double tsum[kSmallResampleTiles];
+    __shared__ double pfx[kSmallResampleTiles + 1];
+    const int b = blockIdx.x, tid = threadIdx.x, quarter = tid >> 8, vt = tid & 255;
+    const int T = (int)((N + kTile - 1) / kTile);
+    const float* wb = w + (int64_t)b * N;
+    // 1. tile sums (tile_sum_kernel)
+    for (int t0 = 0; t0 < T; t0 += 4) {
+        const int t = t0 + quarter;
+        const int64_t i0 = (int64_t)t * kTile + (int64_t)vt * kPerThread;
+        const float4 wv = load_weights4(wb, i0, N, N);                 // (zeros beyond N, tiles beyond T included)
+        const double mine = masked_sum4(wv.x, wv.y, wv.z, wv.w, i0, N);
+        double total;
+        quarter_exclusive_scan(mine, red + 4 * quarter, total);
+        if (vt == 0 && t < T) tsum[t] = total;
+    }
+    __syncthreads();
+    // 2. tile prefix (inline_tile_prefix with one tile sum per thread: everything happens in wavefront 0)
+    if (tid < 64) {
+        const double sv = tid < T ? tsum[tid] : 0.0;
+        const double inc = wave_inclusive_scan(sv, tid);
+        const double excl = wave_shift_up1(inc);
+        if (tid < T) pfx[tid] = excl;
+        if (tid == 63) pfx[T] = inc;
+    }
+    __syncthreads();
+    const double W = pfx[T];
+    const double Nd = (double)N;
+    const float w_uniform = (float)(1.0 / Nd);
+    float* wo = w_out + (int64_t)b * N;
+    int32_t* io = idx_out + (int64_t)b * N;
+    if (!(W > 0.0) || !(W < INFINITY)) {                               // (gather_kernel: every offspring copies Gaussian 0)
+        for (int64_t j = tid; j < N; j += kSmallResampleBlock) {
+            wo[j] = w_uniform;
+            io[j] = 0;
+        }
+        return;
+    }
+    // 3. cumulative weights (cumsum_kernel) into LDS
+    for (int t0 = 0; t0 < T; t0 += 4) {
+        const int t = t0 + quarter;
+        const int64_t i0 = (int64_t)t * kTile + (int64_t)vt * kPerThread;
+        const float4 wv = load_weights4(wb, i0, N, N);
+        double sc[kPerThread];
+        sc[0] = (i0 + 0 < N) ? (double)wv.x : 0.0;
+        sc[1] = sc[0] + ((i0 + 1 < N) ? (double)wv.y : 0.0);
+        sc[2] = sc[1] + ((i0 + 2 < N) ? (double)wv.z : 0.0);
+        sc[3] = sc[2] + ((i0 + 3 < N) ? (double)wv.w : 0.0);
+        double tile_total;
+        const double excl = quarter_exclusive_scan(sc[3], red + 4 * quarter, tile_total);
+        if (t < T) {
+            const double P0 = pfx[t], P1 = pfx[t + 1];
+            const double top = P1 / W;
+            const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p)
+                if (i0 + p < N) c_s[i0 + p] = (i0 + p == last) ? top : fmin((P0 + (excl + sc[p])) / W, top);
+        }
+    }
+    __syncthreads();
+    // 4. ancestors (gather_kernel): first k with c[k] >= (j + r) / N; four outputs of a thread searched side by side
+    const double r = ra.r[b];
+    const int n32 = (int)N;
+    for (int j0 = tid; j0 < n32; j0 += 4 * kSmallResampleBlock) {
+        double thr[4];
+        int out[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) thr[p] = ((double)min(j0 + p * kSmallResampleBlock, n32 - 1) + r) / Nd;
+        span_search4(c_s, n32, thr, out);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int j = j0 + p * kSmallResampleBlock;
+            if (j < n32) {
+                io[j] = out[p];
+                wo[j] = w_uniform;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // moments
 // ------------------------------------------------------------------------------------------------
 // Per-workgroup partial sums of {w, w d, w d d^T} with d = x - pivot, fp64; blocks stride over the tiles.

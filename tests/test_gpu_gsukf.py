@@ -216,6 +216,41 @@ def test_large_bank_lane_kernels_against_the_oracle_and_the_group_kernels():
     np.testing.assert_allclose(gf.weights.get()[:m] * (n / m), o.weights, rtol=2e-3)
 
 
+@pytest.mark.parametrize("n", [65, 1000, 1024, 1025, 4095, 4096, 4097, 9000])
+def test_one_launch_resample_gives_the_ancestors_of_the_three_kernel_path(n):
+    """Banks of at most 4096 Gaussians find their ancestors in ONE launch (small_resample_kernel: tile sums, prefix, cumulative
+    weights in LDS, search); larger ones in three (4097, 9000 here).  Both against the library's stand-alone pieces --
+    gse_cumsum_normalised (the three-kernel path's cumulative weights) + gse_systematic_index -- bit for bit, for smooth and
+    for degenerate weights, in both the deferred (lazy) and the eager form; and the rows really are the ancestors' rows."""
+    from gpu_se_amd import _lib
+    from tests.gpu_util import stream, workspace
+    xss = orc.steady_state()
+    rng = np.random.default_rng(n)
+    means = (xss[None, :] + rng.standard_normal((n, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    for kind in ("smooth", "degenerate", "one"):
+        w = rng.random(n).astype(np.float32)
+        if kind == "degenerate":
+            w = (w ** 40).astype(np.float32)
+        if kind == "one":
+            w[:] = 0
+            w[n // 3] = 1.0
+        r = float(rng.random())
+        wd = torch.as_tensor(w, device="cuda")
+        c = torch.empty(n, dtype=torch.float64, device="cuda")
+        want = torch.empty(n, dtype=torch.int64, device="cuda")
+        _lib.call("gse_cumsum_normalised", wd.data_ptr(), c.data_ptr(), n, workspace(1, n).data_ptr(), stream())
+        _lib.call("gse_systematic_index", c.data_ptr(), want.data_ptr(), n, r, stream())
+        want = want.cpu().numpy()
+        for lazy in (True, False):
+            gf = make(n, means)
+            gf.lazy = lazy
+            gf.weights = w
+            idx = gf.resample(r=r, return_index=True).get()
+            np.testing.assert_array_equal(idx, want)
+            np.testing.assert_array_equal(gf.means.get(), means[want])
+            np.testing.assert_array_equal(gf.weights.get(), np.full(n, np.float32(1.0 / n)))
+
+
 def test_large_bank_deferred_resample_equals_the_eager_calls():
     """Large banks defer the row copy of resample() into the next predict + update launch (gse_gsukf_resample_begin +
     gse_gsukf_predict_update_from): over whole cycles bit-identical to one kernel per method (lazy = False), ancestors
