@@ -20,7 +20,7 @@ GSE_SCAN_MAX_TILES = 2048      # policy: beyond 2^21 particles the two-kernel re
                                # builds the whole tile prefix: at 4096 tiles the single launch takes 131 us against 102)
 GSE_GSUKF_CYCLE_MAX = 64
 GSE_GSUKF_MOMENTS = 46             # doubles per row of gse_gsukf_moments
-GSE_GSUKF_LANES_MIN = 1 << 10    # from this many Gaussians on: one lane per Gaussian, predict + update in one launch,
+GSE_GSUKF_LANES_MIN = 65         # from this many Gaussians on: one lane per Gaussian, predict + update in one launch,
                                  # the row copy of resample() deferred into it (gse_gsukf.hip: lane_per_gaussian)
 
 c_f = ctypes.c_float

@@ -37,18 +37,18 @@ static void pack_sigma_weights(SigmaWeights& sw, const float* w_sigma, int ns) {
     sw.scl64 = numpy_sum<double>(w_sigma, ns);
 }
 
-// Which family of kernels: one lane per Gaussian from 1024 Gaussians on.  (Round 2 first drew the line where the bank fills
-// the chip that way -- 2^16 -- but below that a cycle is bound by its launches, and this family needs four of them -- predict
-// + update in one, tile sums, cumulative weights, ancestors; the row copy rides the next cycle -- against five: 25.5-27 us
-// per cycle from 1024 to 32768 Gaussians against 30-39; at 256 Gaussians the 16-lanes-per-Gaussian kernels still win, 27.5
-// against 33.7.)  GSE_GSUKF_LANES=0 / 1 in the environment forces one or the other (tests, A/B).
+// Which family of kernels: one lane per Gaussian for everything beyond the 64 Gaussians of the one-launch cycle.  (Round 2
+// first drew the line where a bank fills the chip that way -- 2^16 -- but below that a cycle is bound by its launches, and
+// this family needs two of them up to 4096 Gaussians -- predict + update (+ the row copy of the resample before), and the
+// ancestors -- or four beyond, against five: 17-21 us per cycle from 65 to 768 Gaussians against 23-25, 21-23 up to 4096,
+// 27 up to 32768 against 30-39.)  GSE_GSUKF_LANES=0 / 1 in the environment forces one or the other (tests, A/B).
 static bool lane_per_gaussian(int B, int64_t N) {
     static const int forced = [] {
         const char* e = getenv("GSE_GSUKF_LANES");
         return e ? atoi(e) : -1;
     }();
     if (forced >= 0) return forced != 0;
-    return (int64_t)B * N >= 1024;
+    return (int64_t)B * N > 64;
 }
 
 static int check_gsukf(const char* fn, int B, int64_t N) {

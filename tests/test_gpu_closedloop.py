@@ -121,9 +121,9 @@ def test_resident_loop_with_large_banks_of_gaussians():
 @pytest.mark.parametrize("n", [64, 100, 200])
 def test_resident_loop_with_the_gaussian_sum_filter(n):
     """pf=False, resident=True: the whole loop on the device with the batch of GS-UKFs as the estimator -- inputs and
-    measurements read from device memory (gse_gsukf_cycle_dev for 64 Gaussians, the separate _dev calls for 8 x 100, predict
-    + update in one launch with the deferred row copy for 8 x 200), the moments in the particle filter's layout for the
-    controller kernel.  Against the host loop: same statistics."""
+    measurements read from device memory (gse_gsukf_cycle_dev for 64 Gaussians; predict + update in one launch with the
+    deferred row copy beyond), the moments in the particle filter's layout for the controller kernel.  Against the host
+    loop: same statistics."""
     gpu_se_amd.seed(6)
     dev = sim_base.BatchedSimulation(batch=8, N_particles=n, dt_control=0.1, dt_predict=0.1, end_time=5, pf=False, seed=3,
                                      resident=True)

@@ -172,7 +172,7 @@ def test_gsukf_philox_cycle_and_errors():
 def test_large_bank_lane_kernels_against_the_oracle_and_the_group_kernels():
     """2^16 Gaussians: the class runs one lane per Gaussian with predict + update in ONE launch.  Against the same calls
     one kernel each (lazy = False: bit-identical), against the 16-lanes-per-Gaussian kernels through the C ABI
-    (GSE_GSUKF_LANES is read once per process, so those are reached with a bank below the threshold of 1024: same
+    (GSE_GSUKF_LANES is read once per process, so those are reached with a bank of 64, the largest they still serve: same
     arithmetic, same element numbers), and against the NumPy oracle on a slice."""
     n = 1 << 16
     xss = orc.steady_state()
@@ -184,7 +184,7 @@ def test_large_bank_lane_kernels_against_the_oracle_and_the_group_kernels():
         gf = make(n, means)
         gf.lazy = lazy
         banks.append(gf)
-    m_small = 960                                                 # below the threshold (1024): the group kernels
+    m_small = 64                                                  # at most 64 Gaussians: the group kernels
     small = make(m_small, means[:m_small])
     small._seed = banks[0]._seed
     for c in range(2):
@@ -333,9 +333,8 @@ def make_batch(B, n, means, deterministic=False):
 @pytest.mark.parametrize("n", [7, 64, 300, 400, 1 << 15])
 def test_batch_of_banks_equals_single_banks(n):
     """B independent banks through the batch dimension of every launch (per-bank u, z, r and Philox stream) give, bank by
-    bank, bit-identical results to B separate filters: the one-launch cycle (n <= 64), the group kernels (3 x 300 stay
-    below the lane kernels' threshold of 1024 Gaussians), the lane kernels against the group kernels (3 x 400 reach it,
-    the single banks do not) and the lane kernels on both sides (2^15)."""
+    bank, bit-identical results to B separate filters: the one-launch cycle (n <= 64: one workgroup per bank) and the lane
+    kernels with the one-launch (300, 400) and the three-kernel (2^15) search for the ancestors."""
     B = 3 if n < (1 << 15) else 2
     xss = orc.steady_state()
     rng = np.random.default_rng(n)
