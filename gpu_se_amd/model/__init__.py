@@ -2,11 +2,8 @@
 discrete linear model the MPC is built on.  Nothing here touches the GPU."""
 from . import BioreactorModel as _plant
 from . import LinearModel as _linear
-from . import NonlinearModel as _base
 
-NonlinearModel = _base.NonlinearModel
 Bioreactor = _plant.Bioreactor
 LinearModel = _linear.LinearModel
-NonlinearModel.register(Bioreactor)          # the bioreactor implements the interface
 
-__all__ = ("Bioreactor", "LinearModel", "NonlinearModel")
+__all__ = ("Bioreactor", "LinearModel")
