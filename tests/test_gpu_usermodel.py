@@ -152,6 +152,12 @@ def test_a_model_nobody_prebuilt_is_compiled_in_the_process_and_both_backends_ag
                 gf.update([0.8], np.array([15.0, -2.0]))
                 gf.resample(r=0.1 + 0.2 * c)
             results[backend] += (gf.means.get().copy(), gf.covariances.get().copy())
+            gf = ParallelGaussianSumUnscentedKalmanFilter(drift_f, drift_g, 300, x0, state, meas)     # ... and the lane kernels with
+            for c in range(3):                                                                       # the deferred row copy
+                gf.predict([0.8], 0.02)
+                gf.update([0.8], np.array([15.0, -2.0]))
+                gf.resample(r=0.1 + 0.2 * c)
+            results[backend] += (gf.means.get().copy(), gf.covariances.get().copy())
         finally:
             os.environ.pop("GSE_USERMODEL_BACKEND", None) if backend == "hipcc" else None
     assert model.kernels >= 2                              # (the first cycle's launch and the single-launch cycle)
@@ -160,6 +166,8 @@ def test_a_model_nobody_prebuilt_is_compiled_in_the_process_and_both_backends_ag
     np.testing.assert_array_equal(results["rtc"][1], results["hipcc"][1])
     np.testing.assert_array_equal(results["rtc"][3], results["hipcc"][3])
     np.testing.assert_array_equal(results["rtc"][4], results["hipcc"][4])
+    np.testing.assert_array_equal(results["rtc"][5], results["hipcc"][5])
+    np.testing.assert_array_equal(results["rtc"][6], results["hipcc"][6])
     # against the same Python functions in NumPy: one predict with injected noise
     x0, state_d, meas = _two_state_parts(deterministic=True)
     n = 2000
