@@ -231,7 +231,7 @@ def protocol_sum(torch, n, io, dt, runs=100):
                                   "`value` instead times back-to-back cycles without synchronisation"}
 
 
-def gsukf_block(torch, sizes=(64, 1 << 18)):
+def gsukf_block(torch, sizes=(64, 4096, 1 << 18)):
     """BASELINE config 3 and the large-bank end of results/gsf_openloop/gsf_run_seq.py:483-484: device time per GS-UKF
     cycle (HIP events), 760 algorithmic bytes per Gaussian."""
     import gpu_se_amd
@@ -256,8 +256,10 @@ def gsukf_block(torch, sizes=(64, 1 << 18)):
         est = gf.point_estimate()
         assert np.all(np.isfinite(est)), est
         entry = {"device_us_per_cycle": round(dev * 1e6, 2), "wall_us_per_cycle": round(wall * 1e6, 2)}
-        if n <= 4096:
-            entry["bound"] = "launch latency (one workgroup): no roofline fraction"
+        if n <= 64:
+            entry["bound"] = "launch latency (one launch, one workgroup): no roofline fraction"
+        elif n <= 4096:
+            entry["bound"] = "launch latency (two launches per cycle): no roofline fraction"
         else:
             gbs = GSUKF_ALG_BYTES * n / dev / 1e9
             entry.update({"achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
