@@ -262,6 +262,10 @@ static int gsukf_resample_begin(const float* w, float* w_out, int32_t* idx, int 
         GSE_LAUNCH_CHECK("small_resample_kernel");
         return GSE_OK;
     }
+    if (launch_ancestors(w, w_out, idx, B, N, ra, ws, st)) {           // up to 2^21: tile sums, then the ancestors from them
+        GSE_LAUNCH_CHECK("ancestors_kernel");
+        return GSE_OK;
+    }
     if (int rc = launch_cumsum(w, N, B, N, 0, nullptr, ws, ws.cumsum, st)) return rc;
     return launch_index_gather(w_out, idx, B, N, ra, ws, st);
 }

@@ -141,6 +141,9 @@ int launch_gsukf_gather(const GsukfPayload& pl, float* w_out, int32_t* idx, int 
 int launch_index_gather(float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, const Workspace& ws,
                         hipStream_t st);
 // cumulative weights + ancestors of a bank of at most 4 tiles in ONE launch (small_resample_kernel); false: too large
+// ... of a bank of up to 2048 tiles from its weights and tile sums, no cumulative weights written (ancestors_kernel)
+bool launch_ancestors(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, const Workspace& ws,
+                      hipStream_t st);
 bool launch_small_resample(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, hipStream_t st);
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
                            const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, int pivot_count, hipStream_t st);

@@ -52,6 +52,16 @@ int launch_index_gather(float* w_out, int32_t* idx, int B, int64_t N, const Resa
     return GSE_OK;
 }
 
+bool launch_ancestors(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, const Workspace& ws,
+                      hipStream_t st) {
+    const int T = (int)tiles_of(N);
+    if (T > kAncestorsMaxT) return false;
+    hipLaunchKernelGGL(tile_sum_kernel, dim3(T, B), dim3(kBlock), 0, st, w, ws.tile_sums, N, N, T);
+    const size_t lds = ((size_t)(T + 1) * sizeof(double) + (size_t)T + 7) & ~(size_t)7;
+    hipLaunchKernelGGL(ancestors_kernel<0>, dim3(T, B), dim3(kBlock), lds, st, w, ws.tile_sums, w_out, idx, N, T, ra);
+    return true;
+}
+
 bool launch_small_resample(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, hipStream_t st) {
     if (tiles_of(N) > kSmallResampleTiles) return false;
     hipLaunchKernelGGL(small_resample_kernel<0>, dim3(B), dim3(kSmallResampleBlock), 0, st, w, w_out, idx, N, ra);

@@ -1163,6 +1163,132 @@ __global__ __launch_bounds__(kSmallResampleBlock) void small_resample_kernel(con
 }
 
 // ------------------------------------------------------------------------------------------------
+// Larger banks: the ancestors straight from the weights and their tile sums, without materialising the cumulative weights --
+// cumsum_kernel<true> + gather_kernel<NoPayload> in one launch (what is saved is a launch and 16 bytes per Gaussian; at these
+// sizes mostly the launch).  One workgroup per tile of 1024 OUTPUTS:
+//   1. the tile prefix of the whole filter in LDS, the arithmetic of inline_tile_prefix for every tile at once;
+//   2. every output finds the TILE of its ancestor: the first t whose pinned last entry c = Pfx(t+1) / W reaches its threshold
+//      (a search on products, settled on neighbours with the division the cumulative weights are formed with);
+//   3. the tiles that hold an ancestor of this workgroup -- flagged in LDS, one or two as a rule -- are scanned one after the
+//      other exactly as cumsum_kernel scans them (256 threads x 4 weights, the same clamp and pinned end), their 1024
+//      cumulative weights staged in LDS, and the outputs that belong there finish with the reference's comparison.
+// Same doubles, same comparisons: the ancestors of the two-kernel route bit for bit.  T <= 2048 (N <= 2^21 per filter).
+// ------------------------------------------------------------------------------------------------
+constexpr int kAncestorsMaxT = 2048;
+
+template <int kUnused>
+__global__ __launch_bounds__(kBlock) void ancestors_kernel(const float* __restrict__ w, const double* __restrict__ tile_sums,
+                                                           float* __restrict__ w_out, int32_t* __restrict__ idx_out, int64_t N, int T,
+                                                           const ResampleArgs ra) {
+    __shared__ double red[4];
+    __shared__ double seg[kTile];
+    __shared__ int32_t tile_lo_hi[2];
+    extern __shared__ double anc_lds[];                // pfx [T + 1] doubles, then the flags [T] bytes
+    double* pfx_s = anc_lds;
+    unsigned char* flag = reinterpret_cast<unsigned char*>(anc_lds + (T + 1));
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float* wb = w + (int64_t)b * N;
+    const int64_t j0 = (int64_t)blockIdx.x * kTile;
+    const int64_t j1 = min(j0 + kTile, N);
+    // 1. tile prefix: thread j owns chunk [j*m, (j+1)*m) of the tile sums (m <= 8)
+    {
+        const double* sums = tile_sums + (int64_t)b * T;
+        const int m = (T + kBlock - 1) / kBlock;
+        const int qlo = tid * m;
+        double sv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
+        double chunk = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) chunk += sv[i];
+        double total;
+        double run = block_exclusive_scan(chunk, red, total);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < m && qlo + i < T) pfx_s[qlo + i] = run;
+            run += sv[i];
+        }
+        if (tid == 0) pfx_s[T] = total;
+        for (int q = tid; q < T; q += kBlock) flag[q] = 0;
+        __syncthreads();
+    }
+    const double W = pfx_s[T];
+    const double Nd = (double)N, r = ra.r[b];
+    const float w_uniform = (float)(1.0 / Nd);
+    float* wo = w_out + (int64_t)b * N;
+    int32_t* io = idx_out + (int64_t)b * N;
+    if (!(W > 0.0) || !(W < INFINITY)) {                               // (gather_kernel: every offspring copies element 0)
+        for (int64_t j = j0 + tid; j < j1; j += kBlock) {
+            wo[j] = w_uniform;
+            io[j] = 0;
+        }
+        return;
+    }
+    // 2. the ancestor's tile of each of this thread's (up to) four outputs j0 + tid + 256 p
+    double thr[kPerThread];
+    int tj[kPerThread];
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p) {
+        const int64_t j = j0 + tid + (int64_t)p * kBlock;
+        thr[p] = ((double)min(j, j1 - 1) + r) / Nd;
+        const double target = thr[p] * W;                              // candidate by products ...
+        int lo = 0, hi = T - 1;                                        // first t with Pfx(t + 1) >= target
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (pfx_s[mid + 1] < target) lo = mid + 1; else hi = mid;
+        }
+        // ... settled with the quotient itself: tile t ends at c = Pfx(t + 1) / W; the ancestor's tile is the first with
+        // c >= thr (the last tile always qualifies: W / W = 1 > thr)
+        while (lo < T - 1 && pfx_s[lo + 1] / W < thr[p]) ++lo;
+        while (lo > 0 && pfx_s[lo] / W >= thr[p]) --lo;
+        tj[p] = lo;
+        if (j < j1) flag[lo] = 1;
+    }
+    // outputs ascend, so do their tiles: the first belongs to output j0 (thread 0), the last to output j1 - 1
+    if (tid == 0) tile_lo_hi[0] = tj[0];
+    {
+        const int last_p = (int)((j1 - 1 - j0) / kBlock);
+        int t_of_last = tj[0];
+#pragma unroll
+        for (int p = 1; p < kPerThread; ++p) t_of_last = (p == last_p) ? tj[p] : t_of_last;
+        if (tid == (int)((j1 - 1 - j0) % kBlock)) tile_lo_hi[1] = t_of_last;
+    }
+    __syncthreads();
+    const int t_first = tile_lo_hi[0], t_last = tile_lo_hi[1];
+    // 3. the flagged tiles, one after the other
+    for (int t = t_first; t <= t_last; ++t) {
+        if (!flag[t]) continue;                                        // (uniform over the workgroup)
+        const int64_t i0 = (int64_t)t * kTile + (int64_t)tid * kPerThread;
+        const float4 wv = load_weights4(wb, i0, N, N);
+        double sc[kPerThread];
+        sc[0] = (i0 + 0 < N) ? (double)wv.x : 0.0;
+        sc[1] = sc[0] + ((i0 + 1 < N) ? (double)wv.y : 0.0);
+        sc[2] = sc[1] + ((i0 + 2 < N) ? (double)wv.z : 0.0);
+        sc[3] = sc[2] + ((i0 + 3 < N) ? (double)wv.w : 0.0);
+        double tile_total;
+        const double excl = block_exclusive_scan(sc[3], red, tile_total);
+        const double P0 = pfx_s[t], P1 = pfx_s[t + 1];
+        const double top = P1 / W;
+        const int64_t last = min((int64_t)(t + 1) * kTile, N) - 1;
+        const int len = (int)(last - (int64_t)t * kTile) + 1;
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p)
+            if (i0 + p <= last) seg[tid * kPerThread + p] = (i0 + p == last) ? top : fmin((P0 + (excl + sc[p])) / W, top);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p) {
+            const int64_t j = j0 + tid + (int64_t)p * kBlock;
+            if (j < j1 && tj[p] == t) {
+                const int k = span_search(seg, len, thr[p]);
+                io[j] = (int32_t)((int64_t)t * kTile + k);
+                wo[j] = w_uniform;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // moments
 // ------------------------------------------------------------------------------------------------
 // Per-workgroup partial sums of {w, w d, w d d^T} with d = x - pivot, fp64; blocks stride over the tiles.

@@ -216,10 +216,11 @@ def test_large_bank_lane_kernels_against_the_oracle_and_the_group_kernels():
     np.testing.assert_allclose(gf.weights.get()[:m] * (n / m), o.weights, rtol=2e-3)
 
 
-@pytest.mark.parametrize("n", [65, 1000, 1024, 1025, 4095, 4096, 4097, 9000])
+@pytest.mark.parametrize("n", [65, 1000, 1024, 1025, 4095, 4096, 4097, 9000, 70001, (1 << 18) + 5])
 def test_one_launch_resample_gives_the_ancestors_of_the_three_kernel_path(n):
     """Banks of at most 4096 Gaussians find their ancestors in ONE launch (small_resample_kernel: tile sums, prefix, cumulative
-    weights in LDS, search); larger ones in three (4097, 9000 here).  Both against the library's stand-alone pieces --
+    weights in LDS, search); larger ones from their tile sums without materialised cumulative weights (ancestors_kernel; the
+    eager form keeps cumsum + gather).  All against the library's stand-alone pieces --
     gse_cumsum_normalised (the three-kernel path's cumulative weights) + gse_systematic_index -- bit for bit, for smooth and
     for degenerate weights, in both the deferred (lazy) and the eager form; and the rows really are the ancestors' rows."""
     from gpu_se_amd import _lib
@@ -227,13 +228,17 @@ def test_one_launch_resample_gives_the_ancestors_of_the_three_kernel_path(n):
     xss = orc.steady_state()
     rng = np.random.default_rng(n)
     means = (xss[None, :] + rng.standard_normal((n, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
-    for kind in ("smooth", "degenerate", "one"):
+    for kind in ("smooth", "degenerate", "one", "stretch"):
         w = rng.random(n).astype(np.float32)
         if kind == "degenerate":
             w = (w ** 40).astype(np.float32)
         if kind == "one":
             w[:] = 0
             w[n // 3] = 1.0
+        if kind == "stretch":                         # long weightless stretches between a few heavy Gaussians, and tiny weights
+            w[:] = 0
+            w[rng.integers(0, n, 7)] = rng.random(7).astype(np.float32)
+            w[rng.integers(0, n, 50)] += np.float32(1e-12)
         r = float(rng.random())
         wd = torch.as_tensor(w, device="cuda")
         c = torch.empty(n, dtype=torch.float64, device="cuda")
