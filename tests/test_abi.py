@@ -54,6 +54,24 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
         lib.call("gse_pf_predict_injected", 16, 7, 1, 7, lib.doubles([0, 0], 2), 0.1, 16, None)
     with pytest.raises(lib.GseError, match=r"outside \[0, 1\)"):
         lib.call("gse_pf_resample", 16, 32, 48, 64, None, 8, 1, 8, lib.doubles([1.5], 1), 0, None, 80, None)
+    # the Gaussian-sum filter's entry points, the deferred resample included
+    with pytest.raises(lib.GseError, match="B = 40"):
+        lib.call("gse_gsukf_sigma_points", 16, 32, 48, 40, 8, None, None)
+    with pytest.raises(lib.GseError, match="at most 64 Gaussians"):
+        lib.call("gse_gsukf_cycle", 16, 32, 48, None, 1, 65, lib.doubles([0, 0], 2), 0.1, lib.doubles([0, 0], 2), lib.doubles([0.5], 1),
+                 (lib.c_f * 11)(), None, None, 64, None, None, None)
+    with pytest.raises(lib.GseError, match=r"outside \[0, 1\)"):
+        lib.call("gse_gsukf_resample_begin", 16, 32, 48, 1, 100, lib.doubles([-0.1], 1), 64, None)
+    with pytest.raises(lib.GseError, match="aliasing"):
+        lib.call("gse_gsukf_resample_begin", 16, 16, 48, 1, 100, lib.doubles([0.5], 1), 64, None)
+    with pytest.raises(lib.GseError, match="aliasing"):
+        lib.call("gse_gsukf_gather_rows", 16, 32, 48, 16, 64, 1, 100, None)
+    m = lib.Mixture()
+    m.nd, m.nx = 2, 2
+    import ctypes
+    with pytest.raises(lib.GseError, match="source arrays must be given"):
+        lib.call("gse_gsukf_predict_update_from", None, None, 48, 16, 32, 64, 1, 100, lib.doubles([0, 0], 2), 0.1,
+                 lib.doubles([0, 0], 2), (lib.c_f * 11)(), None, None, 80, ctypes.byref(m), None, 0, None)
 
 
 def test_moments_to_mean_cov():
