@@ -212,7 +212,9 @@ struct PlantArgs {
 __global__ __launch_bounds__(256) void plant_step_kernel(double* __restrict__ X, const double* __restrict__ u, int64_t B,
                                                          const PlantArgs a, double* __restrict__ y,
                                                          double* __restrict__ y_meas, double* __restrict__ z,
-                                                         double* __restrict__ log_x, double* __restrict__ log_u) {
+                                                         double* __restrict__ log_x, double* __restrict__ log_u,
+                                                         const float* __restrict__ inj_state,
+                                                         const float* __restrict__ inj_meas) {
     __shared__ DrawParams dp[2];
     {
         const uint32_t* s0 = reinterpret_cast<const uint32_t*>(&a.state_noise);
@@ -236,8 +238,13 @@ __global__ __launch_bounds__(256) void plant_step_kernel(double* __restrict__ X,
     for (int k = 0; k < 4; ++k) x[k] = fmax(x[k], 0.0);    // BioreactorModel.py:108
     uint32_t wd[8];
     float e[5];
-    rng_words8(a.rng_state, (uint64_t)b, 0u, wd);
-    mixture_draw5(dp[0], wd, e);                           // state_pdf.draw(): fp32 values added to the fp64 state
+    if (inj_state) {                                       // parity mode: the draw is an input (gse_plant_step_injected)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) e[k] = inj_state[b * 5 + k];
+    } else {
+        rng_words8(a.rng_state, (uint64_t)b, 0u, wd);
+        mixture_draw5(dp[0], wd, e);                       // state_pdf.draw(): fp32 values added to the fp64 state
+    }
 #pragma unroll
     for (int k = 0; k < 5; ++k) x[k] += (double)e[k];
     const double mm[5] = {180.0, 24.6, 116.0, 46.0, 1.0};   // BioreactorModel.py:118-120
@@ -250,8 +257,13 @@ __global__ __launch_bounds__(256) void plant_step_kernel(double* __restrict__ X,
         if (log_x) log_x[b * 5 + k] = x[k];
         y[b * 5 + k] = out[k];
     }
-    rng_words8(a.rng_meas, (uint64_t)b, 0u, wd);
-    mixture_draw5(dp[1], wd, e);                           // measurement noise on the controlled outputs (Cg, Cfa)
+    if (inj_meas) {
+        e[0] = inj_meas[b * 2];
+        e[1] = inj_meas[b * 2 + 1];
+    } else {
+        rng_words8(a.rng_meas, (uint64_t)b, 0u, wd);
+        mixture_draw5(dp[1], wd, e);                       // measurement noise on the controlled outputs (Cg, Cfa)
+    }
     out[0] += (double)e[0];
     out[2] += (double)e[1];
 #pragma unroll
@@ -348,7 +360,18 @@ int gse_plant_step(double* X, const double* u, double dt, const gse_mixture* sta
     a.rng_meas = make_rng_key(*rng, kPurposePlantMeas);
     a.dt = dt;
     hipLaunchKernelGGL(plant_step_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, u, B, a, y,
-                       y_meas, z, log_x, log_u);
+                       y_meas, z, log_x, log_u, (const float*)nullptr, (const float*)nullptr);
+    GSE_LAUNCH_CHECK("plant_step_kernel");
+    return GSE_OK;
+}
+
+int gse_plant_step_injected(double* X, const double* u, double dt, const float* state_draw, const float* meas_draw, double* y,
+                            double* y_meas, double* z, double* log_x, double* log_u, int64_t B, void* stream) {
+    GSE_REQUIRE(X && u && state_draw && meas_draw && y && y_meas && z && B >= 1, "gse_plant_step_injected: bad argument");
+    PlantArgs a = {};
+    a.dt = dt;
+    hipLaunchKernelGGL(plant_step_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, u, B, a, y,
+                       y_meas, z, log_x, log_u, state_draw, meas_draw);
     GSE_LAUNCH_CHECK("plant_step_kernel");
     return GSE_OK;
 }

@@ -121,16 +121,19 @@ void step_go(const StepLaunch& L) {
 // (ND = 2) for update stages; the scan modes only for the Philox (not injected-noise) variants with ND = 2.
 template <bool G, bool P, bool I, bool U, int ND>
 bool step_pick_scan(int scan, const StepLaunch& L) {
-    constexpr bool kScanOk = !I && (!U || ND == 2);
+    // Injected noise (the parity mode) has the scan modes only where a closed loop needs them: the whole single-launch
+    // cycle (3, 7) and the predict + update launch that leaves tile prefixes behind (2, 6) -- so that a loop fed recorded
+    // noise runs the SAME launches as one that draws from Philox.
+    constexpr bool kScanOk = (!U || ND == 2) && (!I || (P && U));
     if (scan == 0) { step_go<G, P, I, U, ND, 0>(L); return true; }
-    if constexpr (kScanOk && G) if (scan == 1) { step_go<G, P, I, U, ND, 1>(L); return true; }
-    if constexpr (kScanOk && U) if (scan == 2) { step_go<G, P, I, U, ND, 2>(L); return true; }
+    if constexpr (kScanOk && G && !I) if (scan == 1) { step_go<G, P, I, U, ND, 1>(L); return true; }
+    if constexpr (kScanOk && U && (!I || !G)) if (scan == 2) { step_go<G, P, I, U, ND, 2>(L); return true; }
     if constexpr (kScanOk && G && U) if (scan == 3) { step_go<G, P, I, U, ND, 3>(L); return true; }
-    if constexpr (!G && !I) {                                    // + 4: inputs from device memory
+    if constexpr (!G) {                                          // + 4: inputs from device memory
         if (scan == 4) { step_go<G, P, I, U, ND, 4>(L); return true; }
         if constexpr (kScanOk && U) if (scan == 6) { step_go<G, P, I, U, ND, 6>(L); return true; }
     }
-    if constexpr (G && P && !I && U && kScanOk) {                // ... also in the single-launch cycle (resident closed loop)
+    if constexpr (G && P && U && kScanOk) {                      // ... also in the single-launch cycle (resident closed loop)
         if (scan == 7) { step_go<G, P, I, U, ND, 7>(L); return true; }
     }
     return false;
@@ -183,7 +186,6 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const bool u_on_device = (ops & GSE_OP_U_DEVICE) != 0, z_on_device = (ops & GSE_OP_Z_DEVICE) != 0;
     GSE_REQUIRE(!u_on_device || (P && u), "%s: GSE_OP_U_DEVICE needs GSE_OP_PREDICT and a device pointer u", fn);
     GSE_REQUIRE(!z_on_device || (U && z), "%s: GSE_OP_Z_DEVICE needs GSE_OP_UPDATE and a device pointer z", fn);
-    GSE_REQUIRE(!(u_on_device || z_on_device) || !noise, "%s: device-resident u / z are not available with injected noise", fn);
     GSE_REQUIRE(!(u_on_device || z_on_device) || !G || (P && U && scan == 3),
                 "%s: with a gather, device-resident u / z need the whole single-launch cycle (gather + predict + update, scans "
                 "in and out)", fn);

@@ -76,6 +76,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._pend_predict = None
         self._pend_update = None
         self._pend_gather = None                      # ancestors [B, N] int32 of a resample whose row copy is still to come
+        self._replay = None                           # noise a DeterministicGaussianSum handed out at predict() time
         self._idx_buf = None
         self._fusable = n <= _lib.GSE_GSUKF_CYCLE_MAX
         self._fuse_pu = B * n >= _lib.GSE_GSUKF_LANES_MIN  # large banks: predict() is deferred and rides update()'s launch
@@ -219,16 +220,21 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     def predict(self, u, dt):
         """Prediction step (gs_ukf.py:348-367).  With at most 64 Gaussians the step is deferred so that resample() can
         run predict + update + resample as one launch (the bank is launch-latency-bound)."""
-        if self.lazy and (self._fusable or self._fuse_pu) and self._pend_predict is None and self._pend_update is None:
+        deferred = self.lazy and (self._fusable or self._fuse_pu) and self._pend_predict is None and self._pend_update is None
+        if not deferred:
+            self._flush()
+        # a DeterministicGaussianSum (the parity mode) is drawn from NOW, as the reference draws inside predict(): the values
+        # stay with the stage, whatever the replay buffer holds by the time a deferred launch runs
+        self._replay = self._noise_rows() if isinstance(self.state_pdf, DeterministicGaussianSum) else None
+        if deferred:
             self._pend_predict = (self._keep(u), float(dt))
             return
-        self._flush()
         self._predict_now(u, dt)
 
     def _draw_args(self):
         """(state_pdf pod, rng, noise pointer) of a predict: replayed noise for a DeterministicGaussianSum, else Philox."""
-        if isinstance(self.state_pdf, DeterministicGaussianSum):
-            self._noise = self._noise_rows()
+        if self._replay is not None:
+            self._noise, self._replay = self._replay, None
             return None, None, self._noise.data_ptr()
         rng = _lib.Rng(seed=self._seed, step=self._step, filter_offset=self._filter_offset)
         self._step += 1
@@ -245,6 +251,9 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     def update(self, u, z):
         """Update step: local UKF update of every Gaussian, then the global weight update (gs_ukf.py:369-407)."""
+        if self._model is not None and self._pend_predict is not None and not self._same_inputs(self._pend_predict[0], u):
+            self._flush()                             # a fused launch carries ONE u and a user model's g may read it
+                                                      # (gs_ukf.py:369-407 evaluates g with update's own u): predict first
         if self.lazy and self._fusable and self._pend_predict is not None and self._pend_update is None:
             self._pend_update = (self._keep(u), self._keep(z))
             return
@@ -254,6 +263,11 @@ class ParallelGaussianSumUnscentedKalmanFilter:
             return
         self._flush()
         self._update_now(u, z)
+
+    def _same_inputs(self, a, b):
+        if torch.is_tensor(a) or torch.is_tensor(b):
+            return torch.is_tensor(a) and torch.is_tensor(b) and a.data_ptr() == b.data_ptr()
+        return numpy.array_equal(numpy.asarray(a, dtype=numpy.float64).reshape(-1), numpy.asarray(b, dtype=numpy.float64).reshape(-1))
 
     def _predict_update_now(self, u, dt, z):
         """predict(u, dt) and update(., z) of a large bank in one launch (gse_gsukf_predict_update): same bits as the two."""
@@ -283,7 +297,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         """Systematic resample of the Gaussians based on their weights (gs_ukf.py:409-436)."""
         n, B = self.N_particles, self._B
         if B == 1:
-            self._c_r[0] = self._host_rng.random() if r is None else r
+            self._c_r[0] = self._host_rng.random() if r is None else float(numpy.asarray(r, dtype=numpy.float64).reshape(-1)[0])
             rr = self._c_r
         else:
             rr = self._per_bank(self._host_rng.random(B) if r is None else r, 1, self._c_r)

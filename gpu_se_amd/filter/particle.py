@@ -181,9 +181,12 @@ class ParallelParticleFilter:
 
     def _launch_step(self, update):
         """Run the pending gather / predict stages, plus an update if ``update`` = (u, z) is given."""
-        injected = self._pend_predict is not None and isinstance(self.state_pdf, DeterministicGaussianSum)
-        if injected and self._pend_gather and self._gather_slot is not None:
-            # the injected-noise kernels have no scan variants: run the gather on its own first
+        injected = self._pend_predict is not None and self._pend_predict[2] is not None
+        scan_ok = self._scan_capable and self.measurement_pdf._Nd == 2
+        whole = lambda: (self._pend_gather and self._gather_slot is not None and self._pend_predict is not None and
+                         update is not None and scan_ok)       # gather + predict + update in ONE launch, scans in and out
+        if injected and self._pend_gather and self._gather_slot is not None and not whole():
+            # injected noise has the scan variants of the whole cycle only: otherwise run the gather on its own first
             pend, self._pend_predict = self._pend_predict, None
             self._launch_step(update=None)
             self._pend_predict = pend
@@ -194,8 +197,7 @@ class ParallelParticleFilter:
             self._launch_step(update=None)                      # one launch carries one u: predict with its own first
         device_io = (self._pend_predict is not None and torch.is_tensor(self._pend_predict[0])) or \
             (update is not None and torch.is_tensor(update[1]))
-        whole_cycle = (self._pend_gather and self._gather_slot is not None and self._pend_predict is not None and
-                       update is not None and not injected and self._scan_capable and self.measurement_pdf._Nd == 2)
+        whole_cycle = whole()
         if device_io and self._pend_gather and not whole_cycle:
             # inputs that live on the device are read by the single-launch cycle or by the variants without gather: in any
             # other combination copy the ancestors first
@@ -222,16 +224,15 @@ class ParallelParticleFilter:
         cu = self._c_u
         if self._pend_predict is not None:
             ops |= _lib.GSE_OP_PREDICT
-            u, dt = self._pend_predict
+            u, dt, replay = self._pend_predict
             if torch.is_tensor(u):                          # inputs that live on the device (closed loop on the device)
                 ops |= _lib.GSE_OP_U_DEVICE
                 cu = ctypes.cast(ctypes.c_void_p(u.data_ptr()), _lib.P_D)
             else:
                 self._fill(cu, u, _lib.GSE_NU)
             if injected:
-                noise = self.state_pdf.draw((self._B, n)).as_subclass(torch.Tensor)  # (B, n, Nx) replayed values
                 buf = torch.zeros_like(self._x)
-                buf[:, :self._nx, :n] = noise.reshape(self._B, n, self._nx).transpose(1, 2)
+                buf[:, :self._nx, :n] = replay.reshape(self._B, n, self._nx).transpose(1, 2)   # (B, n, Nx) replayed values
                 self._noise_buf = buf
                 noise_ptr = buf.data_ptr()
             else:
@@ -252,7 +253,7 @@ class ParallelParticleFilter:
             else:
                 self._fill(cz, update[1], _lib.GSE_NY)
             pod_meas = ctypes.byref(self.measurement_pdf._pod())
-            if self._scan_capable and not injected and self.measurement_pdf._Nd == 2:
+            if scan_ok and (not injected or not gather or whole_cycle):
                 # leave the tile-local scans of the new weights behind: the next resample then needs no kernel
                 scan_out = 1 if (gather and self._gather_slot == 0) else 0
                 ops |= _lib.GSE_OP_SCAN_OUT | (_lib.GSE_OP_SCAN_OUT_SLOT1 if scan_out else 0)
@@ -324,7 +325,11 @@ class ParallelParticleFilter:
             u = self._device_io(u, _lib.GSE_NU)             # read by the kernel when it runs: do not overwrite before
         else:
             u = self._host_u(u)
-        self._pend_predict = (u, float(dt))
+        # a DeterministicGaussianSum (the parity mode) is drawn from NOW, as the reference draws inside predict(): the values
+        # stay with the deferred stage, whatever the replay buffer holds by the time it runs
+        replay = (self.state_pdf.draw((self._B, self.N_particles)).as_subclass(torch.Tensor)
+                  if isinstance(self.state_pdf, DeterministicGaussianSum) else None)
+        self._pend_predict = (u, float(dt), replay)
         if not self.lazy:
             self._flush()
 
@@ -340,7 +345,7 @@ class ParallelParticleFilter:
         cumulative weights are computed now; the copy of the ancestors is deferred -- see above."""
         self._flush()
         if self._B == 1:
-            self._c_r[0] = self._host_rng.random() if r is None else r
+            self._c_r[0] = self._host_rng.random() if r is None else float(numpy.asarray(r, dtype=numpy.float64).reshape(-1)[0])
         else:
             self._fill(self._c_r, self._host_rng.random(self._B) if r is None else r, 1)
         if self.lazy and self._scan_slot is not None:

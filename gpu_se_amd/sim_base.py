@@ -120,12 +120,59 @@ def _host_mixture_draw(rng, mixture, size):
     return means[comp] + numpy.einsum("nij,nj->ni", chol[comp], z)
 
 
+def _simpson_pairs(y, x):
+    """Composite Simpson's rule over an odd number of samples, interval pairs of unequal width allowed."""
+    h0, h1 = numpy.diff(x)[0::2], numpy.diff(x)[1::2]
+    hs, hp, hq = h0 + h1, h0 * h1, h0 / h1
+    return numpy.sum(hs / 6.0 * (y[0:-2:2] * (2.0 - 1.0 / hq) + y[1:-1:2] * (hs * hs / hp) + y[2::2] * (2.0 - hq)))
+
+
+def simps(y, x):
+    """scipy.integrate.simps(y, x) as the reference's SciPy (>= 1.4.1, environment.yml:8) evaluates it -- the function is
+    gone from SciPy 1.14 on, and scipy.integrate.simpson treats an EVEN number of samples (the loop has end_time * 10 of
+    them) differently.  Default even='avg': the mean of (Simpson over the first N - 1 samples + a trapezoid on the last
+    interval) and (a trapezoid on the first interval + Simpson over the last N - 1 samples)."""
+    y, x = numpy.asarray(y, dtype=float), numpy.asarray(x, dtype=float)
+    if len(y) % 2 == 1:
+        return float(_simpson_pairs(y, x))
+    first = _simpson_pairs(y[:-1], x[:-1]) + 0.5 * (x[-1] - x[-2]) * (y[-1] + y[-2])
+    last = 0.5 * (x[1] - x[0]) * (y[1] + y[0]) + _simpson_pairs(y[1:], x[1:])
+    return float(0.5 * (first + last))
+
+
 def performance(ys, r, ts):
-    """Integral of the time-weighted squared error, summed over the outputs (sim_base.py:164-185; Simpson's rule --
-    scipy.integrate.simps of the reference is scipy.integrate.simpson today)."""
-    import scipy.integrate
+    """Integral of the time-weighted squared error, summed over the outputs (sim_base.py:164-185)."""
     se = (numpy.asarray(ys) - numpy.asarray(r)) ** 2
-    return float(sum(scipy.integrate.simpson(se_ax * ts, x=ts) for se_ax in numpy.rollaxis(se, 1)))
+    return float(sum(simps(se_ax * ts, ts) for se_ax in numpy.rollaxis(se, 1)))
+
+
+class InjectedNoise:
+    """Every random number of a closed loop as an INPUT -- the parity mode of the loop drivers below (what
+    DeterministicGaussianSum is for one filter): with it a loop is a deterministic function of its arguments and can be
+    compared tick by tick with a restatement of the reference's loop.
+
+    plant_state : (ticks - 1, B, 5) fp32   what state_pdf.draw() returns at sim_base.py:282, per tick and rollout
+    plant_meas  : (ticks - 1, B, 2) fp32   measurement_pdf.draw() at sim_base.py:285
+    predict     : sequence, one entry per predict(): (B, N, 5) for the particle filter, (B, N, 11, 5) for the GS-UKF
+    r           : sequence, one entry per resample(): (B,) uniform numbers in [0, 1)
+    (B = 1 for Simulation; the leading rollout axis may then be left out.)"""
+
+    def __init__(self, plant_state, plant_meas, predict, r):
+        self.plant_state = numpy.asarray(plant_state, dtype=numpy.float32)
+        self.plant_meas = numpy.asarray(plant_meas, dtype=numpy.float32)
+        self.predict = [numpy.asarray(v, dtype=numpy.float32) for v in predict]
+        self.r = [numpy.atleast_1d(numpy.asarray(v, dtype=numpy.float64)) for v in r]
+
+    def state(self, tick, B):
+        return self.plant_state[tick].reshape(B, 5)
+
+    def meas(self, tick, B):
+        return self.plant_meas[tick].reshape(B, 2)
+
+
+def _replaying(estimator):
+    """Switch an estimator to replayed state noise (its predict() then takes what DeterministicGaussianSum.preload holds)."""
+    estimator.state_pdf = get_noise(deterministic=True)[0]
 
 
 def hold_controller(x_estimate, u_previous, y_measured):
@@ -139,7 +186,7 @@ class Simulation:
     Parameters as in the reference; ``controller`` optionally replaces the MPC by a callable
     (x_estimate, u_previous, y_measured) -> u, ``seed`` seeds the plant's noise."""
 
-    def __init__(self, N_particles, dt_control, dt_predict, end_time=50, pf=True, controller=None, seed=0):
+    def __init__(self, N_particles, dt_control, dt_predict, end_time=50, pf=True, controller=None, seed=0, noise=None):
         self.ts = numpy.linspace(0, end_time, int(end_time * 10))
         self.dt = self.ts[1]
         self.dt_control = dt_control
@@ -147,6 +194,9 @@ class Simulation:
         self.bioreactor, self.lin_model, self.K, self.f = get_parts(dt_control=dt_control, N_particles=N_particles, pf=pf)
         self.controller = controller
         self._rng = numpy.random.default_rng(seed)
+        self.noise = noise                              # InjectedNoise: every random number is an input (parity mode)
+        if noise is not None:
+            _replaying(self.f)
 
         self.us = [_U_FALLBACK.copy()]
         self.xs = [self.bioreactor.X.copy()]
@@ -179,8 +229,11 @@ class Simulation:
         """Performs a simulation using the simulation parameters (sim_base.py:243-309)."""
         t_next_control, t_next_predict = 0, 0
         solved_count = failed_count = 0
-        for t in self.ts[1:]:
+        noise = self.noise
+        for tick, t in enumerate(self.ts[1:]):
             if t > t_next_predict:
+                if noise is not None:
+                    gaussian_sum_dist.DeterministicGaussianSum.preload(noise.predict[self.predict_count])
                 self.f.predict(self.us[-1], self.dt)
                 self.predict_count += 1
                 t_next_predict += self.dt_predict
@@ -188,7 +241,7 @@ class Simulation:
                 if self.controller is None and self.K.y_predicted is not None:
                     self.biass.append(self.lin_model.yn2d(self.ys_meas[-1]) - self.K.y_predicted)
                 self.f.update(self.us[-1], self.ys_meas[-1][_OUTPUTS])
-                self.f.resample()
+                self.f.resample(r=None if noise is None else float(noise.r[self.update_count][0]))
                 self.update_count += 1
                 self.xs_f.append(self.f.point_estimate())
                 u, solved = self._control()
@@ -199,10 +252,12 @@ class Simulation:
                 self.us.append(self.us[-1])
 
             self.bioreactor.step(self.dt, self.us[-1])
-            self.bioreactor.X += _host_mixture_draw(self._rng, _STATE_NOISE, 1)[0]
+            self.bioreactor.X += (_host_mixture_draw(self._rng, _STATE_NOISE, 1)[0] if noise is None
+                                  else noise.state(tick, 1)[0].astype(numpy.float64))
             outputs = self.bioreactor.outputs(self.us[-1])
             self.ys.append(outputs.copy())
-            outputs[_OUTPUTS] += _host_mixture_draw(self._rng, _MEAS_NOISE, 1)[0]
+            outputs[_OUTPUTS] += (_host_mixture_draw(self._rng, _MEAS_NOISE, 1)[0] if noise is None
+                                  else noise.meas(tick, 1)[0].astype(numpy.float64))
             self.ys_meas.append(outputs)
             self.xs.append(self.bioreactor.X.copy())
             estimate = self.f.point_estimate()
@@ -223,8 +278,9 @@ class BatchedSimulation:
     launch and one synchronisation (the estimates of all rollouts)."""
 
     def __init__(self, batch, N_particles, dt_control, dt_predict, end_time=50, pf=True, controller=None, seed=0,
-                 resident=False):
+                 resident=False, noise=None):
         self.B = int(batch)
+        self.noise = noise                      # InjectedNoise: every random number is an input (parity mode)
         self.resident = bool(resident)          # True: plant, controller and histories live on the device too
         if self.resident and controller is not None:
             raise ValueError("a resident loop runs the MPC on the device; host callables cannot replace it")
@@ -241,6 +297,8 @@ class BatchedSimulation:
                          measurement_pdf, batch=self.B)
         self.controller = controller
         self.pf = bool(pf)
+        if noise is not None:
+            _replaying(self.f)
         self._rng = numpy.random.default_rng(seed)
         self.X = numpy.repeat(xss[None, :], self.B, axis=0)
         self.us = [numpy.repeat(_U_FALLBACK[None, :], self.B, axis=0)]
@@ -279,13 +337,18 @@ class BatchedSimulation:
             return self._simulate_resident()
         t_next_control, t_next_predict = 0, 0
         solved = asked = 0
-        for t in self.ts[1:]:
+        noise, n_predict, n_update = self.noise, 0, 0
+        for tick, t in enumerate(self.ts[1:]):
             if t > t_next_predict:
+                if noise is not None:
+                    gaussian_sum_dist.DeterministicGaussianSum.preload(noise.predict[n_predict])
                 self.f.predict(self.us[-1], self.dt)
+                n_predict += 1
                 t_next_predict += self.dt_predict
             if t > t_next_control:
                 self.f.update(self.us[-1], self.ys_meas[-1][:, _OUTPUTS])
-                self.f.resample()
+                self.f.resample(r=None if noise is None else noise.r[n_update])
+                n_update += 1
                 est = self.f.point_estimate()
                 self.xs_f.append(est)
                 u, ok = self._control(est)
@@ -296,10 +359,12 @@ class BatchedSimulation:
             else:
                 self.us.append(self.us[-1])
             self._plant_step(self.us[-1])
-            self.X += _host_mixture_draw(self._rng, _STATE_NOISE, self.B)
+            self.X += (_host_mixture_draw(self._rng, _STATE_NOISE, self.B) if noise is None
+                       else noise.state(tick, self.B).astype(numpy.float64))
             out = self._outputs()
             self.ys.append(out.copy())
-            out[:, _OUTPUTS] += _host_mixture_draw(self._rng, _MEAS_NOISE, self.B)
+            out[:, _OUTPUTS] += (_host_mixture_draw(self._rng, _MEAS_NOISE, self.B) if noise is None
+                                 else noise.meas(tick, self.B).astype(numpy.float64))
             self.ys_meas.append(out)
             self.xs.append(self.X.copy())
             est, cov = self.f.estimates()
@@ -356,6 +421,10 @@ class BatchedSimulation:
 
         import time
         record_moments(0)
+        noise, n_predict, n_update = self.noise, 0, 0
+        if noise is not None:                             # the plant's draws: uploaded once, sliced per tick
+            inj_state = torch.as_tensor(numpy.ascontiguousarray(noise.plant_state.reshape(ticks - 1, B, 5)), device=dev)
+            inj_meas = torch.as_tensor(numpy.ascontiguousarray(noise.plant_meas.reshape(ticks - 1, B, 2)), device=dev)
         t_next_control, t_next_predict = 0, 0
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()                                      # device time of the loop: first to last kernel of the ticks
@@ -363,11 +432,15 @@ class BatchedSimulation:
         for t in range(1, ticks):
             now = self.ts[t]
             if now > t_next_predict:
+                if noise is not None:
+                    gaussian_sum_dist.DeterministicGaussianSum.preload(noise.predict[n_predict])
                 f.predict(u, self.dt)
+                n_predict += 1
                 t_next_predict += self.dt_predict
             if now > t_next_control:
                 f.update(u, z)
-                f.resample()
+                f.resample(r=None if noise is None else noise.r[n_update])
+                n_update += 1
                 # the estimate the controller acts on, and this tick's record: the moments of the resampled ensemble taken
                 # from the weighted one (offspring counts), so that the resample's copy is deferred into the next tick's
                 # single launch (gather + predict + update); where that does not apply, resample now and take them after
@@ -379,9 +452,14 @@ class BatchedSimulation:
                 control_ticks.append(t)
                 t_next_control += self.dt_control
             rng.step = t
-            _lib.check(lib.gse_plant_step(X.data_ptr(), u.data_ptr(), float(self.dt), state_pod, meas_pod, ctypes.byref(rng),
-                                          ys[t].data_ptr(), ys_meas[t].data_ptr(), z.data_ptr(), xs[t].data_ptr(),
-                                          us[t].data_ptr(), B, stream))
+            if noise is not None:
+                _lib.check(lib.gse_plant_step_injected(X.data_ptr(), u.data_ptr(), float(self.dt), inj_state[t - 1].data_ptr(),
+                                                       inj_meas[t - 1].data_ptr(), ys[t].data_ptr(), ys_meas[t].data_ptr(),
+                                                       z.data_ptr(), xs[t].data_ptr(), us[t].data_ptr(), B, stream))
+            else:
+                _lib.check(lib.gse_plant_step(X.data_ptr(), u.data_ptr(), float(self.dt), state_pod, meas_pod,
+                                              ctypes.byref(rng), ys[t].data_ptr(), ys_meas[t].data_ptr(), z.data_ptr(),
+                                              xs[t].data_ptr(), us[t].data_ptr(), B, stream))
             if last_control != t:                         # (a control tick has recorded this state already)
                 record_moments(t)
         # one synchronisation, one copy: histories to the host, estimates from the recorded moments

@@ -422,6 +422,11 @@ int gse_plant_step(double *X /* [B][5], in/out */, const double *u /* [B][2] */,
                    const gse_mixture *meas_noise, const gse_rng *rng, double *y /* [B][5] */, double *y_meas /* [B][5] */,
                    double *z /* [B][2] */, double *log_x /* [B][5] or NULL */, double *log_u /* [B][2] or NULL */,
                    int64_t B, void *stream);
+/* Parity mode of gse_plant_step: the two draws of sim_base.py:282 / :285 are INPUTS (fp32, as state_pdf.draw() returns
+ * them) -- what lets a closed loop on the device be compared tick by tick with oracle/closed_loop.py. */
+int gse_plant_step_injected(double *X /* [B][5], in/out */, const double *u /* [B][2] */, double dt,
+                            const float *state_draw /* [B][5] */, const float *meas_draw /* [B][2] */, double *y, double *y_meas,
+                            double *z, double *log_x, double *log_u, int64_t B, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Exact systematic resampling of an ensemble SHARDED over several GPUs: the result is, bit for

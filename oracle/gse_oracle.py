@@ -279,7 +279,11 @@ class ParticleFilterOracle:
     particle (the reference's CPU cost model); the ``*_vec`` methods do the same arithmetic
     with array operations."""
 
-    def __init__(self, n, x0, state_pdf, measurement_pdf, rng=None, particles=None):
+    def __init__(self, n, x0, state_pdf, measurement_pdf, rng=None, particles=None, weights_dtype=None):
+        # weights_dtype: None = the reference's own dtypes (fp32 until the first resample, fp64 after it, particle.py:50,
+        # :103); np.float32 = what the device classes store (DESIGN.md section 2: weights are fp32 throughout, sums fp64) --
+        # used where a free-running device loop is compared tick by tick
+        self.weights_dtype = weights_dtype
         self.n = int(n)
         self.state_pdf = state_pdf
         self.measurement_pdf = measurement_pdf
@@ -316,12 +320,14 @@ class ParticleFilterOracle:
         self.weights = (self.weights.astype(np.float64) * p).astype(self.weights.dtype)
 
     # --- resample                                                         (:85-103)
-    def resample(self, r=None, loop=True):
+    def resample(self, r=None, loop=True, idx=None):
+        """``idx``: ancestors to copy INSTEAD of the ones the weights give (replay of a recorded run; the caller compares)."""
         if r is None:
             r = self.rng.random()
-        idx = systematic_index_loop(self.weights, r) if loop else systematic_index(self.weights, r)
+        if idx is None:
+            idx = systematic_index_loop(self.weights, r) if loop else systematic_index(self.weights, r)
         self.particles = self.particles[idx]
-        self.weights = np.full(self.n, 1 / self.n)            # fp64 from here on, as in the reference
+        self.weights = np.full(self.n, 1 / self.n, dtype=self.weights_dtype or np.float64)   # fp64 from here on in the reference
         return idx
 
     # --- moments                                                          (:105-114)
@@ -423,11 +429,12 @@ class GSUKFOracle:
         e = z[None, :] - self.g_rows(self.means, u).astype(np.float64)
         self.weights *= self.measurement_pdf.pdf(e)
 
-    def resample(self, r=None, loop=True):
-        """gs_ukf.py:151-170."""
+    def resample(self, r=None, loop=True, idx=None):
+        """gs_ukf.py:151-170.  ``idx``: ancestors to copy instead of the ones the weights give (replay of a recorded run)."""
         if r is None:
             r = self.rng.random()
-        idx = systematic_index_loop(self.weights, r) if loop else systematic_index(self.weights, r)
+        if idx is None:
+            idx = systematic_index_loop(self.weights, r) if loop else systematic_index(self.weights, r)
         self.means = self.means[idx]
         self.covariances = self.covariances[idx]
         self.weights = np.full(self.n, 1 / self.n)

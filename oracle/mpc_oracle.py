@@ -37,8 +37,15 @@ def layout(P, M, Nx, Ni, No):
     return dict(mu=o_mu, y=o_y, um1=o_um1, du=o_du, n=o_du + (M + 1) * Ni)
 
 
-def assemble_qp(P, M, Q, R, A, B, C, D, ysp, y_bounds=None, u_bounds=None, u_step_bounds=None):
-    """H, q, A, l, u of controller.py:63-229 for x0 = 0, u_-1 = 0 (dense)."""
+def assemble_qp(P, M, Q, R, A, B, C, D, ysp, y_bounds=None, u_bounds=None, u_step_bounds=None, sparse=False):
+    """H, q, A, l, u of controller.py:63-229 for x0 = 0, u_-1 = 0 -- dense arrays, or (sparse=True) scipy.sparse CSC
+    matrices built block by block in the same order (the get_parts horizons for dt_control = 0.1, P = 2999 and M = 1999,
+    give 16 000 variables and 28 000 rows: dense is out of reach there)."""
+    if sparse:
+        import scipy.sparse
+        zeros = lambda shape: scipy.sparse.lil_matrix(shape)
+    else:
+        zeros = np.zeros
     Nx, Ni = B.shape
     No = C.shape[0]
     lay = layout(P, M, Nx, Ni, No)
@@ -51,7 +58,7 @@ def assemble_qp(P, M, Q, R, A, B, C, D, ysp, y_bounds=None, u_bounds=None, u_ste
     um1 = slice(lay["um1"], lay["um1"] + Ni)
     du = lambda j: slice(lay["du"] + j * Ni, lay["du"] + (j + 1) * Ni)          # du_j,  j = 0..M
 
-    H = np.zeros((n, n))
+    H = zeros((n, n))
     q = np.zeros(n)
     for k in range(1, P + 1):                                                   # :99-110
         H[yy(k), yy(k)] = Q
@@ -62,7 +69,7 @@ def assemble_qp(P, M, Q, R, A, B, C, D, ysp, y_bounds=None, u_bounds=None, u_ste
     rows, lows, ups = [], [], []
 
     def block(nrows):
-        blk = np.zeros((nrows, n))
+        blk = zeros((nrows, n))
         rows.append(blk)
         return blk
 
@@ -94,7 +101,7 @@ def assemble_qp(P, M, Q, R, A, B, C, D, ysp, y_bounds=None, u_bounds=None, u_ste
     blk[r(1), yy(1)] = -np.eye(No)
     blk[r(1), um1] = D
     blk[r(1), du(0)] = D
-    blk[r(1), du(1)] += D
+    blk[r(1), du(1)] = (blk[r(1), du(1)].toarray() if sparse else blk[r(1), du(1)]) + D
     for k in range(2, P + 1):
         blk[r(k), mu(k)] = C
         blk[r(k), yy(k)] = -np.eye(No)
@@ -117,6 +124,8 @@ def assemble_qp(P, M, Q, R, A, B, C, D, ysp, y_bounds=None, u_bounds=None, u_ste
     blk[:, um1] = np.eye(Ni)
     blk[:, du(0)] = np.eye(Ni)
     lows.append(u_lo); ups.append(u_hi)
+    if sparse:
+        return H.tocsc(), q, scipy.sparse.vstack(rows).tocsc(), np.concatenate(lows), np.concatenate(ups)
     return H, q, np.vstack(rows), np.concatenate(lows), np.concatenate(ups)
 
 
@@ -207,3 +216,101 @@ def hildreth(law, theta, max_sweeps=2000, eps_abs=1e-13, eps_rel=1e-10):
     du0 = law["Gu"] @ theta + law["gu0"] - (law["Tu"] @ nu if m else 0)
     y1 = law["Gy"] @ theta + law["gy0"] - (law["Ty"] @ nu if m else 0)
     return du0, y1, nu, ok
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The controller of the closed loop as an object (controller.py:9-279), for oracle/closed_loop.py.  The QP is the
+# reference's (assemble_qp, pinned); what solves it is NOT OSQP (not installed, not fetchable: osqp >= 0.6.1,
+# environment.yml:21) but an exact method that shares nothing with the product's condensation + Hildreth sweeps:
+# sparse KKT systems over an enumerated active set.
+# ----------------------------------------------------------------------------------------------------------------------
+class KKTSolver:
+    """min 1/2 z'Hz + q'z, l <= Az <= u with l, u rewritten between solves (the equality PATTERN l == u is fixed at
+    construction, as controller.py:243-262 only rewrites right-hand sides of equality rows).  Every subset of the finite
+    inequality sides is a candidate active set; for a candidate the stationarity + equality + active rows form ONE sparse
+    symmetric indefinite system (scipy.sparse.linalg.splu, factor cached per subset, one round of iterative refinement);
+    the candidate is optimal iff the inactive sides hold and the multipliers of the active ones have the right sign
+    (KKT conditions of a convex QP: necessary and sufficient).  Exact and finite; meant for the handful of bounded rows
+    the closed loop has (two: u_0 >= 0 for both inputs, sim_base.py:82-85)."""
+
+    MAX_SIDES = 10
+
+    def __init__(self, H, q, A, l, u):
+        import scipy.sparse
+        self.H = scipy.sparse.csc_matrix(H)
+        self.q = np.asarray(q, dtype=float)
+        self.A = scipy.sparse.csr_matrix(A)
+        self.eq = np.asarray(l) == np.asarray(u)
+        self.Aeq = self.A[np.flatnonzero(self.eq)]
+        ineq = np.flatnonzero(~self.eq)
+        self.sides = [(int(i), -1) for i in ineq if np.isfinite(l[i])] + [(int(i), +1) for i in ineq if np.isfinite(u[i])]
+        if len(self.sides) > self.MAX_SIDES:
+            raise NotImplementedError("KKTSolver enumerates active sets: %d finite inequality sides are too many" % len(self.sides))
+        self._lu = {}
+
+    def _factor(self, subset):
+        import scipy.sparse
+        import scipy.sparse.linalg
+        if subset not in self._lu:
+            rows = [self.Aeq] + [self.A[self.sides[s][0]] for s in subset]
+            Ar = scipy.sparse.vstack(rows).tocsc()
+            m = Ar.shape[0]
+            K = scipy.sparse.bmat([[self.H, Ar.T], [Ar, scipy.sparse.csc_matrix((m, m))]], format="csc")
+            self._lu[subset] = (scipy.sparse.linalg.splu(K), K)
+        return self._lu[subset]
+
+    def solve(self, l, u):
+        import itertools
+        l, u = np.asarray(l, dtype=float), np.asarray(u, dtype=float)
+        n = self.H.shape[0]
+        n_eq = int(self.eq.sum())
+        beq = l[self.eq]
+        best = None
+        for size in range(len(self.sides) + 1):
+            for subset in itertools.combinations(range(len(self.sides)), size):
+                rows = [self.sides[s][0] for s in subset]
+                if len(set(rows)) < len(rows):
+                    continue                                            # both sides of one row active: only if l == u
+                lu, K = self._factor(subset)
+                rhs = np.concatenate([-self.q, beq, [l[i] if sgn < 0 else u[i] for i, sgn in (self.sides[s] for s in subset)]])
+                sol = lu.solve(rhs)
+                sol += lu.solve(rhs - K @ sol)                          # one round of iterative refinement
+                z, lam = sol[:n], sol[n + n_eq:]
+                Az = self.A @ z
+                scale = 1e-9 * (1.0 + np.abs(Az))
+                feasible = np.all(Az >= l - scale) and np.all(Az <= u + scale)
+                # stationarity: Hz + q + A'lam = 0; a row at its LOWER bound needs lam <= 0, at its UPPER bound lam >= 0
+                signs = all((lam[k] <= 1e-12) if self.sides[s][1] < 0 else (lam[k] >= -1e-12) for k, s in enumerate(subset))
+                if feasible and signs:
+                    return z
+                if best is None and feasible:
+                    best = z
+        raise ValueError("the QP has no KKT point among the enumerated active sets (rows infeasible)")
+
+
+class MPCOracle:
+    """controller.MPC restated around the pinned QP: same constructor arguments (the linear model as its four matrices),
+    same step() contract -- clip to +-1e10 (controller.py:238-241), write u_-1, -x0 and the tiled -bias into l and u
+    (:243-262), solve, first input = du_0 + u_-1 (:272-275), y_predicted = y_1 - bias (:277); raises ValueError where the
+    reference raises on a non-solved status."""
+
+    def __init__(self, P, M, Q, R, A, B, C, D, ysp, y_bounds=None, u_bounds=None, u_step_bounds=None):
+        self.P, self.M = int(P), int(M)
+        self.Nx, self.Ni = B.shape
+        self.No = C.shape[0]
+        H, q, Am, l, u = assemble_qp(P, M, np.asarray(Q, float), np.asarray(R, float), A, B, C, D, np.asarray(ysp, float),
+                                     y_bounds, u_bounds, u_step_bounds, sparse=True)
+        self.l0, self.u0 = l, u
+        self.solver = KKTSolver(H, q, Am, l, u)
+        self.y_predicted = None
+
+    def step(self, x0, um1, y0):
+        clip = lambda v: np.maximum(np.minimum(np.asarray(v, dtype=float), 1e10), -1e10)
+        x0, um1, y0 = clip(x0), clip(um1), clip(y0)
+        bias = y0 - self.y_predicted if self.y_predicted is not None else np.zeros_like(y0)      # :248-251
+        l, u = write_step(self.l0, self.u0, self.P, self.Nx, self.Ni, self.No, x0, um1, bias)
+        z = self.solver.solve(l, u)
+        m = (self.P + 1) * self.Nx + self.P * self.No + self.Ni
+        ctrl = z[m:m + self.Ni] + um1
+        self.y_predicted = z[(self.P + 1) * self.Nx:(self.P + 1) * self.Nx + self.No] - bias
+        return ctrl

@@ -21,6 +21,8 @@ Fixture list:
   G6 pf_stat.npz        posterior-mean envelope over independent seeds (statistical parity)
   G7 constants.npz      mixture constants, inverse covariances, sigma weights, X_ss
   G8 linear_model.npz   LinearModel.create_LinearModel of the bioreactor (get_parts wiring), dt_control in {1, 0.1}
+  G10 closed_loop.npz   sim_base.Simulation.simulate (the reference's own loop text) on the NumPy classes: recorded random
+                        inputs and every record of the loop, particle filter and GS-UKF, control every tick / every 10th
   G9 mpc_qp.npz         controller.MPC: the QP it hands to OSQP (H, q, A, l, u) for several horizons / bounds, and the
                         l, u vectors after step() has written x0, u_{-1} and the bias into them.  (osqp is not
                         installed: the SOLUTION of these QPs is not a reference output and is not stored.)
@@ -472,8 +474,125 @@ def gen_mpc_qp():
     save("mpc_qp.npz", **out)
 
 
+# --------------------------------------------------------------------------- G10
+class _HostArray(numpy.ndarray):
+    """What a cupy array is to the reference's loop: something with .get() (sim_base.py:281-284)."""
+
+    def get(self):
+        return numpy.asarray(self)
+
+
+class _KktOsqp:
+    """Stands where osqp.OSQP stands in controller.py:232-236, :264-267 (osqp >= 0.6.1 is not installed and cannot be
+    fetched).  mode 'exact': solve() returns the exact minimiser of the QP the reference handed to setup() / update()
+    (oracle.mpc_oracle.KKTSolver) with status 1; mode 'fail': solve() reports a non-solved status, which drives the
+    reference's own except branch (sim_base.py:271-273).  The SOLUTION is therefore not a reference output; everything
+    around it -- what the loop feeds the controller, what it does with the answer, the bias bookkeeping -- is."""
+    mode = "exact"
+
+    def setup(self, H, q, A, l, u, verbose=False):
+        ROOT = os.path.dirname(os.path.dirname(OUT))
+        if ROOT not in sys.path:
+            sys.path.append(ROOT)
+        from oracle import mpc_oracle
+        self._solver = mpc_oracle.KKTSolver(H, q, A, l, u)
+        self._l, self._u = numpy.array(l, dtype=float), numpy.array(u, dtype=float)
+
+    def update(self, l=None, u=None):
+        self._l, self._u = numpy.array(l, dtype=float), numpy.array(u, dtype=float)
+
+    def solve(self):
+        info = types.SimpleNamespace(status_val=1, status="solved")
+        if self.mode == "fail":
+            return types.SimpleNamespace(x=None, info=types.SimpleNamespace(status_val=-2, status="maximum iterations reached"))
+        return types.SimpleNamespace(x=self._solver.solve(self._l, self._u), info=info)
+
+
+def _host_noise(lib=numpy, deterministic=False, _orig=sim_base.get_noise):
+    """sim_base.get_noise on NumPy whose draws answer .get() like device arrays do."""
+    pair = _orig(numpy, deterministic)
+    for dist in pair:
+        inner = dist.draw
+        dist.draw = (lambda inner: lambda *a, **k: numpy.asarray(inner(*a, **k)).view(_HostArray))(inner)
+    return pair
+
+
+def gen_closed_loop(seed=1010):
+    """The reference's own Simulation.__init__ / simulate (sim_base.py:207-309) executed on its NumPy classes: get_parts
+    is called with gpu=False (the loop hard-wires the default gpu=True, :215-219), get_noise hands out NumPy mixtures whose
+    draws have .get(), scipy.integrate.simps (removed in SciPy 1.14; the reference pins >= 1.4.1) is the rule of
+    oracle/closed_loop.simps_avg, and osqp is _KktOsqp above.  Recorded: every random input and every record the loop keeps."""
+    import controller  # noqa: F401  (reference)
+    import scipy.integrate
+    ROOT = os.path.dirname(os.path.dirname(OUT))
+    if ROOT not in sys.path:
+        sys.path.append(ROOT)
+    from oracle import closed_loop
+    keep = (sim_base.get_parts, sim_base.get_noise, sys.modules["osqp"].OSQP, getattr(scipy.integrate, "simps", None))
+    sim_base.get_noise = _host_noise
+    sim_base.get_parts = lambda dt_control=1, N_particles=2 * 15, gpu=False, pf=True, _orig=keep[0]: _orig(
+        dt_control=dt_control, N_particles=N_particles, gpu=False, pf=pf)
+    sys.modules["osqp"].OSQP = _KktOsqp
+    controller.osqp.OSQP = _KktOsqp
+    scipy.integrate.simps = lambda y, x: closed_loop.simps_avg(y, x)
+    cases = {
+        #           N    dt_control dt_predict end pf     osqp
+        "pf_c1":   (256, 1.0,       0.1,       6,  True,  "exact"),     # predict every tick, control every 10th
+        "pf_c1p1": (256, 1.0,       1.0,       6,  True,  "exact"),     # predict and control every 10th tick
+        "pf_c01":  (256, 0.1,       0.1,       3,  True,  "exact"),     # control every tick (P = 2999, M = 1999)
+        "pf_fail": (256, 1.0,       0.1,       4,  True,  "fail"),      # the except branch on every control tick
+        "gsf_c1":  (8,   1.0,       0.1,       4,  False, "exact"),
+        "gsf_c01": (6,   0.1,       0.1,       2,  False, "exact"),
+    }
+    out = {"names": numpy.array(sorted(cases))}
+    try:
+        for k, (name, (n, dtc, dtp, end, pf, mode)) in enumerate(sorted(cases.items())):
+            _KktOsqp.mode = mode
+            numpy.random.seed(seed + k)
+            sim = sim_base.Simulation(n, dtc, dtp, end_time=end, pf=pf)
+            est0 = dict(particles0=numpy.array(sim.f.particles)) if pf else dict(
+                means0=numpy.array(sim.f.means), covs0=numpy.array(sim.f.covariances))
+            rec_f, rec_ps, rec_pm = Recorder(sim.f.state_pdf), Recorder(sim.state_pdf), Recorder(sim.measurement_pdf)
+            # the ancestors of every resample: the reference's own resample rerun on row numbers with the same weights and r
+            idx_log, r_log = [], []
+
+            def recording_resample(_orig=sim.f.resample, _f=sim.f):
+                w_before = numpy.array(_f.weights, copy=True)
+                with RandRecorder() as rr:
+                    _orig()
+                r_log.append(float(rr.log[-1]))
+                idx_log.append(ref_resample_idx(w_before, r_log[-1]))
+
+            sim.f.resample = recording_resample
+            sim.simulate()
+            tag = name + "_"
+            out[tag + "ancestors"] = numpy.array(idx_log, dtype=numpy.int32)
+            out[tag + "cfg"] = numpy.array([n, dtc, dtp, end, float(pf)])
+            for key, val in est0.items():
+                out[tag + key] = val
+            out[tag + "predict_noise"] = numpy.array(rec_f.log)
+            out[tag + "plant_state"] = numpy.array(rec_ps.log).reshape(len(rec_ps.log), 5)
+            out[tag + "plant_meas"] = numpy.array(rec_pm.log).reshape(len(rec_pm.log), 2)
+            out[tag + "r"] = numpy.array(r_log)
+            for key in ("us", "xs", "ys", "ys_meas", "xs_f", "ys_f", "covariance_point_size"):
+                out[tag + key] = numpy.array(getattr(sim, key), dtype=numpy.float64)
+            out[tag + "biass"] = numpy.array(sim.biass, dtype=numpy.float64).reshape(len(sim.biass), 2)
+            out[tag + "performance"] = numpy.float64(sim.performance)
+            out[tag + "mpc_frac"] = numpy.float64(sim.mpc_frac)
+            out[tag + "counts"] = numpy.array([sim.predict_count, sim.update_count])
+            print("  closed loop %s: %d predicts, %d updates, mpc_frac %.2f, performance %.4g" %
+                  (name, sim.predict_count, sim.update_count, sim.mpc_frac, sim.performance), flush=True)
+    finally:
+        sim_base.get_parts, sim_base.get_noise = keep[0], keep[1]
+        sys.modules["osqp"].OSQP = keep[2]
+        controller.osqp.OSQP = keep[2]
+        if keep[3] is None:
+            del scipy.integrate.simps
+    save("closed_loop.npz", **out)
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"constants", "model", "pdf", "resample", "pf", "gsukf", "stat", "linear", "mpc"}
+    which = set(sys.argv[1:]) or {"constants", "model", "pdf", "resample", "pf", "gsukf", "stat", "linear", "mpc", "loop"}
     Xss = x_ss()
     print("X_ss =", Xss)
     if "constants" in which:
@@ -494,3 +613,5 @@ if __name__ == "__main__":
         gen_linear_model()
     if "mpc" in which:
         gen_mpc_qp()
+    if "loop" in which:
+        gen_closed_loop()

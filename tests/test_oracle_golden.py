@@ -204,3 +204,54 @@ def test_gsukf_known_answer(golden):
     gf.predict(g["ka_u"], 0.1, noise=np.zeros((2, 11, 5), np.float32))
     np.testing.assert_allclose(gf.means, g["ka_m_pred"], rtol=1e-6, atol=1e-8)
     assert_cov_close(gf.covariances, g["ka_P_pred"], 5e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The closed loop: oracle/closed_loop.py against the reference's own Simulation.simulate, run on the
+# reference's NumPy classes by tests/golden/make_golden.py (G10).
+# ---------------------------------------------------------------------------------------------------------------------
+from loop_util import loop_oracle_from_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["pf_c1", "pf_c1p1", "pf_c01", "pf_fail", "gsf_c1", "gsf_c01"])
+def test_closed_loop_oracle_against_the_reference_loop(golden, name):
+    """Fed the recorded random inputs, the oracle loop reproduces every record of the reference's loop over the whole run
+    (no re-seeding of states from the recording): the order of operations of sim_base.py:243-309 (predict-if-due, bias log,
+    update, resample, estimate, MPC with the except branch, plant step + clamp, the two noise draws, per-tick estimate and
+    covariance), the performance integral and the solved fraction.  The reference's f keeps some terms fp32 under NumPy 2
+     where the oracle restates the device's fp64 arithmetic, so particles differ by fp32 roundings and weights
+    by 2e-6: the oracle's OWN ancestors are counted against the recorded ones (at most 2 flips per resample, a weight
+    within rounding of a threshold -- measured: 8 of 7 424 over the 29 resamples of pf_c01, none elsewhere) and the
+    recorded ones are copied, so that one flip does not send the rest of the run down another path.  Tolerances are the
+    measured deviations rounded up: estimates 2e-6, inputs 1e-6, covariance sizes 1e-5."""
+    g = golden("closed_loop.npz")
+    sim = loop_oracle_from_golden(g, name).simulate()
+    assert (sim.predict_count, sim.update_count) == tuple(g[name + "_counts"])
+    assert max(sim.ancestor_flips) <= 2 and sum(sim.ancestor_flips) <= 8, sim.ancestor_flips
+    np.testing.assert_allclose(sim.us, g[name + "_us"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sim.xs, g[name + "_xs"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(sim.ys, g[name + "_ys"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(sim.ys_meas, g[name + "_ys_meas"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(sim.xs_f, g[name + "_xs_f"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(sim.ys_f, g[name + "_ys_f"], rtol=2e-6)
+    np.testing.assert_allclose(sim.covariance_point_size, g[name + "_covariance_point_size"], rtol=1e-5)
+    np.testing.assert_allclose(np.array(sim.biass).reshape(-1, 2), g[name + "_biass"], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(sim.performance, g[name + "_performance"], rtol=1e-5)
+    assert sim.mpc_frac == g[name + "_mpc_frac"]
+
+
+def test_simps_rule_of_the_reference_scipy():
+    """oracle.closed_loop.simps_avg on an odd sample count is Simpson's rule (= scipy.integrate.simpson there); on an even
+    count it is the published even='avg' rule: exact for cubics only up to the trapezoid ends."""
+    import scipy.integrate
+    from oracle import closed_loop
+    x = np.linspace(0, 3, 31)
+    y = np.sin(x) + x ** 3
+    np.testing.assert_allclose(closed_loop.simps_avg(y, x), scipy.integrate.simpson(y, x=x), rtol=1e-14)
+    x = np.linspace(0, 3, 30)
+    y = 2 * x ** 2 - x
+    first = scipy.integrate.simpson(y[:-1], x=x[:-1]) + 0.5 * (x[-1] - x[-2]) * (y[-1] + y[-2])
+    last = 0.5 * (x[1] - x[0]) * (y[1] + y[0]) + scipy.integrate.simpson(y[1:], x=x[1:])
+    np.testing.assert_allclose(closed_loop.simps_avg(y, x), (first + last) / 2, rtol=1e-14)
+    from gpu_se_amd import sim_base
+    np.testing.assert_allclose(sim_base.simps(y, x), closed_loop.simps_avg(y, x), rtol=1e-15)

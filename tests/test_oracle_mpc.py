@@ -136,3 +136,57 @@ def test_explicit_law_reaches_the_qp_optimum(name):
     if name != "free":
         assert active_seen > 0          # the bounds were exercised
     assert (infeasible_seen > 0) == (name == "boxed")
+
+
+@pytest.mark.parametrize("name", ["small", "square", "free", "parts"])
+def test_kkt_active_set_solver_equals_the_dense_exact_solver(name):
+    """oracle.mpc_oracle.KKTSolver (sparse KKT systems over enumerated active sets: what the closed-loop oracle's MPC and the
+    recording of tests/golden/closed_loop.npz solve the reference's QP with) against solve_qp (null space + NNLS), bounds
+    inactive and active.  Two exact methods that share no step."""
+    sparse = orc.assemble_qp(Q=Q, R=R, A=lin_model().A, B=lin_model().B, C=lin_model().C, D=lin_model().D, ysp=LIN["dt1_ysp"],
+                             sparse=True, **CASES[name])
+    H, q, A, l0, u0 = oracle_qp(name)
+    np.testing.assert_array_equal(sparse[0].toarray(), H)
+    np.testing.assert_array_equal(sparse[2].toarray(), A)
+    solver = orc.KKTSolver(*sparse)
+    P, M = CASES[name]["P"], CASES[name]["M"]
+    rng = np.random.default_rng(5)
+    active = 0
+    for theta in thetas_for(name, rng, 2 if name == "parts" else 8):
+        l, u = orc.write_step(l0, u0, P, 2, 2, 2, theta[:2], theta[2:4], theta[4:])
+        z_dense, objective, info = orc.solve_qp(H, q, A, l, u)
+        z = solver.solve(l, u)
+        active += info["active"]
+        assert 0.5 * z @ H @ z + q @ z <= objective + 1e-9 * (1 + abs(objective))
+        lay = orc.layout(P, M, 2, 2, 2)
+        np.testing.assert_allclose(z[lay["du"]:lay["du"] + 2], z_dense[lay["du"]:lay["du"] + 2], rtol=1e-6, atol=1e-9)
+        # (y_1 ~ 285: the dense route's SVD of the 1204 x 1606 equality block of "parts" is good to 1e-8 relative of that;
+        #  the tight comparison of this solver is the next test, 1e-9 against the product's condensation)
+        np.testing.assert_allclose(z[lay["y"]:lay["y"] + 2], z_dense[lay["y"]:lay["y"] + 2], rtol=1e-7, atol=1e-5)
+    assert (active > 0) == (name != "free")
+
+
+def test_mpc_oracle_step_is_the_explicit_law_at_the_long_horizon():
+    """get_parts(dt_control = 0.1): P = 2999, M = 1999 -- 16 000 variables, out of reach of the dense solvers.  MPCOracle
+    (sparse QP of the reference + KKTSolver) against the product's condensation + the NumPy checker of its device sweeps,
+    over consecutive steps (bias bookkeeping included), bounds inactive and active."""
+    lin = {k: LIN["dt01_sub_" + k] for k in ("A", "B", "C", "D", "x_bar", "u_bar", "f_bar", "y_bar")}
+    lm = model.LinearModel(lin["A"], lin["B"], lin["C"], lin["D"], 0.1, lin["x_bar"], lin["u_bar"], lin["f_bar"], lin["y_bar"])
+    ub = [np.array([0, np.inf]) - lin["u_bar"][0], np.array([0, np.inf]) - lin["u_bar"][1]]
+    K = controller.MPC(P=2999, M=1999, Q=Q, R=R, lin_model=lm, ysp=LIN["dt01_ysp"], u_bounds=ub)
+    O = orc.MPCOracle(2999, 1999, Q, R, lin["A"], lin["B"], lin["C"], lin["D"], LIN["dt01_ysp"], u_bounds=ub)
+    rng = np.random.default_rng(8)
+    y_pred, active = None, 0
+    for k, theta in enumerate(thetas_for("parts", rng, 6)):
+        x0, um1, y0 = theta[:2] * 0.2, theta[2:4], theta[4:]
+        bias = y0 - y_pred if y_pred is not None else np.zeros(2)
+        du0, y1, nu, ok = orc.hildreth(K._law, np.concatenate([x0, um1, bias]))
+        assert ok
+        active += int(np.any(nu != 0))
+        ctrl = O.step(x0, um1, y0)
+        # (the condensed Hessian of this horizon has a condition number of 4.5e14 -- the outputs accumulate over 2999 steps --
+        #  so the law's du_0 carries ~1e-8 relative; the sparse KKT residuals are at 1e-13)
+        np.testing.assert_allclose(du0 + um1, ctrl, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(y1 - bias, O.y_predicted, rtol=1e-7, atol=1e-6)
+        y_pred = y1 - bias
+    assert active > 0
