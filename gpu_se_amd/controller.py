@@ -2,7 +2,9 @@
 
 The reference states the controller as a sparse QP over (state deltas, outputs, u_{-1}, input moves) and calls OSQP on
 every control tick.  Between ticks only theta = (x0, u_{-1}, bias) changes (controller.py:236-262), so here the QP is
-condensed ONCE, on the host, in fp64:
+reduced ONCE, on the host, in fp64, to an explicit law in theta and the multipliers of the bounded rows (its matrices
+through sparse KKT solves in the reference's variable space, _law_from_kkt; the dense condensed form below is what the law
+means and what the tests inspect):
 
     * the equality rows (controller.py:119-178: u_{-1} pinned, the delta-state recursion, the accumulated outputs)
       define every state and output as a linear function of the moves d = (du_0 .. du_M) and of theta:
@@ -75,20 +77,23 @@ class MPC:
         self._u_lim = _bounds(u_bounds, Ni)
         self._du_lim = _bounds(u_step_bounds, Ni)
         self._solver = (int(max_sweeps), float(eps_abs), float(eps_rel))
-        self._built = None          # condensed problem + explicit law: built on first use (a P = 2999 horizon takes
-        self._dev = None            # ~10 s of dense algebra; callers that only want the estimator never pay it)
+        self._built = None          # the explicit law: built on first use (callers that only want the estimator never pay)
+        self._dense = None          # the condensed problem as dense arrays (inspection / tests / singular R)
+        self._dev = None
 
     @property
     def _law(self):
         if self._built is None:
-            self._condense()
+            self._build()
         return self._built[0]
 
     @property
     def _condensed(self):
-        if self._built is None:
-            self._condense()
-        return self._built[1]
+        """The condensed problem as dense arrays (Hc, F, f0, Cin, Pin, Phi, Psi): for inspection and tests; the law itself
+        is built from it only when R is singular (see _build)."""
+        if self._dense is None:
+            self._dense = self._condense()
+        return self._dense
 
     # ------------------------------------------------------------------------------------------------------------
     # host set-up
@@ -116,6 +121,114 @@ class MPC:
             dmus.append(dmu)
         return numpy.vstack(ys), numpy.vstack(dmus)
 
+    def _bounded_rows(self):
+        """The inequality rows of the reference that carry a finite bound, in its order (controller.py:180-219: outputs,
+        input moves, first input): [(kind, step, index, lo, hi)]."""
+        rows = []
+        for k in range(self.P):
+            for o in range(self.No):
+                rows.append(("y", k, o, self._y_lim[0][o], self._y_lim[1][o]))
+        for j in range(self.M + 1):
+            for i in range(self.Ni):
+                rows.append(("du", j, i, self._du_lim[0][i], self._du_lim[1][i]))
+        for i in range(self.Ni):          # u_-1 + du_0 (controller.py:209-219 keeps the bound on the first input only)
+            rows.append(("u", 0, i, self._u_lim[0][i], self._u_lim[1][i]))
+        rows = [r for r in rows if numpy.isfinite(r[3]) or numpy.isfinite(r[4])]
+        if len(rows) > MAX_ROWS:
+            raise NotImplementedError("this MPC has %d bounded rows; the device solver takes at most %d "
+                                      "(bound fewer outputs / moves, or shorten the horizons)" % (len(rows), MAX_ROWS))
+        return rows
+
+    def _build(self):
+        """The explicit law.  R positive definite (every wiring of sim_base.get_parts): through sparse KKT systems in the
+        reference's full variable space -- the condensed Hessian of the long horizons is hopelessly conditioned (4.5e14 at
+        P = 2999: the outputs accumulate), the KKT matrix is not.  R singular (the reference's tank tests): through the dense
+        condensed problem and a pseudo-inverse."""
+        if numpy.all(numpy.linalg.eigvalsh((self.R + self.R.T) / 2) > 0):
+            self._built = (self._law_from_kkt(),)
+        else:
+            self._built = (self._law_from_condensed(),)
+
+    def _law_from_kkt(self):
+        """z = [dmu_0 .. dmu_P | y_1 .. y_P | u_-1 | du_0 .. du_M] (the reference's variable order, controller.py:99-110).
+        The minimiser of the equality-constrained QP is linear in (theta, 1, nu): z = Zt theta + z0 + Zn nu, one sparse
+        symmetric-indefinite solve per column (Nx + Ni + No + 1 + bounded rows of them, one LU).  The law's matrices are rows
+        of those columns: du_0, y_1 and the bounded rows."""
+        import scipy.sparse as sp
+        import scipy.sparse.linalg
+        A, B, C, D = (numpy.asarray(m, dtype=float) for m in (self.model.A, self.model.B, self.model.C, self.model.D))
+        Nx, Ni, No, P, M = self.Nx, self.Ni, self.No, self.P, self.M
+        o_y, o_u, o_d = (P + 1) * Nx, (P + 1) * Nx + P * No, (P + 1) * Nx + P * No + Ni
+        n = o_d + (M + 1) * Ni
+        rr, cc, vv = [], [], []
+
+        def put(r0, c0, blk):
+            blk = numpy.atleast_2d(blk)
+            ri, ci = numpy.nonzero(blk)
+            rr.append(r0 + ri); cc.append(c0 + ci); vv.append(blk[ri, ci])
+
+        I_x, I_y, I_u = numpy.eye(Nx), numpy.eye(No), numpy.eye(Ni)
+        r_state, r_out = Ni, Ni + (P + 1) * Nx
+        put(0, o_u, I_u)                                                   # u_-1 = theta_u
+        put(r_state, 0, -I_x)                                              # -dmu_0 = -x0
+        for k in range(1, P + 1):                                          # dmu_k = A dmu_{k-1} (+ B moves)
+            r0 = r_state + k * Nx
+            put(r0, (k - 1) * Nx, A - I_x if k == 1 else A)
+            put(r0, k * Nx, -I_x)
+            if k == 1:
+                put(r0, o_u, B)
+            if k <= M:
+                put(r0, o_d + (k - 1) * Ni, B)
+        for k in range(1, P + 1):                                          # y_k = y_{k-1} + C dmu_k + D du_k + bias
+            r0 = r_out + (k - 1) * No
+            put(r0, k * Nx, C)
+            put(r0, o_y + (k - 1) * No, -I_y)
+            if k == 1:
+                put(r0, 0, C)
+                put(r0, o_u, D)
+                put(r0, o_d, D)
+                put(r0, o_d + Ni, D)
+            else:
+                put(r0, o_y + (k - 2) * No, I_y)
+                if k <= M:
+                    put(r0, o_d + k * Ni, D)
+        n_eq = Ni + (P + 1) * Nx + P * No
+        Aeq = sp.coo_matrix((numpy.concatenate(vv), (numpy.concatenate(rr), numpy.concatenate(cc))), shape=(n_eq, n)).tocsc()
+        H = sp.block_diag([sp.csc_matrix((o_y, o_y)), sp.kron(sp.eye(P), self.Q), sp.csc_matrix((Ni, Ni)),
+                           sp.kron(sp.eye(M + 1), self.R)], format="csc")
+        q = numpy.zeros(n)
+        q[o_y:o_u] = numpy.tile(-self.Q @ self.ysp, P)
+        rows = self._bounded_rows()
+        m, nt = len(rows), Nx + Ni + No
+        a_rows = numpy.zeros((m, n))
+        for i, (kind, step, idx, _, _) in enumerate(rows):
+            if kind == "y":
+                a_rows[i, o_y + step * No + idx] = 1.0
+            elif kind == "du":
+                a_rows[i, o_d + step * Ni + idx] = 1.0
+            else:
+                a_rows[i, o_u + idx] = a_rows[i, o_d + idx] = 1.0
+        rhs = numpy.zeros((n + n_eq, nt + 1 + m))
+        for k in range(Nx):
+            rhs[n + r_state + k, k] = -1.0                                 # -dmu_0 = -x0
+        for k in range(Ni):
+            rhs[n + k, Nx + k] = 1.0                                       # u_-1
+        for k in range(No):
+            rhs[n + r_out + k:n + n_eq:No, Nx + Ni + k] = -1.0             # ... = -bias on every output row
+        rhs[:n, nt] = -q
+        rhs[:n, nt + 1:] = -a_rows.T                                        # H z + q + Aeq' lam + a_i nu_i = 0
+        K = sp.bmat([[H, Aeq.T], [Aeq, None]], format="csc")
+        lu = scipy.sparse.linalg.splu(K)
+        Z = lu.solve(rhs)
+        Z += lu.solve(rhs - K @ Z)                                          # one round of iterative refinement
+        Z = Z[:n]
+        Zt, z0, Zn = Z[:, :nt], Z[:, nt], Z[:, nt + 1:]
+        du0, y1 = slice(o_d, o_d + Ni), slice(o_y, o_y + No)
+        self._moves_of = (Zt[o_d:], z0[o_d:], Zn[o_d:])
+        return dict(Gc=a_rows @ Zt, gc0=a_rows @ z0, S=-(a_rows @ Zn), lo=numpy.array([r[3] for r in rows], dtype=float),
+                    hi=numpy.array([r[4] for r in rows], dtype=float), Gu=Zt[du0], gu0=z0[du0], Tu=-Zn[du0].reshape(Ni, m),
+                    Gy=Zt[y1], gy0=z0[y1], Ty=-Zn[y1].reshape(No, m))
+
     def _condense(self):
         Nx, Ni, No, P, M = self.Nx, self.Ni, self.No, self.P, self.M
         nd, nt = (M + 1) * Ni, Nx + Ni + No
@@ -127,61 +240,59 @@ class MPC:
             Hc[j * Ni:(j + 1) * Ni, j * Ni:(j + 1) * Ni] += self.R
         F = QPhi.T @ Psi
         f0 = -QPhi.T @ numpy.tile(self.ysp, P)
-        # bounded rows, in the order of the reference's inequality blocks: outputs, input moves, first input
-        rows_d, rows_t, lo, hi = [], [], [], []
+        rows = self._bounded_rows()
+        m = len(rows)
+        Cin, Pin = numpy.zeros((m, nd)), numpy.zeros((m, nt))
+        for i, (kind, step, idx, _, _) in enumerate(rows):
+            if kind == "y":
+                Cin[i], Pin[i] = Phi[step * No + idx], Psi[step * No + idx]
+            elif kind == "du":
+                Cin[i, step * Ni + idx] = 1.0
+            else:
+                Cin[i, idx], Pin[i, Nx + idx] = 1.0, 1.0
+        return dict(Hc=Hc, F=F, f0=f0, Cin=Cin, Pin=Pin, Phi=Phi, Psi=Psi, lo=numpy.array([r[3] for r in rows], dtype=float),
+                    hi=numpy.array([r[4] for r in rows], dtype=float))
 
-        def unit(i):
-            e = numpy.zeros(nd)
-            e[i] = 1.0
-            return e
-
-        def add(row_d, row_t, lo_i, hi_i):
-            if numpy.isfinite(lo_i) or numpy.isfinite(hi_i):
-                rows_d.append(row_d); rows_t.append(row_t); lo.append(lo_i); hi.append(hi_i)
-
-        for k in range(P):
-            for o in range(No):
-                add(Phi[k * No + o], Psi[k * No + o], self._y_lim[0][o], self._y_lim[1][o])
-        for j in range(M + 1):
-            for i in range(Ni):
-                add(unit(j * Ni + i), numpy.zeros(nt), self._du_lim[0][i], self._du_lim[1][i])
-        for i in range(Ni):          # u_-1 + du_0 (controller.py:209-219 keeps the bound on the first input only)
-            add(unit(i), numpy.eye(nt)[Nx + i], self._u_lim[0][i], self._u_lim[1][i])
-        m = len(lo)
-        if m > MAX_ROWS:
-            raise NotImplementedError("this MPC has %d bounded rows; the device solver takes at most %d "
-                                      "(bound fewer outputs / moves, or shorten the horizons)" % (m, MAX_ROWS))
-        Cin = numpy.array(rows_d).reshape(m, nd)
-        Pin = numpy.array(rows_t).reshape(m, nt)
-        try:
-            chol = numpy.linalg.cholesky(Hc)
-            solve = lambda rhs: numpy.linalg.solve(chol.T, numpy.linalg.solve(chol, rhs))
-        except numpy.linalg.LinAlgError:
-            # R = 0 with D = 0 (the reference's tank tests): the last move du_M enters no state and no output, so the cost
-            # is flat along it and Hc is only positive SEMI-definite.  OSQP copes (any minimiser will do); here the
-            # minimiser of least norm is taken -- du_0 and y_1, all the loop uses, are the same for every minimiser as
-            # long as no bounded row pulls along a flat direction (refused below).
-            evals, evecs = numpy.linalg.eigh((Hc + Hc.T) / 2)
-            curved = evals > 1e-12 * evals.max()
-            if not curved.any() or evals.min() < -1e-9 * evals.max():
-                raise
-            if m and numpy.max(numpy.abs(Cin @ evecs[:, ~curved])) > 1e-9:
+    def _law_from_condensed(self):
+        """R = 0 with D = 0 (the reference's tank tests): the last move du_M enters no state and no output, the cost is flat
+        along it and Hc is only positive SEMI-definite.  OSQP copes (any minimiser will do); here the minimiser of least norm
+        is taken, after checking that the choice cannot show: the flat directions must not reach du_0 or y_1 (all the loop
+        uses), and a bounded row that touches flat moves only costs nothing to satisfy and is dropped."""
+        c = self._condensed
+        Hc, F, f0, Cin, Pin, Phi, Psi = (c[k] for k in ("Hc", "F", "f0", "Cin", "Pin", "Phi", "Psi"))
+        Ni, No = self.Ni, self.No
+        evals, evecs = numpy.linalg.eigh((Hc + Hc.T) / 2)
+        curved = evals > 1e-12 * evals.max()
+        if not curved.any() or evals.min() < -1e-9 * evals.max():
+            raise numpy.linalg.LinAlgError("the condensed MPC Hessian is not positive semi-definite")
+        flat = evecs[:, ~curved]
+        lo, hi = c["lo"], c["hi"]
+        if flat.shape[1]:
+            if numpy.max(numpy.abs(flat[:Ni])) > 1e-9 or numpy.max(numpy.abs(Phi[:No] @ flat)) > 1e-9:
+                raise NotImplementedError("the MPC cost is flat along a direction that moves du_0 or y_1 (R is singular "
+                                          "there): the minimiser is not unique where the loop looks; give those moves a weight")
+            along = numpy.abs(Cin @ flat).max(axis=1) > 1e-9 if len(lo) else numpy.zeros(0, dtype=bool)
+            only_flat = along & (numpy.abs(Cin @ evecs[:, curved]).max(axis=1) <= 1e-9) & numpy.all(Pin == 0, axis=1)
+            if numpy.any(along & ~only_flat):
                 raise NotImplementedError("a bounded row acts along a direction in which the MPC cost is flat (R is "
-                                          "singular there): give those moves a weight")
-            pinv = (evecs[:, curved] / evals[curved]) @ evecs[:, curved].T
-            solve = lambda rhs: pinv @ rhs
-        HiF, Hif0, HiCt = solve(F), solve(f0), solve(Cin.T)
-        law = dict(
-            Gc=-Cin @ HiF + Pin, gc0=-Cin @ Hif0, S=Cin @ HiCt, lo=numpy.array(lo, dtype=float), hi=numpy.array(hi, dtype=float),
+                                          "singular there) as well as along curved ones: give those moves a weight")
+            keep = ~only_flat                       # rows on cost-free moves alone (a limit on du_M): any value inside will do
+            Cin, Pin, lo, hi = Cin[keep], Pin[keep], lo[keep], hi[keep]
+        pinv = (evecs[:, curved] / evals[curved]) @ evecs[:, curved].T
+        HiF, Hif0, HiCt = pinv @ F, pinv @ f0, pinv @ Cin.T
+        m = len(lo)
+        self._moves_of = (-HiF, -Hif0, -HiCt)
+        return dict(
+            Gc=-Cin @ HiF + Pin, gc0=-Cin @ Hif0, S=Cin @ HiCt, lo=lo, hi=hi,
             Gu=-HiF[:Ni], gu0=-Hif0[:Ni], Tu=HiCt[:Ni].reshape(Ni, m),
             Gy=-Phi[:No] @ HiF + Psi[:No], gy0=-Phi[:No] @ Hif0, Ty=(Phi[:No] @ HiCt).reshape(No, m))
-        self._built = (law, dict(Hc=Hc, F=F, f0=f0, Cin=Cin, Pin=Pin, Phi=Phi, Psi=Psi, HiF=HiF, Hif0=Hif0, HiCt=HiCt))
 
     def moves(self, theta, nu):
         """All input moves d* for parameter rows ``theta`` [B, n_theta] and multipliers ``nu`` [B, n_rows] (host;
         for inspection and tests -- the loop itself needs only du_0 and y_1)."""
-        c = self._condensed
-        return (-(c["HiF"] @ theta.T) - c["Hif0"][:, None] - c["HiCt"] @ nu.T).T
+        self._law                                    # (built on first use)
+        Zt, z0, Zn = self._moves_of
+        return (Zt @ theta.T + z0[:, None] + Zn @ nu.T).T
 
     # ------------------------------------------------------------------------------------------------------------
     # device evaluation
