@@ -61,7 +61,7 @@ class MPC:
     ``y_predicted``) and ``step`` contract as the reference; ``step_batch`` advances B rollouts at once."""
 
     def __init__(self, P, M, Q, R, lin_model, ysp, y_bounds=None, u_bounds=None, u_step_bounds=None,
-                 max_sweeps=4000, eps_abs=1e-13, eps_rel=1e-10):
+                 max_sweeps=4000, eps_abs=1e-14, eps_rel=1e-12):
         if M > P or M < 1:
             raise ValueError("MPC needs 1 <= M <= P")
         self.P, self.M = int(P), int(M)

@@ -77,6 +77,8 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._pend_update = None
         self._pend_gather = None                      # ancestors [B, N] int32 of a resample whose row copy is still to come
         self._replay = None                           # noise a DeterministicGaussianSum handed out at predict() time
+        self.record_ancestors = False                 # True: every resample's ancestors [B, N] int32 are kept in
+        self.ancestor_log = []                        # ancestor_log (device tensors; parity tests of whole loops)
         self._idx_buf = None
         self._fusable = n <= _lib.GSE_GSUKF_CYCLE_MAX
         self._fuse_pu = B * n >= _lib.GSE_GSUKF_LANES_MIN  # large banks: predict() is deferred and rides update()'s launch
@@ -295,13 +297,17 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     def resample(self, r=None, return_index=False):
         """Systematic resample of the Gaussians based on their weights (gs_ukf.py:409-436)."""
+        wanted = return_index
         n, B = self.N_particles, self._B
         if B == 1:
             self._c_r[0] = self._host_rng.random() if r is None else float(numpy.asarray(r, dtype=numpy.float64).reshape(-1)[0])
             rr = self._c_r
         else:
             rr = self._per_bank(self._host_rng.random(B) if r is None else r, 1, self._c_r)
+        return_index = return_index or self.record_ancestors
         idx = torch.empty((B, n), dtype=torch.int32, device=self._w.device) if return_index else None
+        if self.record_ancestors:
+            self.ancestor_log.append(idx)
         if self._pend_predict is not None and self._pend_update is not None:
             # the whole cycle in one launch, one workgroup per bank (gse_gsukf_cycle); in place
             (u, dt), (_, z) = self._pend_predict, self._pend_update
@@ -334,7 +340,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
             self._means, self._means_alt = self._means_alt, self._means
             self._covs, self._covs_alt = self._covs_alt, self._covs
             self._w, self._w_alt = self._w_alt, self._w
-        if return_index:
+        if wanted:
             return DevArray.wrap(idx[0] if B == 1 else idx)
 
     # ------------------------------------------------------------------ estimates

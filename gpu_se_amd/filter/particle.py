@@ -114,6 +114,8 @@ class ParallelParticleFilter:
         self._pend_predict = None
         self._want_index = False
         self._last_index = None
+        self.record_ancestors = False                       # True: every resample's ancestors [B, ld] int32 are kept in
+        self.ancestor_log = []                              # ancestor_log (device tensors; parity tests of whole loops)
         self.lazy = True                                    # False: every method launches its own kernel at once
         self._moments_host = None                           # cached device moments (cleared by anything that changes x, w)
         self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -216,9 +218,11 @@ class ParallelParticleFilter:
             ops |= _lib.GSE_OP_GATHER
             if self._gather_slot is not None:
                 ops |= _lib.GSE_OP_SCAN_IN | (_lib.GSE_OP_SCAN_IN_SLOT1 if self._gather_slot else 0)
-            if self._want_index:
+            if self._want_index or self.record_ancestors:
                 self._last_index = torch.empty((self._B, self._ld), dtype=torch.int32, device=self._x.device)
                 idx_ptr = self._last_index.data_ptr()
+                if self.record_ancestors:
+                    self.ancestor_log.append(self._last_index)
         pod_state = rng_ref = noise_ptr = None
         dt = 0.0
         cu = self._c_u

@@ -152,7 +152,7 @@ class ClosedLoopOracle:
                 if self.noise.ancestors is None:
                     self.ancestors.append(self.f.resample(r=r, loop=False))
                 else:
-                    own = orc.systematic_index(self.f.weights, r)
+                    own = self.f.ancestors(r)
                     forced = self.noise.ancestors[self.update_count]
                     self.ancestor_flips.append(int(np.sum(own != forced)))
                     self.ancestors.append(self.f.resample(r=r, idx=forced))

@@ -320,23 +320,34 @@ class ParticleFilterOracle:
         self.weights = (self.weights.astype(np.float64) * p).astype(self.weights.dtype)
 
     # --- resample                                                         (:85-103)
+    def _sum_weights(self):
+        """The weights as the sums see them: the reference's own dtype (fp32 weights give an fp32 cumsum and an fp32 dot
+        product before the first resample, particle.py:89, :107), or -- device storage mode -- fp64 values of the stored fp32
+        weights (every sum on the device is fp64)."""
+        return self.weights if self.weights_dtype is None else self.weights.astype(np.float64)
+
+    def ancestors(self, r, loop=False):
+        w = self._sum_weights()
+        return systematic_index_loop(w, r) if loop else systematic_index(w, r)
+
     def resample(self, r=None, loop=True, idx=None):
         """``idx``: ancestors to copy INSTEAD of the ones the weights give (replay of a recorded run; the caller compares)."""
         if r is None:
             r = self.rng.random()
         if idx is None:
-            idx = systematic_index_loop(self.weights, r) if loop else systematic_index(self.weights, r)
+            idx = self.ancestors(r, loop)
         self.particles = self.particles[idx]
         self.weights = np.full(self.n, 1 / self.n, dtype=self.weights_dtype or np.float64)   # fp64 from here on in the reference
         return idx
 
     # --- moments                                                          (:105-114)
     def point_estimate(self):
-        return self.weights @ self.particles
+        return self._sum_weights() @ self.particles
 
     def point_covariance(self):
-        d = self.particles - (self.weights @ self.particles)
-        cov = d.T @ (d * self.weights[:, None])
+        w = self._sum_weights()
+        d = self.particles - (w @ self.particles)
+        cov = d.T @ (d * w[:, None])
         return np.linalg.svd(cov, compute_uv=False)[0]
 
     def moments21(self):
@@ -429,12 +440,15 @@ class GSUKFOracle:
         e = z[None, :] - self.g_rows(self.means, u).astype(np.float64)
         self.weights *= self.measurement_pdf.pdf(e)
 
+    def ancestors(self, r, loop=False):
+        return systematic_index_loop(self.weights, r) if loop else systematic_index(self.weights, r)
+
     def resample(self, r=None, loop=True, idx=None):
         """gs_ukf.py:151-170.  ``idx``: ancestors to copy instead of the ones the weights give (replay of a recorded run)."""
         if r is None:
             r = self.rng.random()
         if idx is None:
-            idx = systematic_index_loop(self.weights, r) if loop else systematic_index(self.weights, r)
+            idx = self.ancestors(r, loop)
         self.means = self.means[idx]
         self.covariances = self.covariances[idx]
         self.weights = np.full(self.n, 1 / self.n)

@@ -187,7 +187,7 @@ def solve_qp(H, q, A, l, u):
     return z, 0.5 * z @ H @ z + q @ z, dict(active=active)
 
 
-def hildreth(law, theta, max_sweeps=2000, eps_abs=1e-13, eps_rel=1e-10):
+def hildreth(law, theta, max_sweeps=4000, eps_abs=1e-14, eps_rel=1e-12):
     """The explicit law of include/gse.h evaluated in NumPy for ONE parameter vector (checker for the device kernel:
     same sweeps, same stopping rule).  law: dict with Gc, gc0, S, lo, hi, Gu, gu0, Tu, Gy, gy0, Ty."""
     m = len(law["lo"])
