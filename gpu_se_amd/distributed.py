@@ -28,9 +28,19 @@ from gpu_se_amd.filter.particle import ParallelParticleFilter, moments_to_mean_c
 MERGE_WIDTH = 22
 
 
-def shard_bounds(n_total, world, rank):
-    """Contiguous split of n_total particles: the first (n_total % world) ranks hold one more."""
-    base, extra = divmod(int(n_total), int(world))
+def shard_bounds(n_total, world, rank, align=1):
+    """Contiguous split of n_total particles: the first (n_total % world) ranks hold one more.  ``align`` > 1 (and at
+    least ``align`` particles per rank): whole blocks of ``align`` particles are dealt out instead and the last rank takes
+    the ragged remainder -- every shard but the last then holds a multiple of ``align``, which is what exact resampling
+    needs of the tile boundaries (align = GSE_TILE)."""
+    n_total, world, align = int(n_total), int(world), int(align)
+    if align > 1 and n_total >= world * align:
+        units = -(-n_total // align)
+        base, extra = divmod(units, world)
+        lo_u = rank * base + min(rank, extra)
+        hi_u = lo_u + base + (1 if rank < extra else 0)
+        return lo_u * align, min(hi_u * align, n_total) - lo_u * align
+    base, extra = divmod(n_total, world)
     lo = rank * base + min(rank, extra)
     return lo, base + (1 if rank < extra else 0)
 
@@ -128,7 +138,12 @@ class ShardedParticleFilter:
         self.world = dist.get_world_size(group) if group is not None else 1
         self.rank = dist.get_rank(group) if group is not None else 0
         self.N_particles = int(N_particles)
-        lo, n_local = shard_bounds(self.N_particles, self.world, self.rank)
+        # shards on tile boundaries whenever every rank can have a tile of its own: exact resampling (and with it the
+        # island policy below) needs that of every shard but the last
+        self._align = _lib.GSE_TILE
+        self._spans = [shard_bounds(self.N_particles, self.world, q, self._align) for q in range(self.world)]
+        self._exact_capable = not any(cnt % _lib.GSE_TILE for _, cnt in self._spans[:-1])
+        lo, n_local = self._spans[self.rank]
         self.local = ParallelParticleFilter(f, g, n_local, x0, state_pdf, measurement_pdf, element_offset=lo)
         dev = self.local._x.device
         self.local._island = torch.zeros((2, 1), dtype=torch.float64, device=dev)
@@ -150,6 +165,13 @@ class ShardedParticleFilter:
         # exact one over the whole ensemble, which levels the shards (every rank sees the same numbers one cycle later,
         # so every rank takes the same decision).  ess_fraction = 0 switches the policy off.
         self.ess_fraction = 0.5
+        if not self._exact_capable:
+            # fewer than one tile per rank: the shards cannot sit on tile boundaries, so no exact resample and no policy that
+            # would call for one in the middle of a run (resample(exact=True) still raises)
+            import warnings
+            warnings.warn("ShardedParticleFilter: %d particles on %d ranks are less than one tile of %d per rank; the island "
+                          "policy is off (ess_fraction = 0)" % (self.N_particles, self.world, _lib.GSE_TILE))
+            self.ess_fraction = 0.0
         self._shares = torch.zeros(self.world, dtype=torch.float64, device=self._merge_device)
         self._shares_cycle = None                           # resample count at which the pending exchange was issued
         self._force_exact = False
@@ -220,8 +242,8 @@ class ShardedParticleFilter:
         f._flush()
         dev = f._x.device
         n, P = f.N_particles, self.world
-        spans = [shard_bounds(self.N_particles, P, q) for q in range(P)]
-        if any(cnt % _lib.GSE_TILE for _, cnt in spans[:-1]):
+        spans = self._spans
+        if not self._exact_capable:
             raise ValueError("exact resampling needs every shard but the last to hold a multiple of %d particles" % _lib.GSE_TILE)
         tiles = [-(-cnt // _lib.GSE_TILE) for _, cnt in spans]
         T_total, tile_offset = sum(tiles), sum(tiles[:self.rank])

@@ -23,6 +23,19 @@ def test_shard_bounds():
         assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
 
 
+def test_shard_bounds_on_tile_boundaries():
+    """What ShardedParticleFilter splits by: whole tiles per rank, the ragged end on the last -- any ensemble with a tile per
+    rank can be resampled exactly (the island policy may call for that in the middle of a run); smaller ones split evenly."""
+    for n, world in ((10000, 4), (1 << 20, 8), (8 * 1024 + 1, 8), (4096, 4), (123457, 3)):
+        spans = [gd.shard_bounds(n, world, r, 1024) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+        for (lo, c), (lo2, _) in zip(spans, spans[1:]):
+            assert lo + c == lo2 and c % 1024 == 0 and c > 0
+        assert spans[-1][1] > 0
+    assert [gd.shard_bounds(3000, 4, r, 1024) for r in range(4)] == [gd.shard_bounds(3000, 4, r) for r in range(4)]
+    assert [c for _, c in (gd.shard_bounds(10000, 4, r, 1024) for r in range(4))] == [3072, 3072, 2048, 1808]
+
+
 def _shard_row(x, w, log_island, common_pivot):
     kp = x[0].astype(np.float64)
     d = x.astype(np.float64) - kp

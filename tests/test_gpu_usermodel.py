@@ -264,6 +264,40 @@ def test_gsukf_with_a_three_state_model_against_the_numpy_class(n):
     np.testing.assert_array_equal(gf.g_vectorize(rows, [0.3, 0.5]).get(), _python_rows(um.three_state_g, rows, [0.3, 0.5]).astype(np.float32))
 
 
+@pytest.mark.parametrize("n", [9, 200])
+def test_gsukf_update_evaluates_g_with_its_own_inputs(n):
+    """predict(u1, dt) followed by update(u2, z) with u2 != u1: the reference evaluates g with UPDATE's u (gs_ukf.py:369-407)
+    and a user model's g may read it (three_state_g does).  The fused launches carry one u, so the class must run the
+    predict on its own first -- against the oracle's NumPy class, which takes each call's u as given."""
+    gpu_se_amd.seed(8)
+    x0 = gsd.MultivariateGaussianSum(means=np.array([[2.0, 1.0, 3.0]]), covariances=np.array([np.diag([0.05, 0.01, 0.08])]),
+                                     weights=np.array([1.0]))
+    state = gsd.DeterministicGaussianSum(means=np.zeros((1, 3)), covariances=np.array([np.diag([1e-3, 2e-3, 1e-3])]),
+                                         weights=np.array([1.0]))
+    meas = gsd.MultivariateGaussianSum(means=np.zeros((2, 2)), covariances=np.array([np.diag([4.0, 1.0]), np.diag([40.0, 9.0])]),
+                                       weights=np.array([0.8, 0.2]))
+    gf = ParallelGaussianSumUnscentedKalmanFilter(um.three_state_f, um.three_state_g, n, x0, state, meas)
+    o = _gsukf_oracle(um.three_state_f, um.three_state_g, n, gf.means.get(), state, meas)
+    o.covariances = gf.covariances.get().copy()
+    rng = np.random.default_rng(4)
+    noise = (rng.standard_normal((n, 7, 3)) * 0.03).astype(np.float32)
+    u1, u2, z = [0.3, 0.5], [1.3, -2.5], np.array([21.0, 2.5])
+    gsd.DeterministicGaussianSum.preload(noise)
+    gf.predict(u1, 0.2)
+    gf.update(u2, z)
+    o.predict(u1, 0.2, noise=noise, loop=False)
+    prior = o.covariances.copy()
+    o_pred_means, o_pred_covs = o.means.copy(), o.covariances.copy()
+    o.update(u2, z)
+    _close(gf.means.get(), o.means, prior)
+    np.testing.assert_allclose(gf.weights.get(), o.weights, rtol=2e-4)
+    # (the answer really depends on update's u: evaluated with predict's u the weights are off by far more than the tolerance)
+    o.means, o.covariances = o_pred_means, o_pred_covs
+    o.weights = np.full(n, 1 / n, dtype=np.float32)
+    o.update(u1, z)
+    assert np.max(np.abs(gf.weights.get() / o.weights - 1)) > 1e-2
+
+
 def test_gsukf_with_a_two_state_model_philox_noise_large_and_batched():
     """Two states, one input, Philox noise: a large bank takes the lane kernels (predict + update in one launch) and gives
     the bits of the same calls one kernel each; a batch of banks equals the single banks; the estimate follows the
