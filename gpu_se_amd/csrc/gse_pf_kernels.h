@@ -236,6 +236,106 @@ __device__ __forceinline__ void expand_quad(const OffspringCount& F, const doubl
     }
 }
 
+// Inverse map, the other way round, for WIDE ancestor ranges (round 3).  When the 1024 outputs of a workgroup descend from
+// particles scattered over many tiles -- a stretch of lineages whose weights are a few hundred times below the average: the
+// first cycles after the prior, a measurement jump -- the census lists one tile per few outputs and expanding them one pair
+// after the other costs 0.45 us each while the other workgroups of the launch are long done (55 us launches among 19 us
+// ones in the first 300 cycles from the prior, 173 us in a long run).  Beyond GSE_SEARCH_FROM listed tiles every output
+// looks its ancestor up instead: output j descends from the first key with fl(x[k] / W) >= u_j, i.e. x[k] >= tau_j (the
+// smallest such x: x -> fl(x / W) is monotone) -- the comparison the offspring counts are DEFINED by, so the ancestors are
+// the same.  Three steps, a thread's four outputs side by side: the tile in the LDS prefix (its last key is pinned to
+// Pfx[t + 1]); the quad inside the tile by bisecting the per-thread prefixes the update stage left (8 dependent 8-byte
+// loads: the quad's last key is P0 + prefix of the NEXT quad up to rounding); then the twelve keys of that quad and its
+// two neighbours re-formed exactly as everywhere else, the ancestor being the key after the last one below tau.  Cost: about
+// 10 us whatever the width.
+#ifndef GSE_SEARCH_FROM
+#define GSE_SEARCH_FROM 20
+#endif
+__device__ __forceinline__ int32_t window_ancestor(const float* __restrict__ wrow, const double* __restrict__ qx, int32_t N,
+                                                   int32_t ld, int tq, int uq, double P0, double P1, double tau, int tl0) {
+    // the quads uq - 1, uq, uq + 1 of tile tq, one after the other (a rolled loop: six registers of loads at a time)
+    const int u0 = max(uq - 1, 0);
+    const int32_t tile_first = tq * kTile;
+    const int32_t tile_last = min(tile_first + kTile, N) - 1;
+    int32_t below = tile_first + u0 * kPerThread - 1;                      // (everything before the window is below tau)
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {
+        const int u = min(u0 + q, kBlock - 1);
+        const int32_t k0 = tile_first + u * kPerThread;
+        const float4 wv = *reinterpret_cast<const float4*>(wrow + min(k0, ld - kPerThread));
+        const double ex = qx[tq * kBlock + u];
+        double sc[kPerThread];
+        sc[0] = (k0 + 0 < N) ? (double)wv.x : 0.0;
+        sc[1] = sc[0] + ((k0 + 1 < N) ? (double)wv.y : 0.0);
+        sc[2] = sc[1] + ((k0 + 2 < N) ? (double)wv.z : 0.0);
+        sc[3] = sc[2] + ((k0 + 3 < N) ? (double)wv.w : 0.0);
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            const double x = (k0 + i >= tile_last) ? P1 : fmin(P0 + (ex + sc[i]), P1);
+            if (k0 + i <= tile_last && !(x >= tau)) below = max(below, k0 + i);
+        }
+    }
+    return min(max(below + 1, tl0 * kTile), N - 1);
+}
+
+// Register discipline: the hot path of the kernel sits at 106 vector registers for four wavefronts per SIMD and the register
+// allocator spreads the pressure of whatever is inlined here over the whole kernel (a first version -- four bisections side
+// by side, all twelve window loads of the four outputs in flight -- cost 300-450 bytes of spills per lane and 1.6 us on EVERY
+// launch, as a real function call too).  So: the four tile searches together (LDS, a few integers each), then ONE output
+// at a time, scheduling barriers in between.
+__device__ __forceinline__ int32_t quad_of(const double* __restrict__ qrow, double P0, double P1, double tau) {
+    // first quad u in [0, 255] whose last key reaches tau, judged by the NEXT quad's prefix (P1 for the last quad): two 16-ary
+    // rounds of independent loads.  Counting the pivots below tau instead of bisecting shrugs off a last-bit wiggle between
+    // neighbouring prefixes.
+    int blk = 0;
+#pragma unroll
+    for (int m = 1; m < 16; ++m) blk += (fmin(P0 + qrow[16 * m], P1) < tau) ? 1 : 0;       // quads 16 blk .. 16 blk + 15
+    int u = 16 * blk;
+#pragma unroll
+    for (int m = 1; m < 16; ++m) u += (fmin(P0 + qrow[16 * blk + m], P1) < tau) ? 1 : 0;
+    return u;
+}
+
+__device__ __forceinline__ void search_ancestors(const OffspringCount& F, const double* pfx_s, const float* __restrict__ wrow,
+                                                 const double* __restrict__ qx, int64_t N, int64_t ld, int tl0, int tl1,
+                                                 int32_t j0, int32_t j1, int tid, int32_t (&anc)[kPerThread]) {
+    double tau[kPerThread];
+    int tq[kPerThread];
+    {
+        int lo[kPerThread], hi[kPerThread];
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p) {
+            const int32_t j = min(j0 + tid + p * kBlock, j1 - 1);
+            tau[p] = smallest_with_quotient_ge(F.u_of(j), F.W);
+            lo[p] = tl0;
+            hi[p] = tl1;
+        }
+        // 1. the tile: first t in [tl0, tl1] with Pfx[t + 1] >= tau (tl1 qualifies by construction of the range)
+        for (int span = tl1 - tl0; span > 0; span >>= 1) {             // (uniform trip count: enough halvings for the range)
+#pragma unroll
+            for (int p = 0; p < kPerThread; ++p) {
+                const int mid = (lo[p] + hi[p]) >> 1;
+                const bool ge = pfx_s[mid + 1] >= tau[p];
+                if (lo[p] < hi[p]) {
+                    if (ge) hi[p] = mid; else lo[p] = mid + 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p) tq[p] = lo[p];
+    }
+    // 2. + 3. per output: the quad, then the keys of that quad and its neighbours exactly as cumsum_kernel forms them;
+    //         ancestor = 1 + last key below tau
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p) {
+        __builtin_amdgcn_sched_barrier(0);
+        const double P0 = pfx_s[tq[p]], P1 = pfx_s[tq[p] + 1];
+        const int u = quad_of(qx + (int64_t)tq[p] * kBlock, P0, P1, tau[p]);
+        anc[p] = window_ancestor(wrow, qx, (int32_t)N, (int32_t)ld, tq[p], u, P0, P1, tau[p], tl0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <bool kGather, bool kPredict, bool kInjected, bool kUpdate, int kNd, int kScan>
 __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     const float* __restrict__ x_in, float* __restrict__ x_out, const float* __restrict__ w_in, float* __restrict__ w_out,
@@ -425,7 +525,16 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                 n_act = act_n;
             }
             auto tile_at = [&](int i) { return direct ? tl0 + i : act_list[i]; };
-            if (n_act > 0) {                                                       // (a census may list nothing)
+            constexpr bool kSearchPath = GSE_SEARCH_FROM < kTile;                  // (a knob >= 1024 compiles the path out)
+            bool wide = false;
+            if constexpr (kSearchPath) wide = !direct && n_act > GSE_SEARCH_FROM;  // workgroup-uniform
+            if (kSearchPath && wide) {
+                if (kDraw && draw_at == 2) {
+                    draw_all();
+                    drawn2 = true;
+                }
+                search_ancestors(F, pfx_s, wrow, qx, N, ld, tl0, tl1, j0, j1, tid, anc);
+            } else if (n_act > 0) {                                                // (a census may list nothing)
                 // (every load below is unconditional, its index clamped instead: with loads under conditions the compiler
                 //  cannot count what is in flight and waits for ALL of it before the first use -- the next pair's loads
                 //  included, which is the opposite of a prefetch)
@@ -459,7 +568,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #endif
             __syncthreads();
             // inclusive max-scan of the 1024 marks: thread t owns slots 4t .. 4t+3
-            {
+            if (!wide) {
                 const uint4 mk = *reinterpret_cast<const uint4*>(&mark[tid * kPerThread]);
                 const uint32_t m0 = mk.x, m1 = max(m0, mk.y), m2 = max(m1, mk.z), m3 = max(m2, mk.w);
                 const uint32_t inc = wave_inclusive_max(m3);

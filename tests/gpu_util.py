@@ -44,3 +44,27 @@ def product_mixtures():
 
 def workspace(B, N):
     return torch.empty(_lib.load().gse_workspace_bytes(B, N), dtype=torch.uint8, device="cuda")
+
+
+def adversarial_weights(n, rng):
+    """Weight patterns chosen to hurt a systematic resample (test_inverse_map_resample_on_adversarial_weights; also what
+    tools/tail_profile.py times): exact ties, one heavy particle at tile edges, a bump over the index, a long weightless
+    stretch over a floor, sums that are zero / NaN -- and, round 3, contiguous lineages a few hundred times lighter than the
+    rest (every output of some workgroup then descends from another tile: the widest work lists the gather stage can meet)."""
+    idx_of = np.arange(n)
+    light_half = np.where(idx_of < n // 2, 1.0, 1.0 / 512.0) * (0.5 + rng.random(n))
+    steps = 10.0 ** -(4.0 * (idx_of * 8 // max(n, 1)) / 7.0) * (0.5 + rng.random(n))
+    return {
+        "uniform": np.ones(n),
+        "one_hot_first": (idx_of == 0).astype(float),
+        "one_hot_last": (idx_of == n - 1).astype(float),
+        "one_hot_tile_edge": ((idx_of == min(1023, n - 1)) | (idx_of == min(1024, n - 1))).astype(float),
+        "zeros_interleaved": rng.random(n) * (rng.random(n) > 0.7),
+        "bump": np.exp(-0.5 * ((idx_of - 0.3 * n) / (0.01 * n + 1)) ** 2) + 1e-30,
+        "floor_and_spikes": np.where(rng.random(n) < 8.0 / n, 1.0, 1e-7),
+        "weightless_stretch": np.where((idx_of > 0.2 * n) & (idx_of < 0.9 * n), 0.0, rng.random(n) ** 8),
+        "light_half": light_half,
+        "eight_steps_down": steps,
+        "zero_sum": np.zeros(n),
+        "nan": np.full(n, np.nan),
+    }

@@ -17,7 +17,7 @@ from gpu_se_amd.filter import ParallelParticleFilter         # noqa: E402
 from gpu_se_amd.gaussian_sum_dist import DeterministicGaussianSum, MultivariateGaussianSum   # noqa: E402
 from gpu_se_amd.model import Bioreactor                      # noqa: E402
 from oracle import gse_oracle as orc                         # noqa: E402
-from tests.gpu_util import dev, host, padded, stream, to_state_major, workspace   # noqa: E402
+from tests.gpu_util import adversarial_weights, dev, host, padded, stream, to_state_major, workspace   # noqa: E402
 
 
 def test_library_is_the_hip_build():
@@ -502,7 +502,8 @@ def test_inverse_map_resample_on_adversarial_weights(n):
     """The single-launch cycle's resample (inverse map from the weights, tools of DESIGN.md section 3) on weight patterns
     chosen to hurt: exact ties (one-hot, interleaved zeros: runs of equal cumulative weights), a single heavy particle at
     tile edges, a bump over the index (ancestor ranges of a few keys next to ranges of many tiles: the census path), a
-    long weightless stretch over a floor, weights that sum to zero or to NaN, r at both ends of [0, 1) -- r = 0 puts
+    long weightless stretch over a floor, contiguous lineages a few hundred times lighter than the rest (round 3: the work lists
+    beyond GSE_SEARCH_FROM tiles, where every output looks its ancestor up), weights that sum to zero or to NaN, r at both ends of [0, 1) -- r = 0 puts
     every threshold ON an integer of the offspring count, i.e. into the guard band, where the count is settled with the
     reference's own comparison.  All particles sit on one state, so the update multiplies the assigned weights by ONE
     likelihood and leaves the pattern in place (plus the tile sums and prefixes the next launch resamples from); the
@@ -512,19 +513,7 @@ def test_inverse_map_resample_on_adversarial_weights(n):
     xss = orc.steady_state().astype(np.float32)
     u, z = [0.06, 0.2], np.array(orc.bioreactor_g(orc.steady_state()))
     rng = np.random.default_rng(n)
-    idx_of = np.arange(n)
-    patterns = {
-        "uniform": np.ones(n),
-        "one_hot_first": (idx_of == 0).astype(float),
-        "one_hot_last": (idx_of == n - 1).astype(float),
-        "one_hot_tile_edge": ((idx_of == min(1023, n - 1)) | (idx_of == min(1024, n - 1))).astype(float),
-        "zeros_interleaved": rng.random(n) * (rng.random(n) > 0.7),
-        "bump": np.exp(-0.5 * ((idx_of - 0.3 * n) / (0.01 * n + 1)) ** 2) + 1e-30,
-        "floor_and_spikes": np.where(rng.random(n) < 8.0 / n, 1.0, 1e-7),
-        "weightless_stretch": np.where((idx_of > 0.2 * n) & (idx_of < 0.9 * n), 0.0, rng.random(n) ** 8),
-        "zero_sum": np.zeros(n),
-        "nan": np.full(n, np.nan),
-    }
+    patterns = adversarial_weights(n, rng)
     for name, w in patterns.items():
         for r in (0.0, 0.37, 1.0 - 2.0 ** -53):
             pf.particles = np.repeat(xss[None, :], n, axis=0)

@@ -8,7 +8,8 @@ from gpu_se_amd import sim_base, _lib
 n = 1 << 20
 gpu_se_amd.seed(2)
 _, _, _, pf = sim_base.get_parts(N_particles=n)
-io = bench.make_inputs(120, 1.0)
+cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+io = bench.make_inputs(cycles, 1.0)
 lib = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * 8192)()
 info = (ctypes.c_longlong * 8192)()
@@ -27,6 +28,7 @@ for c, (u, z) in enumerate(io):
     nact = inf[:, 0] >> 20
     worst = int(np.argmax(dur))
     print("cycle %3d  launch %.1f us  wg median %.1f max %.1f (width %d tiles, expanded %d)  widths: median %d p90 %d max %d  "
-          "sum expanded %d  guard-band hits %d" % (c, total, np.median(dur), dur.max(), width[worst], nact[worst], np.median(width),
-                                                    np.percentile(width, 90), width.max(), nact.sum(), slow.value - prev_slow))
+          "sum expanded %d  max expanded %d  wgs expanding >8: %d >24: %d  guard-band hits %d"
+          % (c, total, np.median(dur), dur.max(), width[worst], nact[worst], np.median(width), np.percentile(width, 90), width.max(),
+             nact.sum(), nact.max(), int(np.sum(nact > 8)), int(np.sum(nact > 24)), slow.value - prev_slow))
     prev_slow = slow.value
