@@ -253,12 +253,12 @@ __device__ __forceinline__ void expand_quad(const OffspringCount& F, const doubl
 #endif
 __device__ __forceinline__ int32_t window_ancestor(const float* __restrict__ wrow, const double* __restrict__ qx, int32_t N,
                                                    int32_t ld, int tq, int uq, double P0, double P1, double tau, int tl0) {
-    // the quads uq - 1, uq, uq + 1 of tile tq, one after the other (a rolled loop: six registers of loads at a time)
+    // the quads uq - 1, uq, uq + 1 of tile tq: 18 registers of loads in flight (what fits; see search_ancestors)
     const int u0 = max(uq - 1, 0);
     const int32_t tile_first = tq * kTile;
     const int32_t tile_last = min(tile_first + kTile, N) - 1;
     int32_t below = tile_first + u0 * kPerThread - 1;                      // (everything before the window is below tau)
-#pragma unroll 1
+#pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int u = min(u0 + q, kBlock - 1);
         const int32_t k0 = tile_first + u * kPerThread;

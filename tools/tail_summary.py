@@ -15,14 +15,13 @@ for r in rows:
     elif cyc(r):
         cur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 parts.append(cur)
-warm, first = np.array(parts[1]) if len(parts) > 1 else np.array([]), None
 print("kernel: pf_step_kernel<gather, predict, update, scan in+out> at N = 2^20; durations from %s" % os.path.basename(path))
-if len(parts) > 2:
-    d = np.array(parts[2])
+if len(parts) > 1:
+    d = np.array(parts[1])
     med = np.median(d)
-    print("first %d cycles from the prior: launches %d  median %.2f us  mean %.2f  p99 %.2f  max %.2f  max/median %.2f  launches > 2 x median: %d"
+    print("first %d cycles from the prior (the first has no resample to run): launches %d  median %.2f us  mean %.2f  p99 %.2f  max %.2f  max/median %.2f  launches > 2 x median: %d"
           % (len(d) + 1, len(d), med, d.mean(), np.percentile(d, 99), d.max(), d.max() / med, int(np.sum(d > 2 * med))))
-    adv = [p[0] for p in parts[3:] if len(p)]
+    adv = [p[-1] for p in parts[2:] if len(p)]
     if adv:
         a = np.array(adv)
         print("adversarial patterns (12 patterns x 3 r, one single-launch cycle each): launches %d  median %.2f us  max %.2f  max / median of the first part %.2f"
