@@ -19,6 +19,7 @@ GSE_IO_U_DEVICE, GSE_IO_Z_DEVICE = 1, 2
 GSE_SCAN_MAX_TILES = 2048      # policy: beyond 2^21 particles the two-kernel resample is faster (every workgroup
                                # builds the whole tile prefix: at 4096 tiles the single launch takes 131 us against 102)
 GSE_GSUKF_CYCLE_MAX = 64
+GSE_SMALL_RESAMPLE_MAX = 4096       # banks up to here find their ancestors in one launch (small_resample_kernel)
 GSE_GSUKF_MOMENTS = 46             # doubles per row of gse_gsukf_moments
 GSE_GSUKF_LANES_MIN = 65         # from this many Gaussians on: one lane per Gaussian, predict + update in one launch,
                                  # the row copy of resample() deferred into it (gse_gsukf.hip: lane_per_gaussian)
@@ -96,6 +97,9 @@ PROTOTYPES = {
     "gse_gsukf_gather_rows": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp]),
     "gse_gsukf_predict_update_from": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d, c_vp, P_F,
                                                      P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_u32, c_vp]),
+    "gse_gsukf_predict_update_sums": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d, c_vp, P_F,
+                                                     P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_vp, c_u32, c_vp]),
+    "gse_gsukf_resample_begin_sums": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_vp, c_vp]),
     "gse_gsukf_gather_rows_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp]),
     "gse_gsukf_predict_update_from_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d,
                                                            c_vp, P_F, P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_u32, c_vp]),

@@ -151,7 +151,7 @@ static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w,
                                 const double* z, const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng,
                                 const float* noise, const gse_mixture* measurement_pdf, int32_t* status, void* stream,
                                 uint32_t where = 0, const float* mu_in = nullptr, const float* P_in = nullptr,
-                                const int32_t* anc = nullptr) {
+                                const int32_t* anc = nullptr, void* workspace = nullptr) {
     if (int rc = check_gsukf("gse_gsukf_predict_update", B, N)) return rc;
     GSE_REQUIRE(mu && P && w && u && z && w_sigma && measurement_pdf, "gse_gsukf_predict_update: null argument");
     GSE_REQUIRE(!anc || (mu_in && P_in && mu_in != mu && P_in != P),
@@ -167,18 +167,20 @@ static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w,
     pack_pdf2(a.pdf, *measurement_pdf);
     const dim3 grid((unsigned)((N + kLaneBank - 1) / kLaneBank), B), block(kLaneBank);
     hipStream_t st = (hipStream_t)stream;
+    // with a workspace the launch also leaves the quarter sums of the new weights there (gse_gsukf_resample_begin_sums)
+    double* quarters = workspace ? gsukf_quarter_sums(carve_workspace(workspace, B, N)) : nullptr;
     if (noise) {
         a.pred.draw = DrawParams{};
         a.pred.rng = RngKey{};
         return launch(model, "gse::gsukf_predict_update_lanes_kernel<true>", gsukf_predict_update_lanes_kernel<true>, grid, block, st,
-                      mu, P, w, noise, N, status, mu_in, P_in, anc, a);
+                      mu, P, w, noise, N, status, mu_in, P_in, anc, quarters, a);
     }
     if (int rc = check_mixture("gse_gsukf_predict_update", state_pdf, nx)) return rc;
     pack_draw(a.pred.draw, *state_pdf);
     a.pred.rng = make_rng_key(*rng, kPurposeGsukf);
     const float* none = nullptr;
     return launch(model, "gse::gsukf_predict_update_lanes_kernel<false>", gsukf_predict_update_lanes_kernel<false>, grid, block, st,
-                  mu, P, w, none, N, status, mu_in, P_in, anc, a);
+                  mu, P, w, none, N, status, mu_in, P_in, anc, quarters, a);
 }
 
 static int gsukf_cycle(UserModel* model, float* mu, float* P, float* w, int32_t* idx, int B, int64_t N, const double* u,
@@ -248,7 +250,7 @@ static int gsukf_resample(UserModel* model, const float* mu_in, const float* P_i
 // The first half of a resample: cumulative weights and ANCESTORS (idx), weights reset to 1 / N -- no row is copied; the copy
 // rides the next gse_gsukf_predict_update_from, or gse_gsukf_gather_rows does it on its own.
 static int gsukf_resample_begin(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const double* r, void* workspace,
-                                void* stream) {
+                                void* stream, bool quarter_sums_valid = false) {
     if (int rc = check_gsukf("gse_gsukf_resample_begin", B, N)) return rc;
     GSE_REQUIRE(w && w_out && idx && r && workspace && w != w_out, "gse_gsukf_resample_begin: null or aliasing argument");
     ResampleArgs ra;
@@ -262,7 +264,7 @@ static int gsukf_resample_begin(const float* w, float* w_out, int32_t* idx, int 
         GSE_LAUNCH_CHECK("small_resample_kernel");
         return GSE_OK;
     }
-    if (launch_ancestors(w, w_out, idx, B, N, ra, ws, st)) {           // up to 2^21: tile sums, then the ancestors from them
+    if (launch_ancestors(w, w_out, idx, B, N, ra, ws, st, quarter_sums_valid)) {   // up to 2^21: tile sums, then the ancestors
         GSE_LAUNCH_CHECK("ancestors_kernel");
         return GSE_OK;
     }
@@ -381,6 +383,21 @@ int gse_gsukf_predict_update_from(const float* mu_in, const float* P_in, const i
                                   const gse_mixture* measurement_pdf, int32_t* status, uint32_t where, void* stream) {
     return gsukf_predict_update(nullptr, mu, P, w, B, N, u, dt, z, w_sigma, state_pdf, rng, noise, measurement_pdf, status, stream,
                                 where, mu_in, P_in, idx);
+}
+// ... and the pair that saves the tile-sum launch of a large bank's resample: the predict + update launch leaves the quarter
+// sums of its new weights in the workspace, the resample that DIRECTLY follows (same weights, same workspace) takes them
+int gse_gsukf_predict_update_sums(const float* mu_in, const float* P_in, const int32_t* idx, float* mu, float* P, float* w, int B,
+                                  int64_t N, const double* u, double dt, const double* z, const float* w_sigma,
+                                  const gse_mixture* state_pdf, const gse_rng* rng, const float* noise,
+                                  const gse_mixture* measurement_pdf, int32_t* status, void* workspace, uint32_t where,
+                                  void* stream) {
+    GSE_REQUIRE(workspace && aligned16(workspace), "gse_gsukf_predict_update_sums: needs the 16-byte aligned device workspace");
+    return gsukf_predict_update(nullptr, mu, P, w, B, N, u, dt, z, w_sigma, state_pdf, rng, noise, measurement_pdf, status, stream,
+                                where, mu_in, P_in, idx, workspace);
+}
+int gse_gsukf_resample_begin_sums(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const double* r, void* workspace,
+                                  void* stream) {
+    return gsukf_resample_begin(w, w_out, idx, B, N, r, workspace, stream, true);
 }
 // gse_gsukf_moments in the particle filter's layout (rows of 26 doubles: S0, S1[5], S2[15] + C[15], pivot[5]): what
 // gse_loop_control and the host post-processing of a closed loop take from either estimator

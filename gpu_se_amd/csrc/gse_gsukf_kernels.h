@@ -100,7 +100,12 @@ __device__ __forceinline__ void sigma_point(const float (&mu)[kNx], const float 
         float col = 0.0f;
 #pragma unroll
         for (int cc = 0; cc <= k; ++cc) col = (c == cc) ? L[tri(k, cc)] : col;
-        s[k] = (c < 0) ? mu[k] : mu[k] + sign * col;
+        // Column c of the LOWER-triangular factor is zero above row c: those states of the sigma point ARE the mean's.  Said so
+        // (rather than adding a signed zero the compiler may not drop), the one-lane-per-Gaussian kernels -- j is a constant
+        // in their unrolled loops -- evaluate whatever part of the model depends on such states once per Gaussian instead of
+        // once per sigma point: for the bioreactor the Monod quotient and the Cx-only rate limits in 6 of the 11 points.
+        // (Bits: mu + (+-0) = mu except that -0 + 0 = +0; a mean component that is exactly -0 does not occur.)
+        s[k] = (c < 0 || c > k) ? mu[k] : mu[k] + sign * col;
     }
 }
 
@@ -636,10 +641,11 @@ template <bool kInjected>
 __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict_update_lanes_kernel(
     float* __restrict__ mu, float* __restrict__ P, float* __restrict__ w, const float* __restrict__ noise, int64_t N,
     int32_t* __restrict__ status, const float* __restrict__ mu_in, const float* __restrict__ P_in,
-    const int32_t* __restrict__ anc, const GsukfPredictUpdateArgs a) {
+    const int32_t* __restrict__ anc, double* __restrict__ quarter_sums, const GsukfPredictUpdateArgs a) {
     __shared__ DrawParams dp;
     __shared__ float stage[kLaneBank * kStageStride];
     __shared__ int anc_s[kLaneBank];
+    __shared__ __attribute__((aligned(16))) float wq[kLaneBank];
     const int t = threadIdx.x, b = blockIdx.y;
     const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
     const int nloc = (int)min((int64_t)kLaneBank, N - g0);
@@ -656,10 +662,29 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
     else
         stage_bank_in(stage, mu_b, P_b, nloc);
     const FilterIO bio = bank_inputs(a.pred.io, a.pred.u_dev, a.pred.z_dev, b);
+    float w_new = 0.0f;
     if (t < nloc) {
         float* mine = stage + t * kStageStride;
         gsukf_predict_lane<kInjected>(mine, b, g0 + t, N, noise, dp, status, a.pred, bio);
-        gsukf_update_lane(mine, w + (int64_t)b * N + g0 + t, bio.u0, bio.u1, bio.z0, bio.z1, status, a.pdf, a.pred.sw);
+        float* wg = w + (int64_t)b * N + g0 + t;
+        w_new = *wg;
+        gsukf_update_lane(mine, &w_new, bio.u0, bio.u1, bio.z0, bio.z1, status, a.pdf, a.pred.sw);
+        *wg = w_new;
+    }
+    if (quarter_sums) {
+        // The workgroup's 256 new weights are one QUARTER of a tile of 1024: the sum tile_sum_kernel's wavefront `quarter`
+        // forms of them -- 64 lanes x 4 consecutive weights, masked_sum4, the wavefront scan -- left for the ancestors kernel,
+        // which adds a tile's four as block_exclusive_scan adds its four wavefront totals: the same tile sums, bit for bit,
+        // without the launch of their own (4.7 us of a 58 us cycle at 2^18 Gaussians).  Nobody waits for anybody: the
+        // consumer is the next kernel on the stream.
+        wq[t] = w_new;
+        __syncthreads();
+        if (t < 64) {
+            const float4 q4 = *reinterpret_cast<const float4*>(&wq[4 * t]);
+            const double mine4 = masked_sum4(q4.x, q4.y, q4.z, q4.w, g0 + 4 * t, N);
+            const double inc = wave_inclusive_scan(mine4, t);
+            if (t == 63) quarter_sums[(int64_t)b * (4 * ((N + kTile - 1) / kTile)) + blockIdx.x] = inc;
+        }
     }
     stage_bank_out(stage, mu_b, P_b, nloc);
 }

@@ -143,7 +143,10 @@ int launch_index_gather(float* w_out, int32_t* idx, int B, int64_t N, const Resa
 // cumulative weights + ancestors of a bank of at most 4 tiles in ONE launch (small_resample_kernel); false: too large
 // ... of a bank of up to 2048 tiles from its weights and tile sums, no cumulative weights written (ancestors_kernel)
 bool launch_ancestors(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, const Workspace& ws,
-                      hipStream_t st);
+                      hipStream_t st, bool quarter_sums_valid = false);
+// where the one-lane-per-Gaussian update launch leaves the quarter sums of its new weights ([B][4 T] doubles): the
+// workspace's first slot of per-thread tile prefixes, which only the particle filter uses
+inline double* gsukf_quarter_sums(const Workspace& ws) { return ws.scan[0]; }
 bool launch_small_resample(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, hipStream_t st);
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
                            const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, int pivot_count, hipStream_t st);

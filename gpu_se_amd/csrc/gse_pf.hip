@@ -53,11 +53,15 @@ int launch_index_gather(float* w_out, int32_t* idx, int B, int64_t N, const Resa
 }
 
 bool launch_ancestors(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, const Workspace& ws,
-                      hipStream_t st) {
+                      hipStream_t st, bool quarter_sums_valid) {
     const int T = (int)tiles_of(N);
     if (T > kAncestorsMaxT) return false;
-    hipLaunchKernelGGL(tile_sum_kernel, dim3(T, B), dim3(kBlock), 0, st, w, ws.tile_sums, N, N, T);
     const size_t lds = ((size_t)(T + 1) * sizeof(double) + (size_t)T + 7) & ~(size_t)7;
+    if (quarter_sums_valid) {           // the update launch left the quarter sums of these weights in the workspace
+        hipLaunchKernelGGL(ancestors_kernel<1>, dim3(T, B), dim3(kBlock), lds, st, w, gsukf_quarter_sums(ws), w_out, idx, N, T, ra);
+        return true;
+    }
+    hipLaunchKernelGGL(tile_sum_kernel, dim3(T, B), dim3(kBlock), 0, st, w, ws.tile_sums, N, N, T);
     hipLaunchKernelGGL(ancestors_kernel<0>, dim3(T, B), dim3(kBlock), lds, st, w, ws.tile_sums, w_out, idx, N, T, ra);
     return true;
 }

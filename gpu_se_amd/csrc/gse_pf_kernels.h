@@ -1285,7 +1285,10 @@ __global__ __launch_bounds__(kSmallResampleBlock) void small_resample_kernel(con
 // ------------------------------------------------------------------------------------------------
 constexpr int kAncestorsMaxT = 2048;
 
-template <int kUnused>
+// kQuarters = 1: tile_sums holds, per filter, the four QUARTER sums of every tile (gsukf_predict_update_lanes_kernel leaves them:
+// what the four wavefronts of tile_sum_kernel would have found) instead of the tile sums; a tile's sum is ((q0 + q1) + q2) + q3,
+// block_exclusive_scan's order.
+template <int kQuarters>
 __global__ __launch_bounds__(kBlock) void ancestors_kernel(const float* __restrict__ w, const double* __restrict__ tile_sums,
                                                            float* __restrict__ w_out, int32_t* __restrict__ idx_out, int64_t N, int T,
                                                            const ResampleArgs ra) {
@@ -1301,12 +1304,25 @@ __global__ __launch_bounds__(kBlock) void ancestors_kernel(const float* __restri
     const int64_t j1 = min(j0 + kTile, N);
     // 1. tile prefix: thread j owns chunk [j*m, (j+1)*m) of the tile sums (m <= 8)
     {
-        const double* sums = tile_sums + (int64_t)b * T;
+        const double* sums = tile_sums + (int64_t)b * T * (kQuarters ? 4 : 1);
         const int m = (T + kBlock - 1) / kBlock;
         const int qlo = tid * m;
+        const int nq = (int)((N + kBlock - 1) / kBlock);               // quarters that exist (the rest of the last tile: 0)
         double sv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
+        for (int i = 0; i < 8; ++i) {
+            if constexpr (kQuarters) {
+                double q4[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int at = 4 * (qlo + i) + h;
+                    q4[h] = (i < m && qlo + i < T && at < nq) ? sums[at] : 0.0;
+                }
+                sv[i] = ((q4[0] + q4[1]) + q4[2]) + q4[3];
+            } else {
+                sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
+            }
+        }
         double chunk = 0.0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) chunk += sv[i];

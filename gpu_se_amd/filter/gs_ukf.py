@@ -77,6 +77,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._pend_update = None
         self._pend_gather = None                      # ancestors [B, N] int32 of a resample whose row copy is still to come
         self._replay = None                           # noise a DeterministicGaussianSum handed out at predict() time
+        self._sums_valid = False                      # the workspace holds the quarter sums of the current weights
         self.record_ancestors = False                 # True: every resample's ancestors [B, N] int32 are kept in
         self.ancestor_log = []                        # ancestor_log (device tensors; parity tests of whole loops)
         self._idx_buf = None
@@ -91,7 +92,13 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._blocks_per_grid = self._bpg = (n - 1) // 1024 + 1
         self._y_dummy = DevArray.wrap(torch.zeros(self._Ny, dtype=torch.float32, device=dev))
 
+    # calls that leave the weights (and the quarter sums a gse_gsukf_predict_update_sums left of them) as they are
+    _KEEPS_WEIGHTS = ("gse_gsukf_predict", "gse_gsukf_predict_dev", "gse_gsukf_gather_rows", "gse_gsukf_moments",
+                      "gse_gsukf_moments26", "gse_gsukf_sigma_points", "gse_model_f", "gse_model_g_u")
+
     def _call(self, name, *args):
+        if name not in self._KEEPS_WEIGHTS:
+            self._sums_valid = False
         rc = getattr(self._lib, name)(*args)
         if rc:
             (self._model.check if self._model else _lib.check)(rc)
@@ -137,11 +144,13 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     @property
     def weights(self):
         self._flush()
+        self._sums_valid = False                      # (the view is writable)
         return DevArray.wrap(self._w[0] if self._B == 1 else self._w)
 
     @weights.setter
     def weights(self, value):
         self._flush()
+        self._sums_valid = False
         self._w.copy_(as_device(value, torch.float32).reshape(self._B, self.N_particles))
 
     def _inputs(self, u):
@@ -279,10 +288,16 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         # results go to the other pair of arrays.
         idx, self._pend_gather = self._pend_gather, None
         out_m, out_c = (self._means_alt, self._covs_alt) if idx is not None else (self._means, self._covs)
-        self._call("gse_gsukf_predict_update_from", self._means.data_ptr(), self._covs.data_ptr(),
-                   idx.data_ptr() if idx is not None else None, out_m.data_ptr(), out_c.data_ptr(), self._w.data_ptr(), self._B,
-                   self.N_particles, u_arg, float(dt), z_arg, self._w_sigma_c, pod, rng, noise,
-                   ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(), where, stream_ptr())
+        args = (self._means.data_ptr(), self._covs.data_ptr(), idx.data_ptr() if idx is not None else None, out_m.data_ptr(),
+                out_c.data_ptr(), self._w.data_ptr(), self._B, self.N_particles, u_arg, float(dt), z_arg, self._w_sigma_c, pod, rng,
+                noise, ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr())
+        if self._model is None and self.N_particles > _lib.GSE_SMALL_RESAMPLE_MAX:
+            # ... and leaves the quarter sums of the new weights in the workspace: the resample that follows needs no
+            # tile-sum launch (valid until anything else touches the weights or the workspace)
+            self._call("gse_gsukf_predict_update_sums", *args, self._ws.data_ptr(), where, stream_ptr())
+            self._sums_valid = True
+        else:
+            self._call("gse_gsukf_predict_update_from", *args, where, stream_ptr())
         if idx is not None:
             self._means, self._means_alt = self._means_alt, self._means
             self._covs, self._covs_alt = self._covs_alt, self._covs
@@ -328,8 +343,9 @@ class ParallelGaussianSumUnscentedKalmanFilter:
                 if self._idx_buf is None:
                     self._idx_buf = torch.empty((B, n), dtype=torch.int32, device=self._w.device)
                 idx = self._idx_buf
-            self._call("gse_gsukf_resample_begin", self._w.data_ptr(), self._w_alt.data_ptr(), idx.data_ptr(), B, n, rr,
-                       self._ws.data_ptr(), stream_ptr())
+            sums = self._sums_valid                  # (read before _call clears it: the resample replaces the weights)
+            self._call("gse_gsukf_resample_begin_sums" if sums else "gse_gsukf_resample_begin", self._w.data_ptr(),
+                       self._w_alt.data_ptr(), idx.data_ptr(), B, n, rr, self._ws.data_ptr(), stream_ptr())
             self._w, self._w_alt = self._w_alt, self._w
             self._pend_gather = idx
         else:

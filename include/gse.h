@@ -266,6 +266,17 @@ int gse_gsukf_predict_update_from(const float *mu_in, const float *P_in, const i
                                   const float *w_sigma, const gse_mixture *state_pdf, const gse_rng *rng,
                                   const float *noise, const gse_mixture *measurement_pdf, int32_t *status,
                                   uint32_t where, void *stream);
+/* The same launch, which also leaves the quarter sums of the new weights ([B][4 T] doubles: what the four wavefronts of the
+ * tile-sum kernel would find per tile of 1024) in the workspace; gse_gsukf_resample_begin_sums -- called DIRECTLY after it on
+ * the same weights and workspace -- forms the tile sums from them (same association, same bits) and saves that kernel's
+ * launch: 4.7 us of a cycle at 2^18 Gaussians (filter/gs_ukf.py:369-436: update, then resample). */
+int gse_gsukf_predict_update_sums(const float *mu_in, const float *P_in, const int32_t *idx, float *mu, float *P, float *w, int B,
+                                  int64_t N, const double *u, double dt, const double *z, const float *w_sigma,
+                                  const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,
+                                  const gse_mixture *measurement_pdf, int32_t *status, void *workspace, uint32_t where,
+                                  void *stream);
+int gse_gsukf_resample_begin_sums(const float *w, float *w_out, int32_t *idx, int B, int64_t N, const double *r, void *workspace,
+                                  void *stream);
 
 /* gse_gsukf_moments in the particle filter's layout -- rows of 26 doubles { S0, S1[5], S2[15] + C[15], p[5] }, so that
  * S2 - S1 e^T - e S1^T + S0 e e^T is the whole covariance (filter/gs_ukf.py:442-449): what gse_loop_control and the host
