@@ -209,10 +209,10 @@ def protocol_sum(torch, n, io, dt, runs=100):
     f.lazy = False
 
     def timed(fn):
-        torch.cuda.synchronize()
+        gpu_se_amd.synchronize()
         t = time.perf_counter()
         fn()
-        torch.cuda.synchronize()
+        gpu_se_amd.synchronize()                  # (polls the stream: gse_stream_synchronize)
         return time.perf_counter() - t
     for u, z in io[:5]:
         f.predict(u, dt); f.update(u, z); f.resample()

@@ -29,4 +29,11 @@ def version():
     return _lib.load().gse_version()
 
 
-__all__ = ["seed", "version", "GseError"]
+def synchronize(spin=True):
+    """Wait for the current stream's work (polling it by default: a microsecond after the last kernel ends instead of the
+    wake-up latency of torch.cuda.synchronize -- what a caller timing single method calls wants)."""
+    from gpu_se_amd.devarray import stream_ptr
+    _lib.check(_lib.load().gse_stream_synchronize(stream_ptr(), 1 if spin else 0))
+
+
+__all__ = ["seed", "version", "synchronize", "GseError"]

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "gse_version": (ctypes.c_int, []),
     "gse_last_error": (ctypes.c_char_p, []),
     "gse_workspace_bytes": (c_i64, [ctypes.c_int, c_i64]),
+    "gse_stream_synchronize": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "gse_pf_predict": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_d, P_MIX, P_RNG, c_vp]),
     "gse_pf_predict_injected": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_d, c_vp, c_vp]),
     "gse_pf_update": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_i64, P_D, P_D, P_MIX, c_vp, c_vp]),

@@ -110,6 +110,22 @@ int gse_version(void) { return GSE_VERSION; }
 
 const char* gse_last_error(void) { return gse::last_error_buffer(); }
 
+int gse_stream_synchronize(void* stream, int spin) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!spin) {
+        const hipError_t e = hipStreamSynchronize(st);
+        return e == hipSuccess ? GSE_OK : gse::fail(-(int)e, "gse_stream_synchronize: %s", hipGetErrorString(e));
+    }
+    // Busy-wait on the stream's state: the caller's next launch should follow the end of this work by a microsecond, not by
+    // the wake-up latency of a blocking wait (the reference's benchmark protocol times every method call by itself,
+    // results/pf_openloop/pf_run_seq.py:15-130 -- there the wait is most of what a small filter costs).
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return GSE_OK;
+        if (e != hipErrorNotReady) return gse::fail(-(int)e, "gse_stream_synchronize: %s", hipGetErrorString(e));
+    }
+}
+
 int64_t gse_workspace_bytes(int B, int64_t N) {
     if (B < 1 || B > GSE_MAX_B || N < 1) return gse::fail(GSE_ERR_ARG, "gse_workspace_bytes: bad B = %d or N = %lld", B, (long long)N);
     return gse::carve_workspace(nullptr, B, N).bytes;

@@ -7,20 +7,30 @@
 // One workgroup = 256 threads = 4 wavefronts owns one TILE of 1024 consecutive particles of one filter;
 // every thread owns 4 consecutive particles, so each state row is read and written with one dwordx4 per
 // lane (1 KiB per wave-instruction, fully coalesced) from the state-major layout x[b][k][i].
-// Everything here is HBM-bound streaming work (140 algorithmic bytes / particle / cycle), and at
+// Everything here is HBM-bound streaming work by the roofline (140 algorithmic bytes / particle / cycle), and at
 // N = 2^20 one kernel is a single generation of workgroups (4 tiles per CU), so every launch costs a fixed
 // 3.5-5 us of ramp-up / latency chain whatever it computes.  The design therefore minimises LAUNCHES and passes:
 //
-//   pf_step_kernel<gather, predict, update>   ONE fused pass over the particles that does any subset of
-//        gather    the offspring's ancestor (resample, second half): 64-ary wavefront search + LDS binary search
-//                  in the normalised cumulative weights, then an indexed read of the 5 state rows
-//        predict   ODE step (fp64 in registers) + Philox/Box-Muller mixture draw (no memory: hides the loads)
-//        update    likelihood in fp64, w *= pdf, workgroup sum of the new weights -> one tile sum
-//   cumsum_kernel   tile prefix + fp64 scan of the weights -> normalised cumulative weights (resample, first half)
+//   pf_step_kernel<gather, predict, injected, update, Nd, scan>   ONE fused pass over the particles that does any subset of
+//        gather    the offspring's ancestors (resample, second half).  With SCAN_IN (the steady state) by the INVERSE MAP:
+//                  the tile prefix of the weights is rebuilt in LDS, the one or two ancestor tiles of the workgroup's 1024
+//                  outputs are found there, their keys are re-formed from the weights and the per-thread tile prefixes the
+//                  previous update left (8 B per 4 particles) and every key marks the outputs it is the last ancestor
+//                  below (LDS atomic max + a max-scan) -- no stored cumulative weights, no search; wide ancestor ranges take
+//                  a census of the tiles first, and beyond GSE_SEARCH_FROM listed tiles every output looks its ancestor
+//                  up (search_ancestors).  Without SCAN_IN (weights assigned by the caller, N > 2^21): the round-1 path --
+//                  64-ary wavefront search + LDS bisection in the materialised cumulative weights of cumsum_kernel.
+//                  Then an indexed read of the 5 state rows.
+//        predict   ODE step (fp64 in registers) + Philox/Box-Muller mixture draw (no memory: hides the loads), or
+//                  injected noise (the parity mode)
+//        update    likelihood in fp64, w *= pdf, workgroup sum of the new weights -> one tile sum; with SCAN_OUT also the
+//                  per-thread tile prefixes the next launch's gather resamples from
+//   cumsum_kernel   tile prefix + fp64 scan of the weights -> normalised cumulative weights (resample, first half, where
+//                   the single-launch cycle does not apply)
 //
-// The steady-state cycle  resample -> predict -> update  is two launches: cumsum, then step<gather,predict,update>
-// (r 8 + 20 B, w 24 B per particle, nothing else touches HBM).  The classic one-method-one-kernel entry points are
-// the same kernel with a single stage enabled.
+// The steady-state cycle  resample -> predict -> update  is ONE launch: step<gather, predict, update, scan in + out>
+// (r 20 + 4..8 + 2..4 B, w 20 + 4 + 2 B per particle; 57 MB per launch at N = 2^20 by the PMC counters).  The classic
+// one-method-one-kernel entry points are the same kernel with a single stage enabled.
 #pragma once
 
 #include "gse_host.h"

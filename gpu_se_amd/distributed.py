@@ -182,6 +182,8 @@ class ShardedParticleFilter:
         # host generator that is the SAME on every rank (exact resampling draws one r for the whole ensemble)
         self._common_rng = numpy.random.default_rng(gpu_se_amd._seed_state["seed"] ^ 0xE4AC7)
         self.last_exact = None
+        self._ends_index = None                             # device indices of the shard ends in the tile prefix (built once)
+        self._merge_buf = torch.zeros((self.world, MERGE_WIDTH), dtype=torch.float64, device=self._merge_device)
 
     @classmethod
     def from_get_parts(cls, n_local, group=None):
@@ -254,18 +256,18 @@ class ShardedParticleFilter:
         #    resamples the A_p differ, so the local weights are brought to one scale first: w_i * exp(log A_p - max_q
         #    log A_q), fp32 like the weights themselves.  (Exact-only sequences on equal shards: every A_p is the same
         #    and the scale is exactly 1 -- nothing is touched and the result is bit for bit the single-GPU one.)
+        #    The scale is formed and applied on the device; the log-weights come to the host with the ONE copy of this
+        #    method (step 3), where they are checked.
         w_src = f._w
         uneven = any(cnt != spans[0][1] for _, cnt in spans)
+        mine_log = None
         if self._islands_apart or uneven:
             mine_log = torch.zeros(P, dtype=torch.float64, device=self._merge_device)
-            mine_log[self.rank] = f._island[0, 0].to(self._merge_device)
+            mine_log[self.rank:self.rank + 1].copy_(f._island[0])
             dist.all_reduce(mine_log, op=dist.ReduceOp.SUM, group=self.group)
-            logs = mine_log.cpu().numpy()
-            if not numpy.all(numpy.isfinite(logs)):
-                raise FloatingPointError("a shard's accumulated log-weight is not finite")
-            scale = float(numpy.exp(logs[self.rank] - logs.max()))
-            if scale != 1.0:
-                w_src = f._w * numpy.float32(scale)
+            mine_log = mine_log.to(dev)
+            scale = torch.exp(mine_log[self.rank] - mine_log.max()).to(torch.float32)      # (exactly 1 on the heaviest shard)
+            w_src = f._w * scale
         # 1. tile sums of every shard
         mine = torch.empty((tiles[self.rank],), dtype=torch.float64, device=dev)
         _lib.check(lib.gse_pf_tile_sums(w_src.data_ptr(), f._ld, 1, n, mine.data_ptr(), stream))
@@ -276,7 +278,15 @@ class ShardedParticleFilter:
         c = torch.empty((n,), dtype=torch.float64, device=dev)
         _lib.check(lib.gse_pf_shard_cumsum(w_src.data_ptr(), n, prefix.data_ptr(), tile_offset, T_total, c.data_ptr(), stream))
         ends = numpy.cumsum(tiles)
-        host = prefix[torch.as_tensor(numpy.concatenate([ends, [T_total]]), device=dev)].cpu().numpy()
+        if self._ends_index is None:
+            self._ends_index = torch.as_tensor(numpy.concatenate([ends, [T_total]]), device=dev)
+        picked = prefix[self._ends_index]
+        # the one device -> host copy of the method: the cumulative weights at the shard ends (they size the all-to-all, whose
+        # split sizes torch.distributed takes from the host) and, if the islands were apart, their log-weights
+        both = (torch.cat([picked, mine_log]) if mine_log is not None else picked).cpu().numpy()
+        host = both[:P + 1]
+        if mine_log is not None and not numpy.all(numpy.isfinite(both[P + 1:])):
+            raise FloatingPointError("a shard's accumulated log-weight is not finite")
         total = host[-1]
         if not (total > 0 and numpy.isfinite(total)):
             raise FloatingPointError("the ensemble's weights do not sum to a positive finite number")
@@ -340,7 +350,8 @@ class ShardedParticleFilter:
         if self.group is None:
             return merge_rows(row[None, :], self._pivot)
         self.wait_collectives()
-        buf = torch.zeros((self.world, MERGE_WIDTH), dtype=torch.float64, device=self._merge_device)
+        buf = self._merge_buf
+        buf.zero_()
         buf[self.rank] = torch.as_tensor(row, dtype=torch.float64, device=self._merge_device)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         return merge_rows(buf.cpu().numpy(), self._pivot)

@@ -352,8 +352,9 @@ class ParallelParticleFilter:
             self._c_r[0] = self._host_rng.random() if r is None else float(numpy.asarray(r, dtype=numpy.float64).reshape(-1)[0])
         else:
             self._fill(self._c_r, self._host_rng.random(self._B) if r is None else r, 1)
-        if self.lazy and self._scan_slot is not None:
-            # the preceding update left the tile-local scans of these weights in the workspace: nothing to launch
+        if self._scan_slot is not None:
+            # the preceding update left the tile sums and per-thread tile prefixes of these weights in the workspace: nothing
+            # to launch now (lazy = False: the gather that follows at once resamples from them, one launch instead of two)
             self._gather_slot = self._scan_slot
         else:
             flags = _lib.GSE_RESAMPLE_TILES_VALID if self._tiles_valid else 0

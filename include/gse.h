@@ -84,6 +84,10 @@ typedef struct gse_rng {
 
 int         gse_version(void);
 const char *gse_last_error(void);
+/* Wait until everything enqueued on `stream` has finished; spin != 0: by polling the stream (the reference's classes are
+ * synchronous at .get() / float(cupy scalar), filter/particle.py:307, :320 -- a caller that times single method calls,
+ * results/pf_openloop/pf_run_seq.py:15-130, sees the wait's wake-up latency in every sample). */
+int         gse_stream_synchronize(void *stream, int spin);
 
 /* Bytes of device workspace the particle-filter / GS-UKF calls below need for (B, N): per filter the tile
  * sums, their prefix and the moment partials.  The workspace carries state only BETWEEN gse_*_update and a
@@ -142,12 +146,18 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
  * equal w_in).  Arguments of stages that are not requested may be NULL.
  *
  * Single-launch cycle (N <= 4096 * GSE_TILE, Philox draw, 2-component measurement mixture):
- *   GSE_OP_SCAN_OUT  (with UPDATE)  also leave the tile-local inclusive scans of the new weights and their tile sums in
- *                    workspace slot 0 (or 1 with GSE_OP_SCAN_OUT_SLOT1): 8 B per particle;
- *   GSE_OP_SCAN_IN   (with GATHER)  take the cumulative weights from slot 0 (1 with GSE_OP_SCAN_IN_SLOT1) instead of
- *                    from gse_pf_resample_begin: c[k] = (tile prefix + scan[k]) / sum, the same arithmetic and bits.
- * Alternating the slots, update -> resample -> predict -> update -> ... is ONE launch per cycle and the weights are
- * never re-read.  island: as for gse_pf_resample, maintained by the GATHER stage when GSE_OP_SCAN_IN is set. */
+ *   GSE_OP_SCAN_OUT  (with UPDATE)  also leave, in workspace slot 0 (or 1 with GSE_OP_SCAN_OUT_SLOT1), the tile sums of the
+ *                    new weights and -- per thread of the update stage, i.e. per 4 consecutive particles -- the exclusive
+ *                    prefix of its weights inside the tile of 1024: 8 B per FOUR particles (round 1 stored the tile-local
+ *                    inclusive scans, 8 B per particle);
+ *   GSE_OP_SCAN_IN   (with GATHER)  resample from slot 0 (1 with GSE_OP_SCAN_IN_SLOT1) and w_in instead of from the
+ *                    cumulative weights of gse_pf_resample_begin: the key of particle k is re-formed as
+ *                    min(tile prefix + (thread prefix + running sum of the thread's weights), next tile prefix) / sum --
+ *                    cumsum_kernel's arithmetic and bits -- and the ancestors follow by the inverse map (offspring counts
+ *                    per key; per-output look-up for wide ancestor ranges), never by materialising c[].
+ * Alternating the slots, update -> resample -> predict -> update -> ... is ONE launch per cycle.  Injected noise (the parity
+ * mode) has these modes where a closed loop needs them: the whole cycle and predict + update.  island: as for
+ * gse_pf_resample, maintained by the GATHER stage when GSE_OP_SCAN_IN is set. */
 #define GSE_OP_GATHER  1u
 #define GSE_OP_PREDICT 2u
 #define GSE_OP_UPDATE  4u
@@ -157,8 +167,8 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
 #define GSE_OP_SCAN_OUT_SLOT1 64u
 #define GSE_OP_U_DEVICE 128u     /* (with PREDICT) u is a DEVICE pointer [B][2] fp64, read when the kernel runs */
 #define GSE_OP_Z_DEVICE 256u     /* (with UPDATE)  z is a DEVICE pointer [B][2] fp64                            */
-                                 /* (both: not with injected noise; with GSE_OP_GATHER only in the whole single- */
-                                 /*  launch cycle GATHER | PREDICT | UPDATE | SCAN_IN | SCAN_OUT)                */
+                                 /* (both: with GSE_OP_GATHER only in the whole single-launch cycle              */
+                                 /*  GATHER | PREDICT | UPDATE | SCAN_IN | SCAN_OUT)                             */
 int gse_pf_step(uint32_t ops, const float *x_in, float *x_out, const float *w_in, float *w_out, int32_t *idx,
                 int64_t ld, int B, int64_t N, const double *u, double dt, const double *z, const double *r,
                 const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,

@@ -16,7 +16,7 @@ Fixture list:
   G1 model_fg.npz       f, g on 256 states x 4 (u, dt)
   G2 mixture_pdf.npz    pdf of both mixtures on 256 points (down to exp(-700) underflow)
   G3 resample.npz       systematic resample cases with recorded r -> ancestor index
-  G4 pf_trace.npz       ParticleFilter N=1024, 10 cycles: inputs, recorded noise/r, states
+  G4 pf_trace.npz       ParticleFilter N=1024, 20 cycles: inputs, recorded noise/r, states
   G5 gsukf_trace.npz    GS-UKF N in {1,7,64}: sigma points, predict, update, resample, estimates
   G6 pf_stat.npz        posterior-mean envelope over independent seeds (statistical parity)
   G7 constants.npz      mixture constants, inverse covariances, sigma weights, X_ss
@@ -268,7 +268,7 @@ def plant_step(x_true, u, dt, sp, mp):
     return x_true, z
 
 
-def gen_pf_trace(X, n=1024, cycles=10, seed=404):
+def gen_pf_trace(X, n=1024, cycles=20, seed=404):
     numpy.random.seed(seed)
     _, _, _, pf = sim_base.get_parts(N_particles=n, gpu=False)
     plant_sp, plant_mp = sim_base.get_noise(lib=numpy)
@@ -370,11 +370,28 @@ def gen_gsukf(X, seed=505):
 
 
 # --------------------------------------------------------------------------- G6
+def _stat_worker(job):
+    """One seed of the reference particle filter on the fixed (u, z) sequence (runs in a worker process)."""
+    n, s, us, zs = job
+    numpy.random.seed(7000 + 13 * s + n)
+    _, _, _, pf = sim_base.get_parts(N_particles=n, gpu=False)
+    est, cov = numpy.zeros((len(us), 5)), numpy.zeros(len(us))
+    for c in range(len(us)):
+        pf.predict(us[c], 0.1)
+        pf.update(us[c], zs[c])
+        pf.resample()
+        est[c] = pf.point_estimate()
+        cov[c] = pf.point_covariance()
+    return n, s, est, cov
+
+
 def gen_pf_stat(X, seed=606):
     """Posterior-mean envelope of the reference PF over independent seeds on ONE fixed
-    (u, z) sequence; the Philox-driven HIP filter must land inside it (3 sigma)."""
+    (u, z) sequence; the Philox-driven HIP filter must land inside it (3 sigma).  SURVEY 8c: 64 seeds, 50 cycles,
+    N = 1024 and N = 16384 (the reference's per-particle Python loops: 25 s per seed at 16384, spread over the cores)."""
+    import multiprocessing
     rng = numpy.random.default_rng(seed)
-    cycles = 30
+    cycles, seeds = 50, 64
     plant_sp, plant_mp = sim_base.get_noise(lib=numpy)
     numpy.random.seed(seed)
     x_true = X.copy()
@@ -385,21 +402,18 @@ def gen_pf_stat(X, seed=606):
         us.append(u), zs.append(z)
     us, zs = numpy.array(us), numpy.array(zs)
     out = dict(u=us, z=zs, dt=numpy.float64(0.1))
-    for n, seeds in ((1024, 48), (8192, 6)):
-        ests = numpy.zeros((seeds, cycles, 5))
-        covs = numpy.zeros((seeds, cycles))
-        for s in range(seeds):
-            numpy.random.seed(7000 + 13 * s + n)
-            _, _, _, pf = sim_base.get_parts(N_particles=n, gpu=False)
-            for c in range(cycles):
-                pf.predict(us[c], 0.1)
-                pf.update(us[c], zs[c])
-                pf.resample()
-                ests[s, c] = pf.point_estimate()
-                covs[s, c] = pf.point_covariance()
-            print("  stat n=%d seed %d/%d" % (n, s + 1, seeds), flush=True)
-        out["est_n%d" % n] = ests
-        out["cov_n%d" % n] = covs
+    jobs = [(n, s, us, zs) for n in (16384, 1024) for s in range(seeds)]
+    with multiprocessing.Pool(min(8, os.cpu_count() or 1)) as pool:
+        done = 0
+        res = {}
+        for n, s, est, cov in pool.imap_unordered(_stat_worker, jobs):
+            res[(n, s)] = (est, cov)
+            done += 1
+            if done % 8 == 0:
+                print("  stat %d/%d" % (done, len(jobs)), flush=True)
+    for n in (1024, 16384):
+        out["est_n%d" % n] = numpy.array([res[(n, s)][0] for s in range(seeds)])
+        out["cov_n%d" % n] = numpy.array([res[(n, s)][1] for s in range(seeds)])
     save("pf_stat.npz", **out)
 
 

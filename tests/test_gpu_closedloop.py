@@ -389,6 +389,77 @@ def test_exact_resample_two_ranks_equals_one_filter_on_the_concatenation():
     np.testing.assert_array_equal(out[0][1], out[1][1])               # and the merged estimate is shared
 
 
+# ------------------------------------------------------------------------------ the collectives through RCCL itself
+def _rccl_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    import gpu_se_amd as g
+    from gpu_se_amd.distributed import ShardedParticleFilter
+    g.seed(31)
+    n_local = 12 * 1024 + 100                                        # (a ragged last tile)
+    spf = ShardedParticleFilter.from_get_parts(n_local=n_local, group=dist.group.WORLD)
+    assert spf._merge_device.type == "cuda" and dist.get_backend() == "nccl"
+    xss = orc.steady_state()
+    z = np.array(orc.bioreactor_g(xss)) + [0.3, -0.2]
+    log = []
+    for c in range(4):
+        spf.predict([0.06, 0.2], 0.1)
+        spf.update([0.06, 0.2], z)
+        if c == 1:
+            spf.resample()                                           # an island resample in between: the log-weights move
+            spf._exchange_shares()                                   # the policy's all-reduce, asynchronous on RCCL
+            spf.wait_collectives()
+            log.append(("shares", spf._shares.cpu().numpy().copy(), float(spf.local._island[0, 0].item())))
+            continue
+        before = (spf.local.particles.get().copy(), spf.local.weights.get().copy())
+        spf._exact_resample(0.25 + 0.2 * c)                          # all-gather of tile sums + all-to-all of rows, on RCCL
+        log.append(("exact", before, spf.local.particles.get().copy(), spf.local.weights.get().copy(), dict(spf.last_exact)))
+    est = spf.point_estimate()                                       # the posterior merge: all-reduce on RCCL
+    out[rank] = (log, est, spf.local.point_estimate())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collectives_run_through_rccl_with_one_rank():
+    """No second GPU on this box, so RCCL carries ONE rank -- but it is RCCL that carries it: the asynchronous all-reduce of
+    the island log-weights, the all-gather + all-to-all of the exact resample and the all-reduce of the posterior merge are
+    issued on the nccl backend with device tensors (the 8-GPU form is the driver's to run; here the entry points are loaded,
+    called and give the single-filter answers bit for bit)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    manager = mp.Manager()
+    out = manager.dict()
+    mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    log, est, local_est = out[0]
+    n = 12 * 1024 + 100
+    state_pdf, meas_pdf = sim_base.get_noise()
+    x0, _ = sim_base.get_noise()
+    one = ParallelParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, state_pdf, meas_pdf)
+    seen = 0
+    for entry in log:
+        if entry[0] == "shares":
+            np.testing.assert_array_equal(entry[1], [entry[2]])
+            continue
+        _, (x, w), new_x, new_w, info = entry
+        one.particles, one.weights = x, w
+        one.resample(r=info["r"])
+        np.testing.assert_array_equal(new_x, one.particles.get())
+        np.testing.assert_array_equal(new_w, np.full(n, np.float32(1.0 / n)))
+        assert info["send"] == [n] and info["recv"] == [n] and info["J"] == [0, n]
+        seen += 1
+    assert seen == 3
+    # (the merged estimate is normalised, the local class's is the raw weights @ particles with n x fp32(1 / n) != 1)
+    np.testing.assert_allclose(est, local_est, rtol=1e-7)
+
+
 def test_config5_size_cycle_properties():
     """BASELINE config 5 per GPU (32 filters x 2^18 particles, 8.4 M particles in one launch): size-independent
     properties of one fused cycle -- ancestors sorted and in range per filter, offspring counts within one of N w,

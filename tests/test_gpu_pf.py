@@ -291,7 +291,7 @@ def make_filter(n, particles, deterministic=False):
 
 
 def test_pf_trace_per_step(golden):
-    """The reference's own 10-cycle trace (golden G4), each step started from the reference's state with its
+    """The reference's own 20-cycle trace (golden G4), each step started from the reference's state with its
     recorded noise and r, through the drop-in class: particles to one fp32 rounding, weights 2e-6,
     ancestors exact."""
     g = golden("pf_trace.npz")
@@ -300,7 +300,7 @@ def test_pf_trace_per_step(golden):
     for c in range(len(g["dt"])):
         DeterministicGaussianSum.preload(g["noise"][c])
         pf.predict(g["u"][c], g["dt"][c])
-        np.testing.assert_allclose(pf.particles.get(), g["after_predict"][c], rtol=5e-7, atol=2e-9)
+        np.testing.assert_allclose(pf.particles.get(), g["after_predict"][c], rtol=5e-7, atol=1e-7)   # (3e-6 of the increments)
         pf.particles = g["after_predict"][c]
         pf.update(g["u"][c], g["z"][c])
         np.testing.assert_allclose(pf.weights.get(), g["w_after_update"][c], rtol=2e-6)
@@ -352,8 +352,8 @@ def test_api_surface():
 def test_statistical_parity_with_reference(golden):
     """Philox-driven HIP filter vs the reference's NumPy filter (MT19937) on one fixed (u, z) sequence: the
     posterior mean must fall inside the envelope of the reference's own seed-to-seed scatter (golden G6)."""
-    g = golden("pf_stat.npz")
-    for n, key in ((1024, "est_n1024"), (8192, "est_n8192")):
+    g = golden("pf_stat.npz")                           # (SURVEY 8c: 64 seeds x 50 cycles at N = 1024 and N = 16384)
+    for n, key in ((1024, "est_n1024"), (16384, "est_n16384")):
         ref = g[key]                                     # (seeds, cycles, 5)
         mu, sd = ref.mean(axis=0), ref.std(axis=0, ddof=1)
         runs = []
