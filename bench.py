@@ -425,10 +425,11 @@ def main():
         steady_gbs = 140.0 * n / steady / 1e9
         traffic, traffic_hash = pmc_traffic(n)
         sources = csrc_hash()
-        single_launch = lp._scan_capable
+        single_launch = not lp._prefix_global
         roofline = {"bound": "hbm",
                     "kernel": "pf_step_kernel<gather,predict,update,scan>" if single_launch
-                    else "cumsum_kernel + pf_step_kernel<gather,predict,update> (two launches per cycle at this N)",
+                    else "tile_scan_kernel (one workgroup) + pf_step_kernel<gather,predict,update,scan from the scanned tile "
+                         "prefix> (two launches per cycle beyond 2^21 particles)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic if traffic_hash == sources else None,

@@ -12,12 +12,16 @@ GSE_NX, GSE_NU, GSE_NY, GSE_NSIGMA = 5, 2, 2, 11
 GSE_MAX_ND, GSE_MAX_B, GSE_TILE = 4, 32, 1024
 GSE_RESAMPLE_TILES_VALID = 1
 GSE_RESAMPLE_SEPARATE_SCAN = 2
+GSE_RESAMPLE_PREFIX_FROM_SLOT, GSE_RESAMPLE_SLOT1 = 4, 8
 GSE_OP_GATHER, GSE_OP_PREDICT, GSE_OP_UPDATE = 1, 2, 4
 GSE_OP_SCAN_IN, GSE_OP_SCAN_OUT, GSE_OP_SCAN_IN_SLOT1, GSE_OP_SCAN_OUT_SLOT1 = 8, 16, 32, 64
 GSE_OP_U_DEVICE, GSE_OP_Z_DEVICE = 128, 256
+GSE_OP_PREFIX_GLOBAL = 512
 GSE_IO_U_DEVICE, GSE_IO_Z_DEVICE = 1, 2
-GSE_SCAN_MAX_TILES = 2048      # policy: beyond 2^21 particles the two-kernel resample is faster (every workgroup
-                               # builds the whole tile prefix: at 4096 tiles the single launch takes 131 us against 102)
+GSE_SCAN_MAX_TILES = 2048      # policy: up to 2^21 particles every workgroup of the cycle kernel rebuilds the tile prefix in LDS
+                               # (one launch per cycle); beyond, a one-workgroup scan of the tile sums runs first and the
+                               # cycle kernel stages windows of ITS prefix (GSE_OP_PREFIX_GLOBAL: two launches, the second
+                               # still the whole cycle -- round 2 fell back to cumsum + staged search there)
 GSE_GSUKF_CYCLE_MAX = 64
 GSE_SMALL_RESAMPLE_MAX = 4096       # banks up to here find their ancestors in one launch (small_resample_kernel)
 GSE_GSUKF_MOMENTS = 46             # doubles per row of gse_gsukf_moments

@@ -528,7 +528,7 @@ __device__ __forceinline__ void wave_search_ge_pair(Value value, int N, double u
     const int half = lane >> 5, l = lane & 31;
     const double u = half ? u_hi : u_lo;
     int lo = 0, hi = N;                                           // per half: answer in [lo, hi)
-    const int rounds = (N <= 32) ? 1 : ((N <= 1024) ? 2 : 3);
+    const int rounds = (N <= 32) ? 1 : ((N <= 1024) ? 2 : ((N <= 32768) ? 3 : 5));
     for (int round = 0; round < rounds; ++round) {
         const int n = hi - lo;
         const int step = (n + 31) >> 5;

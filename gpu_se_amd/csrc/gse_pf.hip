@@ -103,7 +103,8 @@ struct StepLaunch {
 template <bool G, bool P, bool I, bool U, int ND, int S>
 void step_go(const StepLaunch& L) {
     const Workspace& ws = *L.ws;
-    const size_t dyn = (S & 1) ? (size_t)(L.T + 1) * sizeof(double) : 0;
+    const size_t dyn = (S & 8) ? (size_t)kPrefixWindow * sizeof(double) : ((S & 1) ? (size_t)(L.T + 1) * sizeof(double) : 0);
+    const double* prefix_g = (S & 8) ? ws.tile_prefix : nullptr;
     if (L.model) {
         // the same kernel, compiled at run time for the user's model (gse_rtc.hip); same argument list
         char name[160];
@@ -112,13 +113,13 @@ void step_go(const StepLaunch& L) {
         void* params[] = {(void*)&L.x_in, (void*)&L.x_out, (void*)&L.w_in, (void*)&L.w_out, (void*)&L.noise, (void*)&L.idx,
                           (void*)&ws.cumsum, (void*)&ws.totals, (void*)&ws.tile_sums, (void*)&ws.scan_sums[L.slot_in],
                           (void*)&ws.scan[L.slot_in], (void*)&ws.scan_sums[L.slot_out], (void*)&ws.scan[L.slot_out],
-                          (void*)&L.island, (void*)&L.N, (void*)&L.ld, (void*)&L.T, (void*)L.a};
+                          (void*)&prefix_g, (void*)&L.island, (void*)&L.N, (void*)&L.ld, (void*)&L.T, (void*)L.a};
         *L.rc = launch_user_kernel(L.model, name, L.grid, dim3(kBlock), dyn, L.st, params);
         return;
     }
     hipLaunchKernelGGL((pf_step_kernel<G, P, I, U, ND, S>), L.grid, dim3(kBlock), dyn, L.st, L.x_in, L.x_out, L.w_in, L.w_out,
                        L.noise, L.idx, ws.cumsum, ws.totals, ws.tile_sums, ws.scan_sums[L.slot_in], ws.scan[L.slot_in],
-                       ws.scan_sums[L.slot_out], ws.scan[L.slot_out], L.island, L.N, L.ld, L.T, *L.a);
+                       ws.scan_sums[L.slot_out], ws.scan[L.slot_out], prefix_g, L.island, L.N, L.ld, L.T, *L.a);
 }
 
 // Run-time stage flags -> template instance.  Instantiated: every stage combination; the component count folded in
@@ -139,6 +140,10 @@ bool step_pick_scan(int scan, const StepLaunch& L) {
     }
     if constexpr (G && P && U && kScanOk) {                      // ... also in the single-launch cycle (resident closed loop)
         if (scan == 7) { step_go<G, P, I, U, ND, 7>(L); return true; }
+    }
+    if constexpr (G && !I && kScanOk) {                          // + 8: the tile prefix from tile_scan_kernel (N > 2^21)
+        if (scan == 9) { step_go<G, P, I, U, ND, 9>(L); return true; }
+        if constexpr (U) if (scan == 11) { step_go<G, P, I, U, ND, 11>(L); return true; }
     }
     return false;
 }
@@ -170,7 +175,9 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     if (int rc = check_pf_geometry(fn, B, N, ld)) return rc;
     const bool G = ops & GSE_OP_GATHER, P = ops & GSE_OP_PREDICT, U = ops & GSE_OP_UPDATE;
     const uint32_t known = GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE | GSE_OP_SCAN_IN | GSE_OP_SCAN_OUT |
-                           GSE_OP_SCAN_IN_SLOT1 | GSE_OP_SCAN_OUT_SLOT1 | GSE_OP_U_DEVICE | GSE_OP_Z_DEVICE;
+                           GSE_OP_SCAN_IN_SLOT1 | GSE_OP_SCAN_OUT_SLOT1 | GSE_OP_U_DEVICE | GSE_OP_Z_DEVICE |
+                           GSE_OP_PREFIX_GLOBAL;
+    const bool prefix_global = (ops & GSE_OP_PREFIX_GLOBAL) != 0;
     GSE_REQUIRE((ops & (GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE)) != 0 && (ops & ~known) == 0,
                 "%s: bad ops mask 0x%x", fn, ops);
     const int scan = ((ops & GSE_OP_SCAN_IN) ? 1 : 0) | ((ops & GSE_OP_SCAN_OUT) ? 2 : 0);
@@ -179,8 +186,12 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
                 "%s: GSE_OP_SCAN_IN re-forms the cumulative weights from w_in (the weights the tile sums and prefixes of the slot "
                 "were taken from): it must be given", fn);
     GSE_REQUIRE(!(scan & 2) || U, "%s: GSE_OP_SCAN_OUT needs GSE_OP_UPDATE", fn);
-    GSE_REQUIRE(scan == 0 || tiles_of(N) <= kScanMaxT, "%s: the scan modes support at most %d tiles (N <= %d)", fn,
-                kScanMaxT, kScanMaxT * kTile);
+    GSE_REQUIRE(!prefix_global || (scan & 1), "%s: GSE_OP_PREFIX_GLOBAL needs GSE_OP_SCAN_IN", fn);
+    GSE_REQUIRE(!(scan & 1) || prefix_global || tiles_of(N) <= kScanMaxT,
+                "%s: GSE_OP_SCAN_IN rebuilds the tile prefix in LDS for at most %d tiles (N <= %d); beyond, run "
+                "gse_pf_resample_begin(GSE_RESAMPLE_PREFIX_FROM_SLOT) and pass GSE_OP_PREFIX_GLOBAL", fn, kScanMaxT, kScanMaxT * kTile);
+    GSE_REQUIRE(!prefix_global || !((ops & GSE_OP_U_DEVICE) || (ops & GSE_OP_Z_DEVICE)),
+                "%s: GSE_OP_PREFIX_GLOBAL is not available with device-resident u / z", fn);
     GSE_REQUIRE(x_in && aligned16(x_in), "%s: x_in must be a 16-byte aligned device pointer", fn);
     GSE_REQUIRE((workspace && aligned16(workspace)) || !(ops & (GSE_OP_GATHER | GSE_OP_UPDATE)),
                 "%s: gather / update need a 16-byte aligned device workspace", fn);
@@ -246,7 +257,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     L.rc = &model_rc;
     GSE_REQUIRE(!(scan == 3) || L.slot_in != L.slot_out, "%s: SCAN_IN and SCAN_OUT must use different slots", fn);
     const bool nd2 = U && a.pdf.nd == 2;
-    const int variant = scan | ((u_on_device || z_on_device) ? 4 : 0);
+    const int variant = scan | ((u_on_device || z_on_device) ? 4 : 0) | (prefix_global ? 8 : 0);
     const bool ok = G ? step_pick_p<true>(P, I, U, nd2, variant, L) : step_pick_p<false>(P, I, U, nd2, variant, L);
     if (!ok) return fail(GSE_ERR_UNSUPPORTED, "%s: stage combination 0x%x is not available (scan modes need the Philox "
                          "draw and a 2-component measurement mixture)", fn, ops);
@@ -303,6 +314,15 @@ int gse_pf_resample_begin(const float* w, int64_t ld, int B, int64_t N, uint32_t
     if (int rc = check_pf_geometry("gse_pf_resample_begin", B, N, ld)) return rc;
     GSE_REQUIRE(w && workspace && aligned16(w) && aligned16(workspace), "gse_pf_resample_begin: bad pointer");
     const Workspace ws = carve_workspace(workspace, B, N);
+    if (flags & GSE_RESAMPLE_PREFIX_FROM_SLOT) {
+        // only the exclusive prefix over the tile sums a GSE_OP_SCAN_OUT update left in the slot: what a GSE_OP_SCAN_IN |
+        // GSE_OP_PREFIX_GLOBAL gather reads (one workgroup per filter; the island bookkeeping is the gather stage's)
+        const int T = (int)tiles_of(N);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(B), dim3(kBlock), 0, (hipStream_t)stream,
+                           ws.scan_sums[(flags & GSE_RESAMPLE_SLOT1) ? 1 : 0], ws.tile_prefix, T);
+        GSE_LAUNCH_CHECK("tile_scan_kernel");
+        return GSE_OK;
+    }
     return launch_cumsum(w, ld, B, N, flags, island, ws, ws.cumsum, (hipStream_t)stream);
 }
 

@@ -261,6 +261,7 @@ __device__ __forceinline__ void expand_quad(const OffspringCount& F, const doubl
 #ifndef GSE_SEARCH_FROM
 #define GSE_SEARCH_FROM 20
 #endif
+constexpr int kPrefixWindow = 1026;      // entries of the global tile prefix a workgroup stages (ranges of up to 1024 tiles)
 __device__ __forceinline__ int32_t window_ancestor(const float* __restrict__ wrow, const double* __restrict__ qx, int32_t N,
                                                    int32_t ld, int tq, int uq, double P0, double P1, double tau, int tl0) {
     // the quads uq - 1, uq, uq + 1 of tile tq: 18 registers of loads in flight (what fits; see search_ancestors)
@@ -352,8 +353,14 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     const float* __restrict__ noise, int32_t* __restrict__ idx_out, const double* __restrict__ c,
     const double* __restrict__ totals, double* __restrict__ tile_sums, const double* __restrict__ scan_in_sums,
     const double* __restrict__ scan_in, double* __restrict__ scan_out_sums, double* __restrict__ scan_out,
-    double* __restrict__ island, int64_t N, int64_t ld, int T, const StepArgs a) {
+    const double* __restrict__ prefix_g, double* __restrict__ island, int64_t N, int64_t ld, int T, const StepArgs a) {
     constexpr bool kScanIn = (kScan & 1) != 0, kScanOut = (kScan & 2) != 0;
+    // bit 3 (round 3): the tile prefix is not rebuilt by every workgroup from the tile sums but taken from prefix_g
+    // ([B][T + 1], tile_scan_kernel ran on the slot's tile sums) -- beyond 2048 tiles rebuilding costs more than it saves
+    // (every workgroup reads all T sums: 131 us against 102 at 2^22).  A workgroup finds its range of ancestor tiles in the
+    // global prefix (three 32-ary rounds of the wavefront) and stages that WINDOW in LDS; everything after is the same code.
+    constexpr bool kPrefixGlobal = (kScan & 8) != 0;
+    static_assert(!kPrefixGlobal || kScanIn, "the global tile prefix belongs to SCAN_IN");
     constexpr bool kDraw = kPredict && !kInjected;      // noise from Philox (registers only) rather than from memory
     // strided particle <-> thread mapping (see below): whenever the launch gathers or draws -- the Philox blocks of the
     // draw are shared by the four particles a thread owns in THIS mapping (gse_device.h, rng_block_of_group)
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     // anything else -- also before an early noise draw, which then covers their latency
     constexpr int kMaxChunk = 8;
     double sv[kMaxChunk];
-    if (kScanIn) {
+    if (kScanIn && !kPrefixGlobal) {
         const double* sums = scan_in_sums + (int64_t)b * T;
         const int m = (T + kBlock - 1) / kBlock;
         const int qlo = tid * m;
@@ -439,7 +446,17 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     bool drawn2 = false;
     if (kGather) {
         double W;
-        if (kScanIn) {
+        if constexpr (kPrefixGlobal) {
+            if (kInvMap) {
+                *reinterpret_cast<uint4*>(&mark[tid * kPerThread]) = make_uint4(0u, 0u, 0u, 0u);
+                if (tid == 0) act_n = 0;
+            }
+            W = prefix_g[(int64_t)b * (T + 1) + T];
+            if (island && tile_id == 0 && tid == 0) {      // shard bookkeeping (see gse_pf_resample)
+                island[b] += log(W);
+                island[gridDim.y + b] = W;
+            }
+        } else if (kScanIn) {
             // tile prefix into LDS: thread j owns chunk [j*m, (j+1)*m) of the tile sums (as inline_tile_prefix); the sums were
             // loaded at kernel entry and stay in registers for the second sweep
             const int m = (T + kBlock - 1) / kBlock;
@@ -504,7 +521,20 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             const double p_lo = (F.u_of(j0) * W) * (1.0 - 0x1p-50);
             const double p_hi = (F.u_of(j1 - 1) * W) * (1.0 + 0x1p-50);
             int tl0, tl1;
-            wave_search_ge_pair([&](int q) { return pfx_s[q + 1]; }, T, p_lo, p_hi, lane, tl0, tl1);
+            const double* pfx = pfx_s;                                             // tile prefix, indexed by tile (LDS)
+            bool too_wide = false;
+            if constexpr (kPrefixGlobal) {
+                const double* Pg = prefix_g + (int64_t)b * (T + 1);
+                wave_search_ge_pair([&](int q) { return Pg[q + 1]; }, T, p_lo, p_hi, lane, tl0, tl1);
+                const int nwin = tl1 - tl0 + 2;                                    // Pfx[tl0] .. Pfx[tl1 + 1]
+                too_wide = nwin > kPrefixWindow;                                   // workgroup-uniform
+                if (!too_wide)
+                    for (int i = tid; i < nwin; i += kBlock) pfx_s[i] = Pg[tl0 + i];
+                __syncthreads();                                                   // (the window; also the zeroed marks)
+                pfx = pfx_s - tl0;
+            } else {
+                wave_search_ge_pair([&](int q) { return pfx_s[q + 1]; }, T, p_lo, p_hi, lane, tl0, tl1);
+            }
             const float* wrow = w_in + (int64_t)b * ld;
     GSE_STAMP(11);
             const double* qx = scan_in + (int64_t)b * T * kBlock;                  // [T][256] per-thread exclusive prefixes
@@ -516,11 +546,11 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             // treatment -- was measured and dropped: no faster than this loop once its loads really ran ahead.)
             const bool direct = tl1 - tl0 < 2;                                     // workgroup-uniform
             int n_act = tl1 - tl0 + 1;
-            if (!direct) {
+            if (!direct && !too_wide) {
                 for (int q0 = tl0; q0 <= tl1; q0 += kBlock) {                       // (whole wavefronts take part: DPP below)
                     const int q = q0 + tid;
                     const bool have = q <= tl1;
-                    const int32_t e0 = have ? slot_of(pfx_s[q]) : 0, e1 = have ? slot_of(pfx_s[q + 1]) : -1;
+                    const int32_t e0 = have ? slot_of(pfx[q]) : 0, e1 = have ? slot_of(pfx[q + 1]) : -1;
                     // a run of tiles that all fall into one slot: the last of the run speaks for it
                     const uint32_t next_e1 = wave_shift_down1((uint32_t)(e1 + 2));     // (0 in lane 63 -> speak)
                     if (!have) continue;
@@ -538,12 +568,17 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             constexpr bool kSearchPath = GSE_SEARCH_FROM < kTile;                  // (a knob >= 1024 compiles the path out)
             bool wide = false;
             if constexpr (kSearchPath) wide = !direct && n_act > GSE_SEARCH_FROM;  // workgroup-uniform
-            if (kSearchPath && wide) {
+            if constexpr (kPrefixGlobal) wide = wide || too_wide;                  // (a range beyond the window: look up in
+                                                                                   //  the global prefix itself)
+            if ((kSearchPath || kPrefixGlobal) && wide) {
                 if (kDraw && draw_at == 2) {
                     draw_all();
                     drawn2 = true;
                 }
-                search_ancestors(F, pfx_s, wrow, qx, N, ld, tl0, tl1, j0, j1, tid, anc);
+                if (kPrefixGlobal && too_wide)
+                    search_ancestors(F, prefix_g + (int64_t)b * (T + 1), wrow, qx, N, ld, tl0, tl1, j0, j1, tid, anc);
+                else
+                    search_ancestors(F, pfx, wrow, qx, N, ld, tl0, tl1, j0, j1, tid, anc);
             } else if (n_act > 0) {                                                // (a census may list nothing)
                 // (every load below is unconditional, its index clamped instead: with loads under conditions the compiler
                 //  cannot count what is in flight and waits for ALL of it before the first use -- the next pair's loads
@@ -564,8 +599,8 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
                     const int u0 = tile_at(min(i + 2, last)), u1 = tile_at(min(i + 3, last));
                     const float4 n0 = weights_nc(u0), n1 = weights_nc(u1);
                     const double y0 = qx[u0 * kBlock + tid], y1 = qx[u1 * kBlock + tid];
-                    expand_quad<true>(F, pfx_s, mark, N, j0, t0, tid, c0, x0);
-                    if (i + 1 < n_act) expand_quad<true>(F, pfx_s, mark, N, j0, t1, tid, c1, x1);
+                    expand_quad<true>(F, pfx, mark, N, j0, t0, tid, c0, x0);
+                    if (i + 1 < n_act) expand_quad<true>(F, pfx, mark, N, j0, t1, tid, c1, x1);
                     c0 = n0; c1 = n1; x0 = y0; x1 = y1; t0 = u0; t1 = u1;
                 }
             }

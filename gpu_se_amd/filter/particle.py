@@ -110,7 +110,8 @@ class ParallelParticleFilter:
         self._pend_gather = False
         self._gather_slot = None                            # slot of the scans a pending gather reads (None: cumsum array)
         self._scan_slot = None                              # slot holding scans of the CURRENT weights, if any
-        self._scan_capable = (-(-n // _lib.GSE_TILE)) <= _lib.GSE_SCAN_MAX_TILES
+        self._scan_capable = True                           # the cycle kernel resamples from tile sums + per-thread prefixes
+        self._prefix_global = (-(-n // _lib.GSE_TILE)) > _lib.GSE_SCAN_MAX_TILES    # ... beyond 2^21 from a scanned tile prefix
         self._pend_predict = None
         self._want_index = False
         self._last_index = None
@@ -186,7 +187,8 @@ class ParallelParticleFilter:
         injected = self._pend_predict is not None and self._pend_predict[2] is not None
         scan_ok = self._scan_capable and self.measurement_pdf._Nd == 2
         whole = lambda: (self._pend_gather and self._gather_slot is not None and self._pend_predict is not None and
-                         update is not None and scan_ok)       # gather + predict + update in ONE launch, scans in and out
+                         update is not None and scan_ok and     # gather + predict + update in ONE launch, scans in and out
+                         not (injected and self._prefix_global))  # (no injected-noise variant of the scanned-prefix mode)
         if injected and self._pend_gather and self._gather_slot is not None and not whole():
             # injected noise has the scan variants of the whole cycle only: otherwise run the gather on its own first
             pend, self._pend_predict = self._pend_predict, None
@@ -200,7 +202,7 @@ class ParallelParticleFilter:
         device_io = (self._pend_predict is not None and torch.is_tensor(self._pend_predict[0])) or \
             (update is not None and torch.is_tensor(update[1]))
         whole_cycle = whole()
-        if device_io and self._pend_gather and not whole_cycle:
+        if device_io and self._pend_gather and (not whole_cycle or self._prefix_global):
             # inputs that live on the device are read by the single-launch cycle or by the variants without gather: in any
             # other combination copy the ancestors first
             pend, self._pend_predict = self._pend_predict, None
@@ -218,6 +220,8 @@ class ParallelParticleFilter:
             ops |= _lib.GSE_OP_GATHER
             if self._gather_slot is not None:
                 ops |= _lib.GSE_OP_SCAN_IN | (_lib.GSE_OP_SCAN_IN_SLOT1 if self._gather_slot else 0)
+                if self._prefix_global:
+                    ops |= _lib.GSE_OP_PREFIX_GLOBAL
             if self._want_index or self.record_ancestors:
                 self._last_index = torch.empty((self._B, self._ld), dtype=torch.int32, device=self._x.device)
                 idx_ptr = self._last_index.data_ptr()
@@ -356,6 +360,13 @@ class ParallelParticleFilter:
             # the preceding update left the tile sums and per-thread tile prefixes of these weights in the workspace: nothing
             # to launch now (lazy = False: the gather that follows at once resamples from them, one launch instead of two)
             self._gather_slot = self._scan_slot
+            if self._prefix_global:
+                # (beyond 2^21 particles: the tile prefix once, by one workgroup per filter, instead of in every workgroup)
+                flags = _lib.GSE_RESAMPLE_PREFIX_FROM_SLOT | (_lib.GSE_RESAMPLE_SLOT1 if self._scan_slot else 0)
+                rc = self._fn_resample_begin(self._w.data_ptr(), self._ld, self._B, self.N_particles, flags, None,
+                                             self._ws.data_ptr(), stream_ptr(self._dev_index))
+                if rc:
+                    self._check(rc)
         else:
             flags = _lib.GSE_RESAMPLE_TILES_VALID if self._tiles_valid else 0
             rc = self._fn_resample_begin(self._w.data_ptr(), self._ld, self._B, self.N_particles, flags,

@@ -117,6 +117,10 @@ int gse_pf_update(const float *x, float *w, int64_t ld, int B, int64_t N, const 
 #define GSE_RESAMPLE_TILES_VALID 1u   /* workspace tile sums were left by the preceding gse_*_update on w */
 #define GSE_RESAMPLE_SEPARATE_SCAN 2u /* scan the tile sums in a kernel of its own even when N is small enough
                                          (<= 4096 tiles) for the resample kernel to do it itself (test hook) */
+#define GSE_RESAMPLE_PREFIX_FROM_SLOT 4u /* gse_pf_resample_begin only: no cumulative weights -- just the exclusive prefix over
+                                         the tile sums a GSE_OP_SCAN_OUT update left in scan slot 0 (1 with _SLOT1), for a
+                                         GSE_OP_SCAN_IN | GSE_OP_PREFIX_GLOBAL gather */
+#define GSE_RESAMPLE_SLOT1 8u
 
 /* ParallelParticleFilter.resample (filter/particle.py:296-316 with _parallel_resample :223-263):
  * c = cumsum(w) / sum(w) in fp64; ancestor of output j = first k with c_k >= (j + r)/N;
@@ -165,6 +169,9 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
 #define GSE_OP_SCAN_OUT 16u
 #define GSE_OP_SCAN_IN_SLOT1 32u
 #define GSE_OP_SCAN_OUT_SLOT1 64u
+#define GSE_OP_PREFIX_GLOBAL 512u /* (with SCAN_IN) the tile prefix comes from gse_pf_resample_begin(..., GSE_RESAMPLE_PREFIX_FROM_SLOT
+                                  *  [| GSE_RESAMPLE_SLOT1]) instead of being rebuilt by every workgroup: any N; what the class
+                                  *  uses beyond 2^21 particles (2048 tiles) */
 #define GSE_OP_U_DEVICE 128u     /* (with PREDICT) u is a DEVICE pointer [B][2] fp64, read when the kernel runs */
 #define GSE_OP_Z_DEVICE 256u     /* (with UPDATE)  z is a DEVICE pointer [B][2] fp64                            */
                                  /* (both: with GSE_OP_GATHER only in the whole single-launch cycle              */

@@ -413,9 +413,10 @@ def _two_filters(n, seed):
     return out
 
 
-# 2^21 = one shard of BASELINE config 4 and the largest N that runs the single-launch cycle (2048 tiles); one more tile
-# and the policy switches to the two-kernel resample (cumsum + fused gather/predict/update): both sides are covered
-@pytest.mark.parametrize("n", [7, 1024, 5003, 1 << 17, 1 << 20, 1 << 21, (1 << 21) + 1024])
+# 2^21 = one shard of BASELINE config 4 and the largest N whose cycle kernel rebuilds the tile prefix in every workgroup (2048
+# tiles); one more tile and the prefix comes from a one-workgroup scan (GSE_OP_PREFIX_GLOBAL: windows of it staged in LDS):
+# both sides are covered, and 2^22 + 1024
+@pytest.mark.parametrize("n", [7, 1024, 5003, 1 << 17, 1 << 20, 1 << 21, (1 << 21) + 1024, (1 << 22) + 1024])
 def test_fused_cycle_equals_eager_calls(n):
     """resample / predict / update deferred into ONE fused pass must give bit-identical particles and weights to the
     same calls executed one kernel each (lazy=False), for any interleaving of calls and accessors."""
@@ -443,7 +444,7 @@ def test_fused_cycle_equals_eager_calls(n):
     np.testing.assert_array_equal(fused.point_estimate(), eager.point_estimate())
 
 
-@pytest.mark.parametrize("n", [5003, 1 << 20, 1 << 21, (1 << 21) + 1024])
+@pytest.mark.parametrize("n", [5003, 1 << 20, 1 << 21, (1 << 21) + 1024, (1 << 22) + 1024])
 def test_single_launch_philox_cycle_against_oracle(n):
     """The benchmarked kernel variant itself -- pf_step_kernel<gather, predict (Philox), update, scan in + out>, one
     launch per cycle -- against the oracle fed the same Philox words (oracle.predict_noise), at BASELINE config 2's size,
@@ -453,7 +454,7 @@ def test_single_launch_philox_cycle_against_oracle(n):
     the device's particles."""
     gpu_se_amd.seed(2020)
     _, _, _, pf = sim_base.get_parts(N_particles=n)
-    assert pf.lazy and pf._scan_capable == (n <= (1 << 21))
+    assert pf.lazy and pf._prefix_global == (n > (1 << 21))
     osp, omp = orc.bioreactor_noise()
     xss = orc.steady_state()
     rng = np.random.default_rng(n)
@@ -471,7 +472,7 @@ def test_single_launch_philox_cycle_against_oracle(n):
             want_idx = orc.systematic_index(w.astype(np.float64), r)
         pf.predict(u, dt)
         pf.update(u, z)
-        assert pf._scan_slot is not None if pf._scan_capable else pf._scan_slot is None
+        assert pf._scan_slot is not None
         x_new = pf.particles.get().copy()
         w_new = pf.weights.get().copy()
         good = np.ones(n, dtype=bool)
@@ -497,7 +498,7 @@ def test_single_launch_philox_cycle_against_oracle(n):
         x, w = x_new, w_new
 
 
-@pytest.mark.parametrize("n", [8, 1000, 4096, 100003, 1 << 20])
+@pytest.mark.parametrize("n", [8, 1000, 4096, 100003, 1 << 20, (1 << 22) + 1024])
 def test_inverse_map_resample_on_adversarial_weights(n):
     """The single-launch cycle's resample (inverse map from the weights, tools of DESIGN.md section 3) on weight patterns
     chosen to hurt: exact ties (one-hot, interleaved zeros: runs of equal cumulative weights), a single heavy particle at
@@ -543,7 +544,12 @@ def test_inverse_map_resample_on_adversarial_weights(n):
                 lo, hi = np.minimum(got[off], want[off]), np.maximum(got[off], want[off])
                 # (every key between the two answers carries the same cumulative weight to the last bits: a plateau of
                 #  weightless particles, or neighbours)
-                assert len(off) <= 2 and np.all(c_or[hi] - c_or[lo] <= 4.5e-16), "%s, r = %r: %s" % (name, r, off[:10])
+                tie = c_or[hi] - c_or[lo] <= 4.5e-16
+                # ... or, among millions of keys, a threshold that falls between the two sums' ROUNDING of one key: NumPy adds
+                # 4.2 M terms one after the other (error growing like sqrt(n) eps ~ 2e-13), the device per thread, wavefront,
+                # tile and prefix (~1e-15); with thresholds 2.4e-7 apart that happens to about one key in three patterns
+                near = np.abs(c_or[lo] - (off + r) / n) <= 2e-12 if n > (1 << 21) else np.zeros(len(off), dtype=bool)
+                assert len(off) <= 2 and np.all(tie | near), "%s, r = %r: %s" % (name, r, off[:10])
 
 
 def test_in_place_writes_through_the_attribute_views_are_seen():
