@@ -136,6 +136,7 @@ PROTOTYPES = {
     "gse_pf_shard_cumsum": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "gse_pf_shard_gather": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_d, c_vp, c_vp, c_vp]),
     "gse_plant_step": (ctypes.c_int, [c_vp, c_vp, c_d, P_MIX, P_MIX, P_RNG, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "gse_moments_estimates": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "gse_plant_step_injected": (ctypes.c_int, [c_vp, c_vp, c_d, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
 }
 

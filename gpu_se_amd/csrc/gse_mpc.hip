@@ -273,6 +273,70 @@ __global__ __launch_bounds__(256) void plant_step_kernel(double* __restrict__ X,
     if (log_u) { log_u[b * 2] = fg; log_u[b * 2 + 1] = fm; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The per-tick records of a closed loop, from the estimator's moments (rows of 26 doubles: S0, S1[5], S2 upper[15], pivot[5];
+// gse_pf_moments / gse_gsukf_moments26): the point estimate weights @ particles = S1 + pivot S0 (filter/particle.py:318-320)
+// and the largest singular value of the covariance S2 - S1 e^T - e S1^T + S0 e e^T, e = mean - pivot (:322-327) -- for a
+// symmetric matrix the largest |eigenvalue|, by cyclic Jacobi rotations in fp64 (5 x 5: ten rotations a sweep, eight sweeps
+// take the off-diagonal below 1e-30 of the norm).  One thread per row; a 499-tick loop of 32 rollouts is 16 000 rows, which
+// the host used to work off with NumPy for longer than the loop itself ran on the device.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void moments_estimates_kernel(const double* __restrict__ moments, int64_t R,
+                                                                double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    const double* m = moments + i * 26;
+    const double s0 = m[0];
+    double s1[5], pv[5], mean[5], e[5], A[5][5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        s1[k] = m[1 + k];
+        pv[k] = m[21 + k];
+        mean[k] = s1[k] + pv[k] * s0;
+        e[k] = mean[k] - pv[k];
+    }
+    int c = 6;
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int q = r; q < 5; ++q) {
+            const double v = m[c++] - s1[r] * e[q] - e[r] * s1[q] + s0 * e[r] * e[q];
+            A[r][q] = v;
+            A[q][r] = v;
+        }
+    for (int sweep = 0; sweep < 8; ++sweep) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 5; ++q) {
+                const double apq = A[p][q];
+                if (apq != 0.0) {
+                    const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {                       // A <- J^T A J, J the rotation in the (p, q) plane
+                        const double akp = A[k][p], akq = A[k][q];
+                        A[k][p] = cs * akp - sn * akq;
+                        A[k][q] = sn * akp + cs * akq;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const double apk = A[p][k], aqk = A[q][k];
+                        A[p][k] = cs * apk - sn * aqk;
+                        A[q][k] = sn * apk + cs * aqk;
+                    }
+                }
+            }
+    }
+    double big = 0.0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) big = fmax(big, fabs(A[k][k]));
+#pragma unroll
+    for (int k = 0; k < 5; ++k) out[i * 6 + k] = mean[k];
+    out[i * 6 + 5] = big;
+}
+
 }  // namespace gse
 
 using namespace gse;
@@ -362,6 +426,14 @@ int gse_plant_step(double* X, const double* u, double dt, const gse_mixture* sta
     hipLaunchKernelGGL(plant_step_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, u, B, a, y,
                        y_meas, z, log_x, log_u, (const float*)nullptr, (const float*)nullptr);
     GSE_LAUNCH_CHECK("plant_step_kernel");
+    return GSE_OK;
+}
+
+int gse_moments_estimates(const double* moments, int64_t R, double* out, void* stream) {
+    GSE_REQUIRE(moments && out && R >= 1, "gse_moments_estimates: bad argument");
+    hipLaunchKernelGGL(moments_estimates_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, moments, R,
+                       out);
+    GSE_LAUNCH_CHECK("moments_estimates_kernel");
     return GSE_OK;
 }
 

@@ -146,6 +146,14 @@ def performance(ys, r, ts):
     return float(sum(simps(se_ax * ts, ts) for se_ax in numpy.rollaxis(se, 1)))
 
 
+def performance_rollouts(ys, r, ts):
+    """performance() of B rollouts at once: ys, r (ticks, B, outputs) -> (B,)."""
+    se = (numpy.asarray(ys) - numpy.asarray(r)) ** 2 * numpy.asarray(ts)[:, None, None]
+    flat = se.reshape(len(ts), -1)
+    per = numpy.array([simps(flat[:, k], ts) for k in range(flat.shape[1])]).reshape(se.shape[1], se.shape[2])
+    return per.sum(axis=1)
+
+
 class InjectedNoise:
     """Every random number of a closed loop as an INPUT -- the parity mode of the loop drivers below (what
     DeterministicGaussianSum is for one filter): with it a loop is a deterministic function of its arguments and can be
@@ -462,35 +470,30 @@ class BatchedSimulation:
                                               xs[t].data_ptr(), us[t].data_ptr(), B, stream))
             if last_control != t:                         # (a control tick has recorded this state already)
                 record_moments(t)
-        # one synchronisation, one copy: histories to the host, estimates from the recorded moments
+        # the estimates of every tick and rollout from the recorded moments, still on the device (point estimate and the
+        # largest singular value of the covariance: gse_moments_estimates); then one synchronisation and the copies
+        estimates = torch.empty((ticks * B, 6), **f64)
+        _lib.check(lib.gse_moments_estimates(moments.data_ptr(), ticks * B, estimates.data_ptr(), stream))
         ev1.record()
         clock.append(time.perf_counter())
         torch.cuda.synchronize()
         clock.append(time.perf_counter())
         device_s = ev0.elapsed_time(ev1) * 1e-3
         host = flat.cpu().numpy()
+        est6 = estimates.cpu().numpy().reshape(ticks, B, 6)
         clock.append(time.perf_counter())
         back, at = {}, 0
         for name, wdt in widths.items():
             back[name] = host[at:at + ticks * B * wdt].reshape(ticks, B, wdt)
             at += ticks * B * wdt
-        m = back["moments"].reshape(ticks * B, 26)
-        iu = numpy.triu_indices(5)
-        s0, s1, pv = m[:, 0], m[:, 1:6], m[:, 21:26]
-        s2 = numpy.zeros((len(m), 5, 5))
-        s2[:, iu[0], iu[1]] = m[:, 6:21]
-        s2[:, iu[1], iu[0]] = m[:, 6:21]
-        mean = s1 + pv * s0[:, None]
-        e = mean - pv
-        cov = (s2 - s1[:, :, None] * e[:, None, :] - e[:, :, None] * s1[:, None, :] + s0[:, None, None] * e[:, :, None] * e[:, None, :])
+        self.moments = back["moments"]                # (kept: rows of 26 doubles per tick and rollout)
         self.us, self.xs, self.ys, self.ys_meas = back["us"], back["xs"], back["ys"], back["ys_meas"]
         self.X = self.xs[-1].copy()
-        est = mean.reshape(ticks, B, 5)
+        est = est6[..., :5]
         self.xs_f = est[control_ticks]                # appended at control ticks only (sim_base.py:260)
         self.ys_f = numpy.stack([est[..., 0] * 180, est[..., 2] * 116], axis=-1)
-        # largest singular value of a symmetric matrix = largest |eigenvalue| (half the cost of the SVD of point_covariance)
-        self.covariance_point_size = numpy.abs(numpy.linalg.eigvalsh(cov)).max(axis=1).reshape(ticks, B)
-        self.performance = numpy.array([performance(self.ys[:, b][:, _OUTPUTS], self.ys_f[:, b], self.ts) for b in range(B)])
+        self.covariance_point_size = est6[..., 5].copy()
+        self.performance = performance_rollouts(self.ys[:, :, _OUTPUTS], self.ys_f, self.ts)
         self.mpc_frac = 1.0 - float(status.sum().item()) / max(n_control * B, 1)
         clock.append(time.perf_counter())
         self.timing = dict(zip(("enqueue", "device_drain", "copy_back", "host_post"), numpy.diff(clock)))

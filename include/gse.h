@@ -450,6 +450,10 @@ int gse_plant_step(double *X /* [B][5], in/out */, const double *u /* [B][2] */,
                    const gse_mixture *meas_noise, const gse_rng *rng, double *y /* [B][5] */, double *y_meas /* [B][5] */,
                    double *z /* [B][2] */, double *log_x /* [B][5] or NULL */, double *log_u /* [B][2] or NULL */,
                    int64_t B, void *stream);
+/* Rows of estimator moments (26 doubles each: gse_pf_moments / gse_gsukf_moments26) -> per row [mean (5), largest singular
+ * value of the covariance]: point_estimate() and point_covariance() (filter/particle.py:318-327) for every tick and rollout of a
+ * closed loop at once, on the device (sim_base.py:287-296 keeps both per tick). */
+int gse_moments_estimates(const double *moments /* [R][26] */, int64_t R, double *out /* [R][6] */, void *stream);
 /* Parity mode of gse_plant_step: the two draws of sim_base.py:282 / :285 are INPUTS (fp32, as state_pdf.draw() returns
  * them) -- what lets a closed loop on the device be compared tick by tick with oracle/closed_loop.py. */
 int gse_plant_step_injected(double *X /* [B][5], in/out */, const double *u /* [B][2] */, double dt,
