@@ -119,7 +119,12 @@ static int compile_instance(UserModel* m, const char* name_expression, std::vect
 
 hipFunction_t user_kernel(UserModel* m, const char* name_expression) {
     std::lock_guard<std::mutex> lock(g_mutex);
-    auto it = m->functions.find(name_expression);
+    // a module is loaded into the CURRENT device: the handles are kept per (device, instance) -- a process that drives a
+    // model on a second GPU gets a module of its own there instead of a function of the first device's
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const std::string key = std::to_string(dev) + ":" + name_expression;
+    auto it = m->functions.find(key);
     if (it != m->functions.end()) return it->second;
     std::vector<char> code;
     std::string lowered_name;
@@ -134,7 +139,7 @@ hipFunction_t user_kernel(UserModel* m, const char* name_expression) {
         return nullptr;
     }
     m->modules.push_back(mod);
-    m->functions[name_expression] = fn;
+    m->functions[key] = fn;
     return fn;
 }
 

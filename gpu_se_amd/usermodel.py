@@ -294,6 +294,16 @@ class RuntimeModel:
     def check(self, rc):
         _lib.check(rc)
 
+    def __del__(self):
+        # the loaded code objects belong to the handle: unload them with it (compile_model caches models for the life of the
+        # process, so this runs for models created directly and at interpreter exit)
+        handle, self._handle = getattr(self, "_handle", None), None
+        if handle is not None and getattr(self, "_base", None) is not None:
+            try:
+                self._base.gse_model_destroy(handle)
+            except Exception:
+                pass
+
     def prepare(self, name_expression):
         """Compile a kernel instance now, e.g. "gse::pf_step_kernel<true, true, false, true, 2, 3>" (needs the device)."""
         _lib.check(self._base.gse_model_prepare(self._handle, name_expression.encode()))

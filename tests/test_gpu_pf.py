@@ -736,3 +736,48 @@ def test_random_call_sequences_lazy_equals_eager():
                 pf.weights = w / w.sum()
     np.testing.assert_array_equal(fused.particles.get(), eager.particles.get())
     np.testing.assert_array_equal(fused.weights.get(), eager.weights.get())
+
+
+def test_cycles_are_hipgraph_capturable_and_replay_bit_identically():
+    """include/gse.h: every call is enqueued on the caller's stream without synchronising -- so a stream capture records
+    it.  Two cycles of the class (the period of its buffer and scan-slot alternation) captured into a HIP graph and
+    replayed twice, against the same four cycles launched eagerly: bit-identical particles and weights.  (What a replay
+    re-uses is what a launch carries by value: u, z, r and the Philox step -- the eager twin is handed the same ones.)"""
+    n = 1 << 16
+    pfs = []
+    for _ in range(2):
+        gpu_se_amd.seed(404)
+        _, _, _, pf = sim_base.get_parts(N_particles=n)
+        pfs.append(pf)
+    graphed, eager = pfs
+    xss = orc.steady_state()
+    io = [([0.05 + 0.01 * c, 0.2], np.array(orc.bioreactor_g(xss)) + [0.1 * c, -0.1], 0.3 + 0.2 * c) for c in range(2)]
+
+    def two_cycles(pf):
+        for u, z, r in io:
+            pf.predict(u, 0.1)
+            pf.update(u, z)
+            pf.resample(r=r)
+
+    for pf in pfs:                                   # one cycle up front: the steady-state launch is the one captured
+        pf.predict(io[0][0], 0.1)
+        pf.update(io[0][0], io[0][1])
+        pf.resample(r=0.5)
+    torch.cuda.synchronize()
+    step0 = graphed._step
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            two_cycles(graphed)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for rep in range(2):
+        g.replay()
+        eager._step = step0                          # (the replay carries the Philox steps of the capture)
+        two_cycles(eager)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(host(graphed._x), host(eager._x))
+        np.testing.assert_array_equal(host(graphed._w), host(eager._w))
+    np.testing.assert_array_equal(graphed.point_estimate(), eager.point_estimate())
