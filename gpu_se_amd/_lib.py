@@ -53,6 +53,14 @@ class Rng(ctypes.Structure):
                 ("filter_offset", c_u32), ("reserved", c_u32)]
 
 
+class LoopSpec(ctypes.Structure):
+    """struct gse_loop_spec (include/gse.h)."""
+    _fields_ = [("B", c_i32), ("N", c_i32), ("ticks", c_i32), ("reserved", c_i32), ("dt", c_d)] + \
+               [(name, c_vp) for name in ("w_sigma", "state_pdf", "rng", "measurement_pdf", "plant_state_noise",
+                                          "plant_meas_noise", "plant_rng", "law", "glue", "schedule", "r", "mu", "P", "w", "X", "u",
+                                          "z", "y_pred", "known", "us", "xs", "ys", "ys_meas", "moments", "status", "chol_status")]
+
+
 P_MIX = ctypes.POINTER(Mixture)
 P_RNG = ctypes.POINTER(Rng)
 P_D = ctypes.POINTER(c_d)
@@ -136,6 +144,7 @@ PROTOTYPES = {
     "gse_pf_shard_cumsum": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "gse_pf_shard_gather": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_d, c_vp, c_vp, c_vp]),
     "gse_plant_step": (ctypes.c_int, [c_vp, c_vp, c_d, P_MIX, P_MIX, P_RNG, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "gse_gsukf_closed_loop": (ctypes.c_int, [ctypes.POINTER(LoopSpec), c_vp]),
     "gse_moments_estimates": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "gse_plant_step_injected": (ctypes.c_int, [c_vp, c_vp, c_d, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
 }

@@ -332,12 +332,8 @@ class MPC:
         return (torch.zeros((B, self.No), dtype=torch.float64, device=device),
                 torch.zeros((B,), dtype=torch.int32, device=device), torch.zeros((B,), dtype=torch.int32, device=device))
 
-    def loop_control(self, moments, y_meas, u, state, u_fallback, full_dims=(5, 2, 5), theta_out=None):
-        """The controller call of the closed loop on the device (``gse_loop_control``): estimator moments [B, 26],
-        measured outputs [B, n_out] and the current inputs ``u`` [B, n_in] (updated in place) are device tensors;
-        ``state`` comes from ``loop_state``.  Nothing is synchronised."""
-        import torch
-        lib, law, _ = self._device_law()
+    def loop_glue(self, u_fallback, full_dims=(5, 2, 5)):
+        """struct gse_loop_glue for this controller's linear model (cached)."""
         lm = self.model
         key = (tuple(full_dims), tuple(float(v) for v in u_fallback))
         if getattr(self, "_glue_key", None) != key:             # the glue only depends on the model: build it once
@@ -350,7 +346,15 @@ class MPC:
                 for k, v in enumerate(vec):
                     getattr(glue, name)[k] = float(v)
             self._glue_key, self._glue = key, glue
-        glue = self._glue
+        return self._glue
+
+    def loop_control(self, moments, y_meas, u, state, u_fallback, full_dims=(5, 2, 5), theta_out=None):
+        """The controller call of the closed loop on the device (``gse_loop_control``): estimator moments [B, 26],
+        measured outputs [B, n_out] and the current inputs ``u`` [B, n_in] (updated in place) are device tensors;
+        ``state`` comes from ``loop_state``.  Nothing is synchronised."""
+        import torch
+        lib, law, _ = self._device_law()
+        glue = self.loop_glue(u_fallback, full_dims)
         y_pred, known, status = state
         _lib.check(lib.gse_loop_control(ctypes.byref(law), ctypes.byref(glue), moments.data_ptr(), y_meas.data_ptr(),
                                         u.data_ptr(), y_pred.data_ptr(), known.data_ptr(), status.data_ptr(),

@@ -12,31 +12,6 @@
 
 namespace gse {
 
-// numpy.average divides by sum(w): pairwise_sum's order for n values (n < 8: left to right; 8 <= n < 128: eight interleaved
-// accumulators folded as ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), then the n % 8 remaining values in order).
-template <class T>
-static T numpy_sum(const float* a, int n) {
-    if (n < 8) {
-        T res = (T)0;
-        for (int i = 0; i < n; ++i) res += (T)a[i];
-        return res;
-    }
-    T r[8];
-    for (int k = 0; k < 8; ++k) r[k] = (T)a[k];
-    int i = 8;
-    for (; i < n - (n % 8); i += 8)
-        for (int k = 0; k < 8; ++k) r[k] += (T)a[i + k];
-    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; ++i) res += (T)a[i];
-    return res;
-}
-
-static void pack_sigma_weights(SigmaWeights& sw, const float* w_sigma, int ns) {
-    for (int i = 0; i < GSE_NSIGMA; ++i) sw.w[i] = i < ns ? w_sigma[i] : 0.0f;
-    sw.scl32 = numpy_sum<float>(w_sigma, ns);
-    sw.scl64 = numpy_sum<double>(w_sigma, ns);
-}
-
 // Which family of kernels: one lane per Gaussian for everything beyond the 64 Gaussians of the one-launch cycle.  (Round 2
 // first drew the line where a bank fills the chip that way -- 2^16 -- but below that a cycle is bound by its launches, and
 // this family needs two of them up to 4096 Gaussians -- predict + update (+ the row copy of the resample before), and the

@@ -115,6 +115,34 @@ struct SigmaWeights {
     double scl64;         // sum(w) accumulated in fp64 -- its divisor for fp64 data
 };
 
+#ifndef __HIPCC_RTC__            // ---- host only
+// numpy.average divides by sum(w): pairwise_sum's order for n values (n < 8: left to right; 8 <= n < 128: eight interleaved
+// accumulators folded as ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), then the n % 8 remaining values in order).
+template <class T>
+inline T numpy_sum(const float* a, int n) {
+    if (n < 8) {
+        T res = (T)0;
+        for (int i = 0; i < n; ++i) res += (T)a[i];
+        return res;
+    }
+    T r[8];
+    for (int k = 0; k < 8; ++k) r[k] = (T)a[k];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int k = 0; k < 8; ++k) r[k] += (T)a[i + k];
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += (T)a[i];
+    return res;
+}
+
+inline void pack_sigma_weights(SigmaWeights& sw, const float* w_sigma, int ns) {
+    for (int i = 0; i < GSE_NSIGMA; ++i) sw.w[i] = i < ns ? w_sigma[i] : 0.0f;
+    sw.scl32 = numpy_sum<float>(w_sigma, ns);
+    sw.scl64 = numpy_sum<double>(w_sigma, ns);
+}
+
+#endif
+
 // ------------------------------------------------------------------------------------------------
 template <int kUnused>
 __global__ __launch_bounds__(kBlock) void gsukf_sigma_kernel(const float* __restrict__ mu, const float* __restrict__ P,
@@ -221,7 +249,10 @@ __device__ __forceinline__ void read_factor(const float* fac_g, float (&m)[kNx],
 template <bool kInjected, class Src, class Dst>
 __device__ __forceinline__ void gsukf_predict_block(Src src, Dst dst, float (*fac)[kFacStride], float (*tile)[kTileStride],
                                                     int nloc, int b, int64_t g0, const float* noise, const DrawParams& dp,
-                                                    int32_t* status, const GsukfPredictArgs& a, const FilterIO& bio) {
+                                                    int32_t* status, const GsukfPredictArgs& a, const FilterIO& bio,
+                                                    const RngKey& rng) {
+    // rng: a.rng for a launch that predicts once; a kernel that predicts tick after tick (gse_loop.hip) hands in the key of
+    // the tick
     gsukf_factor_block(src, fac, nloc, status);
     // B. one sigma point per lane, packed densely (11 per Gaussian: 704 points keep 11 of the 16 wavefronts busy, the
     //    other five skip the model step and the noise draw altogether)
@@ -238,7 +269,7 @@ __device__ __forceinline__ void gsukf_predict_block(Src src, Dst dst, float (*fa
             for (int k = 0; k < kNx; ++k) e[k] = nz[j * kNx + k];
         } else {
             uint32_t wd[8];
-            rng_words8(a.rng, (uint64_t)((g0 + gl) * kNs + j), (uint32_t)b, wd);
+            rng_words8(rng, (uint64_t)((g0 + gl) * kNs + j), (uint32_t)b, wd);
             mixture_draw5(dp, wd, e);
         }
 #pragma unroll
@@ -282,7 +313,7 @@ __global__ __launch_bounds__(kBankT * kGroup) void gsukf_predict_kernel(float* _
     auto src = [&](int t, const float*& m_, const float*& p_) { m_ = mu_b + t * kNx; p_ = P_b + t * kNxx; };
     auto dst = [&](int t, float*& m_, float*& p_) { m_ = mu_b + t * kNx; p_ = P_b + t * kNxx; };
     gsukf_predict_block<kInjected>(src, dst, fac, tile, nloc, b, g0, kInjected ? noise + (int64_t)b * N * kNs * kNx : nullptr,
-                                   dp, status, a, bank_inputs(a.io, a.u_dev, a.z_dev, b));
+                                   dp, status, a, bank_inputs(a.io, a.u_dev, a.z_dev, b), a.rng);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -712,6 +743,46 @@ __global__ __launch_bounds__(kLaneBank) void gsukf_gather_rows_kernel(const floa
 constexpr int kSmallBank = 64;
 constexpr int kSmallBlock = kSmallBank * kGroup;      // 1024
 
+// Ancestors of a bank of at most 64 Gaussians held by ONE workgroup (weights w_s in LDS): the arithmetic of cumsum_kernel +
+// the gather's comparison for a single tile -- all per-thread sums sit in wavefront 0 -- so the result is bit-identical to the
+// separate launches.  Leaves anc_s[0 .. N) and *total_s; ends with a workgroup barrier.  Every thread must call it.
+__device__ __forceinline__ void small_bank_ancestors(const float* w_s, double* c_s, int* anc_s, double* total_s, int N, double r,
+                                                     int tid) {
+    if (tid < 64) {
+        const int i0 = tid * 4;
+        double sc[4];
+        sc[0] = (i0 + 0 < N) ? (double)w_s[min(i0 + 0, kSmallBank - 1)] : 0.0;
+        sc[1] = sc[0] + ((i0 + 1 < N) ? (double)w_s[min(i0 + 1, kSmallBank - 1)] : 0.0);
+        sc[2] = sc[1] + ((i0 + 2 < N) ? (double)w_s[min(i0 + 2, kSmallBank - 1)] : 0.0);
+        sc[3] = sc[2] + ((i0 + 3 < N) ? (double)w_s[min(i0 + 3, kSmallBank - 1)] : 0.0);
+        const double inc = wave_inclusive_scan(sc[3], tid);
+        const double W = __shfl(inc, 63, 64);                       // workgroup total: wavefronts 1.. hold zeros
+        double excl = wave_shift_up1(inc);
+        if (tid == 0) excl = 0.0;
+        const double top = W / W;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (i0 + p < N) c_s[i0 + p] = (i0 + p == N - 1) ? top : fmin((0.0 + (excl + sc[p])) / W, top);
+        if (tid == 0) *total_s = W;
+    }
+    __syncthreads();
+    if (tid < N) {                                                   // ancestor of output tid
+        const double W = *total_s;
+        int k = 0;
+        if ((W > 0.0) && (W < INFINITY)) {
+            const double u = ((double)tid + r) / (double)N;
+            int lo = 0, hi = N - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (c_s[mid] < u) lo = mid + 1; else hi = mid;
+            }
+            k = lo;
+        }
+        anc_s[tid] = k;
+    }
+    __syncthreads();
+}
+
 struct GsukfCycleArgs {
     GsukfPredictArgs pred;
     Pdf2 pdf;
@@ -752,7 +823,7 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_cycle_kernel(float* __restr
     // 1. predict: global -> LDS
     const FilterIO bio = bank_inputs(a.pred.io, a.pred.u_dev, a.pred.z_dev, b);
     gsukf_predict_block<kInjected>(from_global, to_lds, fac, tile, N, b, 0,
-                                   kInjected ? noise + (int64_t)b * N * kNs * kNx : nullptr, dp, status, a.pred, bio);
+                                   kInjected ? noise + (int64_t)b * N * kNs * kNx : nullptr, dp, status, a.pred, bio, a.pred.rng);
     __syncthreads();
     // 2. update in LDS; the weight goes global -> LDS
     gsukf_update_block(from_lds, to_lds, [&](int t) { return (const float*)(w_b + t); }, [&](int t) { return &w_s[t]; }, fac,
@@ -760,38 +831,9 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_cycle_kernel(float* __restr
     __syncthreads();
     // 3. resample, one tile: thread t < 16 of wavefront 0 owns weights 4t..4t+3, exactly as cumsum_kernel does
     __shared__ double total_s;
-    if (tid < 64) {
-        const int i0 = tid * 4;
-        double sc[4];
-        sc[0] = (i0 + 0 < N) ? (double)w_s[min(i0 + 0, kSmallBank - 1)] : 0.0;
-        sc[1] = sc[0] + ((i0 + 1 < N) ? (double)w_s[min(i0 + 1, kSmallBank - 1)] : 0.0);
-        sc[2] = sc[1] + ((i0 + 2 < N) ? (double)w_s[min(i0 + 2, kSmallBank - 1)] : 0.0);
-        sc[3] = sc[2] + ((i0 + 3 < N) ? (double)w_s[min(i0 + 3, kSmallBank - 1)] : 0.0);
-        const double inc = wave_inclusive_scan(sc[3], tid);
-        const double W = __shfl(inc, 63, 64);                       // workgroup total: wavefronts 1.. hold zeros
-        double excl = wave_shift_up1(inc);
-        if (tid == 0) excl = 0.0;
-        const double top = W / W;
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            if (i0 + p < N) c_s[i0 + p] = (i0 + p == N - 1) ? top : fmin((0.0 + (excl + sc[p])) / W, top);
-        if (tid == 0) total_s = W;
-    }
-    __syncthreads();
-    if (tid < N) {                                                   // ancestor of output tid
-        const double W = total_s;
-        int k = 0;
-        if ((W > 0.0) && (W < INFINITY)) {
-            const double u = ((double)tid + a.r[b]) / (double)N;
-            int lo = 0, hi = N - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (c_s[mid] < u) lo = mid + 1; else hi = mid;
-            }
-            k = lo;
-        }
-        anc_s[tid] = k;
-        if (idx_out) idx_out[(int64_t)b * N + tid] = k;
+    small_bank_ancestors(w_s, c_s, anc_s, &total_s, N, a.r[b], tid);
+    if (tid < N) {
+        if (idx_out) idx_out[(int64_t)b * N + tid] = anc_s[tid];
         w[(int64_t)b * N + tid] = (float)(1.0 / (double)N);
     }
     __syncthreads();

@@ -1,0 +1,232 @@
+// gse_loop_device.h -- device functions of the closed loop shared by its kernels (gse_mpc.hip: one launch per piece;
+// gse_loop.hip: the whole loop of a small Gaussian-sum filter in ONE persistent launch): the explicit MPC law, the
+// controller call, the plant.
+#pragma once
+
+#include "gse_host.h"
+
+namespace gse {
+
+struct MpcLawDev {
+    int32_t n_theta, n_u, n_y, n_rows, max_sweeps;
+    double eps_abs, eps_rel;
+    const double* __restrict__ Gc;
+    const double* __restrict__ gc0;
+    const double* __restrict__ S;
+    const double* __restrict__ lo;
+    const double* __restrict__ hi;
+    const double* __restrict__ Gu;
+    const double* __restrict__ gu0;
+    const double* __restrict__ Tu;
+    const double* __restrict__ Gy;
+    const double* __restrict__ gy0;
+    const double* __restrict__ Ty;
+};
+
+constexpr int kMpcWavesPerBlock = 4;
+
+// The law for one rollout, by one wavefront.  theta_lane: lane k < n_theta holds theta[k].  On return lane k < n_u holds
+// du0[k] in out, lane 32 + k (k < n_y) holds y1[k]; the return value (uniform) is 1 if the sweeps converged.
+__device__ __forceinline__ int mpc_solve(const MpcLawDev& law, double theta_lane, int lane, double& out) {
+    const int m = law.n_rows, nt = law.n_theta;
+    // this lane's row at the unconstrained optimum
+    const bool row = lane < m;
+    double c = 0.0, lo = -INFINITY, hi = INFINITY, sii = 1.0;
+    if (row) {
+        c = law.gc0[lane];
+        lo = law.lo[lane];
+        hi = law.hi[lane];
+        sii = law.S[lane * m + lane];
+    }
+    {   // (all coefficient loads first, in flight together: this kernel is nothing but dependent latencies)
+        double gk[GSE_MPC_MAX_THETA];
+#pragma unroll
+        for (int k = 0; k < GSE_MPC_MAX_THETA; ++k) gk[k] = (row && k < nt) ? law.Gc[lane * nt + k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < GSE_MPC_MAX_THETA; ++k) {
+            const double tk = __shfl(theta_lane, k, 64);
+            if (k < nt) c += gk[k] * tk;
+        }
+    }
+    const double c0 = c;
+    double nu = 0.0;
+    int converged = (m == 0) ? 1 : 0;
+    // a few bounded rows (the usual case: two): this lane's row of S stays in registers, no load inside the sweeps
+    constexpr int kFewRows = 8;
+    const bool few = m <= kFewRows;
+    double srow[kFewRows];
+#pragma unroll
+    for (int i = 0; i < kFewRows; ++i) srow[i] = (few && row && i < m) ? law.S[lane * m + i] : 0.0;
+    auto coordinate = [&](int i, double s_li) {
+        // lane i decides its multiplier; everybody applies the change
+        double delta = 0.0;
+        if (lane == i && sii > 0.0) {
+            const double r = c + sii * nu;
+            const double want = (r > hi) ? (r - hi) / sii : ((r < lo) ? (r - lo) / sii : 0.0);
+            delta = want - nu;
+            nu = want;
+        }
+        delta = __shfl(delta, i, 64);
+        if (row && delta != 0.0) c -= s_li * delta;                           // S symmetric: column i = row i
+    };
+    for (int sweep = 0; sweep < law.max_sweeps && !converged; ++sweep) {
+        if (few) {
+#pragma unroll
+            for (int i = 0; i < kFewRows; ++i)
+                if (i < m) coordinate(i, srow[i]);
+        } else {
+            for (int i = 0; i < m; ++i) coordinate(i, row ? law.S[lane * m + i] : 0.0);
+        }
+        // residual of this lane's row: distance to the bound it is supposed to sit on, or its violation
+        double res = 0.0, scale = fabs(c0);
+        if (row) {
+            if (nu > 0.0) { res = fabs(c - hi); scale += fabs(hi); }
+            else if (nu < 0.0) { res = fabs(c - lo); scale += fabs(lo); }
+            else {
+                res = fmax(fmax(c - hi, lo - c), 0.0);
+                if (c > hi) scale += fabs(hi);
+                if (c < lo) scale += fabs(lo);
+            }
+        }
+        const bool ok = !row || (res <= law.eps_abs + law.eps_rel * scale);
+        converged = __all(ok) ? 1 : 0;
+    }
+    // outputs: lane k < n_u forms du0[k], lane 32 + k forms y1[k]; theta and the multipliers come round by shuffles
+    const bool for_u = lane < law.n_u, for_y = lane >= 32 && lane - 32 < law.n_y;
+    const bool mine = for_u || for_y;
+    const int k = for_u ? lane : lane - 32;
+    const double* G = for_u ? law.Gu : law.Gy;
+    double acc = 0.0;
+    if (mine) acc = for_u ? law.gu0[k] : law.gy0[k];
+    {
+        double gq[GSE_MPC_MAX_THETA];
+#pragma unroll
+        for (int q = 0; q < GSE_MPC_MAX_THETA; ++q) gq[q] = (mine && q < nt) ? G[k * nt + q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < GSE_MPC_MAX_THETA; ++q) {
+            const double tq = __shfl(theta_lane, q, 64);
+            if (q < nt) acc += gq[q] * tq;
+        }
+    }
+    for (int i = 0; i < m; ++i) {
+        const double nui = __shfl(nu, i, 64);
+        if (mine && nui != 0.0) acc -= (for_u ? law.Tu : law.Ty)[k * m + i] * nui;
+    }
+    out = acc;
+    return converged;
+}
+
+struct LoopGlue {
+    int32_t n_state_full, n_input_full, n_output_full, pad;
+    int32_t states[GSE_MPC_MAX_OUT], inputs[GSE_MPC_MAX_OUT], outputs[GSE_MPC_MAX_OUT];
+    double x_bar[GSE_MPC_MAX_OUT], u_bar[GSE_MPC_MAX_OUT], y_bar[GSE_MPC_MAX_OUT], u_fallback[GSE_MPC_MAX_OUT];
+};
+
+// The controller call of the closed loop for rollout b, by ONE wavefront (lane = its lane): the filter's moments -> point
+// estimate -> deviation variables -> MPC -> next input, bias bookkeeping included (sim_base.py:253-274).
+__device__ __forceinline__ void loop_control_wave(const MpcLawDev& law, const LoopGlue& g, const double* __restrict__ moments,
+                                                  const double* __restrict__ y_meas, double* __restrict__ u,
+                                                  double* __restrict__ y_pred, int32_t* __restrict__ known,
+                                                  int32_t* __restrict__ status, double* __restrict__ theta_out, int64_t b,
+                                                  int lane) {
+    const int nx = law.n_theta - law.n_u - law.n_y, ni = law.n_u, no = law.n_y;
+    // theta = (x0, u_-1, bias) in deviation variables, clipped as controller.py:238-241
+    double th = 0.0, bias = 0.0, um1 = 0.0;
+    if (lane < nx) {
+        // point estimate = weights @ particles, NOT normalised (particle.py:318-320): S1 + pivot * S0
+        const double* m = moments + b * 26;
+        const int sidx = g.states[lane];
+        th = (m[1 + sidx] + m[21 + sidx] * m[0]) - g.x_bar[lane];
+    } else if (lane < nx + ni) {
+        const int i = lane - nx;
+        um1 = u[b * g.n_input_full + g.inputs[i]] - g.u_bar[i];
+        th = um1;
+    } else if (lane < nx + ni + no) {
+        const int o = lane - nx - ni;
+        const double ydev = y_meas[b * g.n_output_full + g.outputs[o]] - g.y_bar[o];
+        const double yd = fmax(fmin(ydev, 1e10), -1e10);
+        bias = known[b] ? yd - y_pred[b * no + o] : 0.0;          // no bias before the first solved step (:248-251)
+        th = bias;
+    }
+    if (lane < nx + ni) th = fmax(fmin(th, 1e10), -1e10);
+    if (theta_out && lane < law.n_theta) theta_out[b * law.n_theta + lane] = th;
+    double out;
+    const int converged = mpc_solve(law, th, lane, out);
+    // next input: the first move on top of u_-1 (controller.py:272-275); when the QP is not solved the reference puts
+    // [0.06, 0.2] where the DEVIATION input goes (sim_base.py:271-274), the operating point is added either way
+    const double um1_i = __shfl(um1, nx + (lane < ni ? lane : 0), 64);
+    if (lane < ni) u[b * g.n_input_full + g.inputs[lane]] = (converged ? out + um1_i : g.u_fallback[lane]) + g.u_bar[lane];
+    const double bias_o = __shfl(bias, nx + ni + (lane >= 32 && lane - 32 < no ? lane - 32 : 0), 64);
+    if (converged && lane >= 32 && lane - 32 < no) y_pred[b * no + lane - 32] = out - bias_o;
+    if (lane == 0) {
+        if (converged) known[b] = 1;
+        status[b] = converged ? 0 : 1;
+    }
+}
+
+struct PlantArgs {
+    DrawParams state_noise, meas_noise;
+    RngKey rng_state, rng_meas;
+    double dt;
+};
+
+// The plant of the closed loop for rollout b, by ONE thread (sim_base.py:278-287, BioreactorModel.py:95-122): Euler step of the
+// fp64 model, clamp, state noise, outputs, measurement noise.  dp: the two draws' parameters in LDS (state, measurement).
+__device__ __forceinline__ void plant_step_one(double* __restrict__ X, const double* __restrict__ u, int64_t b,
+                                               const DrawParams* dp, const RngKey& rng_state, const RngKey& rng_meas, double dt,
+                                               double* __restrict__ y, double* __restrict__ y_meas, double* __restrict__ z,
+                                               double* __restrict__ log_x, double* __restrict__ log_u,
+                                               const float* __restrict__ inj_state, const float* __restrict__ inj_meas) {
+    double x[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) x[k] = X[b * 5 + k];
+    const double fg = u[b * 2], fm = u[b * 2 + 1];
+    double dx[5];
+    bioreactor_increment(x, fg, fm, 1.0, dx);              // DEs(): the derivative (homeostatic_DEs with dt = 1)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) x[k] = x[k] + dx[k] * dt;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = fmax(x[k], 0.0);    // BioreactorModel.py:108
+    uint32_t wd[8];
+    float e[5];
+    if (inj_state) {                                       // parity mode: the draw is an input (gse_plant_step_injected)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) e[k] = inj_state[b * 5 + k];
+    } else {
+        rng_words8(rng_state, (uint64_t)b, 0u, wd);
+        mixture_draw5(dp[0], wd, e);                       // state_pdf.draw(): fp32 values added to the fp64 state
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) x[k] += (double)e[k];
+    const double mm[5] = {180.0, 24.6, 116.0, 46.0, 1.0};   // BioreactorModel.py:118-120
+    double out[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) out[k] = x[k] * mm[k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        X[b * 5 + k] = x[k];
+        if (log_x) log_x[b * 5 + k] = x[k];
+        y[b * 5 + k] = out[k];
+    }
+    if (inj_meas) {
+        e[0] = inj_meas[b * 2];
+        e[1] = inj_meas[b * 2 + 1];
+    } else {
+        rng_words8(rng_meas, (uint64_t)b, 0u, wd);
+        mixture_draw5(dp[1], wd, e);                       // measurement noise on the controlled outputs (Cg, Cfa)
+    }
+    out[0] += (double)e[0];
+    out[2] += (double)e[1];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) y_meas[b * 5 + k] = out[k];
+    z[b * 2] = out[0];
+    z[b * 2 + 1] = out[2];
+    if (log_u) { log_u[b * 2] = fg; log_u[b * 2 + 1] = fm; }
+}
+
+#ifndef __HIPCC_RTC__
+int pack_mpc_law(const char* fn, const gse_mpc_law* law, MpcLawDev& d);                          // (gse_mpc.hip)
+int pack_loop_glue(const char* fn, const gse_loop_glue* glue, const MpcLawDev& d, LoopGlue& g);
+#endif
+
+}  // namespace gse

@@ -286,8 +286,9 @@ class BatchedSimulation:
     launch and one synchronisation (the estimates of all rollouts)."""
 
     def __init__(self, batch, N_particles, dt_control, dt_predict, end_time=50, pf=True, controller=None, seed=0,
-                 resident=False, noise=None):
+                 resident=False, noise=None, persistent=True):
         self.B = int(batch)
+        self.persistent = bool(persistent)      # resident loops of small Gaussian-sum filters: the whole loop in one launch
         self.noise = noise                      # InjectedNoise: every random number is an input (parity mode)
         self.resident = bool(resident)          # True: plant, controller and histories live on the device too
         if self.resident and controller is not None:
@@ -429,6 +430,14 @@ class BatchedSimulation:
 
         import time
         record_moments(0)
+        if self._persistent_capable():
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            clock = [time.perf_counter()]
+            ev0.record()
+            control_ticks, n_control = self._launch_persistent(lib, f, K, X, u, z, y_pred, known, status, us, xs, ys, ys_meas,
+                                                               moments, state_pod, meas_pod, rng, stream)
+            return self._finish_resident(lib, torch, time, flat, widths, moments, status, control_ticks, n_control, ev0, ev1,
+                                         clock, f64, stream)
         noise, n_predict, n_update = self.noise, 0, 0
         if noise is not None:                             # the plant's draws: uploaded once, sliced per tick
             inj_state = torch.as_tensor(numpy.ascontiguousarray(noise.plant_state.reshape(ticks - 1, B, 5)), device=dev)
@@ -470,6 +479,69 @@ class BatchedSimulation:
                                               xs[t].data_ptr(), us[t].data_ptr(), B, stream))
             if last_control != t:                         # (a control tick has recorded this state already)
                 record_moments(t)
+        return self._finish_resident(lib, torch, time, flat, widths, moments, status, control_ticks, n_control, ev0, ev1, clock,
+                                     f64, stream)
+
+    def _persistent_capable(self):
+        """The whole loop in ONE launch (gse_gsukf_closed_loop): rollouts whose estimator is a Gaussian-sum filter of at most 64
+        Gaussians on the built-in model, Philox noise.  ``persistent = False`` keeps the launch-per-piece loop."""
+        from gpu_se_amd import _lib
+        return (self.persistent and not self.pf and self.noise is None and self.f._model is None and
+                self.f.N_particles <= _lib.GSE_GSUKF_CYCLE_MAX and self.controller is None)
+
+    def _launch_persistent(self, lib, f, K, X, u, z, y_pred, known, status, us, xs, ys, ys_meas, moments, state_pod, meas_pod, rng,
+                           stream):
+        import ctypes
+        import torch
+        from gpu_se_amd import _lib
+        ticks, B = len(self.ts), self.B
+        # the schedule of sim_base.py:250, :255 and the uniform numbers of the resamples (the class's own host stream, in the
+        # order resample() would draw them)
+        sched = numpy.zeros(ticks, dtype=numpy.uint8)
+        t_next_control, t_next_predict = 0, 0
+        control_ticks = [0]
+        for t in range(1, ticks):
+            if self.ts[t] > t_next_predict:
+                sched[t] |= 1
+                t_next_predict += self.dt_predict
+            if self.ts[t] > t_next_control:
+                sched[t] |= 2
+                control_ticks.append(t)
+                t_next_control += self.dt_control
+        n_control = len(control_ticks) - 1
+        f._flush()
+        r_host = numpy.array([f._host_rng.random(B) for _ in range(n_control)], dtype=numpy.float64).reshape(max(n_control, 1), B) \
+            if n_control else numpy.zeros((1, B))
+        dev = X.device
+        sched_d = torch.as_tensor(sched, device=dev)
+        r_d = torch.as_tensor(numpy.ascontiguousarray(r_host), device=dev)
+        _, law, _keep = K._device_law()
+        glue = K.loop_glue(_U_FALLBACK)
+        frng = _lib.Rng(seed=f._seed, step=f._step, filter_offset=f._filter_offset)
+        spec = _lib.LoopSpec()
+        spec.B, spec.N, spec.ticks, spec.dt = B, f.N_particles, ticks, float(self.dt)
+        addr = lambda obj: ctypes.cast(ctypes.pointer(obj), ctypes.c_void_p).value
+        keep_alive = (frng, law, glue, sched_d, r_d)
+        spec.w_sigma = ctypes.cast(f._w_sigma_c, ctypes.c_void_p).value
+        spec.state_pdf, spec.measurement_pdf = addr(f.state_pdf._pod()), addr(f.measurement_pdf._pod())
+        spec.rng, spec.plant_rng = addr(frng), addr(rng)
+        spec.plant_state_noise, spec.plant_meas_noise = spec.state_pdf, spec.measurement_pdf     # (the same two mixtures)
+        spec.law, spec.glue = addr(law), addr(glue)
+        spec.schedule, spec.r = sched_d.data_ptr(), r_d.data_ptr()
+        spec.mu, spec.P, spec.w = f._means.data_ptr(), f._covs.data_ptr(), f._w.data_ptr()
+        spec.X, spec.u, spec.z = X.data_ptr(), u.data_ptr(), z.data_ptr()
+        spec.y_pred, spec.known = y_pred.data_ptr(), known.data_ptr()
+        spec.us, spec.xs, spec.ys, spec.ys_meas, spec.moments = (t_.data_ptr() for t_ in (us, xs, ys, ys_meas, moments))
+        spec.status, spec.chol_status = status.data_ptr(), f._status.data_ptr()
+        _lib.check(lib.gse_gsukf_closed_loop(ctypes.byref(spec), stream))
+        f._step += int((sched & 1).sum())
+        self._keep_alive = keep_alive
+        return control_ticks, n_control
+
+    def _finish_resident(self, lib, torch, time, flat, widths, moments, status, control_ticks, n_control, ev0, ev1, clock, f64,
+                         stream):
+        from gpu_se_amd import _lib
+        ticks, B = len(self.ts), self.B
         # the estimates of every tick and rollout from the recorded moments, still on the device (point estimate and the
         # largest singular value of the covariance: gse_moments_estimates); then one synchronisation and the copies
         estimates = torch.empty((ticks * B, 6), **f64)

@@ -450,6 +450,37 @@ int gse_plant_step(double *X /* [B][5], in/out */, const double *u /* [B][2] */,
                    const gse_mixture *meas_noise, const gse_rng *rng, double *y /* [B][5] */, double *y_meas /* [B][5] */,
                    double *z /* [B][2] */, double *log_x /* [B][5] or NULL */, double *log_u /* [B][2] or NULL */,
                    int64_t B, void *stream);
+/* A whole closed loop in ONE launch (sim_base.py:243-309 for B rollouts whose estimator is a Gaussian-sum filter of at most 64
+ * Gaussians, results/gsf_closedloop/bioreactor_performance_gsf.py:104-118): one workgroup per rollout runs every tick --
+ * predict if due, on a control tick update / resample / estimate / MPC, then the plant -- with the bank in LDS throughout.
+ * Rollouts do not interact, so nothing needs a launch boundary; what the launch-per-piece loop spends waiting for the host
+ * to enqueue (five launches a tick) is gone.  Same device functions, same Philox elements and steps as gse_gsukf_cycle_dev +
+ * gse_gsukf_moments26 + gse_loop_control + gse_plant_step: the records agree bit for bit.
+ * All pointers device memory unless marked host; records are [ticks][B][...] and row 0 is the caller's (initial values);
+ * schedule[t] bit 0: a predict is due at tick t, bit 1: the controller acts (sim_base.py:250, :255). */
+typedef struct gse_loop_spec {
+    int32_t B, N, ticks, reserved;
+    double dt;
+    const float *w_sigma;                        /* host [11] */
+    const gse_mixture *state_pdf;                /* host: the filter's state noise */
+    const gse_rng *rng;                          /* host: the filter's Philox stream; step = that of its first predict */
+    const gse_mixture *measurement_pdf;          /* host */
+    const gse_mixture *plant_state_noise, *plant_meas_noise;   /* host */
+    const gse_rng *plant_rng;                    /* host: tick t draws with step t */
+    const gse_mpc_law *law;                      /* host struct of device pointers (gse_mpc_step) */
+    const gse_loop_glue *glue;                   /* host */
+    const uint8_t *schedule;                     /* [ticks] */
+    const double *r;                             /* [updates][B] uniform numbers of the resamples, in [0, 1) */
+    float *mu, *P, *w;                           /* the banks [B][N][5], [B][N][5][5], [B][N]: in / out */
+    double *X, *u, *z;                           /* [B][5], [B][2], [B][2]: in / out */
+    double *y_pred;                              /* [B][n_y] in / out */
+    int32_t *known;                              /* [B] in / out */
+    double *us, *xs, *ys, *ys_meas, *moments;    /* [ticks][B][2 | 5 | 5 | 5 | 26] */
+    int32_t *status;                             /* [ticks][B]: 1 where the MPC's QP was not solved */
+    int32_t *chol_status;                        /* [1]: counts covariances that could not be factorised */
+} gse_loop_spec;
+int gse_gsukf_closed_loop(const gse_loop_spec *spec /* host */, void *stream);
+
 /* Rows of estimator moments (26 doubles each: gse_pf_moments / gse_gsukf_moments26) -> per row [mean (5), largest singular
  * value of the covariance]: point_estimate() and point_covariance() (filter/particle.py:318-327) for every tick and rollout of a
  * closed loop at once, on the device (sim_base.py:287-296 keeps both per tick). */

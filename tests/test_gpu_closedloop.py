@@ -491,3 +491,29 @@ def test_config5_size_cycle_properties():
     est = f.point_estimate()
     assert np.all(np.diff(est[:, 0]) > 0)                          # ordered like the measurements
     np.testing.assert_allclose(est[:, 0], xss[0] + shift, atol=1.5e-3)
+
+
+@pytest.mark.parametrize("n,dt_control,dt_predict,end_time", [(64, 0.1, 0.1, 6), (64, 1.0, 0.1, 6), (17, 0.1, 0.1, 3), (64, 1.0, 1.0, 6)])
+def test_persistent_loop_equals_the_launch_per_piece_loop(n, dt_control, dt_predict, end_time):
+    """gse_gsukf_closed_loop -- every tick of B rollouts inside ONE launch, the banks in LDS throughout -- against the resident
+    loop that launches the filter cycle, the moments, the controller and the plant one after the other: every record bit for
+    bit (same device functions, same Philox elements and steps, same uniform numbers of the resamples), the filters' final
+    banks included.  Control every tick and every tenth; predicts between control ticks; a bank that is not a multiple of
+    anything."""
+    B = 5
+    sims = []
+    for persistent in (True, False):
+        gpu_se_amd.seed(77)
+        sim = sim_base.BatchedSimulation(batch=B, N_particles=n, dt_control=dt_control, dt_predict=dt_predict, end_time=end_time,
+                                         pf=False, resident=True, seed=3, persistent=persistent)
+        assert sim._persistent_capable() == persistent
+        sim.simulate()
+        sims.append(sim)
+    one, many = sims
+    for name in ("us", "xs", "ys", "ys_meas", "moments", "xs_f", "ys_f", "covariance_point_size", "performance"):
+        np.testing.assert_array_equal(getattr(one, name), getattr(many, name), err_msg=name)
+    assert one.mpc_frac == many.mpc_frac == 1.0
+    np.testing.assert_array_equal(one.f.means.get(), many.f.means.get())
+    np.testing.assert_array_equal(one.f.covariances.get(), many.f.covariances.get())
+    np.testing.assert_array_equal(one.f.weights.get(), many.f.weights.get())
+    assert one.f._step == many.f._step
