@@ -21,7 +21,7 @@ struct GsukfLoopArgs {
     PlantArgs plant;                // the plant's two draws; Philox keys with step 0 (tick t uses step t)
     MpcLawDev law;
     LoopGlue glue;
-    const uint8_t* schedule;        // [ticks]: bit 0 predict due, bit 1 control due (entry 0 unused)
+    const unsigned char* schedule;  // [ticks]: bit 0 predict due, bit 1 control due (entry 0 unused)
     const double* r;                // [updates][B] uniform numbers of the resamples
     float *mu, *P, *w;              // the banks [B][N][5], [B][N][5][5], [B][N]: in / out
     double *X, *u, *z;              // plant state [B][5], current input [B][2], current measurement [B][2]: in / out

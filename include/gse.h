@@ -469,7 +469,7 @@ typedef struct gse_loop_spec {
     const gse_rng *plant_rng;                    /* host: tick t draws with step t */
     const gse_mpc_law *law;                      /* host struct of device pointers (gse_mpc_step) */
     const gse_loop_glue *glue;                   /* host */
-    const uint8_t *schedule;                     /* [ticks] */
+    const unsigned char *schedule;               /* [ticks] */
     const double *r;                             /* [updates][B] uniform numbers of the resamples, in [0, 1) */
     float *mu, *P, *w;                           /* the banks [B][N][5], [B][N][5][5], [B][N]: in / out */
     double *X, *u, *z;                           /* [B][5], [B][2], [B][2]: in / out */

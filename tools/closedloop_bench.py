@@ -22,15 +22,16 @@ if world > 1:
     dist.init_process_group(backend="gloo" if rehearsal else "nccl", rank=rank, world_size=world)
 gpu_se_amd.seed(1 + rank)
 resident = bool(os.environ.get("GSE_RESIDENT"))
+use_pf = not os.environ.get("GSE_GSF")       # GSE_GSF=1: banks of 2^log2N Gaussians (GS-UKF) as the estimator
 sim = sim_base.BatchedSimulation(batch=B, N_particles=1 << log2n, dt_control=dt_control, dt_predict=0.1, end_time=end_time,
-                                 seed=1 + rank, resident=resident,
+                                 seed=1 + rank, resident=resident, pf=use_pf,
                                  controller=sim_base.hold_controller if os.environ.get("GSE_HOLD") else None)
 t = time.perf_counter()
 if not os.environ.get("GSE_HOLD"):
     sim.K._device_law()                     # condense the QP and upload the law before the clock starts
 print("controller set-up %.2f s" % (time.perf_counter() - t))
-warm = sim_base.BatchedSimulation(batch=B, N_particles=1 << 10, dt_control=dt_control, dt_predict=0.1, end_time=2, seed=2,
-                                  resident=resident, controller=sim.controller)
+warm = sim_base.BatchedSimulation(batch=B, N_particles=(1 << 10) if use_pf else (1 << log2n), dt_control=dt_control, dt_predict=0.1,
+                                  end_time=2, seed=2, resident=resident, pf=use_pf, controller=sim.controller)
 warm.K = sim.K
 warm.simulate()                             # loads every kernel of the loop before the clock starts
 torch.cuda.synchronize()
