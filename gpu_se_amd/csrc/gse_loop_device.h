@@ -69,6 +69,44 @@ __device__ __forceinline__ int mpc_solve(const MpcLawDev& law, double theta_lane
         delta = __shfl(delta, i, 64);
         if (row && delta != 0.0) c -= s_li * delta;                           // S symmetric: column i = row i
     };
+    // One or two bounded rows (every wiring of sim_base.get_parts: u_0 >= 0 for both inputs): the dual has at most nine
+    // candidate active sets -- each row free, on its lower or on its upper bound -- and each is a closed form; lane L tries
+    // candidate (L % 3, L / 3), the first that satisfies the KKT conditions (feasible free rows, multipliers of the right
+    // sign) IS the optimum (convex QP).  No sweeps: the coordinate ascent below needs ~40 of them to reach 1e-12 when the two
+    // rows are coupled, 12 of the controller kernel's 17 us.  Nothing valid (contradictory bounds, a row without curvature)
+    // falls through to the sweeps, which then report what they always did.
+    if (m >= 1 && m <= 2) {
+        const double c0_0 = __shfl(c0, 0, 64), c0_1 = (m > 1) ? __shfl(c0, 1, 64) : 0.0;
+        const double lo0 = __shfl(lo, 0, 64), hi0 = __shfl(hi, 0, 64);
+        const double lo1 = (m > 1) ? __shfl(lo, 1, 64) : -INFINITY, hi1 = (m > 1) ? __shfl(hi, 1, 64) : INFINITY;
+        const double s00 = __shfl(srow[0], 0, 64), s01 = (m > 1) ? __shfl(srow[1], 0, 64) : 0.0;
+        const double s10 = (m > 1) ? __shfl(srow[0], 1, 64) : 0.0, s11 = (m > 1) ? __shfl(srow[1], 1, 64) : 1.0;
+        const int a0 = lane % 3, a1 = (lane / 3) % 3;                  // 0 free, 1 on lo, 2 on hi
+        const double b0 = (a0 == 1) ? lo0 : hi0, b1 = (a1 == 1) ? lo1 : hi1;
+        double n0 = 0.0, n1 = 0.0;
+        if (a0 && !a1) n0 = (c0_0 - b0) / s00;
+        if (!a0 && a1) n1 = (c0_1 - b1) / s11;
+        if (a0 && a1) {
+            const double det = s00 * s11 - s01 * s10, r0 = c0_0 - b0, r1 = c0_1 - b1;
+            n0 = (s11 * r0 - s01 * r1) / det;
+            n1 = (s00 * r1 - s10 * r0) / det;
+        }
+        const double c_0 = a0 ? b0 : c0_0 - s01 * n1, c_1 = a1 ? b1 : c0_1 - s10 * n0;
+        const double t0 = law.eps_abs + law.eps_rel * (fabs(c0_0) + (c_0 > hi0 ? fabs(hi0) : (c_0 < lo0 ? fabs(lo0) : 0.0)));
+        const double t1 = law.eps_abs + law.eps_rel * (fabs(c0_1) + (c_1 > hi1 ? fabs(hi1) : (c_1 < lo1 ? fabs(lo1) : 0.0)));
+        bool valid = lane < (m > 1 ? 9 : 3) && (s00 > 0.0) && (m < 2 || s11 > 0.0);
+        valid = valid && ((a0 == 0) ? (c_0 >= lo0 - t0 && c_0 <= hi0 + t0) : ((a0 == 1) ? (n0 < 0.0) : (n0 > 0.0)));
+        valid = valid && ((a1 == 0) ? (c_1 >= lo1 - t1 && c_1 <= hi1 + t1) : ((a1 == 1) ? (n1 < 0.0) : (n1 > 0.0)));
+        const unsigned long long found = __ballot(valid);
+        if (found) {
+            const int src = __ffsll((long long)found) - 1;
+            const double v0 = __shfl(n0, src, 64), v1 = __shfl(n1, src, 64);
+            const double w0 = __shfl(c_0, src, 64), w1 = __shfl(c_1, src, 64);
+            nu = (lane == 0) ? v0 : ((lane == 1 && m > 1) ? v1 : 0.0);
+            if (row) c = (lane == 0) ? w0 : w1;
+            converged = 1;
+        }
+    }
     for (int sweep = 0; sweep < law.max_sweeps && !converged; ++sweep) {
         if (few) {
 #pragma unroll

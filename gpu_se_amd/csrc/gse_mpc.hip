@@ -9,7 +9,8 @@
 //                                    nu_i > 0 only with c_i = hi_i,  nu_i < 0 only with c_i = lo_i
 //     du0 = Gu theta + gu0 - Tu nu   y1 = Gy theta + gy0 - Ty nu
 //
-// The dual is solved by Hildreth's procedure (exact coordinate ascent, Gauss-Seidel order): for row i, with the other
+// With one or two bounded rows the dual is solved in closed form (mpc_solve: nine candidate active sets, one per lane).
+// Otherwise by Hildreth's procedure (exact coordinate ascent, Gauss-Seidel order): for row i, with the other
 // multipliers fixed, r = c_i + S_ii nu_i is the row's value without its own multiplier; nu_i becomes (r - hi_i) / S_ii
 // if r > hi_i, (r - lo_i) / S_ii if r < lo_i, else 0.  One wavefront per rollout, lane i owns row i: c is kept up to
 // date incrementally (a changed nu_i moves every c_j by -S_ji delta: one broadcast and one FMA per lane), so a

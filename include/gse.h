@@ -396,7 +396,8 @@ int gse_rng_raw(uint32_t *out, int64_t M, const gse_rng *rng, uint32_t purpose, 
  * controller.py:236-262 -- so the QP is condensed ONCE on the host (gpu_se_amd/controller.py) into an explicit law
  *
  *     c0    = Gc theta + gc0                      the bounded rows at the unconstrained optimum   [n_rows]
- *     nu    = argmax of the dual:  lo <= c0 - S nu <= hi,  nu_i (c_i - bound_i) = 0             (Hildreth sweeps)
+ *     nu    = argmax of the dual:  lo <= c0 - S nu <= hi,  nu_i (c_i - bound_i) = 0             (one or two rows: the nine
+ *             candidate active sets in closed form, one per lane; more rows: Hildreth sweeps)
  *     du0   = Gu theta + gu0 - Tu nu              first input move                               [n_u]
  *     y1    = Gy theta + gy0 - Ty nu              first predicted output                         [n_y]
  *
