@@ -114,6 +114,24 @@ def make_inputs(steps, dt, seed=0):
     return out
 
 
+def device_warm_up(torch, n, dt, cycles=500):
+    """`cycles` cycles of a throw-away filter of n particles (nothing of it survives): raises the device's clocks without
+    touching the state of the filter that is measured."""
+    import gpu_se_amd
+    from gpu_se_amd import sim_base
+    gpu_se_amd.seed(99)
+    _, _, _, tmp = sim_base.get_parts(N_particles=n)
+    io = make_inputs(64, dt, seed=7)
+    for c in range(cycles):
+        u, z = io[c % len(io)]
+        tmp.predict(u, dt)
+        tmp.update(u, z)
+        tmp.resample()
+    torch.cuda.synchronize()
+    del tmp
+    return cycles
+
+
 def csrc_hash():
     """sha256 over the kernel sources and the ABI header: ties a committed profile to the build it was taken on."""
     h = hashlib.sha256()
@@ -348,6 +366,11 @@ def main():
 
     # `value` is measured as SURVEY 8d prescribes: particles ~ prior, W warm-up cycles, K timed cycles.  (Round 2 put 2000
     # untimed cycles in front; the figure of a filter that has been running that long is now `steady_state` in the same line.)
+    # The DEVICE is brought up to its clocks first, by a throw-away filter of the same size: setting the workload up (a second of
+    # host work: the plant simulation behind the inputs) leaves it idle, and an idle MI355X needs a few milliseconds of work to
+    # clock up -- that ramp, not the filter's state, was most of what separated round 2's from-the-prior figure from its
+    # steady-state one (tools/cycle_trace.py, which has always warmed the device this way, sees 5 % between them).
+    device_warmup = device_warm_up(torch, n, dt)
     for i in range(burn_in):
         cycle(i)
     io = io[burn_in:]
@@ -398,6 +421,7 @@ def main():
         # is timed again: `steady_state`.
         from gpu_se_amd import sim_base as _sb
         lp_io = make_inputs(2000 + 2 * 400 + 10, dt, seed=1)
+        device_warm_up(torch, n, dt)                # (the host work above left the device idle)
         gpu_se_amd.seed(4321)
         _, _, _, lp = _sb.get_parts(N_particles=n)
         lp_at = [0]
@@ -464,6 +488,7 @@ def main():
                                       else "BASELINE config 2" if (world == 1 and n == 1 << 20)
                                       else "weak scaling of BASELINE config 2"),
                        "particles_per_gpu": n, "total_particles": n * world, "dt": dt, "burn_in_cycles": burn_in,
+                       "device_warmup_cycles": device_warmup,
                        "parallelism": ("particle shards x%d, EXACT global resampling (all-gather of tile sums + all-to-all "
                                        "of particles per cycle), posterior merge at estimates" % world)
                        if (world > 1 and args.exact_resample) else

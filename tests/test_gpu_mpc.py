@@ -223,3 +223,33 @@ def test_resident_loop_matches_the_host_loop_statistically():
     rise_res, rise_host = res.ys[-1, :, 2] - res.ys[0, :, 2], host.ys[-1, :, 2] - host.ys[0, :, 2]
     assert np.all(rise_res > 20) and abs(rise_res.mean() - rise_host.mean()) < 0.35 * abs(rise_host.mean())
     np.testing.assert_allclose(res.us[1:].mean(axis=(0, 1)), host.us[1:].mean(axis=(0, 1)), rtol=0.25, atol=5e-3)
+
+
+def test_moments_estimates_kernel_against_numpy():
+    """gse_moments_estimates (rows of 26 moments -> point estimate, largest singular value of the covariance by Jacobi
+    rotations) against the host formulas of filter.particle.moments_to_mean_cov + numpy.linalg.svd, on moments of weighted
+    ensembles of very different spread (singular values from 1e-9 to 1e2, pivots far from the mean)."""
+    import ctypes
+    from gpu_se_amd import _lib
+    from gpu_se_amd.filter.particle import moments_to_mean_cov
+    rng = np.random.default_rng(12)
+    rows = []
+    for k in range(300):
+        n = 50
+        x = rng.normal(size=(n, 5)) * 10.0 ** rng.uniform(-5, 1, size=5) + rng.normal(size=5) * 3
+        w = rng.random(n) ** 3
+        w /= w.sum() * rng.uniform(0.5, 2.0)                       # (weights need not sum to one: particle.py:318-327)
+        pv = x[0] + rng.normal(size=5) * (0.0 if k % 2 else 1.0)
+        d = x - pv
+        s2 = d.T @ (d * w[:, None])
+        rows.append(np.concatenate([[w.sum()], w @ d, s2[np.triu_indices(5)], pv]))
+    m = np.array(rows)
+    md = torch.as_tensor(m, device="cuda")
+    out = torch.empty((len(m), 6), dtype=torch.float64, device="cuda")
+    _lib.call("gse_moments_estimates", md.data_ptr(), len(m), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    got = out.cpu().numpy()
+    for k, row in enumerate(m):
+        _, mean, cov = moments_to_mean_cov(row[0], row[1:6], row[6:21], row[21:26])
+        np.testing.assert_allclose(got[k, :5], mean, rtol=1e-14, atol=1e-14)
+        sv = np.linalg.svd(cov, compute_uv=False)[0]
+        np.testing.assert_allclose(got[k, 5], sv, rtol=1e-10, atol=1e-300)
