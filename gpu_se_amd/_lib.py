@@ -23,6 +23,7 @@ GSE_SCAN_MAX_TILES = 2048      # policy: up to 2^21 particles every workgroup of
                                # cycle kernel stages windows of ITS prefix (GSE_OP_PREFIX_GLOBAL: two launches, the second
                                # still the whole cycle -- round 2 fell back to cumsum + staged search there)
 GSE_GSUKF_CYCLE_MAX = 64
+GSE_LOOP_ARGS_BYTES = 4096
 GSE_SMALL_RESAMPLE_MAX = 4096       # banks up to here find their ancestors in one launch (small_resample_kernel)
 GSE_GSUKF_MOMENTS = 46             # doubles per row of gse_gsukf_moments
 GSE_GSUKF_LANES_MIN = 65         # from this many Gaussians on: one lane per Gaussian, predict + update in one launch,
@@ -58,7 +59,8 @@ class LoopSpec(ctypes.Structure):
     _fields_ = [("B", c_i32), ("N", c_i32), ("ticks", c_i32), ("reserved", c_i32), ("dt", c_d)] + \
                [(name, c_vp) for name in ("w_sigma", "state_pdf", "rng", "measurement_pdf", "plant_state_noise",
                                           "plant_meas_noise", "plant_rng", "law", "glue", "schedule", "r", "mu", "P", "w", "X", "u",
-                                          "z", "y_pred", "known", "us", "xs", "ys", "ys_meas", "moments", "status", "chol_status")]
+                                          "z", "y_pred", "known", "us", "xs", "ys", "ys_meas", "moments", "status", "chol_status",
+                                          "args_buffer")]
 
 
 P_MIX = ctypes.POINTER(Mixture)

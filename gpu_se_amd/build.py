@@ -11,6 +11,10 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgse_hip.so")
 SOURCES = ["gse_host.hip", "gse_pf.hip", "gse_gsukf.hip", "gse_rows.hip", "gse_mpc.hip", "gse_rtc.hip", "gse_loop.hip"]
 ARCH = "gfx950"
+# per-source flags.  gse_loop.hip holds one kernel whose body is a loop over the ticks of a whole closed-loop run: with
+# machine-level loop-invariant code motion every constant and address a tick needs is materialised before the loop and kept
+# live through all of its phases, which costs 128 vector registers plus scratch; without, a tick allocates like one cycle.
+EXTRA_FLAGS = {"gse_loop.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
 def _hipcc():
@@ -39,7 +43,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
-        cmd[1:1] = os.environ.get("GSE_CXXFLAGS", "").split()
+        cmd[1:1] = os.environ.get("GSE_CXXFLAGS", "").split() + EXTRA_FLAGS.get(src, [])
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -34,46 +34,43 @@ struct GsukfLoopArgs {
 };
 
 // moments of the bank in the particle filter's 26-double row (gse_gsukf_moments26): the arithmetic of gsukf_moments_kernel<1> +
-// moments_finish_kernel for a bank of at most 64 -- every Gaussian is one lane of wavefront 0, the wavefront sum is the total
+// moments_finish_kernel for a bank of at most 64.  There every Gaussian is one lane of wavefront 0 and each of the 21 sums is
+// that wavefront's butterfly; here wavefront c forms sum c (its lane g holds Gaussian g's term, the same expression), so
+// the 21 butterflies run side by side on the 16 wavefronts instead of one after the other on one: 4.8 us -> about 1.
 __device__ __forceinline__ void bank_moments26(const float (*mu_s)[kNx], const float (*P_s)[kNxx], const float* w_s, int N,
                                                double* out26, int tid) {
-    if (tid >= 64) return;
-    double acc[1 + kNx + 2 * kTri];
-#pragma unroll
-    for (int c = 0; c < 1 + kNx + 2 * kTri; ++c) acc[c] = 0.0;
-    double pv[kNx];
-#pragma unroll
-    for (int k = 0; k < kNx; ++k) pv[k] = (double)mu_s[0][k];
-    if (tid < N) {
-        const double wp = (double)w_s[tid];
-        double d[kNx];
-#pragma unroll
-        for (int k = 0; k < kNx; ++k) d[k] = (double)mu_s[tid][k] - pv[k];
-        acc[0] += wp;
-        int c = 1 + kNx;
-#pragma unroll
-        for (int k = 0; k < kNx; ++k) {
-            const double wd = wp * d[k];
-            acc[1 + k] += wd;
-#pragma unroll
-            for (int l = k; l < kNx; ++l) acc[c++] += wd * d[l];
+    // (no contraction: the kernel this restates rounds each product before it adds)
+#pragma clang fp contract(off)
+    constexpr int kSums = 1 + kNx + kTri;
+    const int g = tid & 63, wv = tid >> 6;
+    for (int c = wv; c < kSums; c += kSmallBlock / 64) {
+        // sum c: 0 the weight, 1..5 w d_k, then the upper triangle (k, l >= k) row by row of w d_k d_l + w P_kl.
+        // (gsukf_moments_kernel keeps sum w d d^T and sum w P apart and folds them at the end; with one Gaussian per lane each
+        //  holds a single term, 0 + x = x exactly, so the fold is formed directly)
+        int k = 0, l = 0;
+        if (c > kNx) {
+            int e = c - 1 - kNx;
+            while (e >= kNx - k) { e -= kNx - k; ++k; }
+            l = k + e;
+        } else if (c >= 1) {
+            k = c - 1;
         }
-#pragma unroll
-        for (int k = 0; k < kNx; ++k)
-#pragma unroll
-            for (int l = k; l < kNx; ++l) acc[c++] += wp * (double)P_s[tid][k * kNx + l];
+        double term = 0.0;
+        if (g < N) {
+            const double wp = (double)w_s[g];
+            const double wd = wp * ((double)mu_s[g][k] - (double)mu_s[0][k]);
+            term = c == 0 ? wp : c <= kNx ? wd : wd * ((double)mu_s[g][l] - (double)mu_s[0][l]) + wp * (double)P_s[g][k * kNx + l];
+        }
+        const double total = wave_sum(term);
+        if (g == 0) out26[c] = (total + 0.0) + (0.0 + 0.0);        // (the four wavefront totals of a 256-thread block: three zeros)
     }
-#pragma unroll
-    for (int i = 0; i < kTri; ++i) acc[1 + kNx + i] += acc[1 + kNx + kTri + i];
-#pragma unroll
-    for (int c = 0; c < 1 + kNx + kTri; ++c) {
-        const double total = wave_sum(acc[c]);
-        if (tid == c) out26[c] = (total + 0.0) + (0.0 + 0.0);      // (the four wavefront totals of a 256-thread block: three zeros)
-    }
-    if (tid < kNx) out26[1 + kNx + kTri + tid] = pv[tid];
+    if (tid < kNx) out26[kSums + tid] = (double)mu_s[0][tid];
 }
 
-__global__ __launch_bounds__(kSmallBlock) void gsukf_closed_loop_kernel(const GsukfLoopArgs a) {
+// (The arguments come through device memory, not the kernel-argument segment: the tick loop reads them through a pointer it
+//  launders every tick -- see there -- and taking the address of a by-value kernel argument makes a private copy of it.)
+__global__ __launch_bounds__(kSmallBlock) void gsukf_closed_loop_kernel(const GsukfLoopArgs* __restrict__ args) {
+    const GsukfLoopArgs& a = *args;
     static_assert(kNx == GSE_NX, "the closed loop is the bioreactor's");
     __shared__ DrawParams dp;
     __shared__ DrawParams dpp[2];
@@ -86,7 +83,39 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_closed_loop_kernel(const Gs
     __shared__ double c_s[kSmallBank];
     __shared__ int anc_s[kSmallBank];
     __shared__ double total_s;
-    const int tid = threadIdx.x, b = blockIdx.x, N = a.N, B = a.B;
+    // the rollout's scalars live in LDS for the whole loop (global memory sees them once, at the end) and so do the law's
+    // matrices when there are few bounded rows: the controller call is a chain of dependent reads, now LDS reads
+    __shared__ double st_u[2], st_z[2], st_X[5], st_ypred[GSE_MPC_MAX_OUT], st_ymeas[5], mom_s[26];
+    __shared__ int32_t st_known;
+    constexpr int kLawRows = 8;
+    __shared__ double law_s[2 * kLawRows * GSE_MPC_MAX_THETA + kLawRows * kLawRows + 3 * kLawRows +
+                            2 * GSE_MPC_MAX_OUT * (GSE_MPC_MAX_THETA + 1 + kLawRows) + GSE_MPC_MAX_OUT * GSE_MPC_MAX_THETA];
+    const int tid0 = threadIdx.x, b = blockIdx.x, N0 = a.N, B = a.B;
+    int tid = tid0, N = N0;
+    MpcLawDev law0 = a.law;
+    MpcLawDev& law = law0;
+    if (law.n_rows <= kLawRows) {
+        const int m = law.n_rows, nt = law.n_theta, nu = law.n_u, ny = law.n_y;
+        double* at = law_s;
+        auto stage = [&](const double* __restrict__& field, int count) {
+            for (int i = tid; i < count; i += kSmallBlock) at[i] = field[i];
+            field = at;
+            at += count;
+        };
+        if (m) { stage(law.Gc, m * nt); stage(law.gc0, m); stage(law.S, m * m); stage(law.lo, m); stage(law.hi, m);
+                 stage(law.Tu, nu * m); stage(law.Ty, ny * m); }
+        stage(law.Gu, nu * nt); stage(law.gu0, nu); stage(law.Gy, ny * nt); stage(law.gy0, ny);
+    }
+    if (tid < 2) { st_u[tid] = a.u[2 * b + tid]; st_z[tid] = a.z[2 * b + tid]; }
+    if (tid < 5) { st_X[tid] = a.X[5 * b + tid]; st_ymeas[tid] = a.ys_meas[(int64_t)b * 5 + tid]; }      // (row 0 of the records)
+    if (tid < law.n_y) st_ypred[tid] = a.y_pred[(int64_t)b * law.n_y + tid];
+    if (tid == 0) st_known = a.known[b];
+    __shared__ LoopGlue glue_s;                  // (indexed by lane in the controller call: from LDS, not from the argument block)
+    {
+        const uint32_t* sg = reinterpret_cast<const uint32_t*>(&a.glue);
+        uint32_t* dg = reinterpret_cast<uint32_t*>(&glue_s);
+        for (int i = tid; i < (int)(sizeof(LoopGlue) / 4); i += kSmallBlock) dg[i] = sg[i];
+    }
     {
         const uint32_t* s0 = reinterpret_cast<const uint32_t*>(&a.pred.draw);
         const uint32_t* s1 = reinterpret_cast<const uint32_t*>(&a.plant.state_noise);
@@ -103,25 +132,59 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_closed_loop_kernel(const Gs
     __syncthreads();
     auto from_lds = [&](int t, const float*& m_, const float*& p_) { m_ = mu_s[t]; p_ = P_s[t]; };
     auto to_lds = [&](int t, float*& m_, float*& p_) { m_ = mu_s[t]; p_ = P_s[t]; };
-    const int j = tid & (kGroup - 1), gl = tid / kGroup;
     int n_predict = 0, n_update = 0;
-    for (int t = 1; t < a.ticks; ++t) {
-        const int due = a.schedule[t];
+    // The plant of tick t is one thread's work (an fp64 model step, two draws, the records): it runs on the LAST thread of the
+    // workgroup at the start of tick t + 1, while the other wavefronts factorise and propagate the sigma points of that tick's
+    // predict -- which needs the input the controller left, not the measurement the plant is about to produce.
+    auto plant = [&](const GsukfLoopArgs& aa, int t) {
+        RngKey ks = aa.plant.rng_state, km = aa.plant.rng_meas;
+        ks.step_lo = (uint32_t)t;
+        km.step_lo = (uint32_t)t;
+        plant_step_one(st_X, st_u, 0, b, dpp, ks, km, aa.plant.dt, aa.ys + ((int64_t)t * B + b) * 5, st_ymeas, st_z,
+                       aa.xs + ((int64_t)t * B + b) * 5, aa.us + ((int64_t)t * B + b) * 2, nullptr, nullptr);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) aa.ys_meas[((int64_t)t * B + b) * 5 + k] = st_ymeas[k];
+    };
+    const int ticks = a.ticks;
+    for (int t = 1; t < ticks; ++t) {
+        // (the arguments through a pointer the compiler cannot see through: otherwise everything in the tick that depends on
+        //  them alone -- sigma weights as doubles, mixture constants, the law's pointers -- is hoisted out of the tick loop,
+        //  kept live across all phases and spilled: 576 bytes of scratch per lane and ten of a tick's 26 us)
+        const GsukfLoopArgs* ap = args;
+        asm volatile("" : "+s"(ap));
+        const GsukfLoopArgs& aa = *ap;
+        const int tid = per_iteration(tid0), N = per_iteration_uniform(N0);
+        const int j = tid & (kGroup - 1), gl = tid / kGroup;
+        MpcLawDev law = law0;
+        per_iteration_uniform(law);
+        const int due = aa.schedule[t];
+#ifdef GSE_LOOP_STAMPS
+        double stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) stamp[i] = (double)wall_clock64()
+#else
+#define STAMP(i)
+#endif
+        STAMP(0);
+        if (t > 1 && tid == kSmallBlock - 1) plant(aa, t - 1);
         FilterIO bio;
-        bio.u0 = a.u[2 * b]; bio.u1 = a.u[2 * b + 1]; bio.z0 = a.z[2 * b]; bio.z1 = a.z[2 * b + 1];
+        bio.u0 = st_u[0]; bio.u1 = st_u[1]; bio.z0 = 0.0; bio.z1 = 0.0;
         if (due & 1) {
-            RngKey key = a.pred.rng;
+            RngKey key = aa.pred.rng;
             key.step_lo += (uint32_t)n_predict;          // (the class counts a step per predict; 32 bits last a billion ticks)
             ++n_predict;
-            gsukf_predict_block<false>(from_lds, to_lds, fac, tile, N, b, 0, nullptr, dp, a.chol_status, a.pred, bio, key);
+            gsukf_predict_block<false>(from_lds, to_lds, fac, tile, N, b, 0, nullptr, dp, aa.chol_status, aa.pred, bio, key);
             __syncthreads();
         }
-        double* mom_t = a.moments + ((int64_t)t * B + b) * 26;
+        STAMP(1);
+        double* mom_t = aa.moments + ((int64_t)t * B + b) * 26;
         if (due & 2) {
+            __syncthreads();                              // (the plant of the tick before has left its measurement)
+            bio.z0 = st_z[0]; bio.z1 = st_z[1];
             gsukf_update_block(from_lds, to_lds, [&](int g) { return (const float*)&w_s[g]; }, [&](int g) { return &w_s[g]; }, fac,
-                               tile, eta, N, b, a.chol_status, bio, a.pdf, a.pred.sw);
+                               tile, eta, N, b, aa.chol_status, bio, aa.pdf, aa.pred.sw);
             __syncthreads();
-            small_bank_ancestors(w_s, c_s, anc_s, &total_s, N, a.r[(int64_t)n_update * B + b], tid);
+            STAMP(2);
+            small_bank_ancestors(w_s, c_s, anc_s, &total_s, N, aa.r[(int64_t)n_update * B + b], tid);
             ++n_update;
             // the rows of the ancestors, in place: through registers
             float keep[2];
@@ -142,23 +205,34 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_closed_loop_kernel(const Gs
             }
             if (tid < N) w_s[tid] = (float)(1.0 / (double)N);
             __syncthreads();
-            bank_moments26(mu_s, P_s, w_s, N, mom_t, tid);
+            STAMP(3);
+            bank_moments26(mu_s, P_s, w_s, N, mom_s, tid);
             __syncthreads();
+            STAMP(4);
+            if (tid < 26) mom_t[tid] = mom_s[tid];
             if (tid < 64)
-                loop_control_wave(a.law, a.glue, a.moments + (int64_t)t * B * 26, a.ys_meas + (int64_t)(t - 1) * B * 5, a.u, a.y_pred,
-                                  a.known, a.status + (int64_t)t * B, nullptr, b, tid);
+                loop_control_wave(law, glue_s, mom_s, st_ymeas, st_u, st_ypred, &st_known, aa.status + (int64_t)t * B + b, nullptr, 0,
+                                  tid);
             __syncthreads();
         }
-        if (tid == 0) {
-            RngKey ks = a.plant.rng_state, km = a.plant.rng_meas;
-            ks.step_lo = (uint32_t)t;
-            km.step_lo = (uint32_t)t;
-            plant_step_one(a.X, a.u, b, dpp, ks, km, a.plant.dt, a.ys + (int64_t)t * B * 5, a.ys_meas + (int64_t)t * B * 5, a.z,
-                           a.xs + (int64_t)t * B * 5, a.us + (int64_t)t * B * 2, nullptr, nullptr);
+        if (!(due & 2)) {
+            bank_moments26(mu_s, P_s, w_s, N, mom_s, tid);
+            __syncthreads();
+            if (tid < 26) mom_t[tid] = mom_s[tid];
         }
-        if (!(due & 2)) bank_moments26(mu_s, P_s, w_s, N, mom_t, tid);
         __syncthreads();
+#ifdef GSE_LOOP_STAMPS
+        STAMP(5);
+        if (tid == 0 && b == 0)
+            for (int i = 0; i < 6; ++i) mom_t[6 + i] = stamp[i];
+#endif
     }
+    if (tid == kSmallBlock - 1) plant(a, a.ticks - 1);
+    __syncthreads();
+    if (tid < 2) { a.u[2 * b + tid] = st_u[tid]; a.z[2 * b + tid] = st_z[tid]; }
+    if (tid < 5) a.X[5 * b + tid] = st_X[tid];
+    if (tid < law.n_y) a.y_pred[(int64_t)b * law.n_y + tid] = st_ypred[tid];
+    if (tid == 0) a.known[b] = st_known;
     // the bank: LDS -> global
     for (int i = tid; i < N * kNx; i += kSmallBlock) a.mu[(int64_t)b * N * kNx + i] = mu_s[i / kNx][i % kNx];
     for (int i = tid; i < N * kNxx; i += kSmallBlock) a.P[(int64_t)b * N * kNxx + i] = P_s[i / kNxx][i % kNxx];
@@ -200,7 +274,13 @@ extern "C" int gse_gsukf_closed_loop(const gse_loop_spec* s, void* stream) {
     a.us = s->us; a.xs = s->xs; a.ys = s->ys; a.ys_meas = s->ys_meas; a.moments = s->moments; a.status = s->status;
     a.chol_status = s->chol_status;
     a.ticks = s->ticks; a.N = s->N; a.B = s->B;
-    hipLaunchKernelGGL(gsukf_closed_loop_kernel, dim3((unsigned)s->B), dim3(kSmallBlock), 0, (hipStream_t)stream, a);
+    GSE_REQUIRE(s->args_buffer && aligned16(s->args_buffer),
+                "gse_gsukf_closed_loop: args_buffer must be a 16-byte aligned device buffer of GSE_LOOP_ARGS_BYTES bytes");
+    static_assert(sizeof(GsukfLoopArgs) <= GSE_LOOP_ARGS_BYTES, "GSE_LOOP_ARGS_BYTES is too small");
+    // (from the stack: the runtime stages a pageable source before it returns, so `a` may go out of scope)
+    GSE_HIP_CHECK(hipMemcpyAsync(s->args_buffer, &a, sizeof a, hipMemcpyHostToDevice, (hipStream_t)stream));
+    hipLaunchKernelGGL(gsukf_closed_loop_kernel, dim3((unsigned)s->B), dim3(kSmallBlock), 0, (hipStream_t)stream,
+                       (const GsukfLoopArgs*)s->args_buffer);
     GSE_LAUNCH_CHECK("gsukf_closed_loop_kernel");
     return GSE_OK;
 }

@@ -25,6 +25,17 @@ struct MpcLawDev {
 
 constexpr int kMpcWavesPerBlock = 4;
 
+// Values a long-running loop should recompute per iteration rather than keep: after these the compiler cannot tell that they
+// are the loop's invariants, so nothing derived from them (masks of unrolled bounds checks, addresses) is hoisted and kept
+// live -- in scalar registers that spill into vector lanes, then in scratch -- across every phase of the iteration.
+__device__ __forceinline__ int per_iteration_uniform(int v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ int per_iteration(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ void per_iteration_uniform(MpcLawDev& l) {
+    asm volatile("" : "+s"(l.n_theta), "+s"(l.n_u), "+s"(l.n_y), "+s"(l.n_rows), "+s"(l.max_sweeps));
+    asm volatile("" : "+s"(l.Gc), "+s"(l.gc0), "+s"(l.S), "+s"(l.lo), "+s"(l.hi));
+    asm volatile("" : "+s"(l.Gu), "+s"(l.gu0), "+s"(l.Tu), "+s"(l.Gy), "+s"(l.gy0), "+s"(l.Ty));
+}
+
 // The law for one rollout, by one wavefront.  theta_lane: lane k < n_theta holds theta[k].  On return lane k < n_u holds
 // du0[k] in out, lane 32 + k (k < n_y) holds y1[k]; the return value (uniform) is 1 if the sweeps converged.
 __device__ __forceinline__ int mpc_solve(const MpcLawDev& law, double theta_lane, int lane, double& out) {
@@ -210,7 +221,8 @@ struct PlantArgs {
 
 // The plant of the closed loop for rollout b, by ONE thread (sim_base.py:278-287, BioreactorModel.py:95-122): Euler step of the
 // fp64 model, clamp, state noise, outputs, measurement noise.  dp: the two draws' parameters in LDS (state, measurement).
-__device__ __forceinline__ void plant_step_one(double* __restrict__ X, const double* __restrict__ u, int64_t b,
+// b indexes the arrays, elem is the rollout's random-number element (the same unless the caller keeps its rollout's rows at 0).
+__device__ __forceinline__ void plant_step_one(double* __restrict__ X, const double* __restrict__ u, int64_t b, int64_t elem,
                                                const DrawParams* dp, const RngKey& rng_state, const RngKey& rng_meas, double dt,
                                                double* __restrict__ y, double* __restrict__ y_meas, double* __restrict__ z,
                                                double* __restrict__ log_x, double* __restrict__ log_u,
@@ -231,7 +243,7 @@ __device__ __forceinline__ void plant_step_one(double* __restrict__ X, const dou
 #pragma unroll
         for (int k = 0; k < 5; ++k) e[k] = inj_state[b * 5 + k];
     } else {
-        rng_words8(rng_state, (uint64_t)b, 0u, wd);
+        rng_words8(rng_state, (uint64_t)elem, 0u, wd);
         mixture_draw5(dp[0], wd, e);                       // state_pdf.draw(): fp32 values added to the fp64 state
     }
 #pragma unroll
@@ -250,7 +262,7 @@ __device__ __forceinline__ void plant_step_one(double* __restrict__ X, const dou
         e[0] = inj_meas[b * 2];
         e[1] = inj_meas[b * 2 + 1];
     } else {
-        rng_words8(rng_meas, (uint64_t)b, 0u, wd);
+        rng_words8(rng_meas, (uint64_t)elem, 0u, wd);
         mixture_draw5(dp[1], wd, e);                       // measurement noise on the controlled outputs (Cg, Cfa)
     }
     out[0] += (double)e[0];

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void plant_step_kernel(double* __restrict__ X,
     }
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    plant_step_one(X, u, b, dp, a.rng_state, a.rng_meas, a.dt, y, y_meas, z, log_x, log_u, inj_state, inj_meas);
+    plant_step_one(X, u, b, b, dp, a.rng_state, a.rng_meas, a.dt, y, y_meas, z, log_x, log_u, inj_state, inj_meas);
 }
 
 // ------------------------------------------------------------------------------------------------

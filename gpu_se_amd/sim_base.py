@@ -533,6 +533,9 @@ class BatchedSimulation:
         spec.y_pred, spec.known = y_pred.data_ptr(), known.data_ptr()
         spec.us, spec.xs, spec.ys, spec.ys_meas, spec.moments = (t_.data_ptr() for t_ in (us, xs, ys, ys_meas, moments))
         spec.status, spec.chol_status = status.data_ptr(), f._status.data_ptr()
+        args_buffer = torch.empty(_lib.GSE_LOOP_ARGS_BYTES, dtype=torch.uint8, device=dev)
+        spec.args_buffer = args_buffer.data_ptr()
+        keep_alive = keep_alive + (args_buffer,)
         _lib.check(lib.gse_gsukf_closed_loop(ctypes.byref(spec), stream))
         f._step += int((sched & 1).sum())
         self._keep_alive = keep_alive

@@ -479,7 +479,9 @@ typedef struct gse_loop_spec {
     double *us, *xs, *ys, *ys_meas, *moments;    /* [ticks][B][2 | 5 | 5 | 5 | 26] */
     int32_t *status;                             /* [ticks][B]: 1 where the MPC's QP was not solved */
     int32_t *chol_status;                        /* [1]: counts covariances that could not be factorised */
+    void *args_buffer;                           /* GSE_LOOP_ARGS_BYTES of device memory for the kernel's argument block */
 } gse_loop_spec;
+#define GSE_LOOP_ARGS_BYTES 4096
 int gse_gsukf_closed_loop(const gse_loop_spec *spec /* host */, void *stream);
 
 /* Rows of estimator moments (26 doubles each: gse_pf_moments / gse_gsukf_moments26) -> per row [mean (5), largest singular
