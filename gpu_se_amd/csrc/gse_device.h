@@ -130,22 +130,28 @@ struct DrawParams {
     float cumw[GSE_MAX_ND];                 // normalised cumulative component weights
     float mean[GSE_MAX_ND][GSE_NX];
     float chol[GSE_MAX_ND][15];             // packed lower triangle, row-major: (0,0) (1,0) (1,1) (2,0) ...
-    float pad[2];                           // sizeof = 352, a multiple of 16 (LDS carve alignment)
+    int32_t diagonal;                       // every component's factor is diagonal (pack_draw): see mixture_transform5
+    float pad;                              // sizeof = 352, a multiple of 16 (LDS carve alignment)
 };
 static_assert(sizeof(DrawParams) % 16 == 0, "DrawParams must keep LDS offsets 16-byte aligned");
 
-// One draw from the mixture for a 5-d state: words -> component + 5 normals -> mean + L n.
-__device__ __forceinline__ void mixture_draw5(const DrawParams& dp, const uint32_t (&wd)[8], float (&out)[5]) {
-    float n[6];
-    box_muller(wd[0], wd[1], n[0], n[1]);
-    box_muller(wd[2], wd[3], n[2], n[3]);
-    box_muller(wd[4], wd[5], n[4], n[5]);
-    const float uc = (float)(wd[7] >> 8) * 5.9604644775390625e-08f;   // [0, 1) with 24 bits
+// mean + L n of the component a selector word picks.  L n row by row, j in order, each step one FMA.  A mixture whose factors
+// are all diagonal (independent noise per state: the bioreactor's, sim_base.py:117-140) takes the short way -- the entries
+// below the diagonal are zeros, fma(0, n_j, acc) = acc for the finite n_j Box-Muller gives and an acc that is not -0
+// (pack_draw turns a mean of -0 into +0), so the five FMAs on the diagonal give the same bits as the fifteen; the flag is the
+// same for every lane, the branch is a scalar one.  n: at least 5 normals.
+__device__ __forceinline__ void mixture_transform5(const DrawParams& dp, uint32_t selector, const float* n, float (&out)[5]) {
+    const float uc = (float)(selector >> 8) * 5.9604644775390625e-08f;   // [0, 1) with 24 bits
     int comp = 0;
 #pragma unroll
     for (int d = 0; d < GSE_MAX_ND - 1; ++d) comp += (d < dp.nd - 1 && uc >= dp.cumw[d]) ? 1 : 0;
     const float* L = dp.chol[comp];
     const float* m = dp.mean[comp];
+    if (__builtin_amdgcn_readfirstlane(dp.diagonal)) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) out[k] = fmaf(L[k * (k + 1) / 2 + k], n[k], m[k]);
+        return;
+    }
     int at = 0;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -155,6 +161,15 @@ __device__ __forceinline__ void mixture_draw5(const DrawParams& dp, const uint32
         at += k + 1;
         out[k] = acc;
     }
+}
+
+// One draw from the mixture for a 5-d state: words -> component + 5 normals -> mean + L n.
+__device__ __forceinline__ void mixture_draw5(const DrawParams& dp, const uint32_t (&wd)[8], float (&out)[5]) {
+    float n[6];
+    box_muller(wd[0], wd[1], n[0], n[1]);
+    box_muller(wd[2], wd[3], n[2], n[3]);
+    box_muller(wd[4], wd[5], n[4], n[5]);
+    mixture_transform5(dp, wd[7], n, out);
 }
 
 // The state noise of the four particles of a group (see rng_block_of_group): blocks 0..4 give normals 4b .. 4b+3 (two
@@ -172,23 +187,7 @@ __device__ __forceinline__ void mixture_draw5x4(const DrawParams& dp, const RngK
         box_muller(w[2], w[3], n[4 * blk + 2], n[4 * blk + 3]);
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const float uc = (float)(cw[p] >> 8) * 5.9604644775390625e-08f;   // [0, 1) with 24 bits
-        int comp = 0;
-#pragma unroll
-        for (int d = 0; d < GSE_MAX_ND - 1; ++d) comp += (d < dp.nd - 1 && uc >= dp.cumw[d]) ? 1 : 0;
-        const float* L = dp.chol[comp];
-        const float* m = dp.mean[comp];
-        int at = 0;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            float acc = m[k];
-#pragma unroll
-            for (int j = 0; j <= k; ++j) acc = fmaf(L[at + j], n[5 * p + j], acc);
-            at += k + 1;
-            out[p][k] = acc;
-        }
-    }
+    for (int p = 0; p < 4; ++p) mixture_transform5(dp, cw[p], n + 5 * p, out[p]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -547,6 +547,30 @@ __device__ __forceinline__ void stage_bank_out(const float* stage, float* mu_b, 
     }
 }
 
+// A lane's OWN row between global memory and its LDS row, without the workgroup: a Gaussian's 5 + 25 floats are contiguous
+// in the filter's arrays, dword-aligned, and global memory takes 16-byte accesses at dword alignment -- eight loads (stores)
+// per lane and no index arithmetic, where the staged copy above spends 10 vector instructions per element on i / 5, i / 25 and
+// the padded LDS address (615 of the 4 467 a wavefront of the fused predict + update issues, a kernel bound by exactly that).
+// The accesses of a wavefront are rows 20 / 100 bytes apart: every cache line is used whole, by several instructions, which
+// the texture path -- idle in these kernels -- absorbs.
+#ifndef GSE_GSUKF_DIRECT_ROWS
+#define GSE_GSUKF_DIRECT_ROWS 1
+#endif
+__device__ __forceinline__ void lane_row_in(float* mine, const float* __restrict__ mu_row, const float* __restrict__ P_row) {
+    float r[kRow];
+    __builtin_memcpy(r, mu_row, kNx * sizeof(float));
+    __builtin_memcpy(r + kNx, P_row, kNxx * sizeof(float));
+#pragma unroll
+    for (int k = 0; k < kRow; ++k) mine[k] = r[k];
+}
+__device__ __forceinline__ void lane_row_out(const float* mine, float* __restrict__ mu_row, float* __restrict__ P_row) {
+    float r[kRow];
+#pragma unroll
+    for (int k = 0; k < kRow; ++k) r[k] = mine[k];
+    __builtin_memcpy(mu_row, r, kNx * sizeof(float));
+    __builtin_memcpy(P_row, r + kNx, kNxx * sizeof(float));
+}
+
 #ifndef GSE_GSUKF_PRED_WAVES
 #define GSE_GSUKF_PRED_WAVES 1   // waves per SIMD the register allocator must leave room for (tuning knob)
 #endif
@@ -635,10 +659,20 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
         uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
         for (int i = t; i < (int)(sizeof(DrawParams) / 4); i += kLaneBank) dst[i] = src[i];
     }
-    stage_bank_in(stage, mu_b, P_b, nloc);
     const FilterIO bio = bank_inputs(a.io, a.u_dev, a.z_dev, b);
+#if GSE_GSUKF_DIRECT_ROWS
+    if (!kInjected) __syncthreads();                                   // (the draw's parameters)
+    if (t < nloc) {
+        float* mine = stage + t * kStageStride;
+        lane_row_in(mine, mu_b + t * kNx, P_b + t * kNxx);
+        gsukf_predict_lane<kInjected>(mine, b, g0 + t, N, noise, dp, status, a, bio);
+        lane_row_out(mine, mu_b + t * kNx, P_b + t * kNxx);
+    }
+#else
+    stage_bank_in(stage, mu_b, P_b, nloc);
     if (t < nloc) gsukf_predict_lane<kInjected>(stage + t * kStageStride, b, g0 + t, N, noise, dp, status, a, bio);
     stage_bank_out(stage, mu_b, P_b, nloc);
+#endif
 }
 
 template <int kUnused>
@@ -651,12 +685,21 @@ __global__ __launch_bounds__(kLaneBank) void gsukf_update_lanes_kernel(float* __
     const int nloc = (int)min((int64_t)kLaneBank, N - g0);
     float* mu_b = mu + ((int64_t)b * N + g0) * kNx;
     float* P_b = P + ((int64_t)b * N + g0) * kNxx;
-    stage_bank_in(stage, mu_b, P_b, nloc);
     const FilterIO bio = bank_inputs(a.io, a.u_dev, a.z_dev, b);
+#if GSE_GSUKF_DIRECT_ROWS
+    if (t < nloc) {
+        float* mine = stage + t * kStageStride;
+        lane_row_in(mine, mu_b + t * kNx, P_b + t * kNxx);
+        gsukf_update_lane(mine, w + (int64_t)b * N + g0 + t, bio.u0, bio.u1, bio.z0, bio.z1, status, a.pdf, a.sw);
+        lane_row_out(mine, mu_b + t * kNx, P_b + t * kNxx);
+    }
+#else
+    stage_bank_in(stage, mu_b, P_b, nloc);
     if (t < nloc)
         gsukf_update_lane(stage + t * kStageStride, w + (int64_t)b * N + g0 + t, bio.u0, bio.u1, bio.z0, bio.z1, status, a.pdf,
                           a.sw);
     stage_bank_out(stage, mu_b, P_b, nloc);
+#endif
 }
 
 // predict and update of a large bank in ONE launch (the class defers predict() until update()): what predict leaves in
@@ -687,15 +730,27 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
         uint32_t* dst = reinterpret_cast<uint32_t*>(&dp);
         for (int i = t; i < (int)(sizeof(DrawParams) / 4); i += kLaneBank) dst[i] = src[i];
     }
+#if GSE_GSUKF_DIRECT_ROWS
+    if (!kInjected) __syncthreads();                                   // (the draw's parameters)
+#else
     if (anc)
         stage_bank_in_gathered(stage, anc_s, mu_in + (int64_t)b * N * kNx, P_in + (int64_t)b * N * kNxx,
                                anc + (int64_t)b * N + g0, nloc);
     else
         stage_bank_in(stage, mu_b, P_b, nloc);
+#endif
     const FilterIO bio = bank_inputs(a.pred.io, a.pred.u_dev, a.pred.z_dev, b);
     float w_new = 0.0f;
     if (t < nloc) {
         float* mine = stage + t * kStageStride;
+#if GSE_GSUKF_DIRECT_ROWS
+        if (anc) {
+            const int64_t row = (int64_t)b * N + anc[(int64_t)b * N + g0 + t];
+            lane_row_in(mine, mu_in + row * kNx, P_in + row * kNxx);
+        } else {
+            lane_row_in(mine, mu_b + t * kNx, P_b + t * kNxx);
+        }
+#endif
         gsukf_predict_lane<kInjected>(mine, b, g0 + t, N, noise, dp, status, a.pred, bio);
         float* wg = w + (int64_t)b * N + g0 + t;
         w_new = *wg;
@@ -717,7 +772,11 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
             if (t == 63) quarter_sums[(int64_t)b * (4 * ((N + kTile - 1) / kTile)) + blockIdx.x] = inc;
         }
     }
+#if GSE_GSUKF_DIRECT_ROWS
+    if (t < nloc) lane_row_out(stage + t * kStageStride, mu_b + t * kNx, P_b + t * kNxx);
+#else
     stage_bank_out(stage, mu_b, P_b, nloc);
+#endif
 }
 
 // The copy of a deferred resample on its own (an accessor looks at the bank before the next predict + update): rows by index.

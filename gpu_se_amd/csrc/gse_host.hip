@@ -51,13 +51,18 @@ void pack_draw(DrawParams& dp, const gse_mixture& m) {
     double total = 0.0;
     for (int d = 0; d < m.nd; ++d) total += (double)m.weights[d];
     double run = 0.0;
+    dp.diagonal = 1;
     for (int d = 0; d < m.nd; ++d) {
         run += (double)m.weights[d];
         dp.cumw[d] = (float)(run / total);
         int at = 0;
         for (int k = 0; k < GSE_NX; ++k) {
-            dp.mean[d][k] = k < m.nx ? m.means[d][k] : 0.f;
-            for (int j = 0; j <= k; ++j) dp.chol[d][at++] = (k < m.nx && j < m.nx) ? m.chol[d][k][j] : 0.f;
+            dp.mean[d][k] = (k < m.nx ? m.means[d][k] : 0.f) + 0.0f;       // (-0 -> +0: mixture_transform5)
+            for (int j = 0; j <= k; ++j) {
+                const float l = (k < m.nx && j < m.nx) ? m.chol[d][k][j] : 0.f;
+                if (j < k && l != 0.f) dp.diagonal = 0;
+                dp.chol[d][at++] = l;
+            }
         }
     }
     for (int d = m.nd; d < GSE_MAX_ND; ++d) dp.cumw[d] = 2.0f;

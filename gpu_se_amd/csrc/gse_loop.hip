@@ -5,7 +5,7 @@
 // Why: a tick of such a loop is five small launches (the one-launch filter cycle, two for the moments, the controller, the
 // plant: sim_base.py:243-309 for B rollouts) and the device idles between them -- 499 ticks took 0.021 s, which was the rate at
 // which the host can enqueue (42 us per tick), not device work.  Rollouts do not talk to each other, so nothing forces a
-// launch boundary: here a tick is ~15 us of dependent work and the loop 7 ms.  Every piece is the device function the
+// launch boundary: here a tick is 19 us of dependent work and the loop 9.7 ms (DESIGN.md section 6 has the phases).  Every piece is the device function the
 // separate launches run (gsukf_predict_block / gsukf_update_block / small_bank_ancestors of the cycle kernel, the wavefront
 // reduction of gsukf_moments_kernel, loop_control_wave, plant_step_one), same Philox elements and steps, same order of
 // operations within a tick -- so the records are those of the launch-per-piece loop bit for bit
