@@ -57,12 +57,20 @@ bool launch_ancestors(const float* w, float* w_out, int32_t* idx, int B, int64_t
     const int T = (int)tiles_of(N);
     if (T > kAncestorsMaxT) return false;
     const size_t lds = ((size_t)(T + 1) * sizeof(double) + (size_t)T + 7) & ~(size_t)7;
+    static const bool by_search = getenv("GSE_ANCESTORS_BY_SEARCH") != nullptr;     // (the round-2 kernel, kept for A/B runs)
     if (quarter_sums_valid) {           // the update launch left the quarter sums of these weights in the workspace
-        hipLaunchKernelGGL(ancestors_kernel<1>, dim3(T, B), dim3(kBlock), lds, st, w, gsukf_quarter_sums(ws), w_out, idx, N, T, ra);
+        if (by_search)
+            hipLaunchKernelGGL(ancestors_kernel<1>, dim3(T, B), dim3(kBlock), lds, st, w, gsukf_quarter_sums(ws), w_out, idx, N, T, ra);
+        else
+            hipLaunchKernelGGL(ancestors_scatter_kernel<1>, dim3(T, B), dim3(kBlock), lds, st, w, gsukf_quarter_sums(ws), w_out, idx,
+                               N, T, ra);
         return true;
     }
     hipLaunchKernelGGL(tile_sum_kernel, dim3(T, B), dim3(kBlock), 0, st, w, ws.tile_sums, N, N, T);
-    hipLaunchKernelGGL(ancestors_kernel<0>, dim3(T, B), dim3(kBlock), lds, st, w, ws.tile_sums, w_out, idx, N, T, ra);
+    if (by_search)
+        hipLaunchKernelGGL(ancestors_kernel<0>, dim3(T, B), dim3(kBlock), lds, st, w, ws.tile_sums, w_out, idx, N, T, ra);
+    else
+        hipLaunchKernelGGL(ancestors_scatter_kernel<0>, dim3(T, B), dim3(kBlock), lds, st, w, ws.tile_sums, w_out, idx, N, T, ra);
     return true;
 }
 

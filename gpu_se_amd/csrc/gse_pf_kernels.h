@@ -1459,6 +1459,180 @@ __global__ __launch_bounds__(kBlock) void ancestors_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same ancestors by the INVERSE MAP (round 3): one workgroup per tile of 1024 WEIGHTS.  Instead of every output searching
+// for its ancestor -- tile prefix, a bisection for the tile, then per flagged tile a load, a scan, four divisions and a
+// bisection in LDS: ten dependent steps of 0.5-1 us on a kernel of 256 workgroups, 10.3 us at 2^18 Gaussians -- every KEY
+// says which outputs it owns: x[k] formed exactly as above (and as cumsum_kernel forms it: P0 + (excl + s_p) clamped to the
+// tile's pinned last key P1), F(k) = #{ j : u_j <= fl(x[k] / W) } by OffspringCount (gse_device.h: arithmetic, settled with the
+// reference's own comparison inside the guard band), and key k writes itself to idx[F(k-1) .. F(k)).  Same keys, the
+// comparison the search applies read the other way round: the same ancestors (tests/test_gpu_gsukf.py holds both against the
+// oracle and against each other).  The tile's weights and the tile sums are loaded side by side and scanned with ONE
+// exchange; what remains is load -> scan -> count -> store.  The stores of a key are its own thread's while they are few, sixteen
+// lanes' up to 256, a wavefront's up to 4096 and the workgroup's beyond (a degenerate bank -- one Gaussian owning every output -- is 1 MB of
+// stores by one workgroup at 2^18); profiles/r03_gsukf_ancestors_tail.txt times the adversarial patterns on both kernels.
+// ------------------------------------------------------------------------------------------------
+constexpr int kInlineOffspring = 16;     // a key with at most this many offspring is written by its own thread
+constexpr int kGroupOffspring = 256;      // ... this many: by 16 lanes
+constexpr int kWaveOffspring = 4096;      // ... this many: by one wavefront; beyond: by the whole workgroup
+
+template <int kQuarters>
+__global__ __launch_bounds__(kBlock) void ancestors_scatter_kernel(const float* __restrict__ w, const double* __restrict__ tile_sums,
+                                                                   float* __restrict__ w_out, int32_t* __restrict__ idx_out,
+                                                                   int64_t N, int T, const ResampleArgs ra) {
+    __shared__ double red[8];
+    __shared__ int32_t wave_last[4];
+    __shared__ int32_t heavy_n, heavier_n;
+    __shared__ int32_t heavy_lo[kTile], heavy_hi[kTile], heavy_k[kTile];
+    extern __shared__ double anc_lds[];                // pfx [T + 1] doubles
+    double* pfx_s = anc_lds;
+    const int b = blockIdx.y, tid = threadIdx.x, tq = blockIdx.x;
+    const int lane = tid & 63, wvf = tid >> 6;
+    const float* wb = w + (int64_t)b * N;
+    const int64_t k0 = (int64_t)tq * kTile + (int64_t)tid * kPerThread;
+    // both loads in flight together
+    const float4 wv = load_weights4(wb, k0, N, N);
+    const double* sums = tile_sums + (int64_t)b * T * (kQuarters ? 4 : 1);
+    const int m = (T + kBlock - 1) / kBlock;
+    const int qlo = tid * m;
+    const int nq = (int)((N + kBlock - 1) / kBlock);                   // quarters that exist (the rest of the last tile: 0)
+    double sv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if constexpr (kQuarters) {
+            double q4[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int at = 4 * (qlo + i) + h;
+                q4[h] = (i < m && qlo + i < T && at < nq) ? sums[at] : 0.0;
+            }
+            sv[i] = ((q4[0] + q4[1]) + q4[2]) + q4[3];
+        } else {
+            sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
+        }
+    }
+    double chunk = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) chunk += sv[i];
+    double sc[kPerThread];
+    sc[0] = (k0 + 0 < N) ? (double)wv.x : 0.0;
+    sc[1] = sc[0] + ((k0 + 1 < N) ? (double)wv.y : 0.0);
+    sc[2] = sc[1] + ((k0 + 2 < N) ? (double)wv.z : 0.0);
+    sc[3] = sc[2] + ((k0 + 3 < N) ? (double)wv.w : 0.0);
+    // the tile prefix of the filter and this tile's exclusive scan: block_exclusive_scan's arithmetic for each, one exchange
+    double run, excl, W;
+    {
+        const double inc0 = wave_inclusive_scan(chunk, lane), inc1 = wave_inclusive_scan(sc[3], lane);
+        if (lane == 63) {
+            red[wvf] = inc0;
+            red[4 + wvf] = inc1;
+        }
+        if (tid == 0) heavy_n = heavier_n = 0;
+        __syncthreads();
+        const double a0 = red[0], a1 = red[1], a2 = red[2], a3 = red[3];
+        double base0 = 0.0, base1 = 0.0;
+        if (wvf > 0) { base0 = a0; base1 = red[4]; }
+        if (wvf > 1) { base0 += a1; base1 += red[5]; }
+        if (wvf > 2) { base0 += a2; base1 += red[6]; }
+        W = ((a0 + a1) + a2) + a3;
+        run = base0 + wave_shift_up1(inc0);
+        excl = base1 + wave_shift_up1(inc1);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i < m && qlo + i < T) pfx_s[qlo + i] = run;
+        run += sv[i];
+    }
+    if (tid == 0) pfx_s[T] = W;
+    __syncthreads();
+    const double Nd = (double)N, r = ra.r[b];
+    const float w_uniform = (float)(1.0 / Nd);
+    float* wo = w_out + (int64_t)b * N;
+    int32_t* io = idx_out + (int64_t)b * N;
+    const bool degenerate = !(W > 0.0) || !(W < INFINITY);             // (gather_kernel: every offspring copies element 0)
+    // the new weights of this tile's outputs (and their ancestors when the weights do not sum to a positive finite number)
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p)
+        if (k0 + p < N) {
+            wo[k0 + p] = w_uniform;
+            if (degenerate) io[k0 + p] = 0;
+        }
+    if (degenerate) return;
+    const double P0 = pfx_s[tq], P1 = pfx_s[tq + 1];
+    const int32_t tile_last = (int32_t)(min((int64_t)(tq + 1) * kTile, N) - 1);
+    OffspringCount F;
+    F.init(N, r, W);
+    const int32_t n32 = (int32_t)N, kk = (int32_t)k0;
+    double xs[kPerThread];
+    int32_t fs[kPerThread];
+    bool near[kPerThread];
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p) {
+        xs[p] = (kk + p >= tile_last) ? P1 : fmin(P0 + (excl + sc[p]), P1);
+        fs[p] = F.candidate(xs[p], near[p]);
+    }
+    if (near[0] || near[1] || near[2] || near[3]) {
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p)
+            if (near[p]) fs[p] = F.settle(xs[p], fs[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p) fs[p] = min(max(fs[p] + 1, 0), n32);
+    // F of the key before this thread's first: the lane below, the wavefront below, the tile below (whose last key is P0)
+    if (lane == 63) wave_last[wvf] = fs[kPerThread - 1];
+    const int32_t tile_first_f = tq ? F(P0) : 0;
+    __syncthreads();
+    int32_t prev = (int32_t)wave_shift_up1((uint32_t)fs[kPerThread - 1]);
+    if (lane == 0) prev = wvf ? wave_last[wvf - 1] : min(max(tile_first_f, 0), n32);
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p) {
+        const int32_t lo = prev, hi = max(fs[p], prev);
+        prev = hi;
+        if (kk + p > tile_last || hi == lo) continue;
+        if (hi - lo <= kInlineOffspring) {
+            // (the common case: a handful; the first four without a loop)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (lo + q < hi) io[lo + q] = kk + p;
+            for (int32_t j = lo + 4; j < hi; ++j) io[j] = kk + p;
+        } else {
+            // two lists in one array: up to kGroupOffspring from the bottom, beyond from the top
+            const int slot = (hi - lo <= kGroupOffspring) ? atomicAdd(&heavy_n, 1) : kTile - 1 - atomicAdd(&heavier_n, 1);
+            heavy_lo[slot] = lo;
+            heavy_hi[slot] = hi;
+            heavy_k[slot] = kk + p;
+        }
+    }
+    __syncthreads();
+    const int n_heavy = heavy_n, n_heavier = heavier_n;
+    // keys with up to kGroupOffspring offspring: 16 lanes each, sixteen keys side by side ...
+    for (int e = tid >> 4; e < n_heavy; e += kBlock / 16) {
+        const int32_t lo = heavy_lo[e], hi = heavy_hi[e], k = heavy_k[e];
+        for (int32_t j = lo + (tid & 15); j < hi; j += 16) io[j] = k;
+    }
+    // ... up to kWaveOffspring: one wavefront each ...
+    for (int e = wvf; e < n_heavier; e += kBlock / 64) {
+        const int32_t lo = heavy_lo[kTile - 1 - e], hi = heavy_hi[kTile - 1 - e], k = heavy_k[kTile - 1 - e];
+        if (hi - lo > kWaveOffspring) continue;
+        for (int32_t j = lo + lane; j < hi; j += 64) io[j] = k;
+    }
+    // ... and the few that own thousands: the whole workgroup, 16 bytes per store
+    for (int e0 = 0; e0 < n_heavier; ++e0) {
+        const int e = kTile - 1 - e0;
+        const int32_t k = heavy_k[e], count = heavy_hi[e] - heavy_lo[e];
+        if (count <= kWaveOffspring) continue;
+        int32_t* p = io + heavy_lo[e];
+        // up to three single entries to a 16-byte boundary, four entries per store from there, the rest singly
+        const int head = min(count, (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u)) >> 2) & 3u));
+        if (tid < head) p[tid] = k;
+        const int body4 = (count - head) >> 2;
+        int4* q = reinterpret_cast<int4*>(p + head);
+        for (int i = tid; i < body4; i += kBlock) q[i] = make_int4(k, k, k, k);
+        const int done = head + 4 * body4;
+        if (tid < count - done) p[done + tid] = k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // moments
 // ------------------------------------------------------------------------------------------------
 // Per-workgroup partial sums of {w, w d, w d d^T} with d = x - pivot, fp64; blocks stride over the tiles.

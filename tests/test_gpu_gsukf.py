@@ -305,6 +305,34 @@ def test_one_launch_resample_gives_the_ancestors_of_the_three_kernel_path(n):
             np.testing.assert_array_equal(gf.weights.get(), np.full(n, np.float32(1.0 / n)))
 
 
+@pytest.mark.parametrize("n", [4097, 70001, (1 << 18) + 5])
+def test_inverse_map_ancestors_on_adversarial_weights(n):
+    """The deferred resample of a large bank finds its ancestors by the inverse map (ancestors_scatter_kernel: every key writes
+    itself to the outputs it owns; keys with many offspring are left to the whole workgroup): on weights chosen to hurt --
+    exact ties, one Gaussian owning every output, heavy Gaussians at tile edges, weightless stretches, steps of four decades,
+    sums that are zero or NaN -- and with r = 0, bit for bit the ancestors of the eager route (cumsum_kernel + the searching
+    gather_kernel), which the tests above hold against the oracle."""
+    from tests.gpu_util import adversarial_weights
+    xss = orc.steady_state()
+    rng = np.random.default_rng(n + 1)
+    means = (xss[None, :] + rng.standard_normal((n, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    for name, w in adversarial_weights(n, rng).items():
+        w = w.astype(np.float32)
+        for r in (0.0, float(rng.random()), 1.0 - 2.0 ** -53):
+            got = {}
+            for lazy in (True, False):
+                gf = make(n, means)
+                gf.lazy = lazy
+                gf.weights = w
+                got[lazy] = gf.resample(r=r, return_index=True).get()
+            np.testing.assert_array_equal(got[True], got[False], err_msg="%s r=%r" % (name, r))
+            if np.isfinite(w.sum()) and w.sum() > 0:
+                own = orc.systematic_index(w.astype(np.float64), r)
+                assert np.sum(own != got[True]) <= 2, (name, r, int(np.sum(own != got[True])))
+            else:
+                assert not got[True].any(), name
+
+
 def test_large_bank_deferred_resample_equals_the_eager_calls():
     """Large banks defer the row copy of resample() into the next predict + update launch (gse_gsukf_resample_begin +
     gse_gsukf_predict_update_from): over whole cycles bit-identical to one kernel per method (lazy = False), ancestors
