@@ -63,6 +63,13 @@ class LoopSpec(ctypes.Structure):
                                           "args_buffer")]
 
 
+class LoopTail(ctypes.Structure):
+    """struct gse_loop_tail (include/gse.h)."""
+    _fields_ = [(name, c_vp) for name in ("law", "glue", "y_meas", "u", "y_pred", "known", "status", "X")] + [("dt", c_d)] + \
+               [(name, c_vp) for name in ("state_noise", "meas_noise", "rng", "state_draw", "meas_draw", "y", "y_meas_out", "z",
+                                          "log_x", "log_u")]
+
+
 P_MIX = ctypes.POINTER(Mixture)
 P_RNG = ctypes.POINTER(Rng)
 P_D = ctypes.POINTER(c_d)
@@ -83,6 +90,8 @@ PROTOTYPES = {
                                    P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_vp, c_vp]),
     "gse_pf_moments": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
     "gse_pf_moments_resampled": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_i64, P_D, ctypes.c_int, c_vp, c_vp, c_vp]),
+    "gse_pf_moments_resampled_tail": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_i64, P_D, ctypes.c_int, c_vp, c_vp,
+                                                     ctypes.POINTER(LoopTail), c_vp]),
     "gse_model_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, c_u64, ctypes.c_char_p, ctypes.c_char_p,
                                         ctypes.c_char_p, ctypes.POINTER(c_vp)]),
     "gse_model_destroy": (ctypes.c_int, [c_vp]),

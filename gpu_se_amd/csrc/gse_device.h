@@ -428,6 +428,45 @@ __device__ __forceinline__ void block_sums(double (&v)[kCount], double* lds, Emi
     }
 }
 
+// Fixed-order reduction of a filter's per-workgroup moment partials -> out[b][0 .. width); appends pivot_count pivot values.
+// 1024 threads: thread (g, c) = (tid / 64, tid % 64) adds the partials q = g, g + 16, ... of column c into 8 interleaved
+// accumulators (8 loads in flight), folds them pairwise, and the 16 group totals are folded pairwise after one barrier: a
+// fixed order, so the result does not depend on timing; <= 4 dependent load rounds for 512 partials.
+constexpr int kFinishGroups = 16;
+// pb: THIS filter's partials, rows of `pitch` doubles.
+__device__ __forceinline__ void moments_finish_block(const double* __restrict__ pb, int pitch, int nblk, int width,
+                                                     double* __restrict__ out, int out_stride,
+                                                     const float* __restrict__ pivot_src, int64_t pivot_filter_stride,
+                                                     int64_t pivot_elem_stride, int pivot_at, int pivot_count, int b,
+                                                     double (*part)[64]) {
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (c < width) {
+        for (int q0 = g; q0 < nblk; q0 += 8 * kFinishGroups) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = q0 + j * kFinishGroups;
+                if (q < nblk) a[j] += pb[(int64_t)q * pitch + c];
+            }
+        }
+    }
+    part[g][c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (g == 0 && c < width) {
+        double t[kFinishGroups];
+#pragma unroll
+        for (int k = 0; k < kFinishGroups; ++k) t[k] = part[k][c];
+#pragma unroll
+        for (int span = 1; span < kFinishGroups; span *= 2)
+#pragma unroll
+            for (int k = 0; k < kFinishGroups; k += 2 * span) t[k] += t[k + span];
+        out[(int64_t)b * out_stride + c] = t[0];
+    }
+    if ((int)threadIdx.x < pivot_count)
+        out[(int64_t)b * out_stride + pivot_at + threadIdx.x] =
+            (double)pivot_src[(int64_t)b * pivot_filter_stride + threadIdx.x * pivot_elem_stride];
+}
+
 // Exclusive scan over the workgroup of one value per thread; also returns the workgroup total.
 __device__ __forceinline__ double block_exclusive_scan(double v, double* lds, double& total) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

@@ -147,6 +147,10 @@ bool launch_ancestors(const float* w, float* w_out, int32_t* idx, int B, int64_t
 // where the one-lane-per-Gaussian update launch leaves the quarter sums of its new weights ([B][4 T] doubles): the
 // workspace's first slot of per-thread tile prefixes, which only the particle filter uses
 inline double* gsukf_quarter_sums(const Workspace& ws) { return ws.scan[0]; }
+// the partial sums of gse_pf_moments_resampled without the reduction that finishes them (gse_pf.hip); returns the number of
+// partials per filter, or a negative error code
+int launch_moments_resampled_partials(const char* fn, const float* x, const float* w, int64_t ld, int B, int64_t N, const double* r,
+                                      int slot, void* workspace, hipStream_t st);
 bool launch_small_resample(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, hipStream_t st);
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
                            const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, int pivot_count, hipStream_t st);

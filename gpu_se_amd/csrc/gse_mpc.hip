@@ -79,6 +79,49 @@ __global__ __launch_bounds__(256) void plant_step_kernel(double* __restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------------------
+// The rest of a control tick of the resident closed loop in ONE launch (round 3): the reduction that finishes the estimator's
+// moment partials, the controller call and the plant -- three launches of one workgroup / wavefront / thread per rollout each
+// (4.7 + 8.0 + 4.6 us of a 192 us tick at 32 x 2^18 particles, mostly launch and drain), chained inside one workgroup per
+// rollout.  The device functions of the three kernels, in their order: the same records bit for bit.
+// ------------------------------------------------------------------------------------------------
+struct LoopTailArgs {
+    const double* partials;         // [B][kMomentBlocks][kMomentWidth]
+    int nblk, width, pivot_at, pivot_count;
+    const float* pivot_src;
+    int64_t pivot_filter_stride, pivot_elem_stride;
+    double* moments;                // [B][26]
+    MpcLawDev law;
+    LoopGlue glue;
+    const double* y_meas;
+    double *u, *y_pred;
+    int32_t *known, *status;
+    PlantArgs plant;
+    double *X, *y, *y_meas_out, *z, *log_x, *log_u;
+    const float *inj_state, *inj_meas;
+};
+
+__global__ __launch_bounds__(64 * kFinishGroups) void loop_tail_kernel(const LoopTailArgs a) {
+    __shared__ double part[kFinishGroups][64];
+    __shared__ DrawParams dp[2];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    {
+        const uint32_t* s0 = reinterpret_cast<const uint32_t*>(&a.plant.state_noise);
+        const uint32_t* s1 = reinterpret_cast<const uint32_t*>(&a.plant.meas_noise);
+        uint32_t* d0 = reinterpret_cast<uint32_t*>(&dp[0]);
+        uint32_t* d1 = reinterpret_cast<uint32_t*>(&dp[1]);
+        for (int i = tid; i < (int)(sizeof(DrawParams) / 4); i += 64 * kFinishGroups) { d0[i] = s0[i]; d1[i] = s1[i]; }
+    }
+    moments_finish_block(a.partials + (int64_t)b * kMomentBlocks * kMomentWidth, kMomentWidth, a.nblk, a.width, a.moments, 26,
+                         a.pivot_src, a.pivot_filter_stride, a.pivot_elem_stride, a.pivot_at, a.pivot_count, b, part);
+    __syncthreads();                                   // (the row, written to global memory by this workgroup)
+    if (tid < 64) loop_control_wave(a.law, a.glue, a.moments, a.y_meas, a.u, a.y_pred, a.known, a.status, nullptr, b, tid);
+    __syncthreads();                                   // (the new input)
+    if (tid == 0)
+        plant_step_one(a.X, a.u, b, b, dp, a.plant.rng_state, a.plant.rng_meas, a.plant.dt, a.y, a.y_meas_out, a.z, a.log_x,
+                       a.log_u, a.inj_state, a.inj_meas);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The per-tick records of a closed loop, from the estimator's moments (rows of 26 doubles: S0, S1[5], S2 upper[15], pivot[5];
 // gse_pf_moments / gse_gsukf_moments26): the point estimate weights @ particles = S1 + pivot S0 (filter/particle.py:318-320)
 // and the largest singular value of the covariance S2 - S1 e^T - e S1^T + S0 e e^T, e = mean - pivot (:322-327) -- for a
@@ -235,6 +278,41 @@ int gse_plant_step(double* X, const double* u, double dt, const gse_mixture* sta
     hipLaunchKernelGGL(plant_step_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, u, B, a, y,
                        y_meas, z, log_x, log_u, (const float*)nullptr, (const float*)nullptr);
     GSE_LAUNCH_CHECK("plant_step_kernel");
+    return GSE_OK;
+}
+
+int gse_pf_moments_resampled_tail(const float* x, const float* w, int64_t ld, int B, int64_t N, const double* r, int slot,
+                                  double* out, void* workspace, const gse_loop_tail* t, void* stream) {
+    GSE_REQUIRE(out && t, "gse_pf_moments_resampled_tail: null argument");
+    GSE_REQUIRE(t->glue && t->y_meas && t->u && t->y_pred && t->known && t->status && t->X && t->y && t->y_meas_out && t->z,
+                "gse_pf_moments_resampled_tail: null argument in the tail");
+    GSE_REQUIRE((t->state_draw != nullptr) == (t->meas_draw != nullptr),
+                "gse_pf_moments_resampled_tail: the plant's two draws are injected together or not at all");
+    LoopTailArgs a = {};
+    if (int rc = pack_mpc_law("gse_pf_moments_resampled_tail", t->law, a.law)) return rc;
+    if (int rc = pack_loop_glue("gse_pf_moments_resampled_tail", t->glue, a.law, a.glue)) return rc;
+    if (!t->state_draw) {
+        GSE_REQUIRE(t->state_noise && t->meas_noise && t->rng, "gse_pf_moments_resampled_tail: null noise argument");
+        if (int rc = check_mixture("gse_pf_moments_resampled_tail", t->state_noise, GSE_NX)) return rc;
+        if (int rc = check_mixture("gse_pf_moments_resampled_tail", t->meas_noise, GSE_NY)) return rc;
+        pack_draw(a.plant.state_noise, *t->state_noise);
+        pack_draw(a.plant.meas_noise, *t->meas_noise);
+        a.plant.rng_state = make_rng_key(*t->rng, kPurposePlantState);
+        a.plant.rng_meas = make_rng_key(*t->rng, kPurposePlantMeas);
+    }
+    a.plant.dt = t->dt;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = launch_moments_resampled_partials("gse_pf_moments_resampled_tail", x, w, ld, B, N, r, slot, workspace, st);
+    if (nblk < 0) return nblk;
+    a.partials = carve_workspace(workspace, B, N).partials;
+    a.nblk = nblk; a.width = 21; a.pivot_at = 21; a.pivot_count = GSE_NX;
+    a.pivot_src = x; a.pivot_filter_stride = GSE_NX * ld; a.pivot_elem_stride = ld;
+    a.moments = out;
+    a.y_meas = t->y_meas; a.u = t->u; a.y_pred = t->y_pred; a.known = t->known; a.status = t->status;
+    a.X = t->X; a.y = t->y; a.y_meas_out = t->y_meas_out; a.z = t->z; a.log_x = t->log_x; a.log_u = t->log_u;
+    a.inj_state = t->state_draw; a.inj_meas = t->meas_draw;
+    hipLaunchKernelGGL(loop_tail_kernel, dim3((unsigned)B), dim3(64 * kFinishGroups), 0, st, a);
+    GSE_LAUNCH_CHECK("loop_tail_kernel");
     return GSE_OK;
 }
 

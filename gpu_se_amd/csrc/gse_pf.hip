@@ -80,6 +80,33 @@ bool launch_small_resample(const float* w, float* w_out, int32_t* idx, int B, in
     return true;
 }
 
+#ifndef GSE_MOMRES_TOTAL_BLOCKS
+#define GSE_MOMRES_TOTAL_BLOCKS 1024   // workgroups of the resampled-moments pass over all filters (4 per CU: one resident generation)
+#endif
+#ifndef GSE_MOMRES_MIN_BLOCKS
+#define GSE_MOMRES_MIN_BLOCKS 32
+#endif
+int launch_moments_resampled_partials(const char* fn, const float* x, const float* w, int64_t ld, int B, int64_t N, const double* r,
+                                      int slot, void* workspace, hipStream_t st) {
+    if (int rc = check_pf_geometry(fn, B, N, ld)) return rc;
+    if (!(x && w && r && workspace)) return fail(GSE_ERR_ARG, "%s: null argument", fn);
+    if (!(aligned16(x) && aligned16(w) && aligned16(workspace))) return fail(GSE_ERR_ARG, "%s: pointers must be 16-byte aligned", fn);
+    if (!(slot == 0 || slot == 1)) return fail(GSE_ERR_ARG, "%s: slot must be 0 or 1", fn);
+    const int T = (int)tiles_of(N);
+    if (T > 2048) return fail(GSE_ERR_ARG, "%s: at most 2048 tiles (N <= 2^21)", fn);
+    ResampleArgs ra;
+    for (int b = 0; b < B; ++b) {
+        if (!(r[b] >= 0.0 && r[b] < 1.0)) return fail(GSE_ERR_ARG, "%s: r[%d] = %g is outside [0, 1)", fn, b, r[b]);
+        ra.r[b] = r[b];
+    }
+    Workspace ws = carve_workspace(workspace, B, N);
+    const int nblk = (int)std::min<int64_t>(std::min<int64_t>(kMomentBlocks, T), std::max<int64_t>(GSE_MOMRES_TOTAL_BLOCKS / B, GSE_MOMRES_MIN_BLOCKS));
+    hipLaunchKernelGGL(pf_moments_resampled_kernel, dim3(nblk, B), dim3(kBlock), (size_t)(T + 1) * sizeof(double), st, x, w,
+                       ws.scan_sums[slot], ws.scan[slot], ws.partials, N, ld, T, ra);
+    if (hipGetLastError() != hipSuccess) return fail(GSE_ERR_HIP, "%s: pf_moments_resampled_kernel did not launch", fn);
+    return nblk;
+}
+
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
                            const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, int pivot_count, hipStream_t st) {
     hipLaunchKernelGGL(moments_finish_kernel, dim3(B), dim3(64 * kFinishGroups), 0, st, partials, nblk, width, out,
@@ -437,32 +464,13 @@ int gse_pf_moments(const float* x, const float* w, int64_t ld, int B, int64_t N,
     return GSE_OK;
 }
 
-#ifndef GSE_MOMRES_TOTAL_BLOCKS
-#define GSE_MOMRES_TOTAL_BLOCKS 1024   // workgroups of the resampled-moments pass over all filters (4 per CU: one resident generation)
-#endif
-#ifndef GSE_MOMRES_MIN_BLOCKS
-#define GSE_MOMRES_MIN_BLOCKS 32
-#endif
 int gse_pf_moments_resampled(const float* x, const float* w, int64_t ld, int B, int64_t N, const double* r, int slot,
                              double* out, void* workspace, void* stream) {
-    if (int rc = check_pf_geometry("gse_pf_moments_resampled", B, N, ld)) return rc;
-    GSE_REQUIRE(x && w && r && out && workspace, "gse_pf_moments_resampled: null argument");
-    GSE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(workspace), "gse_pf_moments_resampled: pointers must be 16-byte aligned");
-    GSE_REQUIRE(slot == 0 || slot == 1, "gse_pf_moments_resampled: slot must be 0 or 1");
-    const int T = (int)tiles_of(N);
-    GSE_REQUIRE(T <= 2048, "gse_pf_moments_resampled: at most 2048 tiles (N <= 2^21)");
-    ResampleArgs ra;
-    for (int b = 0; b < B; ++b) {
-        GSE_REQUIRE(r[b] >= 0.0 && r[b] < 1.0, "gse_pf_moments_resampled: r[%d] = %g is outside [0, 1)", b, r[b]);
-        ra.r[b] = r[b];
-    }
-    Workspace ws = carve_workspace(workspace, B, N);
-    const int nblk = (int)std::min<int64_t>(std::min<int64_t>(kMomentBlocks, T), std::max<int64_t>(GSE_MOMRES_TOTAL_BLOCKS / B, GSE_MOMRES_MIN_BLOCKS));
+    GSE_REQUIRE(out, "gse_pf_moments_resampled: null argument");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pf_moments_resampled_kernel, dim3(nblk, B), dim3(kBlock), (size_t)(T + 1) * sizeof(double), st, x, w,
-                       ws.scan_sums[slot], ws.scan[slot], ws.partials, N, ld, T, ra);
-    GSE_LAUNCH_CHECK("pf_moments_resampled_kernel");
-    launch_moments_finish(ws.partials, nblk, 21, out, 26, B, x, GSE_NX * ld, ld, 21, GSE_NX, st);
+    const int nblk = launch_moments_resampled_partials("gse_pf_moments_resampled", x, w, ld, B, N, r, slot, workspace, st);
+    if (nblk < 0) return nblk;
+    launch_moments_finish(carve_workspace(workspace, B, N).partials, nblk, 21, out, 26, B, x, GSE_NX * ld, ld, 21, GSE_NX, st);
     GSE_LAUNCH_CHECK("moments_finish_kernel");
     return GSE_OK;
 }

@@ -1622,7 +1622,7 @@ __global__ __launch_bounds__(kBlock) void ancestors_scatter_kernel(const float* 
         if (count <= kWaveOffspring) continue;
         int32_t* p = io + heavy_lo[e];
         // up to three single entries to a 16-byte boundary, four entries per store from there, the rest singly
-        const int head = min(count, (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u)) >> 2) & 3u));
+        const int head = min(count, (int)(((16u - (uint32_t)(reinterpret_cast<unsigned long long>(p) & 15ull)) >> 2) & 3u));
         if (tid < head) p[tid] = k;
         const int body4 = (count - head) >> 2;
         int4* q = reinterpret_cast<int4*>(p + head);
@@ -1807,8 +1807,8 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
     block_sums<21>(acc, red, [&](int c, double total) { out[c] = total; });
 }
 
-// Fixed-order reduction of the per-workgroup partials -> out[b][0..width); appends pivot_count pivot values.
-constexpr int kFinishGroups = 16;        // 1024 threads: (group, column) = (tid / 64, tid % 64)
+// Fixed-order reduction of the per-workgroup partials -> out[b][0..width); appends pivot_count pivot values
+// (moments_finish_block, gse_device.h: the closed loop's fused tail kernel runs the same arithmetic).
 __global__ __launch_bounds__(64 * kFinishGroups) void moments_finish_kernel(const double* __restrict__ partials, int nblk,
                                                                            int width, double* __restrict__ out,
                                                                            int out_stride,
@@ -1816,37 +1816,9 @@ __global__ __launch_bounds__(64 * kFinishGroups) void moments_finish_kernel(cons
                                                                            int64_t pivot_filter_stride,
                                                                            int64_t pivot_elem_stride, int pivot_at,
                                                                            int pivot_count) {
-    // Thread (g, c) adds the partials q = g, g + 16, ... of column c into 8 interleaved accumulators (8 loads in flight),
-    // folds them pairwise, and the 16 group totals are folded pairwise after one barrier: a fixed order, so the result
-    // does not depend on timing; <= 4 dependent load rounds for 512 partials.
     __shared__ double part[kFinishGroups][64];
-    const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const double* pb = partials + (int64_t)b * kMomentBlocks * kMomentWidth;
-    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (c < width) {
-        for (int q0 = g; q0 < nblk; q0 += 8 * kFinishGroups) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int q = q0 + j * kFinishGroups;
-                if (q < nblk) a[j] += pb[(int64_t)q * kMomentWidth + c];
-            }
-        }
-    }
-    part[g][c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    __syncthreads();
-    if (g == 0 && c < width) {
-        double t[kFinishGroups];
-#pragma unroll
-        for (int k = 0; k < kFinishGroups; ++k) t[k] = part[k][c];
-#pragma unroll
-        for (int span = 1; span < kFinishGroups; span *= 2)
-#pragma unroll
-            for (int k = 0; k < kFinishGroups; k += 2 * span) t[k] += t[k + span];
-        out[(int64_t)b * out_stride + c] = t[0];
-    }
-    if ((int)threadIdx.x < pivot_count)
-        out[(int64_t)b * out_stride + pivot_at + threadIdx.x] =
-            (double)pivot_src[(int64_t)b * pivot_filter_stride + threadIdx.x * pivot_elem_stride];
+    moments_finish_block(partials + (int64_t)blockIdx.x * kMomentBlocks * kMomentWidth, kMomentWidth, nblk, width, out, out_stride,
+                         pivot_src, pivot_filter_stride, pivot_elem_stride, pivot_at, pivot_count, blockIdx.x, part);
 }
 
 }  // namespace gse

@@ -412,6 +412,19 @@ class ParallelParticleFilter:
                    self._c_r, int(self._gather_slot), out.data_ptr(), self._ws.data_ptr(), stream_ptr(self._dev_index))
         return True
 
+    def _resampled_moments_tail(self, out, tail):
+        """_resampled_moments_into followed, in the same launch as the reduction that finishes the moments, by the controller
+        call and the plant step ``tail`` (a _lib.LoopTail) describes: gse_pf_moments_resampled_tail, two launches for what
+        were five.  Returns False (nothing done) where _resampled_moments_into would."""
+        import ctypes
+        if not (self._pend_gather and self._gather_slot is not None and self._pend_predict is None) or \
+                self.N_particles > (1 << 21):
+            return False
+        self._call("gse_pf_moments_resampled_tail", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
+                   self._c_r, int(self._gather_slot), out.data_ptr(), self._ws.data_ptr(), ctypes.byref(tail),
+                   stream_ptr(self._dev_index))
+        return True
+
     def _moments26_into(self, out):
         """gse_pf_moments of the current ensemble into the device tensor ``out`` [B, 26]; no synchronisation (closed loop
         on the device)."""

@@ -286,9 +286,10 @@ class BatchedSimulation:
     launch and one synchronisation (the estimates of all rollouts)."""
 
     def __init__(self, batch, N_particles, dt_control, dt_predict, end_time=50, pf=True, controller=None, seed=0,
-                 resident=False, noise=None, persistent=True):
+                 resident=False, noise=None, persistent=True, fused_tail=True):
         self.B = int(batch)
         self.persistent = bool(persistent)      # resident loops of small Gaussian-sum filters: the whole loop in one launch
+        self.fused_tail = bool(fused_tail)      # resident particle-filter loops: moments' reduction + controller + plant in one launch
         self.noise = noise                      # InjectedNoise: every random number is an input (parity mode)
         self.resident = bool(resident)          # True: plant, controller and histories live on the device too
         if self.resident and controller is not None:
@@ -442,12 +443,26 @@ class BatchedSimulation:
         if noise is not None:                             # the plant's draws: uploaded once, sliced per tick
             inj_state = torch.as_tensor(numpy.ascontiguousarray(noise.plant_state.reshape(ticks - 1, B, 5)), device=dev)
             inj_meas = torch.as_tensor(numpy.ascontiguousarray(noise.plant_meas.reshape(ticks - 1, B, 2)), device=dev)
+        # the rest of a control tick behind the particle filter's deferred moments -- their reduction, the controller call, the
+        # plant -- rides ONE launch (gse_pf_moments_resampled_tail) where it can: two launches for what were five
+        tail = None
+        if self.pf and self.fused_tail:
+            _, law, _keep_law = K._device_law()
+            glue = K.loop_glue(_U_FALLBACK)
+            addr = lambda obj: ctypes.cast(ctypes.pointer(obj), ctypes.c_void_p).value
+            tail = _lib.LoopTail(law=addr(law), glue=addr(glue), u=u.data_ptr(), y_pred=y_pred.data_ptr(), known=known.data_ptr(),
+                                 X=X.data_ptr(), dt=float(self.dt), state_noise=addr(f.state_pdf._pod()),
+                                 meas_noise=addr(f.measurement_pdf._pod()), rng=addr(rng), z=z.data_ptr())
+            rows = {k: (hist[k].data_ptr(), B * widths[k] * 8) for k in ("us", "xs", "ys", "ys_meas")}
+            row = lambda k, t_: rows[k][0] + t_ * rows[k][1]
+            status_base = status.data_ptr()
         t_next_control, t_next_predict = 0, 0
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()                                      # device time of the loop: first to last kernel of the ticks
         clock = [time.perf_counter()]
         for t in range(1, ticks):
             now = self.ts[t]
+            fused = False
             if now > t_next_predict:
                 if noise is not None:
                     gaussian_sum_dist.DeterministicGaussianSum.preload(noise.predict[n_predict])
@@ -461,15 +476,25 @@ class BatchedSimulation:
                 # the estimate the controller acts on, and this tick's record: the moments of the resampled ensemble taken
                 # from the weighted one (offspring counts), so that the resample's copy is deferred into the next tick's
                 # single launch (gather + predict + update); where that does not apply, resample now and take them after
-                if not (self.pf and f._resampled_moments_into(moments[t])):
-                    record_moments(t)
-                K.loop_control(moments[t], ys_meas[t - 1], u, (y_pred, known, status[t]), _U_FALLBACK)
+                if tail is not None:
+                    rng.step = t
+                    tail.y_meas, tail.status = row("ys_meas", t - 1), status_base + t * B * 4
+                    tail.y, tail.y_meas_out, tail.log_x, tail.log_u = row("ys", t), row("ys_meas", t), row("xs", t), row("us", t)
+                    if noise is not None:
+                        tail.state_draw, tail.meas_draw = inj_state[t - 1].data_ptr(), inj_meas[t - 1].data_ptr()
+                    fused = f._resampled_moments_tail(moments[t], tail)
+                if not fused:
+                    if not (self.pf and f._resampled_moments_into(moments[t])):
+                        record_moments(t)
+                    K.loop_control(moments[t], ys_meas[t - 1], u, (y_pred, known, status[t]), _U_FALLBACK)
                 n_control += 1
                 last_control = t
                 control_ticks.append(t)
                 t_next_control += self.dt_control
             rng.step = t
-            if noise is not None:
+            if fused:
+                pass                                      # (the plant ran in the tail's launch)
+            elif noise is not None:
                 _lib.check(lib.gse_plant_step_injected(X.data_ptr(), u.data_ptr(), float(self.dt), inj_state[t - 1].data_ptr(),
                                                        inj_meas[t - 1].data_ptr(), ys[t].data_ptr(), ys_meas[t].data_ptr(),
                                                        z.data_ptr(), xs[t].data_ptr(), us[t].data_ptr(), B, stream))

@@ -451,6 +451,28 @@ int gse_plant_step(double *X /* [B][5], in/out */, const double *u /* [B][2] */,
                    const gse_mixture *meas_noise, const gse_rng *rng, double *y /* [B][5] */, double *y_meas /* [B][5] */,
                    double *z /* [B][2] */, double *log_x /* [B][5] or NULL */, double *log_u /* [B][2] or NULL */,
                    int64_t B, void *stream);
+/* The rest of a control tick of the resident particle-filter loop behind the moments of the pending resample, in two launches
+ * instead of five: gse_pf_moments_resampled's partial sums, then ONE kernel that finishes them into out[B][26], makes the
+ * controller call (gse_loop_control: reads y_meas, updates u / y_pred / known, writes status) and advances the plant
+ * (gse_plant_step, or gse_plant_step_injected when the two draws are given) -- sim_base.py:253-287 for B rollouts.  Same
+ * device functions in the same order: the records of the separate calls bit for bit.  Pointers device memory unless host. */
+typedef struct gse_loop_tail {
+    const gse_mpc_law *law;                      /* host struct of device pointers */
+    const gse_loop_glue *glue;                   /* host */
+    const double *y_meas;                        /* [B][n_output_full]: the measured outputs the controller sees */
+    double *u, *y_pred;                          /* [B][n_input_full], [B][n_y]: in / out */
+    int32_t *known, *status;                     /* [B] in / out, [B] out */
+    double *X;                                   /* [B][5] plant state, in / out */
+    double dt;
+    const gse_mixture *state_noise, *meas_noise; /* host; unused with injected draws */
+    const gse_rng *rng;                          /* host; rng->step numbers the tick */
+    const float *state_draw, *meas_draw;         /* [B][5], [B][2] injected draws, or both NULL */
+    double *y, *y_meas_out, *z;                  /* [B][5], [B][5], [B][2]: the plant's records of this tick */
+    double *log_x, *log_u;                       /* [B][5], [B][2] or NULL */
+} gse_loop_tail;
+int gse_pf_moments_resampled_tail(const float *x, const float *w, int64_t ld, int B, int64_t N, const double *r /* host [B] */,
+                                  int slot, double *out /* [B][26] */, void *workspace, const gse_loop_tail *tail /* host */,
+                                  void *stream);
 /* A whole closed loop in ONE launch (sim_base.py:243-309 for B rollouts whose estimator is a Gaussian-sum filter of at most 64
  * Gaussians, results/gsf_closedloop/bioreactor_performance_gsf.py:104-118): one workgroup per rollout runs every tick --
  * predict if due, on a control tick update / resample / estimate / MPC, then the plant -- with the bank in LDS throughout.

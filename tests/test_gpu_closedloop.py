@@ -517,3 +517,26 @@ def test_persistent_loop_equals_the_launch_per_piece_loop(n, dt_control, dt_pred
     np.testing.assert_array_equal(one.f.covariances.get(), many.f.covariances.get())
     np.testing.assert_array_equal(one.f.weights.get(), many.f.weights.get())
     assert one.f._step == many.f._step
+
+
+@pytest.mark.parametrize("n,dt_control,dt_predict,end_time", [(4096, 0.1, 0.1, 5), (5000, 1.0, 0.1, 6), (1 << 16, 0.1, 0.1, 3)])
+def test_fused_loop_tail_equals_the_separate_launches(n, dt_control, dt_predict, end_time):
+    """gse_pf_moments_resampled_tail -- the reduction of the deferred moments, the controller call and the plant in ONE launch
+    behind the partial sums -- against the resident particle-filter loop that launches gse_pf_moments_resampled,
+    gse_loop_control and gse_plant_step one after the other: every record and the filters' particles bit for bit, with control
+    every tick and every tenth (plant-only ticks in between), a ragged ensemble, and the injected-noise mode the parity
+    tests use."""
+    B = 3
+    sims = []
+    for fused in (True, False):
+        gpu_se_amd.seed(78)
+        sim = sim_base.BatchedSimulation(batch=B, N_particles=n, dt_control=dt_control, dt_predict=dt_predict, end_time=end_time,
+                                         pf=True, resident=True, seed=4, fused_tail=fused)
+        sim.simulate()
+        sims.append(sim)
+    one, many = sims
+    for name in ("us", "xs", "ys", "ys_meas", "moments", "xs_f", "ys_f", "covariance_point_size", "performance"):
+        np.testing.assert_array_equal(getattr(one, name), getattr(many, name), err_msg=name)
+    assert one.mpc_frac == many.mpc_frac
+    np.testing.assert_array_equal(one.f.particles.get(), many.f.particles.get())
+    np.testing.assert_array_equal(one.f.weights.get(), many.f.weights.get())
