@@ -97,6 +97,16 @@ __device__ __forceinline__ void rng_words8(const RngKey& key, uint64_t elem, uin
     }
 }
 
+// One Philox block of element `elem` (filter `fb` of this call), sub = 0 .. 15.
+__device__ __forceinline__ void rng_block_of_elem(const RngKey& key, uint64_t elem, uint32_t fb, uint32_t sub, uint32_t (&c)[4]) {
+    const uint64_t e = key.elem0 + elem;
+    c[0] = (uint32_t)e;
+    c[1] = (uint32_t)(e >> 32);
+    c[2] = key.step_lo;
+    c[3] = (key.hi + fb) | (sub << 16);
+    philox4x32_10(c, key.k0, key.k1);
+}
+
 // The particle filter's predict stage draws the noise of FOUR particles from SIX Philox blocks (24 words: 20 for ten
 // Box-Muller pairs = 20 normals, 4 for the mixture components) instead of two blocks per particle (8 words of which 7
 // are used).  The four particles of a group are the ones a thread owns in the strided mapping of pf_step_kernel:
@@ -140,6 +150,10 @@ static_assert(sizeof(DrawParams) % 16 == 0, "DrawParams must keep LDS offsets 16
 // below the diagonal are zeros, fma(0, n_j, acc) = acc for the finite n_j Box-Muller gives and an acc that is not -0
 // (pack_draw turns a mean of -0 into +0), so the five FMAs on the diagonal give the same bits as the fifteen; the flag is the
 // same for every lane, the branch is a scalar one.  n: at least 5 normals.
+// kDiagonal: 1 / 0 when the caller has looked at the flag already (one branch around several draws instead of one in each: a
+// branch ends a basic block, and the values alive across it are copied), -1: look here.
+__device__ __forceinline__ bool mixture_is_diagonal(const DrawParams& dp) { return __builtin_amdgcn_readfirstlane(dp.diagonal) != 0; }
+template <int kDiagonal = -1>
 __device__ __forceinline__ void mixture_transform5(const DrawParams& dp, uint32_t selector, const float* n, float (&out)[5]) {
     const float uc = (float)(selector >> 8) * 5.9604644775390625e-08f;   // [0, 1) with 24 bits
     int comp = 0;
@@ -147,7 +161,7 @@ __device__ __forceinline__ void mixture_transform5(const DrawParams& dp, uint32_
     for (int d = 0; d < GSE_MAX_ND - 1; ++d) comp += (d < dp.nd - 1 && uc >= dp.cumw[d]) ? 1 : 0;
     const float* L = dp.chol[comp];
     const float* m = dp.mean[comp];
-    if (__builtin_amdgcn_readfirstlane(dp.diagonal)) {
+    if (kDiagonal == 1 || (kDiagonal < 0 && mixture_is_diagonal(dp))) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) out[k] = fmaf(L[k * (k + 1) / 2 + k], n[k], m[k]);
         return;
@@ -186,8 +200,13 @@ __device__ __forceinline__ void mixture_draw5x4(const DrawParams& dp, const RngK
         box_muller(w[0], w[1], n[4 * blk + 0], n[4 * blk + 1]);
         box_muller(w[2], w[3], n[4 * blk + 2], n[4 * blk + 3]);
     }
+    if (mixture_is_diagonal(dp)) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) mixture_transform5(dp, cw[p], n + 5 * p, out[p]);
+        for (int p = 0; p < 4; ++p) mixture_transform5<1>(dp, cw[p], n + 5 * p, out[p]);
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) mixture_transform5<0>(dp, cw[p], n + 5 * p, out[p]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -154,8 +154,11 @@ static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w,
     pack_draw(a.pred.draw, *state_pdf);
     a.pred.rng = make_rng_key(*rng, kPurposeGsukf);
     const float* none = nullptr;
-    return launch(model, "gse::gsukf_predict_update_lanes_kernel<false>", gsukf_predict_update_lanes_kernel<false>, grid, block, st,
-                  mu, P, w, none, N, status, mu_in, P_in, anc, quarters, a);
+    if (a.pred.draw.diagonal)
+        return launch(model, "gse::gsukf_predict_update_lanes_kernel<false, 1>", gsukf_predict_update_lanes_kernel<false, 1>, grid,
+                      block, st, mu, P, w, none, N, status, mu_in, P_in, anc, quarters, a);
+    return launch(model, "gse::gsukf_predict_update_lanes_kernel<false, 0>", gsukf_predict_update_lanes_kernel<false, 0>, grid, block,
+                  st, mu, P, w, none, N, status, mu_in, P_in, anc, quarters, a);
 }
 
 static int gsukf_cycle(UserModel* model, float* mu, float* P, float* w, int32_t* idx, int B, int64_t N, const double* u,

@@ -215,6 +215,51 @@ __device__ __forceinline__ void sigma_mean_cov(const float (&sg)[kNs * kNx], con
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The state noise of the sigma points of Gaussian g (filter/gs_ukf.py:87-91 draws once per sigma point).  Round 3: the points
+// come in PAIRS (2i, 2i + 1) that share THREE Philox blocks -- 12 words for ten normals and two selectors -- where every point
+// used to take two blocks of its own and leave a word and a normal unused: 17 blocks and 28 Box-Muller pairs per Gaussian
+// instead of 22 and 33, in kernels that are bound by exactly such instructions.  Counter element g * 11 + 2i, sub-blocks
+//   A (sub 0): two Box-Muller pairs = normals 0..3 of point 2i,        C (sub 2): the same for point 2i + 1,
+//   B (sub 1): words 0, 1 one Box-Muller pair whose cosine half is normal 4 of point 2i and whose sine half normal 4 of
+//              point 2i + 1;  word 3 selects the component of point 2i, word 2 that of point 2i + 1 (top 24 bits);
+// the last point (no partner) is the even half of a pair.  So point j reads its own block (sub 2 (j & 1)) and block B of
+// element g * 11 + (j & ~1): two blocks for a lane that holds one sigma point, as before.  (oracle: gsukf_predict_noise.)
+// ------------------------------------------------------------------------------------------------
+template <int kDiagonal = -1>
+__device__ __forceinline__ void gsukf_point_noise(const DrawParams& dp, const RngKey& rng, int64_t g, int j, uint32_t fb,
+                                                  float (&e)[GSE_NX]) {
+    const uint32_t odd = (uint32_t)j & 1u;
+    const uint64_t elem = (uint64_t)(g * kNs + (j & ~1));
+    uint32_t own[4], shared[4];
+    rng_block_of_elem(rng, elem, fb, 2u * odd, own);
+    rng_block_of_elem(rng, elem, fb, 1u, shared);
+    float n[6], c4, s4;
+    box_muller(own[0], own[1], n[0], n[1]);
+    box_muller(own[2], own[3], n[2], n[3]);
+    box_muller(shared[0], shared[1], c4, s4);
+    n[4] = odd ? s4 : c4;
+    mixture_transform5<kDiagonal>(dp, odd ? shared[2] : shared[3], n, e);
+}
+// both points of pair i at once (a lane that holds the whole Gaussian): three blocks, five Box-Muller pairs
+template <int kDiagonal>
+__device__ __forceinline__ void gsukf_pair_noise(const DrawParams& dp, const RngKey& rng, int64_t g, int i, uint32_t fb,
+                                                 float (&e0)[GSE_NX], float (&e1)[GSE_NX]) {
+    const uint64_t elem = (uint64_t)(g * kNs + 2 * i);
+    uint32_t A[4], B[4], C[4];
+    rng_block_of_elem(rng, elem, fb, 0u, A);
+    rng_block_of_elem(rng, elem, fb, 1u, B);
+    rng_block_of_elem(rng, elem, fb, 2u, C);
+    float n0[5], n1[5];
+    box_muller(A[0], A[1], n0[0], n0[1]);
+    box_muller(A[2], A[3], n0[2], n0[3]);
+    box_muller(C[0], C[1], n1[0], n1[1]);
+    box_muller(C[2], C[3], n1[2], n1[3]);
+    box_muller(B[0], B[1], n0[4], n1[4]);
+    mixture_transform5<kDiagonal>(dp, B[3], n0, e0);
+    mixture_transform5<kDiagonal>(dp, B[2], n1, e1);
+}
+
 // Phase A of predict and update: lane t < nloc of the workgroup factorises local Gaussian t and leaves (m, L) in fac[t].
 // Src: t -> (mu pointer, P pointer); global memory or LDS.  Ends with a workgroup barrier.
 template <class Src>
@@ -268,9 +313,7 @@ __device__ __forceinline__ void gsukf_predict_block(Src src, Dst dst, float (*fa
 #pragma unroll
             for (int k = 0; k < kNx; ++k) e[k] = nz[j * kNx + k];
         } else {
-            uint32_t wd[8];
-            rng_words8(rng, (uint64_t)((g0 + gl) * kNs + j), (uint32_t)b, wd);
-            mixture_draw5(dp, wd, e);
+            gsukf_point_noise(dp, rng, g0 + gl, j, (uint32_t)b, e);
         }
 #pragma unroll
         for (int k = 0; k < kNx; ++k) tile[gl][j * kNx + k] = s[k] + e[k];
@@ -578,7 +621,8 @@ __device__ __forceinline__ void lane_row_out(const float* mine, float* __restric
 #define GSE_GSUKF_PRED_SERIAL 0  // 1: a scheduling barrier between the sigma points of a lane (tuning knob)
 #endif
 // predict of ONE Gaussian held in `mine` (mu[kNx], P[kNx][kNx]); g: its index in the filter (random-number element)
-template <bool kInjected>
+// kDiagonal: what the launch knows about the noise mixture's factors (1 all diagonal, 0 not, -1 look at the flag in each draw)
+template <bool kInjected, int kDiagonal = -1>
 __device__ __forceinline__ void gsukf_predict_lane(float* mine, int b, int64_t g, int64_t N, const float* noise,
                                                    const DrawParams& dp, int32_t* status, const GsukfPredictArgs& a,
                                                    const FilterIO& bio) {
@@ -587,22 +631,37 @@ __device__ __forceinline__ void gsukf_predict_lane(float* mine, int b, int64_t g
     load_and_factor(mine, mine + kNx, m, L, ok);
     if (!ok && status) atomicAdd(status, 1);
     float sg[kNs * kNx];
+    // the sigma points two at a time: a pair shares its Philox blocks (gsukf_pair_noise); the last one is half a pair
 #pragma unroll
-    for (int j = 0; j < kNs; ++j) {
-        float s[GSE_NX], e[GSE_NX];
-        sigma_point(m, L, j, s);
-        model_step(s, bio.u0, bio.u1, a.dt);
+    for (int i = 0; i < (kNs + 1) / 2; ++i) {
+        const int j0 = 2 * i, j1 = 2 * i + 1;
+        const bool both = j1 < kNs;
+        float s0[GSE_NX], s1[GSE_NX], e0[GSE_NX], e1[GSE_NX];
+        sigma_point(m, L, j0, s0);
+        model_step(s0, bio.u0, bio.u1, a.dt);
+        if (both) {
+            sigma_point(m, L, j1, s1);
+            model_step(s1, bio.u0, bio.u1, a.dt);
+        }
         if (kInjected) {
-            const float* nz = noise + (((int64_t)b * N + g) * kNs + j) * kNx;
+            const float* nz = noise + (((int64_t)b * N + g) * kNs + j0) * kNx;
 #pragma unroll
-            for (int k = 0; k < kNx; ++k) e[k] = nz[k];
+            for (int k = 0; k < kNx; ++k) e0[k] = nz[k];
+            if (both) {
+#pragma unroll
+                for (int k = 0; k < kNx; ++k) e1[k] = nz[kNx + k];
+            }
+        } else if (both) {
+            gsukf_pair_noise<kDiagonal>(dp, a.rng, g, i, (uint32_t)b, e0, e1);
         } else {
-            uint32_t wd[8];
-            rng_words8(a.rng, (uint64_t)(g * kNs + j), (uint32_t)b, wd);
-            mixture_draw5(dp, wd, e);
+            gsukf_point_noise<kDiagonal>(dp, a.rng, g, j0, (uint32_t)b, e0);
         }
 #pragma unroll
-        for (int k = 0; k < kNx; ++k) sg[j * kNx + k] = s[k] + e[k];
+        for (int k = 0; k < kNx; ++k) sg[j0 * kNx + k] = s0[k] + e0[k];
+        if (both) {
+#pragma unroll
+            for (int k = 0; k < kNx; ++k) sg[j1 * kNx + k] = s1[k] + e1[k];
+        }
 #if GSE_GSUKF_PRED_SERIAL
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -711,7 +770,9 @@ struct GsukfPredictUpdateArgs {
 };
 // anc != null: the bank's rows are first gathered from mu_in / P_in (the ancestors of a resample that left its copy to this
 // launch -- gse_gsukf_resample_begin) and the results go to mu / P, which must then be other arrays; anc == null: in place.
-template <bool kInjected>
+// kDiagonal: see gsukf_predict_lane (the host knows the mixture when it launches; a branch per draw inside the kernel costs
+// copies of what is alive across it, and both variants side by side in ONE kernel overflow the instruction cache: 53 us).
+template <bool kInjected, int kDiagonal = -1>
 __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict_update_lanes_kernel(
     float* __restrict__ mu, float* __restrict__ P, float* __restrict__ w, const float* __restrict__ noise, int64_t N,
     int32_t* __restrict__ status, const float* __restrict__ mu_in, const float* __restrict__ P_in,
@@ -751,7 +812,7 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
             lane_row_in(mine, mu_b + t * kNx, P_b + t * kNxx);
         }
 #endif
-        gsukf_predict_lane<kInjected>(mine, b, g0 + t, N, noise, dp, status, a.pred, bio);
+        gsukf_predict_lane<kInjected, kDiagonal>(mine, b, g0 + t, N, noise, dp, status, a.pred, bio);
         float* wg = w + (int64_t)b * N + g0 + t;
         w_new = *wg;
         gsukf_update_lane(mine, &w_new, bio.u0, bio.u1, bio.z0, bio.z1, status, a.pdf, a.pred.sw);

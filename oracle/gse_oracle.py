@@ -542,6 +542,56 @@ def words_to_draw(words, mixture):
     return out, comp
 
 
+def gsukf_predict_noise(seed, step, n_gaussians, mixture, filter_id=0, n_sigma=11):
+    """The state noise the Gaussian-sum filter's predict adds to the sigma points of Gaussians 0 .. n_gaussians - 1 at Philox
+    step `step` (one draw per sigma point, filter/gs_ukf.py:87-91): (noise fp64 (N, n_sigma, nx), component (N, n_sigma)).
+
+    Mapping of gsukf_point_noise / gsukf_pair_noise (gse_gsukf_kernels.h): the sigma points of Gaussian g come in pairs
+    (2i, 2i + 1) that share three Philox blocks with counter (elem_lo, elem_hi, step_lo, (step_hi & 0xff) << 24 | purpose << 20
+    | sub << 16 | filter), elem = g * n_sigma + 2i: block A (sub 0) is two Box-Muller pairs = normals 0..3 of point 2i,
+    block C (sub 2) the same for point 2i + 1, block B (sub 1) one Box-Muller pair (words 0, 1) whose cosine half is normal 4 of
+    point 2i and whose sine half normal 4 of point 2i + 1; word 3 of B selects the component of point 2i, word 2 that of point
+    2i + 1 (top 24 bits).  The last point, without a partner, is the even half of a pair."""
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    g = np.arange(n_gaussians, dtype=np.uint64)
+
+    def block(elem, sub):
+        hi = ((((step >> 32) & 0xFF) << 24) | ((RNG_PURPOSE["gsukf"] & 0xF) << 20) | (filter_id & 0xFFFF)) | (sub << 16)
+        ctr = np.stack([elem & _MASK32, elem >> np.uint64(32), np.full_like(elem, step & 0xFFFFFFFF), np.full_like(elem, hi)],
+                       axis=-1)
+        return philox4x32_10(ctr, key).astype(np.float64)
+
+    def box_muller(a, b):
+        r = np.sqrt(-2.0 * np.log((a + 0.5) / 2.0 ** 32))
+        ang = 2 * np.pi * b / 2.0 ** 32
+        return r * np.cos(ang), r * np.sin(ang)
+
+    cw = np.cumsum(mixture.weights.astype(np.float64))
+    cw = (cw / cw[-1]).astype(np.float32).astype(np.float64)
+    chols = [np.linalg.cholesky(mixture.covariances[d].astype(np.float64)).astype(np.float32).astype(np.float64)
+             for d in range(mixture.nd)]
+    out = np.zeros((n_gaussians, n_sigma, mixture.nx))
+    comps = np.zeros((n_gaussians, n_sigma), dtype=np.int64)
+    for j in range(n_sigma):
+        odd = j & 1
+        elem = g * np.uint64(n_sigma) + np.uint64(j & ~1)
+        own, shared = block(elem, 2 * odd), block(elem, 1)
+        normals = np.zeros((n_gaussians, 5))
+        normals[:, 0], normals[:, 1] = box_muller(own[:, 0], own[:, 1])
+        normals[:, 2], normals[:, 3] = box_muller(own[:, 2], own[:, 3])
+        normals[:, 4] = box_muller(shared[:, 0], shared[:, 1])[odd]
+        sel = shared[:, 2 if odd else 3].astype(np.uint64)
+        uc = (sel >> np.uint64(8)).astype(np.float64) / 2.0 ** 24
+        comp = np.zeros(n_gaussians, dtype=np.int64)
+        for d in range(mixture.nd - 1):
+            comp += (uc >= cw[d]).astype(np.int64)
+        comps[:, j] = comp
+        for d in range(mixture.nd):
+            rows = comp == d
+            out[rows, j] = mixture.means[d].astype(np.float64) + normals[rows, :mixture.nx] @ chols[d].T
+    return out, comps
+
+
 def predict_noise(seed, step, elements, mixture, filter_id=0, element_offset=0):
     """The state noise the particle filter's predict stage adds to the particles with LOCAL indices `elements` (within
     their filter / shard, whose first particle has the global index `element_offset`) at Philox step `step`:

@@ -147,6 +147,33 @@ def test_row_helpers_on_the_gsukf():
     np.testing.assert_array_equal(ys, orc.bioreactor_g_vec(gf.means.get()))
 
 
+@pytest.mark.parametrize("n", [64, 300, 5000])
+def test_gsukf_philox_predict_against_the_oracle(n):
+    """The Philox noise of the Gaussian-sum filter's predict is pinned in the oracle (oracle.gsukf_predict_noise: sigma points
+    in pairs sharing three Philox blocks): the device's predict in its own random-number mode against the NumPy oracle fed
+    the restated noise, for the one-launch / group / lane kernels (64, 300, 5000 Gaussians), two steps.  The device's normals
+    are fp32 fast-math (2e-5 sigma from the fp64 ones): the predicted means
+    agree to 1e-3 sigma of the noise / sqrt(11) and a rounding."""
+    sp, mp = orc.bioreactor_noise()
+    xss = orc.steady_state()
+    rng = np.random.default_rng(n)
+    means = (xss[None, :] + rng.standard_normal((n, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    gf = make(n, means)
+    o = orc.GSUKFOracle(n, None, sp, mp, means=means)
+    o.covariances = gf.covariances.get().copy()
+    sd = np.sqrt(np.diagonal(sp.covariances, axis1=1, axis2=2)).max(axis=0)
+    for step in range(2):
+        u = [0.05 + 0.01 * step, 0.2]
+        noise, comp = orc.gsukf_predict_noise(gf._seed, step, n, sp, filter_id=gf._filter_offset)
+        assert set(np.unique(comp)) <= {0, 1} and 0.6 < np.mean(comp == 0) < 0.9          # (weights 0.75 / 0.25)
+        gf.predict(u, 0.1)
+        o.predict(u, 0.1, noise=noise.astype(np.float32), loop=False)
+        err = np.abs(gf.means.get() - o.means)
+        assert np.all(err <= 1e-3 * sd + 2.4e-7 * np.abs(o.means)), float(np.max(err / (1e-3 * sd + 2.4e-7 * np.abs(o.means))))
+        assert_cov_close(gf.covariances.get(), o.covariances, 2e-3)
+        gf.means, gf.covariances = o.means, o.covariances
+
+
 def test_gsukf_philox_cycle_and_errors():
     gpu_se_amd.seed(5)
     _, _, _, gf = sim_base.get_parts(N_particles=64, pf=False)

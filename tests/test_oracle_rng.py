@@ -28,3 +28,29 @@ def test_words_to_draw_statistics():
         var = sel.var(axis=0)
         np.testing.assert_allclose(var, np.diag(sp.covariances[d]), rtol=0.03)
         assert np.all(np.abs(sel.mean(axis=0)) < 4 * np.sqrt(np.diag(sp.covariances[d]) / len(sel)))
+
+
+def test_gsukf_predict_noise_statistics():
+    """The Gaussian-sum filter's noise mapping (sigma points in pairs sharing three Philox blocks): every point's draw has the
+    mixture's component frequencies and moments, and the two halves of a pair -- which share one Box-Muller pair and one
+    block of selectors -- are uncorrelated, as are neighbouring pairs and steps."""
+    sp, _ = orc.bioreactor_noise()
+    n = 20000
+    x, comp = orc.gsukf_predict_noise(seed=987654321, step=5, n_gaussians=n, mixture=sp)
+    assert x.shape == (n, 11, 5) and comp.shape == (n, 11)
+    for j in range(11):
+        frac = np.mean(comp[:, j] == 0)
+        assert abs(frac - 0.75) < 0.015, (j, frac)
+        for d in range(2):
+            sel = x[comp[:, j] == d, j]
+            np.testing.assert_allclose(sel.var(axis=0), np.diag(sp.covariances[d]), rtol=0.12, err_msg=str((j, d)))
+            assert np.all(np.abs(sel.mean(axis=0)) < 5 * np.sqrt(np.diag(sp.covariances[d]) / len(sel)))
+    # standardised draws: correlations between the points of a Gaussian stay at the sampling noise (1 / sqrt(n) = 0.007)
+    sd = np.sqrt(np.array([np.diag(c) for c in sp.covariances]))[comp]            # (n, 11, 5)
+    zs = (x / sd).reshape(n, 55)
+    corr = np.corrcoef(zs, rowvar=False)
+    off = corr - np.eye(55)
+    assert np.max(np.abs(off)) < 0.04, float(np.max(np.abs(off)))
+    assert abs(np.corrcoef(comp[:, 0], comp[:, 1])[0, 1]) < 0.03                     # the pair's selectors: words 3 and 2 of B
+    y, _ = orc.gsukf_predict_noise(seed=987654321, step=6, n_gaussians=n, mixture=sp)
+    assert abs(np.corrcoef(x[:, 3, 0], y[:, 3, 0])[0, 1]) < 0.03

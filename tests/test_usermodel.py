@@ -50,7 +50,8 @@ def test_kernels_compile_at_run_time_for_a_user_model():
     assert three.nx == 3
     # the GS-UKF kernels (a translation unit of their own) for a model with 3 states: 7 sigma points, 3 x 3 covariances
     for name in ("gse::gsukf_cycle_kernel<false>", "gse::gsukf_predict_kernel<true, 64>", "gse::gsukf_update_kernel<64>",
-                 "gse::gsukf_predict_update_lanes_kernel<false>", "gse::gsukf_sigma_kernel<0>", "gse::gsukf_moments_kernel<0>",
+                 "gse::gsukf_predict_update_lanes_kernel<false, 1>", "gse::gsukf_predict_update_lanes_kernel<false, 0>",
+                 "gse::gsukf_sigma_kernel<0>", "gse::gsukf_moments_kernel<0>",
                  "gse::gather_kernel<gse::GsukfPayload>"):
         assert three.compile_check(name) > 5000
 
