@@ -196,7 +196,12 @@ __device__ __forceinline__ void sigma_mean_cov(const float (&sg)[kNs * kNx], con
             float acc = sg[k] * sw.w[0];
 #pragma unroll
             for (int q = 1; q < kNs; ++q) acc = acc + sg[q * kNx + k] * sw.w[q];
-            mean[k] = acc / sw.scl32;
+            mean[k] = acc;
+        }
+        // (the usual sigma weights sum to exactly 1 in fp32, and x / 1 = x: one scalar branch around five IEEE divisions)
+        if (sw.scl32 != 1.0f) {
+#pragma unroll
+            for (int k = 0; k < kNx; ++k) mean[k] = mean[k] / sw.scl32;
         }
     }
 #pragma unroll
