@@ -388,8 +388,8 @@ def main():
     # (the stream is polled until the last cycle has ended, then the bracket's synchronisations find nothing left to wait for:
     #  a blocking wait alone adds its wake-up latency -- 20-40 us, a tenth of the driver's K = 20 cycles -- to the timed region)
     gpu_se_amd.synchronize()
-    torch.cuda.synchronize()
     if world > 1:
+        torch.cuda.synchronize()
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

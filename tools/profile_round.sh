@@ -3,7 +3,7 @@
 # under gpurun_out/<tag>_*.  part 1: kernel-trace statistics of bench.py, of the GS-UKF cycle and of the resident closed loops;
 # the two PMC passes (FETCH_SIZE, WRITE_SIZE) of bench.py and the traffic json; the tail profile (first 300 cycles from the
 # prior + the adversarial patterns) and the per-cycle trace.  part 2: the shader counters (PF cycle and GS-UKF lanes), the
-# open-loop run sequences, the size sweep.
+# open-loop run sequences, the size sweep, the large-bank ancestors kernel on the adversarial weight patterns.
 tag=$1
 part=${2:-all}
 export TMPDIR=/tmp
@@ -44,5 +44,11 @@ tools/pmc_sq.sh ${tag}gsf tools/gsf_bench.py 262144 > $O/${tag}_gsukf_pmc_sq.txt
 python tools/run_seq.py pf 24 50 > $O/${tag}_run_seq_pf.txt 2>&1
 python tools/run_seq.py gsf 18 50 > $O/${tag}_run_seq_gsf.txt 2>&1
 tools/sweep.sh > $O/${tag}_sweep.txt 2>&1
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $O/prof_${tag}_anc -- python3 $R/tools/gsf_ancestors_tail.py > $O/${tag}_anc.log 2>&1
+GSE_ANCESTORS_BY_SEARCH=1 rocprofv3 --kernel-trace --output-format csv -d $O/prof_${tag}_anc_search -- python3 $R/tools/gsf_ancestors_tail.py > $O/${tag}_anc_search.log 2>&1
+cd $R
+python tools/gsf_ancestors_tail.py gpurun_out/prof_${tag}_anc > $O/${tag}_gsukf_ancestors_tail.txt
+python tools/gsf_ancestors_tail.py gpurun_out/prof_${tag}_anc_search > $O/${tag}_gsukf_ancestors_tail_by_search.txt
 echo "part 2 done"
 fi
