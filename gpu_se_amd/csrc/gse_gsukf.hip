@@ -243,7 +243,7 @@ static int gsukf_resample_begin(const float* w, float* w_out, int32_t* idx, int 
         return GSE_OK;
     }
     if (launch_ancestors(w, w_out, idx, B, N, ra, ws, st, quarter_sums_valid)) {   // up to 2^21: tile sums, then the ancestors
-        GSE_LAUNCH_CHECK("ancestors_kernel");
+        GSE_LAUNCH_CHECK("ancestors_scatter_kernel");
         return GSE_OK;
     }
     if (int rc = launch_cumsum(w, N, B, N, 0, nullptr, ws, ws.cumsum, st)) return rc;

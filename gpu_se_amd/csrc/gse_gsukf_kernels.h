@@ -433,6 +433,11 @@ __device__ __forceinline__ void gsukf_update_gaussian(Eta eta, Dev dev, const fl
         pyy[1][1] = fma(e1, ew1, pyy[1][1]);
 #pragma unroll
         for (int k = 0; k < kNx; ++k) {
+            // Sigma point q is the mean in the states above its column of the lower-triangular factor (sigma_point): there
+            // the deviation is m - m = +0, the product a signed zero, and pxy -- which starts at +0 and is never -0 -- keeps
+            // its bits.  With q a constant (the unrolled form of the one-lane-per-Gaussian kernels) 25 of the 55 pairs
+            // drop out, a conversion and two fp64 FMAs each; the rolled form multiplies by the zero it read.
+            if (kUnrolled && (q == 0 || (q - 1) % kNx > k)) continue;
             const double dk = (double)dev(q, k);
             pxy[k][0] = fma(dk, ew0, pxy[k][0]);
             pxy[k][1] = fma(dk, ew1, pxy[k][1]);
@@ -549,10 +554,11 @@ __global__ __launch_bounds__(kBankT * kGroup) void gsukf_update_kernel(float* __
 // for 2^18: the single-lane phases run in one wavefront of sixteen while the workgroup holds a whole CU (round 1: 143 us
 // per cycle, 0.17 of the HBM roofline).  Here a workgroup of 256 threads takes 256 Gaussians and a lane does everything for
 // its own: factorisation, the 11 sigma points one after the other (model step + noise draw, or output function), the
-// contractions -- all in registers, no hand-off, no barrier inside, every lane busy in every phase.  (mu, P) travel through
-// LDS only to make the global traffic coalesced: the workgroup's rows are one contiguous block of 256 x 120 bytes, staged
-// with stride 31 floats (conflict-free when a lane walks its row).  Same device functions, same sigma-point order and the
-// same random-number elements as the kernels above: results agree bit for bit.
+// contractions -- all in registers, no hand-off, no barrier inside, every lane busy in every phase.  A lane's row (mu, P: 30
+// floats) lives in LDS between the phases, stride 31 floats (conflict-free when a lane walks its row), and the lane itself
+// moves it from and to global memory (lane_row_in / lane_row_out below; rounds 1-2 staged the workgroup's rows cooperatively,
+// stage_bank_*: kept for the row-copy kernel and as GSE_GSUKF_DIRECT_ROWS=0).  Same device functions, same sigma-point
+// order and the same random-number elements as the kernels above: results agree bit for bit.
 constexpr int kLaneBank = 256;
 constexpr int kStageStride = kRow | 1;           // mu + P of a Gaussian, padded to an odd stride (31 floats for 5 states)
 

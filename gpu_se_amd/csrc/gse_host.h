@@ -141,7 +141,8 @@ int launch_gsukf_gather(const GsukfPayload& pl, float* w_out, int32_t* idx, int 
 int launch_index_gather(float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, const Workspace& ws,
                         hipStream_t st);
 // cumulative weights + ancestors of a bank of at most 4 tiles in ONE launch (small_resample_kernel); false: too large
-// ... of a bank of up to 2048 tiles from its weights and tile sums, no cumulative weights written (ancestors_kernel)
+// ... of a bank of up to 2048 tiles from its weights and tile sums, no cumulative weights written (ancestors_scatter_kernel;
+// GSE_ANCESTORS_BY_SEARCH=1 in the environment: round 2's ancestors_kernel)
 bool launch_ancestors(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, const Workspace& ws,
                       hipStream_t st, bool quarter_sums_valid = false);
 // where the one-lane-per-Gaussian update launch leaves the quarter sums of its new weights ([B][4 T] doubles): the

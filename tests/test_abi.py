@@ -37,6 +37,33 @@ def test_struct_layout_matches_header(lib):
     assert ctypes.sizeof(lib.Rng) == 32
 
 
+def test_loop_structs_match_the_header_as_a_c_compiler_lays_them_out(lib, tmp_path):
+    """gse_loop_spec and gse_loop_tail cross the boundary by pointer: size and every field offset of the ctypes mirrors
+    against include/gse.h compiled by gcc."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"gse_loop_spec": lib.LoopSpec, "gse_loop_tail": lib.LoopTail}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gse.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for field, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, field, cname, field))
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(out[cname]) == ctypes.sizeof(cls), cname
+        for field, _ in cls._fields_:
+            assert int(out["%s.%s" % (cname, field)]) == getattr(cls, field).offset, (cname, field)
+
+
 def test_argument_errors_are_reported_without_a_gpu(lib):
     handle = lib.load()
     assert handle.gse_workspace_bytes(0, 10) < 0
