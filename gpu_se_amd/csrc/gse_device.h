@@ -156,9 +156,10 @@ __device__ __forceinline__ bool mixture_is_diagonal(const DrawParams& dp) { retu
 template <int kDiagonal = -1>
 __device__ __forceinline__ void mixture_transform5(const DrawParams& dp, uint32_t selector, const float* n, float (&out)[5]) {
     const float uc = (float)(selector >> 8) * 5.9604644775390625e-08f;   // [0, 1) with 24 bits
+    // (pack_draw leaves cumw[nd - 1] = 1 and 2 beyond: uc < 1 never reaches those, no need to look at nd)
     int comp = 0;
 #pragma unroll
-    for (int d = 0; d < GSE_MAX_ND - 1; ++d) comp += (d < dp.nd - 1 && uc >= dp.cumw[d]) ? 1 : 0;
+    for (int d = 0; d < GSE_MAX_ND - 1; ++d) comp += (uc >= dp.cumw[d]) ? 1 : 0;
     const float* L = dp.chol[comp];
     const float* m = dp.mean[comp];
     if (kDiagonal == 1 || (kDiagonal < 0 && mixture_is_diagonal(dp))) {

@@ -54,7 +54,7 @@ void pack_draw(DrawParams& dp, const gse_mixture& m) {
     dp.diagonal = 1;
     for (int d = 0; d < m.nd; ++d) {
         run += (double)m.weights[d];
-        dp.cumw[d] = (float)(run / total);
+        dp.cumw[d] = d == m.nd - 1 ? 1.0f : (float)(run / total);      // (the last one IS 1: mixture_transform5 relies on it)
         int at = 0;
         for (int k = 0; k < GSE_NX; ++k) {
             dp.mean[d][k] = (k < m.nx ? m.means[d][k] : 0.f) + 0.0f;       // (-0 -> +0: mixture_transform5)
