@@ -631,15 +631,16 @@ __device__ __forceinline__ void lane_row_out(const float* mine, float* __restric
 #ifndef GSE_GSUKF_PRED_SERIAL
 #define GSE_GSUKF_PRED_SERIAL 0  // 1: a scheduling barrier between the sigma points of a lane (tuning knob)
 #endif
-// predict of ONE Gaussian held in `mine` (mu[kNx], P[kNx][kNx]); g: its index in the filter (random-number element)
+// predict of ONE Gaussian: read from (mu_src, P_src) -- global memory or the lane's LDS row: the mean and the lower triangle are
+// all it needs -- and left in `mine` (mu[kNx], P[kNx][kNx]); g: its index in the filter (random-number element)
 // kDiagonal: what the launch knows about the noise mixture's factors (1 all diagonal, 0 not, -1 look at the flag in each draw)
 template <bool kInjected, int kDiagonal = -1>
-__device__ __forceinline__ void gsukf_predict_lane(float* mine, int b, int64_t g, int64_t N, const float* noise,
-                                                   const DrawParams& dp, int32_t* status, const GsukfPredictArgs& a,
-                                                   const FilterIO& bio) {
+__device__ __forceinline__ void gsukf_predict_lane(const float* __restrict__ mu_src, const float* __restrict__ P_src, float* mine,
+                                                   int b, int64_t g, int64_t N, const float* noise, const DrawParams& dp,
+                                                   int32_t* status, const GsukfPredictArgs& a, const FilterIO& bio) {
     float m[kNx], L[kTri];
     bool ok;
-    load_and_factor(mine, mine + kNx, m, L, ok);
+    load_and_factor(mu_src, P_src, m, L, ok);
     if (!ok && status) atomicAdd(status, 1);
     float sg[kNs * kNx];
     // the sigma points two at a time: a pair shares its Philox blocks (gsukf_pair_noise); the last one is half a pair
@@ -734,13 +735,15 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
     if (!kInjected) __syncthreads();                                   // (the draw's parameters)
     if (t < nloc) {
         float* mine = stage + t * kStageStride;
-        lane_row_in(mine, mu_b + t * kNx, P_b + t * kNxx);
-        gsukf_predict_lane<kInjected>(mine, b, g0 + t, N, noise, dp, status, a, bio);
+        gsukf_predict_lane<kInjected>(mu_b + t * kNx, P_b + t * kNxx, mine, b, g0 + t, N, noise, dp, status, a, bio);
         lane_row_out(mine, mu_b + t * kNx, P_b + t * kNxx);
     }
 #else
     stage_bank_in(stage, mu_b, P_b, nloc);
-    if (t < nloc) gsukf_predict_lane<kInjected>(stage + t * kStageStride, b, g0 + t, N, noise, dp, status, a, bio);
+    if (t < nloc) {
+        float* mine = stage + t * kStageStride;
+        gsukf_predict_lane<kInjected>(mine, mine + kNx, mine, b, g0 + t, N, noise, dp, status, a, bio);
+    }
     stage_bank_out(stage, mu_b, P_b, nloc);
 #endif
 }
@@ -816,14 +819,15 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
     if (t < nloc) {
         float* mine = stage + t * kStageStride;
 #if GSE_GSUKF_DIRECT_ROWS
-        if (anc) {
-            const int64_t row = (int64_t)b * N + anc[(int64_t)b * N + g0 + t];
-            lane_row_in(mine, mu_in + row * kNx, P_in + row * kNxx);
-        } else {
-            lane_row_in(mine, mu_b + t * kNx, P_b + t * kNxx);
-        }
+        // (predict reads the mean and the lower triangle straight from the row in global memory -- the ancestor's, when a
+        //  resample left its copy to this launch -- and leaves its result in the lane's LDS row for update)
+        const int64_t row = anc ? (int64_t)b * N + anc[(int64_t)b * N + g0 + t] : (int64_t)b * N + g0 + t;
+        const float* mu_row = (anc ? mu_in : mu) + row * kNx;
+        const float* P_row = (anc ? P_in : P) + row * kNxx;
+#else
+        const float *mu_row = mine, *P_row = mine + kNx;
 #endif
-        gsukf_predict_lane<kInjected, kDiagonal>(mine, b, g0 + t, N, noise, dp, status, a.pred, bio);
+        gsukf_predict_lane<kInjected, kDiagonal>(mu_row, P_row, mine, b, g0 + t, N, noise, dp, status, a.pred, bio);
         float* wg = w + (int64_t)b * N + g0 + t;
         w_new = *wg;
         gsukf_update_lane(mine, &w_new, bio.u0, bio.u1, bio.z0, bio.z1, status, a.pdf, a.pred.sw);
