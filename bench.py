@@ -268,9 +268,11 @@ def gsukf_block(torch, sizes=(64, 4096, 1 << 18)):
 
         def cycle(_i):
             gf.predict(u, 0.1); gf.update(u, z); gf.resample()
-        for i in range(20):
+        # (setting a bank up leaves the device idle for a while: 200 untimed cycles -- 9 ms at 2^18 -- clock it up again, as
+        #  device_warm_up does for the particle filter's figure; tools/gsf_bench.py has always measured this way)
+        for i in range(200):
             cycle(i)
-        reps = 300 if n <= 4096 else 100
+        reps = 300
         t0 = time.perf_counter()
         dev = time_method_events(torch, cycle, reps)
         wall = (time.perf_counter() - t0) / reps

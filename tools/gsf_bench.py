@@ -13,7 +13,7 @@ for n in [int(a) for a in sys.argv[1:]] or [64, 1024, 16384, 262144]:
     u = [0.06, 0.2]
     def cycle():
         gf.predict(u, 0.1); gf.update(u, z); gf.resample()
-    for _ in range(30): cycle()
+    for _ in range(200): cycle()          # (clocks the device up after the set-up: 9 ms at 2^18)
     torch.cuda.synchronize()
     reps = 300
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
