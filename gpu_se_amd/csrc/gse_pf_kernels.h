@@ -261,6 +261,12 @@ __device__ __forceinline__ void expand_quad(const OffspringCount& F, const doubl
 #ifndef GSE_SEARCH_FROM
 #define GSE_SEARCH_FROM 20
 #endif
+#ifndef GSE_SEARCH_QUADS_TOGETHER
+#define GSE_SEARCH_QUADS_TOGETHER 1
+#endif
+#ifndef GSE_SEARCH_WINDOWS_TOGETHER
+#define GSE_SEARCH_WINDOWS_TOGETHER 1   // outputs whose three-quad windows are loaded side by side (1, 2 or 4: no difference measured)
+#endif
 constexpr int kPrefixWindow = 1026;      // entries of the global tile prefix a workgroup stages (ranges of up to 1024 tiles)
 __device__ __forceinline__ int32_t window_ancestor(const float* __restrict__ wrow, const double* __restrict__ qx, int32_t N,
                                                    int32_t ld, int tq, int uq, double P0, double P1, double tau, int tl0) {
@@ -290,10 +296,12 @@ __device__ __forceinline__ int32_t window_ancestor(const float* __restrict__ wro
 }
 
 // Register discipline: the hot path of the kernel sits at 106 vector registers for four wavefronts per SIMD and the register
-// allocator spreads the pressure of whatever is inlined here over the whole kernel (a first version -- four bisections side
+// allocator spreads the pressure of whatever is inlined here over the whole kernel (a first version -- four 16-ary searches side
 // by side, all twelve window loads of the four outputs in flight -- cost 300-450 bytes of spills per lane and 1.6 us on EVERY
-// launch, as a real function call too).  So: the four tile searches together (LDS, a few integers each), then ONE output
-// at a time, scheduling barriers in between.
+// launch, as a real function call too).  So: the four tile searches together (LDS, a few integers each), the four quads
+// together in 4-ary rounds (quads_of4: 24 registers of loads in flight), then the windows one output at a time, scheduling
+// barriers in between.  (quad_of, the 16-ary search of one output, is what quads_of4 replaced: 37 -> 35 us on the launches
+// that take this path.)
 __device__ __forceinline__ int32_t quad_of(const double* __restrict__ qrow, double P0, double P1, double tau) {
     // first quad u in [0, 255] whose last key reaches tau, judged by the NEXT quad's prefix (P1 for the last quad): two 16-ary
     // rounds of independent loads.  Counting the pivots below tau instead of bisecting shrugs off a last-bit wiggle between
@@ -305,6 +313,34 @@ __device__ __forceinline__ int32_t quad_of(const double* __restrict__ qrow, doub
 #pragma unroll
     for (int m = 1; m < 16; ++m) u += (fmin(P0 + qrow[16 * blk + m], P1) < tau) ? 1 : 0;
     return u;
+}
+
+// The quads of a thread's four outputs TOGETHER: four 4-ary rounds (pivots 64, 16, 4, 1 quads apart), the twelve loads of a
+// round -- three per output -- in flight side by side, where quad_of runs two 16-ary rounds per output, one output after the
+// other: four dependent round trips for eight, with 24 registers of loads in flight for 30.  P0 / P1 are re-read from LDS in
+// every round instead of being kept (16 registers the kernel does not have).  The same count of pivots below tau, level by
+// level; window_ancestor looks at the quad and both neighbours either way.
+__device__ __forceinline__ void quads_of4(const double* __restrict__ qx, const double* pfx_s, const int (&tq)[kPerThread],
+                                          const double (&tau)[kPerThread], int (&u)[kPerThread]) {
+#pragma unroll
+    for (int p = 0; p < kPerThread; ++p) u[p] = 0;
+#pragma unroll
+    for (int stride = 64; stride >= 1; stride >>= 2) {
+        double v[kPerThread][3];
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p)
+#pragma unroll
+            for (int m = 1; m < 4; ++m) v[p][m - 1] = qx[(int64_t)tq[p] * kBlock + u[p] + m * stride];
+#pragma unroll
+        for (int p = 0; p < kPerThread; ++p) {
+            const double P0 = pfx_s[tq[p]], P1 = pfx_s[tq[p] + 1];
+            int below = 0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) below += (fmin(P0 + v[p][m], P1) < tau[p]) ? 1 : 0;
+            u[p] += below * stride;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 __device__ __forceinline__ void search_ancestors(const OffspringCount& F, const double* pfx_s, const float* __restrict__ wrow,
@@ -337,6 +373,20 @@ __device__ __forceinline__ void search_ancestors(const OffspringCount& F, const 
     }
     // 2. + 3. per output: the quad, then the keys of that quad and its neighbours exactly as cumsum_kernel forms them;
     //         ancestor = 1 + last key below tau
+#if GSE_SEARCH_QUADS_TOGETHER
+    int uq[kPerThread];
+    __builtin_amdgcn_sched_barrier(0);
+    quads_of4(qx, pfx_s, tq, tau, uq);
+#pragma unroll
+    for (int p = 0; p < kPerThread; p += GSE_SEARCH_WINDOWS_TOGETHER) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = p; q < p + GSE_SEARCH_WINDOWS_TOGETHER; ++q) {
+            const double P0 = pfx_s[tq[q]], P1 = pfx_s[tq[q] + 1];
+            anc[q] = window_ancestor(wrow, qx, (int32_t)N, (int32_t)ld, tq[q], uq[q], P0, P1, tau[q], tl0);
+        }
+    }
+#else
 #pragma unroll
     for (int p = 0; p < kPerThread; ++p) {
         __builtin_amdgcn_sched_barrier(0);
@@ -344,6 +394,7 @@ __device__ __forceinline__ void search_ancestors(const OffspringCount& F, const 
         const int u = quad_of(qx + (int64_t)tq[p] * kBlock, P0, P1, tau[p]);
         anc[p] = window_ancestor(wrow, qx, (int32_t)N, (int32_t)ld, tq[p], u, P0, P1, tau[p], tl0);
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
