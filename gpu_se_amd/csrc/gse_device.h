@@ -614,6 +614,16 @@ __device__ __forceinline__ double smallest_with_quotient_ge(double u, double W) 
     if (!(u > 0.0)) return 0.0;                       // fl(0 / W) = 0 >= u
     double x = u * W;
     if (!(x < INFINITY)) return x;
+    // The answer lies within an ulp or two of u * W (one rounding there, one in the quotient): the five candidates around it
+    // are tried side by side -- five INDEPENDENT divisions, where walking by single ulps chains four or five of them, each
+    // waiting for the last -- and the walk remains for whatever they do not settle.
+    const long long bits = __double_as_longlong(x);
+    if (bits > 2) {
+        const double c0 = __longlong_as_double(bits - 2), c1 = __longlong_as_double(bits - 1);
+        const double c3 = __longlong_as_double(bits + 1), c4 = __longlong_as_double(bits + 2);
+        const bool q0 = c0 / W >= u, q1 = c1 / W >= u, q2 = x / W >= u, q3 = c3 / W >= u, q4 = c4 / W >= u;
+        if (!q0 && q4) return q1 ? c1 : (q2 ? x : (q3 ? c3 : c4));
+    }
     // down while the predecessor still satisfies the predicate, then up until the predicate holds
     for (int it = 0; it < 8; ++it) {
         const double y = __longlong_as_double(__double_as_longlong(x) - 1);     // next below (x > 0)

@@ -295,6 +295,38 @@ __device__ __forceinline__ int32_t window_ancestor(const float* __restrict__ wro
     return min(max(below + 1, tl0 * kTile), N - 1);
 }
 
+// The same from the quad alone where that is certain -- two loads for six: the key before the quad (P0 + the quad's own
+// exclusive prefix, which it loads anyway; for the first quad the previous tile's pinned end, exactly) lies a clear margin
+// below tau and the quad's last key a clear margin at or above it, margins 2^-49 against a last-bit wiggle of neighbouring
+// keys that associate differently.  Anything else -- a threshold within that margin of a quad boundary -- takes the window.
+// (The look-up path is bound by the texture unit's rate of scattered requests, not by their latency: profiles r03, stamps.)
+__device__ __forceinline__ int32_t quad_ancestor(const float* __restrict__ wrow, const double* __restrict__ qx, int32_t N,
+                                                 int32_t ld, int tq, int uq, double P0, double P1, double tau, int tl0) {
+    const int32_t tile_first = tq * kTile;
+    const int32_t tile_last = min(tile_first + kTile, N) - 1;
+    const int32_t k0 = tile_first + uq * kPerThread;
+    const float4 wv = *reinterpret_cast<const float4*>(wrow + min(k0, ld - kPerThread));
+    const double ex = qx[tq * kBlock + uq];
+    double sc[kPerThread];
+    sc[0] = (k0 + 0 < N) ? (double)wv.x : 0.0;
+    sc[1] = sc[0] + ((k0 + 1 < N) ? (double)wv.y : 0.0);
+    sc[2] = sc[1] + ((k0 + 2 < N) ? (double)wv.z : 0.0);
+    sc[3] = sc[2] + ((k0 + 3 < N) ? (double)wv.w : 0.0);
+    int32_t below = k0 - 1;
+    double x_last = 0.0;
+#pragma unroll
+    for (int i = 0; i < kPerThread; ++i) {
+        const double x = (k0 + i >= tile_last) ? P1 : fmin(P0 + (ex + sc[i]), P1);
+        if (k0 + i <= tile_last) {
+            x_last = x;
+            if (!(x >= tau)) below = max(below, k0 + i);
+        }
+    }
+    const bool certain = k0 <= tile_last && fmin(P0 + ex, P1) < tau * (1.0 - 0x1p-49) && x_last >= tau * (1.0 + 0x1p-49);
+    if (!certain) return window_ancestor(wrow, qx, N, ld, tq, uq, P0, P1, tau, tl0);
+    return min(max(below + 1, tl0 * kTile), N - 1);
+}
+
 // Register discipline: the hot path of the kernel sits at 106 vector registers for four wavefronts per SIMD and the register
 // allocator spreads the pressure of whatever is inlined here over the whole kernel (a first version -- four 16-ary searches side
 // by side, all twelve window loads of the four outputs in flight -- cost 300-450 bytes of spills per lane and 1.6 us on EVERY
@@ -383,7 +415,7 @@ __device__ __forceinline__ void search_ancestors(const OffspringCount& F, const 
 #pragma unroll
         for (int q = p; q < p + GSE_SEARCH_WINDOWS_TOGETHER; ++q) {
             const double P0 = pfx_s[tq[q]], P1 = pfx_s[tq[q] + 1];
-            anc[q] = window_ancestor(wrow, qx, (int32_t)N, (int32_t)ld, tq[q], uq[q], P0, P1, tau[q], tl0);
+            anc[q] = quad_ancestor(wrow, qx, (int32_t)N, (int32_t)ld, tq[q], uq[q], P0, P1, tau[q], tl0);
         }
     }
 #else

@@ -1,0 +1,31 @@
+import ctypes, os, sys
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import numpy as np, torch
+import gpu_se_amd, bench
+from gpu_se_amd import sim_base, _lib
+from gpu_util import adversarial_weights
+n = 1 << 20
+gpu_se_amd.seed(1234)
+_, _, _, pf = sim_base.get_parts(N_particles=n)
+lib = ctypes.CDLL(_lib.LIB_PATH)
+bench.device_warm_up(torch, n, 1.0)
+xss = np.array([1.55555556, 26.01626016, 5.2711538, 0.0, 15.18857143], dtype=np.float32)
+u, z = [0.06, 0.2], np.array([280.0, 611.4538406938659])
+rng = np.random.default_rng(n)
+pats = adversarial_weights(n, rng)
+names = {14: "wg start", 15: "wide branch", 16: "draw done", 17: "tiles found", 18: "quads found", 19: "windows done", 20: "wg end"}
+for name in ("light_half", "eight_steps_down"):
+    w = pats[name]
+    for rep in range(3):
+        pf.particles = np.repeat(xss[None, :], n, axis=0)
+        pf.weights = (w / np.nansum(w)).astype(np.float32)
+        pf.update(u, z); pf.resample(r=0.37); pf.predict(u, 0.1); pf.update(u, z)
+        torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 32)()
+    lib.gse_debug_stamps(buf)
+    t = {i: int(buf[i]) for i in names}
+    print(name, "span", int(buf[21]) & 0xfffff, "listed", int(buf[21]) >> 20)
+    prev = t[14]
+    for i in sorted(names):
+        print("   %-14s +%8d ticks (phase %7d)" % (names[i], t[i] - t[14], t[i] - prev))
+        prev = t[i]
