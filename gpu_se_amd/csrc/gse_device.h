@@ -614,15 +614,21 @@ __device__ __forceinline__ double smallest_with_quotient_ge(double u, double W) 
     if (!(u > 0.0)) return 0.0;                       // fl(0 / W) = 0 >= u
     double x = u * W;
     if (!(x < INFINITY)) return x;
-    // The answer lies within an ulp or two of u * W (one rounding there, one in the quotient): the five candidates around it
-    // are tried side by side -- five INDEPENDENT divisions, where walking by single ulps chains four or five of them, each
-    // waiting for the last -- and the walk remains for whatever they do not settle.
+    // The answer lies within an ulp or two of u * W (one rounding there, one in the quotient): u * W itself says which way to
+    // look, and its two neighbours on that side are tried side by side -- three divisions, two deep, where walking by single
+    // ulps chains four or five -- and the walk remains for whatever they do not settle.
     const long long bits = __double_as_longlong(x);
     if (bits > 2) {
-        const double c0 = __longlong_as_double(bits - 2), c1 = __longlong_as_double(bits - 1);
-        const double c3 = __longlong_as_double(bits + 1), c4 = __longlong_as_double(bits + 2);
-        const bool q0 = c0 / W >= u, q1 = c1 / W >= u, q2 = x / W >= u, q3 = c3 / W >= u, q4 = c4 / W >= u;
-        if (!q0 && q4) return q1 ? c1 : (q2 ? x : (q3 ? c3 : c4));
+        const bool here = x / W >= u;
+        const double a = __longlong_as_double(here ? bits - 1 : bits + 1), b = __longlong_as_double(here ? bits - 2 : bits + 2);
+        const bool qa = a / W >= u, qb = b / W >= u;
+        if (here) {
+            if (!qa) return x;
+            if (!qb) return a;
+        } else {
+            if (qa) return a;
+            if (qb) return b;
+        }
     }
     // down while the predecessor still satisfies the predicate, then up until the predicate holds
     for (int it = 0; it < 8; ++it) {

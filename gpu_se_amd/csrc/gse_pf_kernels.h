@@ -381,27 +381,33 @@ __device__ __forceinline__ void search_ancestors(const OffspringCount& F, const 
     double tau[kPerThread];
     int tq[kPerThread];
     {
-        int lo[kPerThread], hi[kPerThread];
+        int lo[kPerThread];
 #pragma unroll
         for (int p = 0; p < kPerThread; ++p) {
             const int32_t j = min(j0 + tid + p * kBlock, j1 - 1);
             tau[p] = smallest_with_quotient_ge(F.u_of(j), F.W);
             lo[p] = tl0;
-            hi[p] = tl1;
         }
-        // 1. the tile: first t in [tl0, tl1] with Pfx[t + 1] >= tau (tl1 qualifies by construction of the range)
-        for (int span = tl1 - tl0; span > 0; span >>= 1) {             // (uniform trip count: enough halvings for the range)
+        // 1. the tile: first t in [tl0, tl1] with Pfx[t + 1] >= tau (tl1 qualifies by construction of the range).  4-ary: the
+        //    answer lies in [lo, lo + width); three pivots a round, counted (five dependent rounds of LDS reads for a range of
+        //    a thousand tiles where a bisection takes ten)
+        int width = 1;
+        while (width < tl1 - tl0 + 1) width <<= 2;                       // (uniform)
+        for (; width > 1; width >>= 2) {
+            const int step = width >> 2;
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p) {
-                const int mid = (lo[p] + hi[p]) >> 1;
-                const bool ge = pfx_s[mid + 1] >= tau[p];
-                if (lo[p] < hi[p]) {
-                    if (ge) hi[p] = mid; else lo[p] = mid + 1;
+                int below = 0;
+#pragma unroll
+                for (int m = 1; m < 4; ++m) {
+                    const int at = lo[p] + m * step - 1;
+                    below += (at < tl1 && pfx_s[min(at, tl1) + 1] < tau[p]) ? 1 : 0;
                 }
+                lo[p] += below * step;
             }
         }
 #pragma unroll
-        for (int p = 0; p < kPerThread; ++p) tq[p] = lo[p];
+        for (int p = 0; p < kPerThread; ++p) tq[p] = min(lo[p], tl1);
     }
     // 2. + 3. per output: the quad, then the keys of that quad and its neighbours exactly as cumsum_kernel forms them;
     //         ancestor = 1 + last key below tau
