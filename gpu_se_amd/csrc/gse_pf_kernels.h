@@ -1777,12 +1777,18 @@ __global__ __launch_bounds__(kBlock) void pf_moments_kernel(const float* __restr
 // the closed loop -- where 3 % to 70 % of them do, 16 % on average -- 59 us against 53: pushing and flushing cost what the
 // occupancy wins.  Fetching a step's state rows whole and coalesced instead of each such particle's own 20 bytes, and a
 // software pipeline over the steps (inputs requested one step ahead, states used one step late) changed nothing either way.
+#ifndef GSE_MOMRES_COMPACT
+#define GSE_MOMRES_COMPACT 1
+#endif
 __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                       const double* __restrict__ tile_sums,
                                                                       const double* __restrict__ qx_all,
                                                                       double* __restrict__ partials, int64_t N, int64_t ld,
                                                                       int T, const ResampleArgs ra) {
     __shared__ double red[4 * 21];
+#if GSE_MOMRES_COMPACT
+    __shared__ int2 items[kBlock / 64][64 * kPerThread];           // per wavefront: (particle, offspring count)
+#endif
     extern __shared__ double pfx_m[];              // [T + 1]
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* xb = x + (int64_t)b * GSE_NX * ld;
@@ -1862,6 +1868,48 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p)
                 n_off[p] = (k0 + p <= tile_last) ? fs[p] - (p == 0 ? prev : fs[(p + 3) % kPerThread]) : 0;
+#if GSE_MOMRES_COMPACT
+            // The particles with offspring -- one in six inside a closed loop -- are COMPACTED through the wavefront's list in LDS
+            // and worked off 64 at a time, every lane busy: taken where they stand, each of a lane's four particles costs the
+            // whole wavefront the 60 fp64 instructions of the accumulation if any lane has offspring there, i.e. always.
+            {
+                int2* mine = &items[wv][0];
+                int base = 0;
+#pragma unroll
+                for (int p = 0; p < kPerThread; ++p) {
+                    const unsigned long long m = __ballot(n_off[p] > 0);
+                    if (n_off[p] > 0)
+                        mine[base + __popcll(m & ((1ull << lane) - 1ull))] = make_int2((int)(k0 + p), n_off[p]);
+                    base += __popcll(m);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int at = 0; at < base; at += 64) {
+                    const bool have = at + lane < base;
+                    const int2 it = have ? mine[at + lane] : make_int2(0, 0);
+                    float xv[GSE_NX];
+#pragma unroll
+                    for (int k = 0; k < GSE_NX; ++k) xv[k] = xb[k * ld + it.x];
+                    if (have) {
+                        const double wp = (double)it.y * wu;
+                        double d[GSE_NX];
+#pragma unroll
+                        for (int k = 0; k < GSE_NX; ++k) d[k] = (double)xv[k] - pv[k];
+                        acc[0] += wp;
+                        int c = 6;
+#pragma unroll
+                        for (int k = 0; k < GSE_NX; ++k) {
+                            const double wd = wp * d[k];
+                            acc[1 + k] += wd;
+#pragma unroll
+                            for (int l = k; l < GSE_NX; ++l) acc[c++] += wd * d[l];
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                          // (the list is rewritten in the next step)
+            }
+#else
             float xv[kPerThread][GSE_NX];
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p)
@@ -1886,6 +1934,7 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
                         for (int l = k; l < GSE_NX; ++l) acc[c++] += wd * d[l];
                     }
                 }
+#endif
         }
     }
     if (!valid && blockIdx.x == 0 && tid == 0) {
