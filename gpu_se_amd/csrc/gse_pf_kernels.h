@@ -1777,6 +1777,14 @@ __global__ __launch_bounds__(kBlock) void pf_moments_kernel(const float* __restr
 // the closed loop -- where 3 % to 70 % of them do, 16 % on average -- 59 us against 53: pushing and flushing cost what the
 // occupancy wins.  Fetching a step's state rows whole and coalesced instead of each such particle's own 20 bytes, and a
 // software pipeline over the steps (inputs requested one step ahead, states used one step late) changed nothing either way.
+// Round 3 kept the 21 accumulators per lane and compacted only the WORK: per step of 256 particles a wavefront lists the
+// (particle, count) pairs with offspring in LDS -- ballots and population counts, so the order is the particles' own and the
+// sums do not depend on timing -- and works the list off 64 at a time, every lane busy.  Taken where they stand, each of a
+// lane's four particles costs the whole wavefront the 60 fp64 instructions of the accumulation whenever any lane has
+// offspring there, i.e. always: 400 vector instructions a step against about 230 now, and with one particle's states in
+// flight instead of four the kernel needs 124 registers for 204 (four wavefronts per SIMD for two): 55.6 -> 47.0 us per
+// tick of 32 x 2^18 particles.  Not better: twice the workgroups (52.2), the next step's inputs requested a step ahead
+// (48.7), full groups of 64 carried over the steps (48.5).
 #ifndef GSE_MOMRES_COMPACT
 #define GSE_MOMRES_COMPACT 1
 #endif
