@@ -296,11 +296,16 @@ __device__ __forceinline__ void read_factor(const float* fac_g, float (&m)[kNx],
 // where (mu, P) are read / written (may be the same memory: every read precedes a barrier that every write follows).
 // g0: filter index of local Gaussian 0 (RNG element), noise: injected rows [N][11][5] of this filter or null.
 // Must be called by every thread of the workgroup.
-template <bool kInjected, class Src, class Dst>
+// meanwhile: called by every thread between phases B and C (after the barrier): what it does on lanes other than the first 64
+// runs beside phase C, which occupies one wavefront (the persistent loop puts the plant's step there).
+struct NothingMeanwhile {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <bool kInjected, class Src, class Dst, class Meanwhile = NothingMeanwhile>
 __device__ __forceinline__ void gsukf_predict_block(Src src, Dst dst, float (*fac)[kFacStride], float (*tile)[kTileStride],
                                                     int nloc, int b, int64_t g0, const float* noise, const DrawParams& dp,
                                                     int32_t* status, const GsukfPredictArgs& a, const FilterIO& bio,
-                                                    const RngKey& rng) {
+                                                    const RngKey& rng, Meanwhile meanwhile = Meanwhile()) {
     // rng: a.rng for a launch that predicts once; a kernel that predicts tick after tick (gse_loop.hip) hands in the key of
     // the tick
     gsukf_factor_block(src, fac, nloc, status);
@@ -324,6 +329,7 @@ __device__ __forceinline__ void gsukf_predict_block(Src src, Dst dst, float (*fa
         for (int k = 0; k < kNx; ++k) tile[gl][j * kNx + k] = s[k] + e[k];
     }
     __syncthreads();
+    meanwhile();
     // C. one Gaussian per lane: mean and covariance of its sigma points
     const int t = threadIdx.x;
     if (t < nloc) {

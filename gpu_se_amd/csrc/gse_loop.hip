@@ -133,9 +133,9 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_closed_loop_kernel(const Gs
     auto from_lds = [&](int t, const float*& m_, const float*& p_) { m_ = mu_s[t]; p_ = P_s[t]; };
     auto to_lds = [&](int t, float*& m_, float*& p_) { m_ = mu_s[t]; p_ = P_s[t]; };
     int n_predict = 0, n_update = 0;
-    // The plant of tick t is one thread's work (an fp64 model step, two draws, the records): it runs on the LAST thread of the
-    // workgroup at the start of tick t + 1, while the other wavefronts factorise and propagate the sigma points of that tick's
-    // predict -- which needs the input the controller left, not the measurement the plant is about to produce.
+    // The plant of tick t is one thread's work (an fp64 model step, two draws, the records: 2.2 us): it runs on the LAST thread of
+    // the workgroup during tick t + 1's predict -- which needs the input the controller left, not the measurement the plant is
+    // about to produce -- beside the phase that forms the sigma points' mean and covariance on the first wavefront (2.5 us).
     auto plant = [&](const GsukfLoopArgs& aa, int t) {
         RngKey ks = aa.plant.rng_state, km = aa.plant.rng_meas;
         ks.step_lo = (uint32_t)t;
@@ -165,14 +165,18 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_closed_loop_kernel(const Gs
 #define STAMP(i)
 #endif
         STAMP(0);
-        if (t > 1 && tid == kSmallBlock - 1) plant(aa, t - 1);
+        // (beside phase C of the predict -- one wavefront's work, 2.5 us -- rather than beside the first factorisation, 0.8 us,
+        //  which it kept waiting; a tick without a predict runs it here)
+        const bool plant_due = t > 1 && tid == kSmallBlock - 1;
+        if (plant_due && !(due & 1)) plant(aa, t - 1);
         FilterIO bio;
         bio.u0 = st_u[0]; bio.u1 = st_u[1]; bio.z0 = 0.0; bio.z1 = 0.0;
         if (due & 1) {
             RngKey key = aa.pred.rng;
             key.step_lo += (uint32_t)n_predict;          // (the class counts a step per predict; 32 bits last a billion ticks)
             ++n_predict;
-            gsukf_predict_block<false>(from_lds, to_lds, fac, tile, N, b, 0, nullptr, dp, aa.chol_status, aa.pred, bio, key);
+            gsukf_predict_block<false>(from_lds, to_lds, fac, tile, N, b, 0, nullptr, dp, aa.chol_status, aa.pred, bio, key,
+                                       [&]() { if (plant_due) plant(aa, t - 1); });
             __syncthreads();
         }
         STAMP(1);
