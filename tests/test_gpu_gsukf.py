@@ -480,6 +480,33 @@ def test_batch_of_banks_equals_single_banks(n):
     np.testing.assert_array_equal(sig[1], singles[1]._get_sigma_points().get())
 
 
+def test_inverse_map_ancestors_of_a_batch_of_banks():
+    """Three banks of 70001 Gaussians in one launch of the inverse-map ancestors kernel, each with weights of another kind --
+    one Gaussian owning every output (the whole-workgroup stores), a bump (16 lanes / a wavefront per key), exact ties -- and a
+    uniform number of its own: every bank's ancestors are those of the single bank (the eager route, itself held against the
+    oracle above) and the rows are the ancestors' rows."""
+    from tests.gpu_util import adversarial_weights
+    B, n = 3, 70001
+    xss = orc.steady_state()
+    rng = np.random.default_rng(77)
+    means = (xss[None, None, :] + rng.standard_normal((B, n, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    pats = adversarial_weights(n, rng)
+    ws = np.stack([pats[k] for k in ("one_hot_tile_edge", "bump", "uniform")]).astype(np.float32)
+    r = np.array([0.0, 0.37, 1.0 - 2.0 ** -53])
+    batch = make_batch(B, n, means)
+    assert batch.lazy
+    batch.weights = ws
+    idx = batch.resample(r=r, return_index=True).get()
+    for b in range(B):
+        gf = make(n, means[b])
+        gf.lazy = False
+        gf.weights = ws[b]
+        want = gf.resample(r=float(r[b]), return_index=True).get()
+        np.testing.assert_array_equal(idx[b], want, err_msg=str(b))
+        np.testing.assert_array_equal(batch.means.get()[b], means[b][want])
+    np.testing.assert_array_equal(batch.weights.get(), np.full((B, n), np.float32(1.0 / n)))
+
+
 def test_batch_of_banks_with_injected_noise_tracks_the_oracle():
     """The batched class in the parity mode: every bank against its own NumPy oracle fed the same noise."""
     B, n = 2, 40
