@@ -468,7 +468,10 @@ def main():
                     "measured_on": "a filter drawn from its prior, 10 warm-up cycles, %d timed cycles" % reps,
                     "note": "achieved = 140 B x N / average launch-to-launch device time of one cycle (HIP events on "
                             "the launch stream); traffic = PMC bytes of the committed profile, null when the kernel "
-                            "sources changed since it was taken"}
+                            "sources changed since it was taken.  The 140 bytes are the reference's five passes over a "
+                            "particle (SURVEY 8d); the fused launch really moves `traffic` (about 56 MB at 2^20, 0.38 of the "
+                            "algorithmic bytes), which is why `frac` can pass 1: the kernel is bound by its instruction count "
+                            "and fixed cost, not by HBM"}
         fresh_prior = {"cycles_per_s": round(1.0 / fresh_wall, 1), "device_us_per_cycle": round(per["cycle"] * 1e6, 2),
                        "frac": round(achieved / HBM_PEAK_GBS, 4), "warmup": 10, "timed_cycles": reps,
                        "note": "SURVEY 8d protocol: particles ~ prior, 10 warm-ups, then the timed cycles back to back (one "
