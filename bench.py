@@ -119,8 +119,10 @@ def device_warm_up(torch, n, dt, cycles=500):
     touching the state of the filter that is measured."""
     import gpu_se_amd
     from gpu_se_amd import sim_base
+    keep = dict(gpu_se_amd._seed_state)           # (the throw-away filter must not move the streams of what is measured)
     gpu_se_amd.seed(99)
     _, _, _, tmp = sim_base.get_parts(N_particles=n)
+    gpu_se_amd._seed_state.update(keep)
     io = make_inputs(64, dt, seed=7)
     for c in range(cycles):
         u, z = io[c % len(io)]
@@ -291,6 +293,21 @@ def gsukf_block(torch, sizes=(64, 4096, 1 << 18)):
     return out
 
 
+def reference_itse(tag):
+    """Median (and 10 / 90 % quantiles) of the ITSE ``performance`` of the reference's OWN Simulation over 32 seeds
+    (tests/golden/loop_envelope.npz, G11: the reference's NumPy classes run by tests/golden/make_golden.py) for the
+    configuration ``tag``, e.g. pf1024_c01; None when the fixture is not there."""
+    path = os.path.join(ROOT, "tests", "golden", "loop_envelope.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if tag + "_performance" not in g:
+        return None
+    q = np.quantile(g[tag + "_performance"], [0.1, 0.5, 0.9])
+    return {"config": tag, "seeds": int(len(g[tag + "_performance"])), "median_ITSE": float(q[1]), "q10": float(q[0]),
+            "q90": float(q[2])}
+
+
 def closed_loop_block(torch, B=32, log2n=18, end_time=50, pf=True):
     """BASELINE config 5 per GPU: 32 closed-loop rollouts x 2^18 particles, 499 ticks, MPC every tick, everything
     resident on the device (sim_base.BatchedSimulation(resident=True)).  pf=False: the same loop with banks of 2^log2n
@@ -315,7 +332,9 @@ def closed_loop_block(torch, B=32, log2n=18, end_time=50, pf=True):
             "wall_s": round(wall, 4), "host_enqueue_s": round(float(sim.timing["enqueue"]), 4),
             "ticks_per_s_device": round(ticks / dev_s, 1),
             "particle_cycles_per_s_device": round(ticks * B * (1 << log2n) / dev_s, 1),
-            "median_ITSE": float(np.median(sim.performance)), "mpc_solved_fraction": round(float(sim.mpc_frac), 4)}
+            "median_ITSE": float(np.median(sim.performance)), "mpc_solved_fraction": round(float(sim.mpc_frac), 4),
+            "wall_over_device": round(wall / dev_s, 3),
+            "reference_ITSE": reference_itse("pf1024_c01" if pf else "gsf64_c01")}
 
 
 def main():
@@ -357,6 +376,9 @@ def main():
     from gpu_se_amd.distributed import ShardedParticleFilter
     pf = ShardedParticleFilter.from_get_parts(n_local=n, group=dist.group.WORLD if use_dist else None)
     steps, warmup, burn_in = args.steps, args.warmup, max(args.burn_in, 0)
+    # the island bookkeeping's all-reduce fires every reduce_every-th resample: at the driver's K = 20 the default of 32 would
+    # leave the timed region without a single collective -- at least four of them now, whatever K is
+    pf.reduce_every = max(1, min(32, steps // 4))
     dt = 1.0                                                    # pf_run_seq.py:48
     io = make_inputs(burn_in + steps + warmup, dt)
 
@@ -383,6 +405,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    collectives_before = pf.collectives_issued
     t0 = time.perf_counter()
     for i in range(warmup, warmup + steps):
         cycle(i)
@@ -399,8 +422,51 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    collectives_timed = pf.collectives_issued - collectives_before
     est = pf.point_estimate()                                   # merges the shards (all-reduce of the moments)
     assert np.all(np.isfinite(est)), est
+
+    # ---- the same cycles, each ENDING IN THE POSTERIOR MERGE (the reference's loop asks for an estimate every tick,
+    #      sim_base.py:262, :287-295): moments of the shard, its row of the merge buffer, the all-reduce of [P][22] doubles
+    #      (asynchronous on RCCL), the combination -- all on the device, stream-ordered, nothing comes to the host
+    #      (ShardedParticleFilter.merge_begin / merge_end).  Same bracket as above: barrier + synchronize on both sides, max
+    #      over the ranks.
+    io2 = make_inputs(steps + 5, dt, seed=11)
+    sink = torch.zeros((1, 6), dtype=torch.float64, device="cuda")
+    from gpu_se_amd import _lib as _gl
+
+    def cycle_with_estimate(i):
+        u, z = io2[i]
+        pf.predict(u, dt)
+        pf.update(u, z)
+        pf.resample()
+        pf.merge_begin()
+        m = pf.merge_end()
+        _gl.call("gse_moments_estimates", m.data_ptr(), 1, sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for i in range(5):
+        cycle_with_estimate(i)
+    pf.wait_collectives()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    collectives_before = pf.collectives_issued
+    t1 = time.perf_counter()
+    for i in range(5, 5 + steps):
+        cycle_with_estimate(i)
+    pf.wait_collectives()
+    gpu_se_amd.synchronize()
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed_est = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([elapsed_est], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed_est = float(tt.item())
+    collectives_est = pf.collectives_issued - collectives_before
+    assert np.all(np.isfinite(sink.cpu().numpy())), "merged estimate is not finite"
     # what torch.distributed / RCCL saw (so that a multi-GPU line can be checked against the launcher's own record)
     rccl_info = {"initialised": bool(use_dist), "world_size": world, "backend": None, "devices": [local_rank]}
     if use_dist:
@@ -455,7 +521,14 @@ def main():
         traffic, traffic_hash = pmc_traffic(n)
         sources = csrc_hash()
         single_launch = not lp._prefix_global
+        measured = (traffic / per["cycle"] / 1e9) if (traffic and traffic_hash == sources) else None
         roofline = {"bound": "hbm",
+                    "limited_by": "vector-instruction issue + fixed launch cost (the fused launch moves 0.38 of the algorithmic "
+                                  "bytes; see hbm_measured)",
+                    "hbm_measured": None if measured is None else
+                    {"GBps": round(measured, 1), "frac_of_peak": round(measured / HBM_PEAK_GBS, 4),
+                     "note": "PMC bytes of the committed profile / this run's device time per launch: what the launch really "
+                             "moves through HBM"},
                     "kernel": "pf_step_kernel<gather,predict,update,scan>" if single_launch
                     else "tile_scan_kernel (one workgroup) + pf_step_kernel<gather,predict,update,scan from the scanned tile "
                          "prefix> (two launches per cycle beyond 2^21 particles)",
@@ -495,7 +568,8 @@ def main():
                                       "BASELINE config 4: 2^24 particles over 8 GPUs" if (world == 8 and n == 1 << 21)
                                       else "BASELINE config 2" if (world == 1 and n == 1 << 20)
                                       else "weak scaling of BASELINE config 2"),
-                       "particles_per_gpu": n, "total_particles": n * world, "dt": dt, "burn_in_cycles": burn_in,
+                       "particles_per_gpu": n, "particles_per_rank": [cnt for _, cnt in pf._spans],
+                       "total_particles": n * world, "dt": dt, "burn_in_cycles": burn_in, "reduce_every": pf.reduce_every,
                        "device_warmup_cycles": device_warmup,
                        "parallelism": ("particle shards x%d, EXACT global resampling (all-gather of tile sums + all-to-all "
                                        "of particles per cycle), posterior merge at estimates" % world)
@@ -507,6 +581,13 @@ def main():
                        if world > 1 else "single GPU"},
             "ensemble_cycles_per_s": round(steps / elapsed, 2),
             "particles_per_s": round(particle_cycles, 1),
+            "collectives_in_timed_region": int(collectives_timed),
+            "with_estimate_every_cycle": {
+                "value": round(float(world) * n * steps / elapsed_est / UNIT_PARTICLES, 2),
+                "unit": "cycles/s per 2^20 particles", "ms_per_step": round(elapsed_est / steps * 1e3, 5),
+                "collectives_in_timed_region": int(collectives_est),
+                "note": "every cycle ends in the posterior merge over all ranks: shard moments -> merge row (device) -> all-reduce "
+                        "of [P][22] doubles (RCCL, async) -> combination (device); stream-ordered, no host copy"},
             "roofline": roofline,
             "fresh_prior": fresh_prior,
             "steady_state": steady_state,
@@ -516,6 +597,10 @@ def main():
             result["protocol_sum_us"] = protocol_sum(torch, n, io, dt)
             result["gsukf"] = gsukf_block(torch)
             result["closed_loop"] = closed_loop_block(torch)
+            # one real-time loop, and a few: the ticks are enqueued from C++ (gse_pf_closed_loop), so the wall time of a small
+            # loop is its device time, not the host's
+            result["closed_loop_small"] = {"B=%d,N=2^%d" % (b_, l_): closed_loop_block(torch, B=b_, log2n=l_)
+                                           for b_, l_ in ((1, 16), (1, 18), (4, 16), (8, 18))}
             result["closed_loop_gsukf"] = closed_loop_block(torch, log2n=6, pf=False)     # 32 rollouts x 64 Gaussians (config 3's bank)
         if world == 1 and not args.no_cpu_baseline:
             full, small, vec = cpu_baseline(n, dt)

@@ -17,6 +17,8 @@ GSE_OP_GATHER, GSE_OP_PREDICT, GSE_OP_UPDATE = 1, 2, 4
 GSE_OP_SCAN_IN, GSE_OP_SCAN_OUT, GSE_OP_SCAN_IN_SLOT1, GSE_OP_SCAN_OUT_SLOT1 = 8, 16, 32, 64
 GSE_OP_U_DEVICE, GSE_OP_Z_DEVICE = 128, 256
 GSE_OP_PREFIX_GLOBAL = 512
+GSE_OP_WEIGHT_SCALE = 1024
+GSE_RESAMPLE_WEIGHT_SCALE = 16
 GSE_IO_U_DEVICE, GSE_IO_Z_DEVICE = 1, 2
 GSE_SCAN_MAX_TILES = 2048      # policy: up to 2^21 particles every workgroup of the cycle kernel rebuilds the tile prefix in LDS
                                # (one launch per cycle); beyond, a one-workgroup scan of the tile sums runs first and the
@@ -70,6 +72,20 @@ class LoopTail(ctypes.Structure):
                                           "log_x", "log_u")]
 
 
+class PfLoopSpec(ctypes.Structure):
+    """struct gse_pf_loop_spec (include/gse.h)."""
+    _fields_ = [("B", c_i32), ("ticks", c_i32), ("N", c_i64), ("ld", c_i64), ("dt", c_d), ("flags", c_u32), ("reserved", c_u32),
+                ("x", c_vp * 2), ("w", c_vp * 2), ("workspace", c_vp), ("state_pdf", c_vp), ("measurement_pdf", c_vp),
+                ("rng", Rng), ("law", c_vp), ("glue", c_vp), ("X", c_vp), ("u", c_vp), ("z", c_vp), ("y_pred", c_vp),
+                ("known", c_vp), ("plant_state_noise", c_vp), ("plant_meas_noise", c_vp), ("plant_rng", Rng),
+                ("schedule", c_vp), ("r", c_vp), ("us", c_vp), ("xs", c_vp), ("ys", c_vp), ("ys_meas", c_vp), ("moments", c_vp),
+                ("status", c_vp),
+                ("x_current", c_i32), ("w_current", c_i32), ("pend_gather", c_i32), ("pend_predict", c_i32),
+                ("gather_slot", c_i32), ("scan_slot", c_i32), ("r_pending", c_d * GSE_MAX_B)]
+
+
+GSE_PF_LOOP_WEIGHT_SCALE = 1
+
 P_MIX = ctypes.POINTER(Mixture)
 P_RNG = ctypes.POINTER(Rng)
 P_D = ctypes.POINTER(c_d)
@@ -80,11 +96,13 @@ PROTOTYPES = {
     "gse_version": (ctypes.c_int, []),
     "gse_last_error": (ctypes.c_char_p, []),
     "gse_workspace_bytes": (c_i64, [ctypes.c_int, c_i64]),
+    "gse_workspace_weight_scale_offset": (c_i64, [ctypes.c_int, c_i64]),
     "gse_stream_synchronize": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "gse_pf_predict": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_d, P_MIX, P_RNG, c_vp]),
     "gse_pf_predict_injected": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_d, c_vp, c_vp]),
     "gse_pf_update": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_int, c_i64, P_D, P_D, P_MIX, c_vp, c_vp]),
     "gse_pf_resample": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_u32, c_vp, c_vp, c_vp]),
+    "gse_pf_gather_index": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_int, c_i64, c_vp]),
     "gse_pf_resample_begin": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_u32, c_vp, c_vp, c_vp]),
     "gse_pf_step": (ctypes.c_int, [c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_d, P_D, P_D,
                                    P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_vp, c_vp]),
@@ -156,7 +174,10 @@ PROTOTYPES = {
     "gse_pf_shard_gather": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_d, c_vp, c_vp, c_vp]),
     "gse_plant_step": (ctypes.c_int, [c_vp, c_vp, c_d, P_MIX, P_MIX, P_RNG, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "gse_gsukf_closed_loop": (ctypes.c_int, [ctypes.POINTER(LoopSpec), c_vp]),
+    "gse_pf_closed_loop": (ctypes.c_int, [ctypes.POINTER(PfLoopSpec), c_vp]),
     "gse_moments_estimates": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "gse_merge_row": (ctypes.c_int, [c_vp, c_vp, c_vp, P_D, c_vp, c_vp]),
+    "gse_merge_rows": (ctypes.c_int, [c_vp, ctypes.c_int, P_D, c_vp, c_vp, c_vp]),
     "gse_plant_step_injected": (ctypes.c_int, [c_vp, c_vp, c_d, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
 }
 

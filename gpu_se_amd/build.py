@@ -9,7 +9,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgse_hip.so")
-SOURCES = ["gse_host.hip", "gse_pf.hip", "gse_gsukf.hip", "gse_rows.hip", "gse_mpc.hip", "gse_rtc.hip", "gse_loop.hip"]
+SOURCES = ["gse_host.hip", "gse_pf.hip", "gse_gsukf.hip", "gse_rows.hip", "gse_mpc.hip", "gse_rtc.hip", "gse_loop.hip", "gse_pf_loop.hip"]
 ARCH = "gfx950"
 # per-source flags.  gse_loop.hip holds one kernel whose body is a loop over the ticks of a whole closed-loop run: with
 # machine-level loop-invariant code motion every constant and address a tick needs is materialised before the loop and kept

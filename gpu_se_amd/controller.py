@@ -34,7 +34,7 @@ MAX_ROWS = 64            # GSE_MPC_MAX_ROWS
 
 class _Law(ctypes.Structure):
     _fields_ = [("n_theta", ctypes.c_int32), ("n_u", ctypes.c_int32), ("n_y", ctypes.c_int32), ("n_rows", ctypes.c_int32),
-                ("max_sweeps", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("max_sweeps", ctypes.c_int32), ("report_unsolved", ctypes.c_int32),
                 ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double)] + \
                [(name, ctypes.c_void_p) for name in ("Gc", "gc0", "S", "lo", "hi", "Gu", "gu0", "Tu", "Gy", "gy0", "Ty")]
 
@@ -77,6 +77,9 @@ class MPC:
         self._u_lim = _bounds(u_bounds, Ni)
         self._du_lim = _bounds(u_step_bounds, Ni)
         self._solver = (int(max_sweeps), float(eps_abs), float(eps_rel))
+        # fault injection: True -> every step reports "not solved", as OSQP does when it returns a non-solved status
+        # (controller.py:268-269); step() then raises and the loops take the reference's fallback (sim_base.py:271-273)
+        self.report_unsolved = False
         self._built = None          # the explicit law: built on first use (callers that only want the estimator never pay)
         self._dense = None          # the condensed problem as dense arrays (inspection / tests / singular R)
         self._dev = None
@@ -310,6 +313,7 @@ class MPC:
             for k, t in keep.items():
                 setattr(law, k, t.data_ptr() if t.numel() else None)
             self._dev = (lib, law, keep)
+        self._dev[1].report_unsolved = 1 if self.report_unsolved else 0
         return self._dev
 
     def step_device(self, theta, du0=None, y1=None, status=None):

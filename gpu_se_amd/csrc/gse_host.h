@@ -63,6 +63,7 @@ struct Workspace {
     double* scan_sums[2];  // [B][T]       tile sums that go with scan[slot]
     double* scan[2];       // [B][T][256]  per-thread exclusive prefixes inside each tile (GSE_OP_SCAN_OUT / _IN), two slots
     double* cumsum;        // [B][N]       normalised cumulative weights
+    double* wscale;        // [B]          GSE_OP_WEIGHT_SCALE: log2 of the factor between the stored and the true weights
     int64_t bytes;
 };
 Workspace carve_workspace(void* base, int B, int64_t N);

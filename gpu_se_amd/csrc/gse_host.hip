@@ -3,6 +3,7 @@
 #include "gse_host.h"
 
 #include <math.h>
+#include <chrono>
 #include <string.h>
 
 namespace gse {
@@ -73,6 +74,7 @@ void pack_pdf2(Pdf2& p, const gse_mixture& m) {
     p.nd = m.nd;
     for (int d = 0; d < m.nd; ++d) {
         p.cw[d] = (double)(m.consts[d] * m.weights[d]);          // fp32 product, then widened (MultivariateGaussianSum.py:61)
+        p.l2cw[d] = p.cw[d] > 0.0 ? log2(p.cw[d]) : -INFINITY;
         for (int i = 0; i < 2; ++i) {
             p.mean[d][i] = (double)m.means[d][i];
             for (int j = 0; j < 2; ++j) p.inv[d][i][j] = m.inv_cov[d][i][j];
@@ -103,6 +105,8 @@ Workspace carve_workspace(void* base, int B, int64_t N) {
     }
     ws.cumsum = reinterpret_cast<double*>(p + at);
     at += round256((int64_t)B * N * 8);
+    ws.wscale = reinterpret_cast<double*>(p + at);
+    at += round256((int64_t)B * 8);
     ws.bytes = at;
     return ws;
 }
@@ -117,18 +121,22 @@ const char* gse_last_error(void) { return gse::last_error_buffer(); }
 
 int gse_stream_synchronize(void* stream, int spin) {
     hipStream_t st = (hipStream_t)stream;
-    if (!spin) {
-        const hipError_t e = hipStreamSynchronize(st);
-        return e == hipSuccess ? GSE_OK : gse::fail(-(int)e, "gse_stream_synchronize: %s", hipGetErrorString(e));
-    }
     // Busy-wait on the stream's state: the caller's next launch should follow the end of this work by a microsecond, not by
     // the wake-up latency of a blocking wait (the reference's benchmark protocol times every method call by itself,
-    // results/pf_openloop/pf_run_seq.py:15-130 -- there the wait is most of what a small filter costs).
-    for (;;) {
-        const hipError_t e = hipStreamQuery(st);
-        if (e == hipSuccess) return GSE_OK;
-        if (e != hipErrorNotReady) return gse::fail(-(int)e, "gse_stream_synchronize: %s", hipGetErrorString(e));
+    // results/pf_openloop/pf_run_seq.py:15-130 -- there the wait is most of what a small filter costs).  Bounded: after
+    // 20 ms of polling the work is no short kernel any more (or hangs) and the blocking wait takes over -- a host core is not
+    // spun for ever inside a library call.
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int polls = 0;; ++polls) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e == hipSuccess) return GSE_OK;
+            if (e != hipErrorNotReady) return gse::fail(GSE_ERR_HIP, "gse_stream_synchronize: %s", hipGetErrorString(e));
+            if ((polls & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
     }
+    const hipError_t e = hipStreamSynchronize(st);
+    return e == hipSuccess ? GSE_OK : gse::fail(GSE_ERR_HIP, "gse_stream_synchronize: %s", hipGetErrorString(e));
 }
 
 int64_t gse_workspace_bytes(int B, int64_t N) {

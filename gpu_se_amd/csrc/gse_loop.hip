@@ -243,6 +243,16 @@ __global__ __launch_bounds__(kSmallBlock) void gsukf_closed_loop_kernel(const Gs
     for (int i = tid; i < N; i += kSmallBlock) a.w[(int64_t)b * N + i] = w_s[i];
 }
 
+// The loop kernel reads its argument block through a pointer (see above); this launch puts the block there.  A by-value
+// kernel argument travels in the launch's own kernarg segment: nothing is read from host memory after the call returns, the
+// call stays enqueue-only and capturable (a hipMemcpyAsync from the pageable stack frame was neither: the copy blocks the
+// host until the stream reaches it, and under capture the node would keep a dangling host pointer).
+__global__ __launch_bounds__(256) void store_loop_args_kernel(const GsukfLoopArgs a, GsukfLoopArgs* __restrict__ dst) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&a);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    for (int i = threadIdx.x; i < (int)(sizeof(GsukfLoopArgs) / 4); i += 256) d[i] = src[i];
+}
+
 }  // namespace gse
 
 using namespace gse;
@@ -281,8 +291,9 @@ extern "C" int gse_gsukf_closed_loop(const gse_loop_spec* s, void* stream) {
     GSE_REQUIRE(s->args_buffer && aligned16(s->args_buffer),
                 "gse_gsukf_closed_loop: args_buffer must be a 16-byte aligned device buffer of GSE_LOOP_ARGS_BYTES bytes");
     static_assert(sizeof(GsukfLoopArgs) <= GSE_LOOP_ARGS_BYTES, "GSE_LOOP_ARGS_BYTES is too small");
-    // (from the stack: the runtime stages a pageable source before it returns, so `a` may go out of scope)
-    GSE_HIP_CHECK(hipMemcpyAsync(s->args_buffer, &a, sizeof a, hipMemcpyHostToDevice, (hipStream_t)stream));
+    static_assert(sizeof(GsukfLoopArgs) % 4 == 0, "argument block copied word by word");
+    hipLaunchKernelGGL(store_loop_args_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, (GsukfLoopArgs*)s->args_buffer);
+    GSE_LAUNCH_CHECK("store_loop_args_kernel");
     hipLaunchKernelGGL(gsukf_closed_loop_kernel, dim3((unsigned)s->B), dim3(kSmallBlock), 0, (hipStream_t)stream,
                        (const GsukfLoopArgs*)s->args_buffer);
     GSE_LAUNCH_CHECK("gsukf_closed_loop_kernel");

@@ -8,7 +8,7 @@
 namespace gse {
 
 struct MpcLawDev {
-    int32_t n_theta, n_u, n_y, n_rows, max_sweeps;
+    int32_t n_theta, n_u, n_y, n_rows, max_sweeps, report_unsolved;
     double eps_abs, eps_rel;
     const double* __restrict__ Gc;
     const double* __restrict__ gc0;
@@ -162,7 +162,7 @@ __device__ __forceinline__ int mpc_solve(const MpcLawDev& law, double theta_lane
         if (mine && nui != 0.0) acc -= (for_u ? law.Tu : law.Ty)[k * m + i] * nui;
     }
     out = acc;
-    return converged;
+    return law.report_unsolved ? 0 : converged;     // (fault injection: the caller's fallback branch, include/gse.h)
 }
 
 struct LoopGlue {

@@ -185,6 +185,71 @@ __global__ __launch_bounds__(256) void moments_estimates_kernel(const double* __
     out[i * 6 + 5] = big;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Posterior merge of a SHARDED ensemble on the device (gpu_se_amd/distributed.py).  merge_row_kernel: one shard's
+// moments (26 doubles about its own pivot) -> its row of the merge buffer { log A, S0, sum w (x - p0) (5), upper triangle of
+// sum w (x - p0)(x - p0)^T (15) } about the pivot p0 all ranks share (distributed.pack_merge_row).  merge_rows_kernel: the
+// all-reduced rows of all shards -> the moments of the WHOLE ensemble in the 26-double layout every consumer here takes
+// (S0 = 1, first and second moments about p0, p0): shard p enters with a_p = A_p S0_p / sum_q A_q S0_q, formed in the log
+// domain (distributed.merge_rows / shard_shares).  One thread each: a few hundred flops between a moments kernel and the
+// controller, so that a sharded closed loop never brings an estimate to the host.
+// ------------------------------------------------------------------------------------------------
+struct Pivot5 { double p[GSE_NX]; };
+
+__global__ void merge_row_kernel(const double* __restrict__ m, const double* __restrict__ log_island,
+                                 const double* __restrict__ wscale, const Pivot5 common, double* __restrict__ row) {
+#pragma clang fp contract(off)                            // (the host formulas of distributed.pack_merge_row, operation by operation)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int ws = wscale ? (int)wscale[0] : 0;           // (GSE_OP_WEIGHT_SCALE: the sums are those of the stored weights)
+    const double s0 = ldexp(m[0], ws);
+    double s1[GSE_NX], delta[GSE_NX];
+#pragma unroll
+    for (int k = 0; k < GSE_NX; ++k) {
+        s1[k] = ldexp(m[1 + k], ws);
+        delta[k] = m[21 + k] - common.p[k];
+    }
+    row[0] = log_island[0];
+    row[1] = s0;
+#pragma unroll
+    for (int k = 0; k < GSE_NX; ++k) row[2 + k] = s1[k] + delta[k] * s0;
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < GSE_NX; ++r)
+#pragma unroll
+        for (int q = r; q < GSE_NX; ++q, ++c)
+            row[7 + c] = ((ldexp(m[6 + c], ws) + s1[r] * delta[q]) + delta[r] * s1[q]) + s0 * (delta[r] * delta[q]);
+}
+
+__global__ void merge_rows_kernel(const double* __restrict__ rows, int P, const Pivot5 common, double* __restrict__ out,
+                                  int32_t* __restrict__ status) {
+#pragma clang fp contract(off)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double top = -INFINITY;
+    for (int p = 0; p < P; ++p) {
+        const double la = rows[p * 22], s0 = rows[p * 22 + 1];
+        const bool live = (s0 > 0.0) && (fabs(la) < INFINITY) && (s0 < INFINITY);
+        if (live) top = fmax(top, la + log(s0));
+    }
+    double acc[20], total = 0.0;
+#pragma unroll
+    for (int k = 0; k < 20; ++k) acc[k] = 0.0;
+    if (status) status[0] = (top > -INFINITY) ? 0 : 1;   // 1: every shard has zero weight (all likelihoods underflowed)
+    for (int p = 0; p < P; ++p) {
+        const double la = rows[p * 22], s0 = rows[p * 22 + 1];
+        const bool live = (s0 > 0.0) && (fabs(la) < INFINITY) && (s0 < INFINITY);
+        if (!live) continue;
+        const double a = exp((la + log(s0)) - top);
+        total += a;
+#pragma unroll
+        for (int k = 0; k < 20; ++k) acc[k] += a * rows[p * 22 + 2 + k] / s0;
+    }
+    out[0] = 1.0;
+#pragma unroll
+    for (int k = 0; k < 20; ++k) out[1 + k] = acc[k] / total;
+#pragma unroll
+    for (int k = 0; k < GSE_NX; ++k) out[21 + k] = common.p[k];
+}
+
 }  // namespace gse
 
 using namespace gse;
@@ -203,6 +268,7 @@ int pack_mpc_law(const char* fn, const gse_mpc_law* law, MpcLawDev& d) {
     GSE_REQUIRE(law->n_rows == 0 || (law->Gc && law->gc0 && law->S && law->lo && law->hi && law->Tu && law->Ty),
                 "%s: null law matrix", fn);
     d.n_theta = law->n_theta; d.n_u = law->n_u; d.n_y = law->n_y; d.n_rows = law->n_rows; d.max_sweeps = law->max_sweeps;
+    d.report_unsolved = law->report_unsolved;
     d.eps_abs = law->eps_abs; d.eps_rel = law->eps_rel;
     d.Gc = law->Gc; d.gc0 = law->gc0; d.S = law->S; d.lo = law->lo; d.hi = law->hi;
     d.Gu = law->Gu; d.gu0 = law->gu0; d.Tu = law->Tu; d.Gy = law->Gy; d.gy0 = law->gy0; d.Ty = law->Ty;
@@ -313,6 +379,25 @@ int gse_pf_moments_resampled_tail(const float* x, const float* w, int64_t ld, in
     a.inj_state = t->state_draw; a.inj_meas = t->meas_draw;
     hipLaunchKernelGGL(loop_tail_kernel, dim3((unsigned)B), dim3(64 * kFinishGroups), 0, st, a);
     GSE_LAUNCH_CHECK("loop_tail_kernel");
+    return GSE_OK;
+}
+
+int gse_merge_row(const double* moments26, const double* log_island, const double* wscale, const double* common_pivot,
+                  double* row, void* stream) {
+    GSE_REQUIRE(moments26 && log_island && common_pivot && row, "gse_merge_row: null argument");
+    Pivot5 pv;
+    for (int k = 0; k < GSE_NX; ++k) pv.p[k] = common_pivot[k];
+    hipLaunchKernelGGL(merge_row_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, moments26, log_island, wscale, pv, row);
+    GSE_LAUNCH_CHECK("merge_row_kernel");
+    return GSE_OK;
+}
+
+int gse_merge_rows(const double* rows, int P, const double* common_pivot, double* moments26_out, int32_t* status, void* stream) {
+    GSE_REQUIRE(rows && common_pivot && moments26_out && P >= 1 && P <= 4096, "gse_merge_rows: bad argument");
+    Pivot5 pv;
+    for (int k = 0; k < GSE_NX; ++k) pv.p[k] = common_pivot[k];
+    hipLaunchKernelGGL(merge_rows_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rows, P, pv, moments26_out, status);
+    GSE_LAUNCH_CHECK("merge_rows_kernel");
     return GSE_OK;
 }
 

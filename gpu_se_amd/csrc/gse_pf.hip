@@ -15,14 +15,15 @@ int launch_cumsum(const float* w, int64_t ldw, int B, int64_t N, uint32_t flags,
         hipLaunchKernelGGL(tile_sum_kernel, dim3(T, B), dim3(kBlock), 0, st, w, ws.tile_sums, N, ldw, T);
         GSE_LAUNCH_CHECK("tile_sum_kernel");
     }
+    const double* wscale = (flags & GSE_RESAMPLE_WEIGHT_SCALE) ? ws.wscale : nullptr;     // (read by the island bookkeeping only)
     if (T <= kInlinePrefixMaxT && !(flags & GSE_RESAMPLE_SEPARATE_SCAN)) {
         hipLaunchKernelGGL(cumsum_kernel<true>, dim3(T, B), dim3(kBlock), 0, st, w, c_out, ws.tile_sums, ws.totals, island,
-                           N, ldw, T, (int64_t)0, (int64_t)0, (int64_t)0);
+                           N, ldw, T, (int64_t)0, (int64_t)0, (int64_t)0, wscale);
     } else {
         hipLaunchKernelGGL(tile_scan_kernel, dim3(B), dim3(kBlock), 0, st, ws.tile_sums, ws.tile_prefix, T);
         GSE_LAUNCH_CHECK("tile_scan_kernel");
         hipLaunchKernelGGL(cumsum_kernel<false>, dim3(T, B), dim3(kBlock), 0, st, w, c_out, ws.tile_prefix, ws.totals,
-                           island, N, ldw, T, (int64_t)(T + 1), (int64_t)0, (int64_t)T);
+                           island, N, ldw, T, (int64_t)(T + 1), (int64_t)0, (int64_t)T, wscale);
     }
     GSE_LAUNCH_CHECK("cumsum_kernel");
     return GSE_OK;
@@ -211,7 +212,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const bool G = ops & GSE_OP_GATHER, P = ops & GSE_OP_PREDICT, U = ops & GSE_OP_UPDATE;
     const uint32_t known = GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE | GSE_OP_SCAN_IN | GSE_OP_SCAN_OUT |
                            GSE_OP_SCAN_IN_SLOT1 | GSE_OP_SCAN_OUT_SLOT1 | GSE_OP_U_DEVICE | GSE_OP_Z_DEVICE |
-                           GSE_OP_PREFIX_GLOBAL;
+                           GSE_OP_PREFIX_GLOBAL | GSE_OP_WEIGHT_SCALE;
     const bool prefix_global = (ops & GSE_OP_PREFIX_GLOBAL) != 0;
     GSE_REQUIRE((ops & (GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE)) != 0 && (ops & ~known) == 0,
                 "%s: bad ops mask 0x%x", fn, ops);
@@ -254,7 +255,12 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     if (P) {
         GSE_REQUIRE(u, "%s: predict needs u", fn);
         GSE_REQUIRE(x_out && aligned16(x_out), "%s: predict needs an aligned x_out (may equal x_in without gather)", fn);
-        GSE_REQUIRE(G || x_out == x_in, "%s: without gather the step is in place: x_out must equal x_in", fn);
+        GSE_REQUIRE(G || x_out == x_in || ((ops & GSE_OP_WEIGHT_SCALE) && U),
+                    "%s: without gather the step is in place: x_out must equal x_in (except predict + update with "
+                    "GSE_OP_WEIGHT_SCALE, which must NOT be in place)", fn);
+        GSE_REQUIRE(!((ops & GSE_OP_WEIGHT_SCALE) && U) || x_out != x_in,
+                    "%s: with GSE_OP_WEIGHT_SCALE a launch that predicts and updates reads the scale's anchor (particle 0) from "
+                    "x_in while other workgroups write x_out: the two must be separate buffers", fn);
         if (noise) {
             GSE_REQUIRE(aligned16(noise), "%s: noise must be 16-byte aligned", fn);
             a.draw = DrawParams{};
@@ -277,6 +283,8 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const bool I = P && noise != nullptr;
     const int T = (int)tiles_of(N);
     const Workspace ws = carve_workspace(workspace, B, N);
+    GSE_REQUIRE(!(ops & GSE_OP_WEIGHT_SCALE) || workspace, "%s: GSE_OP_WEIGHT_SCALE keeps the exponent in the workspace", fn);
+    a.wscale = (ops & GSE_OP_WEIGHT_SCALE) ? ws.wscale : nullptr;
     StepLaunch L;
     L.grid = dim3((unsigned)T, (unsigned)B);
     L.st = (hipStream_t)stream;
@@ -344,6 +352,12 @@ int gse_pf_update(const float* x, float* w, int64_t ld, int B, int64_t N, const 
                    measurement_pdf, nullptr, workspace, stream, "gse_pf_update");
 }
 
+int64_t gse_workspace_weight_scale_offset(int B, int64_t N) {
+    if (B < 1 || B > GSE_MAX_B || N < 1) return -1;
+    const Workspace ws = carve_workspace(nullptr, B, N);
+    return (int64_t)(reinterpret_cast<char*>(ws.wscale) - static_cast<char*>(nullptr));
+}
+
 int gse_pf_resample_begin(const float* w, int64_t ld, int B, int64_t N, uint32_t flags, double* island, void* workspace,
                           void* stream) {
     if (int rc = check_pf_geometry("gse_pf_resample_begin", B, N, ld)) return rc;
@@ -373,6 +387,16 @@ int gse_pf_resample(const float* x_in, const float* w, float* x_out, float* w_ou
                    nullptr, nullptr, nullptr, workspace, stream, "gse_pf_resample");
 }
 
+int gse_pf_gather_index(const float* x_in, const int32_t* idx, float* x_out, float* w_out, int64_t ld, int B, int64_t N,
+                        void* stream) {
+    if (int rc = check_pf_geometry("gse_pf_gather_index", B, N, ld)) return rc;
+    GSE_REQUIRE(x_in && idx && x_out && w_out && x_in != x_out, "gse_pf_gather_index: x_out must be a buffer separate from x_in");
+    hipLaunchKernelGGL(index_gather_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock), (unsigned)B), dim3(kBlock), 0,
+                       (hipStream_t)stream, x_in, idx, x_out, w_out, N, ld);
+    GSE_LAUNCH_CHECK("index_gather_kernel");
+    return GSE_OK;
+}
+
 // ---- exact resampling of an ensemble sharded over several GPUs (gpu_se_amd/distributed.py) ----------
 int gse_pf_tile_sums(const float* w, int64_t ld, int B, int64_t N, double* sums, void* stream) {
     if (int rc = check_pf_geometry("gse_pf_tile_sums", B, N, ld)) return rc;
@@ -400,7 +424,8 @@ int gse_pf_shard_cumsum(const float* w, int64_t N_local, const double* prefix_al
                 "gse_pf_shard_cumsum: every shard but the last must hold a multiple of %d particles", kTile);
     const int64_t ldw = (N_local + 3) / 4 * 4;
     hipLaunchKernelGGL(cumsum_kernel<false>, dim3(T, 1), dim3(kBlock), 0, (hipStream_t)stream, w, c, prefix_all,
-                       (double*)nullptr, (double*)nullptr, N_local, ldw, T, (int64_t)0, tile_offset, T_total);
+                       (double*)nullptr, (double*)nullptr, N_local, ldw, T, (int64_t)0, tile_offset, T_total,
+                       (const double*)nullptr);
     GSE_LAUNCH_CHECK("cumsum_kernel<shard>");
     return GSE_OK;
 }

@@ -49,6 +49,7 @@ struct StepArgs {
     double dt;
     const double* u_dev;   // GSE_OP_U_DEVICE / GSE_OP_Z_DEVICE: [B][2] in device memory instead of io (a closed loop
     const double* z_dev;   // whose controller and plant run on the device never brings them to the host)
+    double* wscale;        // GSE_OP_WEIGHT_SCALE: [B] accumulated binary exponent of the stored weights (workspace), or null
 };
 
 #ifndef GSE_STEP_MIN_WAVES
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     __shared__ __attribute__((aligned(16))) float wtile[(kStrided && kUpdate) ? kTile : 4];
     __shared__ int64_t span[2];
     __shared__ double red[4];
+    __shared__ int kexp_s;                    // GSE_OP_WEIGHT_SCALE: this launch's binary exponent
     extern __shared__ double pfx_s[];         // [T + 1] with SCAN_IN (dynamic; statics above total a multiple of 16 B)
 
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -542,8 +544,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             }
             W = prefix_g[(int64_t)b * (T + 1) + T];
             if (island && tile_id == 0 && tid == 0) {      // shard bookkeeping (see gse_pf_resample)
-                island[b] += log(W);
-                island[gridDim.y + b] = W;
+                const double ws_b = a.wscale ? a.wscale[b] : 0.0;      // (stored weights = true weights * 2^-ws_b)
+                island[b] += log(W) + ws_b * 0.69314718055994530942;
+                island[gridDim.y + b] = ldexp(W, (int)ws_b);
             }
         } else if (kScanIn) {
             // tile prefix into LDS: thread j owns chunk [j*m, (j+1)*m) of the tile sums (as inline_tile_prefix); the sums were
@@ -582,8 +585,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             W = pfx_s[T];
     GSE_STAMP(2);
             if (island && tile_id == 0 && tid == 0) {      // shard bookkeeping (see gse_pf_resample)
-                island[b] += log(W);
-                island[gridDim.y + b] = W;
+                const double ws_b = a.wscale ? a.wscale[b] : 0.0;      // (stored weights = true weights * 2^-ws_b)
+                island[b] += log(W) + ws_b * 0.69314718055994530942;
+                island[gridDim.y + b] = ldexp(W, (int)ws_b);
             }
         } else {
             W = totals[b];
@@ -881,6 +885,42 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     }
     if (kDraw && draw_at == 2 && !drawn2) draw_all();      // (weights that do not sum to a positive number: no search)
     GSE_STAMP(4);
+    // ---- GSE_OP_WEIGHT_SCALE: the launch's binary exponent (gse_device.h, likelihood_exponent).  Wavefront 0 of every
+    //      workgroup scores the same 64 sample particles of x_in -- exponent of the old weight + exponent of the likelihood
+    //      under this launch's measurement -- and the best one fixes k; identical in every workgroup.
+    int kexp = 0;
+    if (kUpdate && a.wscale) {                               // (workgroup-uniform)
+        if (wv == 0) {
+            double fg0 = a.io.f[b].u0, fm0 = a.io.f[b].u1, za = a.io.f[b].z0, zb = a.io.f[b].z1;
+            if constexpr (kDevIO) {
+                if (a.u_dev) { fg0 = a.u_dev[2 * b]; fm0 = a.u_dev[2 * b + 1]; }
+                if (a.z_dev) { za = a.z_dev[2 * b]; zb = a.z_dev[2 * b + 1]; }
+            }
+            const int64_t is = (int64_t)lane * N / kScaleSamples;
+            float s0[GSE_NX], o0[kObsKept], ya, yb;
+#pragma unroll
+            for (int k = 0; k < GSE_NX; ++k) s0[k] = xin_b[(int64_t)k * ld + is];
+            const bool have_w = (!kGather || kScanIn) && w_in != nullptr;
+            const float ws = have_w ? w_in[(int64_t)b * ld + is] : 1.f;
+            model_keep(s0, o0);
+            model_output_kept(o0, fg0, fm0, ya, yb);
+            const int e_lik = likelihood_exponent<kNd>(a.pdf, za - (double)ya, zb - (double)yb);
+            const int e_w = (ws > 0.f) ? ilogbf(ws) : -1000000;            // (no weight: out of the running)
+            int score = e_lik + (have_w ? e_w : 0), cand = e_lik + ((have_w && !kGather) ? e_w : 0);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const int s2 = __shfl_xor(score, m, 64), c2 = __shfl_xor(cand, m, 64);
+                if (s2 > score || (s2 == score && c2 > cand)) { score = s2; cand = c2; }
+            }
+            // gather: the offspring weigh lik / N, so k = the anchor's likelihood exponent; otherwise its new weight
+            // w lik 2^-k is brought to about 1 / N
+            int k = kGather ? cand : cand + (int)ceil(log2((double)N));
+            k = (k < -kWeightScaleFrom) ? max(k, kWeightScaleMin) : 0;
+            if (lane == 0) kexp_s = k;
+        }
+        __syncthreads();
+        kexp = kexp_s;
+    }
     // a thread is live if it owns at least one particle (its first one)
     const bool live = jp[0] < Nu;
     float wnew[kPerThread] = {w_uniform, w_uniform, w_uniform, w_uniform};
@@ -1015,13 +1055,18 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             for (int p = 0; p < kPerThread; ++p) wnew[p] = (jp[p] < Nu) ? wb[jp[p]] : 0.f;
         }
         if (kUpdate) {
+            // GSE_OP_WEIGHT_SCALE: kexp (above) taken out of every likelihood of the launch; the accumulated exponent
+            if (a.wscale && tile_id == 0 && tid == 0) a.wscale[b] = (kGather ? 0.0 : a.wscale[b]) + (double)kexp;
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p) {
                 float y0, y1;
                 model_output_kept(obs[p], fg, fm, y0, y1);
-                const double lik = mixture_pdf2<kNd>(a.pdf, z0 - (double)y0, z1 - (double)y1);
-                wnew[p] = (float)((double)wnew[p] * lik);
+                const double lik = mixture_pdf2_scaled<kNd>(a.pdf, z0 - (double)y0, z1 - (double)y1, kexp);
+                // (with a scale: saturate instead of overflowing -- a particle 2^127 heavier than the anchor)
+                wnew[p] = (float)(a.wscale ? fmin((double)wnew[p] * lik, 3.4028234663852886e38) : (double)wnew[p] * lik);
             }
+        } else if (kGather) {
+            if (a.wscale && tile_id == 0 && tid == 0) a.wscale[b] = 0.0;     // (the offspring weigh 1 / N each)
         }
 
         // ---- ancestor indices; the uniform weights of a resample without update (an update stores its weights below,
@@ -1078,6 +1123,25 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     }
     GSE_STAMP(10);
     GSE_BLOCK_TIME(1);
+}
+
+// A resample whose ancestors are GIVEN (the replay of a recorded run: tests/golden/closed_loop.npz holds the ancestors the
+// reference's own resample chose): offspring j copies particle idx[j] and weighs 1 / N.  One thread per offspring.
+__global__ __launch_bounds__(kBlock) void index_gather_kernel(const float* __restrict__ x_in, const int32_t* __restrict__ idx,
+                                                              float* __restrict__ x_out, float* __restrict__ w_out, int64_t N,
+                                                              int64_t ld) {
+    const int b = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= N) return;
+    const int64_t anc = min(max((int64_t)idx[(int64_t)b * ld + j], (int64_t)0), N - 1);
+    const float* s = x_in + (int64_t)b * GSE_NX * ld + anc;
+    float* d = x_out + (int64_t)b * GSE_NX * ld + j;
+    float v[GSE_NX];
+#pragma unroll
+    for (int k = 0; k < GSE_NX; ++k) v[k] = s[k * ld];
+#pragma unroll
+    for (int k = 0; k < GSE_NX; ++k) d[k * ld] = v[k];
+    w_out[(int64_t)b * ld + j] = (float)(1.0 / (double)N);
 }
 
 // Tile sums for a resample that does not directly follow an update (weights assigned by the caller).
@@ -1174,7 +1238,8 @@ __global__ __launch_bounds__(kBlock) void cumsum_kernel(const float* __restrict_
                                                         const double* __restrict__ tile_src,
                                                         double* __restrict__ totals, double* __restrict__ island,
                                                         int64_t N, int64_t ldw, int T, int64_t prefix_stride,
-                                                        int64_t tile_offset, int64_t total_at) {
+                                                        int64_t tile_offset, int64_t total_at,
+                                                        const double* __restrict__ wscale) {
     __shared__ double red[4];
     __shared__ double pfx[3];
     const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
@@ -1189,8 +1254,9 @@ __global__ __launch_bounds__(kBlock) void cumsum_kernel(const float* __restrict_
     if (t == 0 && tid == 0 && totals) {
         totals[b] = W;
         if (island) {                          // shard bookkeeping: accumulated log-weight and this cycle's sum
-            island[b] += log(W);
-            island[gridDim.y + b] = W;
+            const double ws_b = wscale ? wscale[b] : 0.0;      // (GSE_RESAMPLE_WEIGHT_SCALE: stored = true * 2^-ws_b)
+            island[b] += log(W) + ws_b * 0.69314718055994530942;
+            island[gridDim.y + b] = ldexp(W, (int)ws_b);
         }
     }
     const int64_t i0 = (int64_t)t * kTile + (int64_t)tid * kPerThread;

@@ -132,6 +132,8 @@ class ShardedParticleFilter:
     because shards cannot share one un-normalised weight scale without the exchange this design avoids.
     """
 
+    collectives_issued = 0                                  # all-reduces / all-gathers / all-to-alls issued by this object
+
     def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, group=None, merge_device=None,
                  reduce_every=32):
         self.group = group
@@ -184,6 +186,9 @@ class ShardedParticleFilter:
         self.last_exact = None
         self._ends_index = None                             # device indices of the shard ends in the tile prefix (built once)
         self._merge_buf = torch.zeros((self.world, MERGE_WIDTH), dtype=torch.float64, device=self._merge_device)
+        self._dev_rows = self._dev_moments = self._dev_status = self._pivot_c = None      # device merge (merge_begin)
+        self._merge_work, self._merge_pending = None, False
+        self.collectives_issued = 0                         # all-reduces / all-gathers / all-to-alls this object has issued
 
     @classmethod
     def from_get_parts(cls, n_local, group=None):
@@ -261,10 +266,12 @@ class ShardedParticleFilter:
         w_src = f._w
         uneven = any(cnt != spans[0][1] for _, cnt in spans)
         mine_log = None
-        if self._islands_apart or uneven:
+        if self._islands_apart or uneven or f.weight_scale:
+            # (with scaled weights -- GSE_OP_WEIGHT_SCALE -- a shard's live weights also carry a binary exponent of their own)
             mine_log = torch.zeros(P, dtype=torch.float64, device=self._merge_device)
-            mine_log[self.rank:self.rank + 1].copy_(f._island[0])
+            mine_log[self.rank:self.rank + 1].copy_(f._island[0] + (f._wscale * 0.6931471805599453 if f.weight_scale else 0.0))
             dist.all_reduce(mine_log, op=dist.ReduceOp.SUM, group=self.group)
+            self.collectives_issued += 1
             mine_log = mine_log.to(dev)
             scale = torch.exp(mine_log[self.rank] - mine_log.max()).to(torch.float32)      # (exactly 1 on the heaviest shard)
             w_src = f._w * scale
@@ -300,6 +307,8 @@ class ShardedParticleFilter:
         got = self._all_to_all_rows(rows[:count], send, recv)
         f._x[0, :, :n] = got.to(dev).t()
         f._w[0, :n] = 1.0 / n                               # every particle of the ensemble weighs 1 / N again:
+        if f.weight_scale:
+            f._wscale.zero_()
         f._island[0, 0] = float(numpy.log(n / self.N_particles))     # the shard's share is its share of the particles
         f._tiles_valid, f._scan_slot, f._moments_host = False, None, None
         self._islands_apart = False
@@ -313,12 +322,14 @@ class ShardedParticleFilter:
         padded[:mine.numel()] = mine.to(self._merge_device)
         parts = [torch.empty_like(padded) for _ in counts]
         dist.all_gather(parts, padded, group=self.group)
+        self.collectives_issued += 1
         return torch.cat([p[:k] for p, k in zip(parts, counts)])
 
     def _all_to_all_rows(self, rows, send, recv):
         src = rows.to(self._merge_device).contiguous()
         dst = torch.empty((sum(recv), rows.shape[1]), dtype=rows.dtype, device=self._merge_device)
         dist.all_to_all_single(dst, src, output_split_sizes=recv, input_split_sizes=send, group=self.group)
+        self.collectives_issued += 1
         return dst
 
     def _exchange_shares(self):
@@ -332,6 +343,7 @@ class ShardedParticleFilter:
         else:
             self._shares[self.rank] = float(self.local._island[0, 0].item())
         self._pending = dist.all_reduce(self._shares, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.collectives_issued += 1
         self._shares_cycle = self._resamples
 
     def wait_collectives(self):
@@ -341,11 +353,13 @@ class ShardedParticleFilter:
 
     # ------------------------------------------------------------------ posterior merge
     def _local_row(self):
-        s0, s1, s2, kernel_pivot = self.local._raw_moments()      # synchronises this rank's stream
+        """This shard's row of the merge buffer, formed on the HOST (the round-1..3 path; kept as the reference the device
+        merge is tested against): synchronises this rank's stream."""
+        s0, s1, s2, kernel_pivot = self.local._raw_moments()
         log_island = float(self.local._island[0, 0].item())
         return pack_merge_row(log_island, s0, s1, s2, kernel_pivot, self._pivot)
 
-    def _merged(self):
+    def _merged_host(self):
         row = self._local_row()
         if self.group is None:
             return merge_rows(row[None, :], self._pivot)
@@ -355,6 +369,60 @@ class ShardedParticleFilter:
         buf[self.rank] = torch.as_tensor(row, dtype=torch.float64, device=self._merge_device)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         return merge_rows(buf.cpu().numpy(), self._pivot)
+
+    def merge_begin(self):
+        """Enqueue the posterior merge and return at once: the shard's moments (gse_pf_moments; a pending resample's copy
+        runs first, which is where the shard's log-weight absorbs the weight sum), its row of the merge buffer written ON THE
+        DEVICE (gse_merge_row: pivot shift, accumulated log-weight, binary exponent of the stored weights), and the
+        all-reduce of the [P][22] buffer -- asynchronous on RCCL, so that it overlaps whatever the caller enqueues next.
+        Nothing comes to the host (with the gloo backend of the CPU tests the buffer has to: gloo reduces host tensors)."""
+        f = self.local
+        f._flush()
+        dev = f._x.device
+        stream = torch.cuda.current_stream().cuda_stream
+        if self._dev_rows is None:
+            self._dev_rows = torch.zeros((self.world, MERGE_WIDTH), dtype=torch.float64, device=dev)
+            self._dev_moments = torch.zeros((2, 26), dtype=torch.float64, device=dev)      # [0] the shard's, [1] the ensemble's
+            self._dev_status = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._pivot_c = _lib.doubles(self._pivot, 5)
+        f._call("gse_pf_moments", f._x.data_ptr(), f._w.data_ptr(), f._ld, 1, f.N_particles, self._dev_moments[0].data_ptr(),
+                f._ws.data_ptr(), stream)
+        rows = self._dev_rows
+        rows.zero_()
+        _lib.call("gse_merge_row", self._dev_moments[0].data_ptr(), f._island.data_ptr(),
+                  f._wscale.data_ptr() if f.weight_scale else None, self._pivot_c, rows[self.rank].data_ptr(), stream)
+        self._merge_work = None
+        if self.group is not None:
+            self.wait_collectives()
+            if self._merge_device.type == "cuda":
+                self._merge_work = dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                host_rows = rows.cpu()
+                dist.all_reduce(host_rows, op=dist.ReduceOp.SUM, group=self.group)
+                rows.copy_(host_rows)
+            self.collectives_issued += 1
+        self._merge_pending = True
+
+    def merge_end(self):
+        """The moments of the whole ensemble as a DEVICE tensor of 26 doubles (gse_pf_moments layout: what gse_loop_control and
+        gse_moments_estimates take), after merge_begin: the current stream waits for the all-reduce (no host wait), then one
+        small kernel combines the shards' rows (gse_merge_rows)."""
+        if not self._merge_pending:
+            self.merge_begin()
+        if self._merge_work is not None:
+            self._merge_work.wait()                       # (stream-ordered: the host does not block)
+            self._merge_work = None
+        _lib.call("gse_merge_rows", self._dev_rows.data_ptr(), self.world, self._pivot_c, self._dev_moments[1].data_ptr(),
+                  self._dev_status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        self._merge_pending = False
+        return self._dev_moments[1]
+
+    def _merged(self):
+        m = torch.cat([self.merge_end(), self._dev_status.to(torch.float64)]).cpu().numpy()    # the one copy of an estimate
+        if m[26] != 0:
+            raise FloatingPointError("every shard has zero weight (all likelihoods underflowed)")
+        _, mean, cov = moments_to_mean_cov(m[0], m[1:6], m[6:21], m[21:26])
+        return mean, cov
 
     def point_estimate(self):
         """Posterior mean over ALL shards, host array (5,)."""

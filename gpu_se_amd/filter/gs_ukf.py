@@ -78,8 +78,10 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._pend_gather = None                      # ancestors [B, N] int32 of a resample whose row copy is still to come
         self._replay = None                           # noise a DeterministicGaussianSum handed out at predict() time
         self._sums_valid = False                      # the workspace holds the quarter sums of the current weights
+        self._sums_ok = True                          # ... may be used at all: not once a writable view of the weights is out
         self.record_ancestors = False                 # True: every resample's ancestors [B, N] int32 are kept in
         self.ancestor_log = []                        # ancestor_log (device tensors; parity tests of whole loops)
+        self.ancestor_flips = []                      # resample(ancestors=..., r=...): own ancestors that differ, per resample
         self._idx_buf = None
         self._fusable = n <= _lib.GSE_GSUKF_CYCLE_MAX
         self._fuse_pu = B * n >= _lib.GSE_GSUKF_LANES_MIN  # large banks: predict() is deferred and rides update()'s launch
@@ -144,7 +146,10 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     @property
     def weights(self):
         self._flush()
-        self._sums_valid = False                      # (the view is writable)
+        # the view is writable and may be kept: from here on the quarter sums an update launch leaves behind cannot be trusted
+        # to describe the weights a later resample finds (sticky: that resample forms its tile sums itself, one launch more)
+        self._sums_valid = False
+        self._sums_ok = False
         return DevArray.wrap(self._w[0] if self._B == 1 else self._w)
 
     @weights.setter
@@ -189,7 +194,9 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         """What a deferred stage remembers of an argument: the tensor itself (read when the kernel runs) or a host copy."""
         if torch.is_tensor(v):
             return v
-        return [float(x) for x in v] if self._B == 1 else numpy.array(v, dtype=numpy.float64)
+        if self._B == 1:                                  # ((2,) or (1, 2): a batch of one bank)
+            return [float(x) for x in numpy.asarray(v, dtype=numpy.float64).reshape(-1)]
+        return numpy.array(v, dtype=numpy.float64)
 
     def _per_bank(self, values, width, buf=None):
         """Host values for every bank as the C ABI takes them ([B][width] doubles; one row is broadcast to all banks), written
@@ -291,7 +298,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         args = (self._means.data_ptr(), self._covs.data_ptr(), idx.data_ptr() if idx is not None else None, out_m.data_ptr(),
                 out_c.data_ptr(), self._w.data_ptr(), self._B, self.N_particles, u_arg, float(dt), z_arg, self._w_sigma_c, pod, rng,
                 noise, ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr())
-        if self._model is None and self.N_particles > _lib.GSE_SMALL_RESAMPLE_MAX:
+        if self._model is None and self.N_particles > _lib.GSE_SMALL_RESAMPLE_MAX and self._sums_ok:
             # ... and leaves the quarter sums of the new weights in the workspace: the resample that follows needs no
             # tile-sum launch (valid until anything else touches the weights or the workspace)
             self._call("gse_gsukf_predict_update_sums", *args, self._ws.data_ptr(), where, stream_ptr())
@@ -310,8 +317,41 @@ class ParallelGaussianSumUnscentedKalmanFilter:
             return self._call("gse_gsukf_update_dev", *args, where, stream_ptr())
         self._call("gse_gsukf_update", *args, stream_ptr())
 
-    def resample(self, r=None, return_index=False):
-        """Systematic resample of the Gaussians based on their weights (gs_ukf.py:409-436)."""
+    def _resample_given(self, ancestors, r=None):
+        """resample() with the ancestors GIVEN ((N,) or (B, N) integers): the replay of a recorded run -- Gaussian j copies the
+        row of Gaussian ancestors[j] (gse_gsukf_gather_rows), weights 1 / N.  Runs at once.  With ``r`` the filter's OWN
+        resample runs first and the number of ancestors in which it differs from the given ones is appended to
+        ``ancestor_flips`` (per bank, device tensors) before the given ones are copied."""
+        self._flush()
+        n, B = self.N_particles, self._B
+        idx = as_device(ancestors, torch.int32).reshape(B, n).clamp_(0, n - 1).contiguous()
+        src_m, src_c, dst_m, dst_c = self._means, self._covs, self._means_alt, self._covs_alt
+        swap = True
+        if r is not None:
+            keep, self.record_ancestors = self.record_ancestors, False
+            own = self.resample(r=r, return_index=True).as_subclass(torch.Tensor).reshape(B, n)
+            self.record_ancestors = keep
+            self.ancestor_flips.append((own != idx).sum(dim=1))
+            if self._pend_gather is not None:          # (large banks: the rows have not moved yet -- the given ancestors instead)
+                self._pend_gather = None
+            else:                                      # the rows as they were are in the other pair of arrays now
+                src_m, src_c, dst_m, dst_c = self._means_alt, self._covs_alt, self._means, self._covs
+                swap = False
+        self._call("gse_gsukf_gather_rows", src_m.data_ptr(), src_c.data_ptr(), idx.data_ptr(), dst_m.data_ptr(), dst_c.data_ptr(),
+                   B, n, stream_ptr())
+        if swap:
+            self._means, self._means_alt = self._means_alt, self._means
+            self._covs, self._covs_alt = self._covs_alt, self._covs
+        self._w.fill_(1.0 / n)
+        self._sums_valid = False
+        if self.record_ancestors:
+            self.ancestor_log.append(idx)
+
+    def resample(self, r=None, return_index=False, ancestors=None):
+        """Systematic resample of the Gaussians based on their weights (gs_ukf.py:409-436).  ``ancestors``: copy these instead of
+        computing them (replay of a recorded run)."""
+        if ancestors is not None:
+            return self._resample_given(ancestors, r)
         wanted = return_index
         n, B = self.N_particles, self._B
         if B == 1:

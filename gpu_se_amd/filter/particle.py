@@ -92,7 +92,14 @@ class ParallelParticleFilter:
         self._x_alt = torch.zeros_like(self._x)
         self._w = torch.zeros((B, self._ld), dtype=torch.float32, device=dev)
         self._w_alt = torch.zeros_like(self._w)
-        self._ws = torch.empty(lib.gse_workspace_bytes(B, n), dtype=torch.uint8, device=dev)
+        self._ws = torch.zeros(lib.gse_workspace_bytes(B, n), dtype=torch.uint8, device=dev)
+        # The reference's weights are fp64 from the first resample on (particle.py:103, :316), so ``weights *= pdf`` survives
+        # likelihoods down to 1e-308.  The fp32 weights here keep that RANGE through a launch-uniform power of two
+        # (GSE_OP_WEIGHT_SCALE, include/gse.h): true weight = stored weight * 2^_wscale[b], _wscale a view of the workspace
+        # the kernels maintain (0 unless a likelihood fell below 2^-40).  ``weight_scale = False``: the plain fp32 product.
+        at = lib.gse_workspace_weight_scale_offset(B, n)
+        self._wscale = self._ws[at:at + 8 * B].view(torch.float64)
+        self.weight_scale = True
         self._moments = torch.empty((B, 26), dtype=torch.float64, device=dev)
         self._tiles_valid = False
         self._island = None                                 # [2][B] fp64 shard bookkeeping (ShardedParticleFilter)
@@ -117,6 +124,7 @@ class ParallelParticleFilter:
         self._last_index = None
         self.record_ancestors = False                       # True: every resample's ancestors [B, ld] int32 are kept in
         self.ancestor_log = []                              # ancestor_log (device tensors; parity tests of whole loops)
+        self.ancestor_flips = []                            # resample(ancestors=..., r=...): own ancestors that differ, per resample
         self.lazy = True                                    # False: every method launches its own kernel at once
         self._moments_host = None                           # cached device moments (cleared by anything that changes x, w)
         self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -208,11 +216,14 @@ class ParallelParticleFilter:
             pend, self._pend_predict = self._pend_predict, None
             self._launch_step(update=None)
             self._pend_predict = pend
-        ops = 0
+        ops = _lib.GSE_OP_WEIGHT_SCALE if (self.weight_scale and (update is not None or self._pend_gather)) else 0
         n = self.N_particles
         gather = self._pend_gather
+        # (predict + update without a gather is out of place too when the weights are scaled: the launch reads the scale's
+        #  anchor, particle 0, from x_in while other workgroups write their new states)
+        swap_x = gather or (bool(ops) and update is not None and self._pend_predict is not None)
         x_in = self._x
-        x_out = self._x_alt if gather else self._x
+        x_out = self._x_alt if swap_x else self._x
         w_in = self._w
         w_out = self._w_alt if gather else self._w
         idx_ptr = None
@@ -271,8 +282,9 @@ class ParallelParticleFilter:
                            stream_ptr(self._dev_index))
         if rc:
             self._check(rc)
-        if gather:
+        if swap_x:
             self._x, self._x_alt = self._x_alt, self._x
+        if gather:
             self._w, self._w_alt = self._w_alt, self._w
         self._pend_gather = False
         self._gather_slot = None
@@ -306,9 +318,29 @@ class ParallelParticleFilter:
         self._x[:, :self._nx, :self.N_particles] = v.transpose(1, 2)
         self._moments_host = None
 
+    def _fold_weight_scale(self):
+        """Bring the stored weights to the scale 1 (what fp32 can hold of the true weights) and clear the exponent: a
+        caller who is handed the array, or assigns to it, deals in plain numbers."""
+        if self.weight_scale:
+            s = self._wscale
+            self._w.copy_((self._w.double() * torch.exp2(s)[:, None]).float())
+            s.zero_()
+
+    @property
+    def weight_log2_scale(self):
+        """Binary exponent the stored weights are to be multiplied by, per filter (host array (B,); synchronises)."""
+        self._flush()
+        return self._wscale.cpu().numpy().copy() if self.weight_scale else numpy.zeros(self._B)
+
+    def _scaled_weights(self):
+        """(stored fp32 weights (B, N) as a host array, their binary exponents (B,)) without folding the two."""
+        self._flush()
+        return self._w[:, :self.N_particles].cpu().numpy(), self.weight_log2_scale
+
     @property
     def weights(self):
         self._flush()
+        self._fold_weight_scale()
         self._handed_out()
         v = self._w[:, :self.N_particles]
         return DevArray.wrap(v[0] if self._B == 1 else v)
@@ -319,6 +351,8 @@ class ParallelParticleFilter:
         v = as_device(value, torch.float32).reshape(self._B, self.N_particles)
         self._flush()
         self._w[:, :self.N_particles] = v
+        if self.weight_scale:
+            self._wscale.zero_()
         self._tiles_valid = False
         self._scan_slot = None
         self._moments_host = None
@@ -347,10 +381,43 @@ class ParallelParticleFilter:
         pass."""
         self._launch_step(update=(u, z))
 
-    def resample(self, r=None, return_index=False):
+    def _resample_given(self, ancestors, r=None):
+        """resample() with the ancestors GIVEN ((N,) or (B, N) integers): the replay of a recorded run (the reference's own
+        choices, tests/golden/closed_loop.npz) -- offspring j copies particle ancestors[j], weights 1 / N.  Runs at once.
+        With ``r`` the filter's OWN resample runs first (cumulative weights, ancestors: everything a normal resample does)
+        and the number of ancestors in which it differs from the given ones is appended to ``ancestor_flips`` (per filter,
+        device tensors) -- the replay then checks the weights too -- before the given ones are copied."""
+        self._flush()
+        n = self.N_particles
+        idx = torch.zeros((self._B, self._ld), dtype=torch.int32, device=self._x.device)
+        idx[:, :n] = as_device(ancestors, torch.int32).reshape(self._B, n)
+        if r is not None:
+            keep, self.record_ancestors = self.record_ancestors, False
+            own = self.resample(r=r, return_index=True).as_subclass(torch.Tensor).reshape(self._B, n)
+            self.record_ancestors = keep
+            self.ancestor_flips.append((own != idx[:, :n]).sum(dim=1))
+            src, dst, wdst = self._x_alt, self._x, self._w          # the ensemble as it was; over the filter's own offspring
+        else:
+            src, dst, wdst = self._x, self._x_alt, self._w_alt
+        self._call("gse_pf_gather_index", src.data_ptr(), idx.data_ptr(), dst.data_ptr(), wdst.data_ptr(),
+                   self._ld, self._B, n, stream_ptr(self._dev_index))
+        if r is None:
+            self._x, self._x_alt = self._x_alt, self._x
+            self._w, self._w_alt = self._w_alt, self._w
+        if self.weight_scale:
+            self._wscale.zero_()
+        self._tiles_valid, self._scan_slot, self._moments_host = False, None, None
+        self._last_index = idx
+        if self.record_ancestors:
+            self.ancestor_log.append(idx)
+
+    def resample(self, r=None, return_index=False, ancestors=None):
         """Systematic resample of the particles based on their weights (particle.py:296-316).  The one
         uniform number comes from a host generator (no device round trip); ``r`` overrides it (tests).  The
-        cumulative weights are computed now; the copy of the ancestors is deferred -- see above."""
+        cumulative weights are computed now; the copy of the ancestors is deferred -- see above.  ``ancestors``: copy these
+        instead of computing them (replay of a recorded run)."""
+        if ancestors is not None:
+            return self._resample_given(ancestors, r)
         self._flush()
         if self._B == 1:
             self._c_r[0] = self._host_rng.random() if r is None else float(numpy.asarray(r, dtype=numpy.float64).reshape(-1)[0])
@@ -368,7 +435,8 @@ class ParallelParticleFilter:
                 if rc:
                     self._check(rc)
         else:
-            flags = _lib.GSE_RESAMPLE_TILES_VALID if self._tiles_valid else 0
+            flags = (_lib.GSE_RESAMPLE_TILES_VALID if self._tiles_valid else 0) | \
+                (_lib.GSE_RESAMPLE_WEIGHT_SCALE if self.weight_scale else 0)
             rc = self._fn_resample_begin(self._w.data_ptr(), self._ld, self._B, self.N_particles, flags,
                                          self._island.data_ptr() if self._island is not None else None,
                                          self._ws.data_ptr(), stream_ptr(self._dev_index))
@@ -393,6 +461,11 @@ class ParallelParticleFilter:
             self._call("gse_pf_moments", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
                        self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
             self._moments_host = self._moments.cpu().numpy()
+            if self.weight_scale:
+                # the kernel sums the STORED weights; the reference's quantities are un-normalised sums of the true ones
+                k = self._wscale.cpu().numpy()
+                if numpy.any(k != 0):
+                    self._moments_host[:, :21] = numpy.ldexp(self._moments_host[:, :21], k.astype(numpy.int64)[:, None])
         m = self._moments_host
         iu = numpy.triu_indices(_lib.GSE_NX)
         s2 = numpy.zeros((self._B, _lib.GSE_NX, _lib.GSE_NX))

@@ -163,13 +163,22 @@ class InjectedNoise:
     plant_meas  : (ticks - 1, B, 2) fp32   measurement_pdf.draw() at sim_base.py:285
     predict     : sequence, one entry per predict(): (B, N, 5) for the particle filter, (B, N, 11, 5) for the GS-UKF
     r           : sequence, one entry per resample(): (B,) uniform numbers in [0, 1)
+    ancestors   : optional sequence, one entry per resample(): (B, N) integers -- the ancestors a RECORDED run chose (the
+                  reference's own resample, tests/golden/closed_loop.npz); given, the estimator copies those instead of
+                  computing its own, so that a run whose weights sit within rounding of a threshold somewhere is still
+                  comparable to the end (the replay of the reference's recorded runs)
     (B = 1 for Simulation; the leading rollout axis may then be left out.)"""
 
-    def __init__(self, plant_state, plant_meas, predict, r):
+    def __init__(self, plant_state, plant_meas, predict, r, ancestors=None):
         self.plant_state = numpy.asarray(plant_state, dtype=numpy.float32)
         self.plant_meas = numpy.asarray(plant_meas, dtype=numpy.float32)
         self.predict = [numpy.asarray(v, dtype=numpy.float32) for v in predict]
         self.r = [numpy.atleast_1d(numpy.asarray(v, dtype=numpy.float64)) for v in r]
+        self.ancestors = None if ancestors is None else [numpy.asarray(a, dtype=numpy.int64) for a in ancestors]
+
+    def given(self, k):
+        """The recorded ancestors of resample k, or None."""
+        return None if self.ancestors is None else self.ancestors[k]
 
     def state(self, tick, B):
         return self.plant_state[tick].reshape(B, 5)
@@ -249,7 +258,8 @@ class Simulation:
                 if self.controller is None and self.K.y_predicted is not None:
                     self.biass.append(self.lin_model.yn2d(self.ys_meas[-1]) - self.K.y_predicted)
                 self.f.update(self.us[-1], self.ys_meas[-1][_OUTPUTS])
-                self.f.resample(r=None if noise is None else float(noise.r[self.update_count][0]))
+                self.f.resample(r=None if noise is None else float(noise.r[self.update_count][0]),
+                                ancestors=None if noise is None else noise.given(self.update_count))
                 self.update_count += 1
                 self.xs_f.append(self.f.point_estimate())
                 u, solved = self._control()
@@ -286,9 +296,10 @@ class BatchedSimulation:
     launch and one synchronisation (the estimates of all rollouts)."""
 
     def __init__(self, batch, N_particles, dt_control, dt_predict, end_time=50, pf=True, controller=None, seed=0,
-                 resident=False, noise=None, persistent=True, fused_tail=True):
+                 resident=False, noise=None, persistent=True, fused_tail=True, native_loop=True):
         self.B = int(batch)
         self.persistent = bool(persistent)      # resident loops of small Gaussian-sum filters: the whole loop in one launch
+        self.native_loop = bool(native_loop)    # resident particle-filter loops: the ticks are enqueued from C++ (gse_pf_closed_loop)
         self.fused_tail = bool(fused_tail)      # resident particle-filter loops: moments' reduction + controller + plant in one launch
         self.noise = noise                      # InjectedNoise: every random number is an input (parity mode)
         self.resident = bool(resident)          # True: plant, controller and histories live on the device too
@@ -357,7 +368,8 @@ class BatchedSimulation:
                 t_next_predict += self.dt_predict
             if t > t_next_control:
                 self.f.update(self.us[-1], self.ys_meas[-1][:, _OUTPUTS])
-                self.f.resample(r=None if noise is None else noise.r[n_update])
+                self.f.resample(r=None if noise is None else noise.r[n_update],
+                                ancestors=None if noise is None else noise.given(n_update))
                 n_update += 1
                 est = self.f.point_estimate()
                 self.xs_f.append(est)
@@ -439,6 +451,14 @@ class BatchedSimulation:
                                                                moments, state_pod, meas_pod, rng, stream)
             return self._finish_resident(lib, torch, time, flat, widths, moments, status, control_ticks, n_control, ev0, ev1,
                                          clock, f64, stream)
+        if self._native_capable():
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            clock = [time.perf_counter()]
+            ev0.record()
+            control_ticks, n_control = self._launch_native(lib, f, K, X, u, z, y_pred, known, status, us, xs, ys, ys_meas, moments,
+                                                           rng, stream)
+            return self._finish_resident(lib, torch, time, flat, widths, moments, status, control_ticks, n_control, ev0, ev1,
+                                         clock, f64, stream)
         noise, n_predict, n_update = self.noise, 0, 0
         if noise is not None:                             # the plant's draws: uploaded once, sliced per tick
             inj_state = torch.as_tensor(numpy.ascontiguousarray(noise.plant_state.reshape(ticks - 1, B, 5)), device=dev)
@@ -471,7 +491,8 @@ class BatchedSimulation:
                 t_next_predict += self.dt_predict
             if now > t_next_control:
                 f.update(u, z)
-                f.resample(r=None if noise is None else noise.r[n_update])
+                f.resample(r=None if noise is None else noise.r[n_update],
+                           ancestors=None if noise is None else noise.given(n_update))
                 n_update += 1
                 # the estimate the controller acts on, and this tick's record: the moments of the resampled ensemble taken
                 # from the weighted one (offspring counts), so that the resample's copy is deferred into the next tick's
@@ -506,6 +527,76 @@ class BatchedSimulation:
                 record_moments(t)
         return self._finish_resident(lib, torch, time, flat, widths, moments, status, control_ticks, n_control, ev0, ev1, clock,
                                      f64, stream)
+
+    def _schedule(self):
+        """(schedule [ticks] uint8: bit 0 a predict is due, bit 1 the controller acts -- sim_base.py:250, :255; control ticks)."""
+        ticks = len(self.ts)
+        sched = numpy.zeros(ticks, dtype=numpy.uint8)
+        t_next_control, t_next_predict = 0, 0
+        control_ticks = [0]
+        for t in range(1, ticks):
+            if self.ts[t] > t_next_predict:
+                sched[t] |= 1
+                t_next_predict += self.dt_predict
+            if self.ts[t] > t_next_control:
+                sched[t] |= 2
+                control_ticks.append(t)
+                t_next_control += self.dt_control
+        return sched, control_ticks
+
+    def _native_capable(self):
+        """The ticks of a resident particle-filter loop enqueued from C++ (gse_pf_closed_loop): Philox noise, the built-in
+        model, the fused tail, up to 2^21 particles.  ``native_loop = False`` keeps the Python loop below (the same launches)."""
+        f = self.f
+        return (self.native_loop and self.pf and self.fused_tail and self.noise is None and self.controller is None and
+                f._model is None and f.N_particles <= (1 << 21) and f.measurement_pdf._Nd == 2 and f.lazy and
+                f._island is None and not f.record_ancestors)
+
+    def _launch_native(self, lib, f, K, X, u, z, y_pred, known, status, us, xs, ys, ys_meas, moments, rng, stream):
+        import ctypes
+        from gpu_se_amd import _lib
+        sched, control_ticks = self._schedule()
+        n_control = len(control_ticks) - 1
+        B = self.B
+        f._flush()
+        # the uniform numbers of the resamples: the class's own host stream, in the order resample() would draw them
+        r_host = numpy.ascontiguousarray(numpy.array([f._host_rng.random(B) if B > 1 else [f._host_rng.random()]
+                                                      for _ in range(max(n_control, 1))], dtype=numpy.float64).reshape(-1, B))
+        _, law, _keep_law = K._device_law()
+        glue = K.loop_glue(_U_FALLBACK)
+        addr = lambda obj: ctypes.cast(ctypes.pointer(obj), ctypes.c_void_p).value
+        spec = _lib.PfLoopSpec()
+        spec.B, spec.ticks, spec.N, spec.ld, spec.dt = B, len(self.ts), f.N_particles, f._ld, float(self.dt)
+        spec.flags = _lib.GSE_PF_LOOP_WEIGHT_SCALE if f.weight_scale else 0
+        spec.x[0], spec.x[1], spec.w[0], spec.w[1] = f._x.data_ptr(), f._x_alt.data_ptr(), f._w.data_ptr(), f._w_alt.data_ptr()
+        spec.workspace = f._ws.data_ptr()
+        spec.state_pdf, spec.measurement_pdf = addr(f.state_pdf._pod()), addr(f.measurement_pdf._pod())
+        spec.rng = _lib.Rng(seed=f._seed, step=f._step, element_offset=f._element_offset)
+        spec.law, spec.glue = addr(law), addr(glue)
+        spec.X, spec.u, spec.z, spec.y_pred, spec.known = X.data_ptr(), u.data_ptr(), z.data_ptr(), y_pred.data_ptr(), known.data_ptr()
+        spec.plant_state_noise, spec.plant_meas_noise = spec.state_pdf, spec.measurement_pdf        # (the same two mixtures)
+        spec.plant_rng = _lib.Rng(seed=rng.seed, step=0, element_offset=rng.element_offset, filter_offset=rng.filter_offset)
+        spec.schedule, spec.r = sched.ctypes.data, r_host.ctypes.data
+        spec.us, spec.xs, spec.ys, spec.ys_meas, spec.moments = (t_.data_ptr() for t_ in (us, xs, ys, ys_meas, moments))
+        spec.status = status.data_ptr()
+        _lib.check(lib.gse_pf_closed_loop(ctypes.byref(spec), stream))
+        # the filter object carries on from where the loop left it
+        if spec.x_current:
+            f._x, f._x_alt = f._x_alt, f._x
+        if spec.w_current:
+            f._w, f._w_alt = f._w_alt, f._w
+        f._step = int(spec.rng.step)
+        f._pend_gather = bool(spec.pend_gather)
+        f._gather_slot = int(spec.gather_slot) if spec.gather_slot >= 0 else None
+        f._scan_slot = int(spec.scan_slot) if spec.scan_slot >= 0 else None
+        f._tiles_valid = False
+        f._moments_host = None
+        if spec.pend_predict:
+            f._pend_predict = (u, float(self.dt), None)
+        for b in range(B):
+            f._c_r[b] = spec.r_pending[b]
+        self._keep_alive = (sched, r_host, law, glue, _keep_law)
+        return control_ticks, n_control
 
     def _persistent_capable(self):
         """The whole loop in ONE launch (gse_gsukf_closed_loop): rollouts whose estimator is a Gaussian-sum filter of at most 64

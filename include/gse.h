@@ -121,6 +121,8 @@ int gse_pf_update(const float *x, float *w, int64_t ld, int B, int64_t N, const 
                                          the tile sums a GSE_OP_SCAN_OUT update left in scan slot 0 (1 with _SLOT1), for a
                                          GSE_OP_SCAN_IN | GSE_OP_PREFIX_GLOBAL gather */
 #define GSE_RESAMPLE_SLOT1 8u
+#define GSE_RESAMPLE_WEIGHT_SCALE 16u /* the weights carry the workspace's binary exponent (GSE_OP_WEIGHT_SCALE below): the island
+                                         bookkeeping adds it to the logarithm of their sum */
 
 /* ParallelParticleFilter.resample (filter/particle.py:296-316 with _parallel_resample :223-263):
  * c = cumsum(w) / sum(w) in fp64; ancestor of output j = first k with c_k >= (j + r)/N;
@@ -133,6 +135,12 @@ int gse_pf_update(const float *x, float *w, int64_t ld, int B, int64_t N, const 
 int gse_pf_resample(const float *x_in, const float *w, float *x_out, float *w_out, int32_t *idx,
                     int64_t ld, int B, int64_t N, const double *r, uint32_t flags, double *island,
                     void *workspace, void *stream);
+
+/* The copy of a resample whose ancestors are GIVEN: x_out[:, j] = x_in[:, idx[j]], w_out[j] = 1 / N; idx [B][ld] int32
+ * (entries clamped to [0, N)).  For replaying a recorded run of the reference -- the ancestors its own
+ * filter/particle.py:296-316 chose -- through the drivers; x_out / w_out separate buffers. */
+int gse_pf_gather_index(const float *x_in, const int32_t *idx, float *x_out, float *w_out, int64_t ld, int B, int64_t N,
+                        void *stream);
 
 /* First half of a resample only: the normalised cumulative weights (and the weight sum) go to the workspace, where a
  * following gse_pf_step(GSE_OP_GATHER | ...) finds them.  flags / island as for gse_pf_resample. */
@@ -176,6 +184,20 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
 #define GSE_OP_Z_DEVICE 256u     /* (with UPDATE)  z is a DEVICE pointer [B][2] fp64                            */
                                  /* (both: with GSE_OP_GATHER only in the whole single-launch cycle              */
                                  /*  GATHER | PREDICT | UPDATE | SCAN_IN | SCAN_OUT)                             */
+/* The reference's weight RANGE (filter/particle.py:103, :316 re-create the weights as fp64 after every resample, so
+ * ``weights *= pdf`` at :294 survives likelihoods down to 1e-308; fp32 storage flushes below 1e-38 N):
+ *   GSE_OP_WEIGHT_SCALE  (with UPDATE: multiplies by pdf * 2^-k instead of pdf, k = the binary exponent of the likelihood at
+ *                    particle 0 of the filter as the launch found it -- one value per filter and launch, a power of two, so no
+ *                    mantissa bit of any weight changes; k = 0 unless that likelihood is below 2^-40, i.e. launches whose
+ *                    weights fp32 holds anyway are bit for bit what they are without the flag) the accumulated exponent
+ *                    lives in the workspace at gse_workspace_weight_scale_offset(B, N): [B] doubles, true weight = stored
+ *                    weight * 2^scale[b].  The CALLER zeroes it when it sets the weights itself; UPDATE adds its k, GATHER
+ *                    resets it (offspring weigh 1 / N); the island bookkeeping includes it.  Everything normalised (resampling,
+ *                    offspring counts, S1 / S0) is invariant; the un-normalised sums of gse_pf_moments are those of the STORED
+ *                    weights: multiply by 2^scale[b].  A PREDICT | UPDATE launch without GATHER must then be out of place
+ *                    (x_out != x_in): the anchor is read from x_in while other workgroups write x_out. */
+#define GSE_OP_WEIGHT_SCALE 1024u
+int64_t gse_workspace_weight_scale_offset(int B, int64_t N);   /* byte offset of scale[B] inside the workspace; < 0: bad B / N */
 int gse_pf_step(uint32_t ops, const float *x_in, float *x_out, const float *w_in, float *w_out, int32_t *idx,
                 int64_t ld, int B, int64_t N, const double *u, double dt, const double *z, const double *r,
                 const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,
@@ -411,7 +433,10 @@ int gse_rng_raw(uint32_t *out, int64_t M, const gse_rng *rng, uint32_t purpose, 
 #define GSE_MPC_MAX_OUT 8        /* Ni, No                                                            */
 typedef struct gse_mpc_law {
     int32_t n_theta, n_u, n_y, n_rows;
-    int32_t max_sweeps, reserved;
+    int32_t max_sweeps;
+    int32_t report_unsolved;     /* fault injection: != 0 -> every step reports status 1 (what OSQP does when it returns a
+                                    non-solved status, controller.py:268-269), so that the caller's fallback branch
+                                    (sim_base.py:271-273) can be driven on the device; 0 in normal use */
     double  eps_abs, eps_rel;    /* row residual <= eps_abs + eps_rel * (|c0_i| + |bound_i|) ends the sweeps */
     const double *Gc, *gc0;      /* [n_rows][n_theta], [n_rows]  */
     const double *S;             /* [n_rows][n_rows] symmetric positive semi-definite */
@@ -506,6 +531,42 @@ typedef struct gse_loop_spec {
 #define GSE_LOOP_ARGS_BYTES 4096
 int gse_gsukf_closed_loop(const gse_loop_spec *spec /* host */, void *stream);
 
+/* The resident closed loop of the PARTICLE filter, its ticks enqueued from C++ (sim_base.py:243-309 for B rollouts; the
+ * Monte-Carlo loops of results/pf_closedloop/bioreactor_performance_pf.py:104-118): per control tick gse_pf_step (the
+ * pending resample's copy + predict + update in one launch), gse_pf_moments_resampled_tail (the estimate of the resampled
+ * ensemble, the MPC law, the plant), per other tick gse_plant_step + gse_pf_moments -- exactly the calls, arguments and order
+ * of a host loop over those entry points that defers resample and predict into the next update's launch, so the records
+ * are that loop's bit for bit; what is saved is the host's time between launches.  Philox noise, the built-in model,
+ * N <= 2^21, a 2-component measurement mixture.  Pointers are device memory unless marked host.  On return the spec's
+ * trailing fields say where the ensemble is and what is still pending (a resample's copy rides the NEXT launch). */
+#define GSE_PF_LOOP_WEIGHT_SCALE 1u              /* launches carry GSE_OP_WEIGHT_SCALE */
+typedef struct gse_pf_loop_spec {
+    int32_t B, ticks;
+    int64_t N, ld;
+    double dt;
+    uint32_t flags, reserved;
+    float *x[2], *w[2];                          /* the filter's buffer pairs [B][5][ld], [B][ld]; [0] holds the ensemble */
+    void *workspace;                             /* gse_workspace_bytes(B, N) */
+    const gse_mixture *state_pdf, *measurement_pdf;          /* host */
+    gse_rng rng;                                 /* the filter's Philox stream, step = that of its next predict (in / out) */
+    const gse_mpc_law *law;                      /* host struct of device pointers */
+    const gse_loop_glue *glue;                   /* host */
+    double *X, *u, *z, *y_pred;                  /* [B][5], [B][2], [B][2], [B][n_y]: in / out */
+    int32_t *known;                              /* [B] in / out */
+    const gse_mixture *plant_state_noise, *plant_meas_noise; /* host */
+    gse_rng plant_rng;                           /* tick t draws with step t */
+    const unsigned char *schedule;               /* HOST [ticks]: bit 0 a predict is due, bit 1 the controller acts */
+    const double *r;                             /* HOST [updates][B]: the uniform numbers of the resamples, in [0, 1) */
+    double *us, *xs, *ys, *ys_meas, *moments;    /* records [ticks][B][2 | 5 | 5 | 5 | 26]; row 0 is the caller's */
+    int32_t *status;                             /* [ticks][B]: 1 where the MPC's QP was not solved */
+    /* out */
+    int32_t x_current, w_current;                /* which of x[] / w[] holds the ensemble now */
+    int32_t pend_gather, pend_predict;           /* a resample's copy / a predict still to be launched */
+    int32_t gather_slot, scan_slot;              /* scan slot the pending copy resamples from; slot of the current weights' scans */
+    double r_pending[GSE_MAX_B];                 /* the uniform numbers of the pending resample */
+} gse_pf_loop_spec;
+int gse_pf_closed_loop(gse_pf_loop_spec *spec /* host, in / out */, void *stream);
+
 /* Rows of estimator moments (26 doubles each: gse_pf_moments / gse_gsukf_moments26) -> per row [mean (5), largest singular
  * value of the covariance]: point_estimate() and point_covariance() (filter/particle.py:318-327) for every tick and rollout of a
  * closed loop at once, on the device (sim_base.py:287-296 keeps both per tick). */
@@ -515,6 +576,19 @@ int gse_moments_estimates(const double *moments /* [R][26] */, int64_t R, double
 int gse_plant_step_injected(double *X /* [B][5], in/out */, const double *u /* [B][2] */, double dt,
                             const float *state_draw /* [B][5] */, const float *meas_draw /* [B][2] */, double *y, double *y_meas,
                             double *z, double *log_x, double *log_u, int64_t B, void *stream);
+
+/* The posterior merge of an ensemble SHARDED over several GPUs, on the device (no reference counterpart -- the
+ * reference is single-GPU): between them sits ONE all-reduce of [P][22] doubles (RCCL over xGMI; 1.4 KB at P = 8).
+ * gse_merge_row: this shard's moments (gse_pf_moments layout, about its own pivot), its accumulated log-weight log_island[0]
+ * and the binary exponent of its stored weights (wscale[0], or NULL) -> row[22] = { log A, S0, sum w (x - p0) (5), upper
+ * triangle of sum w (x - p0)(x - p0)^T (15) } about the pivot p0 = common_pivot (host [5]) every rank shares.
+ * gse_merge_rows: the rows of all P shards -> the moments of the whole ensemble, 26 doubles in the gse_pf_moments layout
+ * (S0 = 1, moments about p0, p0) that gse_loop_control / gse_moments_estimates take; shard p weighs A_p S0_p (log domain);
+ * status[0] (optional) = 1 when no shard has weight. */
+int gse_merge_row(const double *moments26, const double *log_island, const double *wscale, const double *common_pivot /* host */,
+                  double *row /* [22] */, void *stream);
+int gse_merge_rows(const double *rows /* [P][22] */, int P, const double *common_pivot /* host */, double *moments26_out,
+                   int32_t *status, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Exact systematic resampling of an ensemble SHARDED over several GPUs: the result is, bit for

@@ -274,6 +274,12 @@ def systematic_index(weights, r):
 # --------------------------------------------------------------------------------------
 # Particle filter  (filter/particle.py:9-114)
 # --------------------------------------------------------------------------------------
+def round24(x):
+    """fp64 values rounded to an fp32 MANTISSA (24 bits, round to nearest even) with their fp64 exponent range kept."""
+    m, e = np.frexp(np.asarray(x, dtype=np.float64))
+    return np.ldexp(m.astype(np.float32).astype(np.float64), e)
+
+
 class ParticleFilterOracle:
     """Bootstrap particle filter on the host.  ``loop=True`` methods make one Python call per
     particle (the reference's CPU cost model); the ``*_vec`` methods do the same arithmetic
@@ -281,7 +287,9 @@ class ParticleFilterOracle:
 
     def __init__(self, n, x0, state_pdf, measurement_pdf, rng=None, particles=None, weights_dtype=None):
         # weights_dtype: None = the reference's own dtypes (fp32 until the first resample, fp64 after it, particle.py:50,
-        # :103); np.float32 = what the device classes store (weights are fp32 throughout, sums fp64) --
+        # :103); np.float32 = plain fp32 storage (sums fp64); "scaled32" = what the device classes store since round 4
+        # (an fp32 MANTISSA per weight under a launch-uniform power of two, GSE_OP_WEIGHT_SCALE -- the
+        # reference's exponent range, 24 bits of its mantissa; held here as fp64 values rounded to 24 bits, sums fp64) --
         # used where a free-running device loop is compared tick by tick
         self.weights_dtype = weights_dtype
         self.n = int(n)
@@ -317,7 +325,10 @@ class ParticleFilterOracle:
 
     def update_vec(self, u, z):
         p = self.likelihood_vec(z)
-        self.weights = (self.weights.astype(np.float64) * p).astype(self.weights.dtype)
+        if self.weights_dtype == "scaled32":
+            self.weights = round24(self.weights.astype(np.float64) * p)
+        else:
+            self.weights = (self.weights.astype(np.float64) * p).astype(self.weights.dtype)
 
     # --- resample                                                         (:85-103)
     def _sum_weights(self):
@@ -337,7 +348,10 @@ class ParticleFilterOracle:
         if idx is None:
             idx = self.ancestors(r, loop)
         self.particles = self.particles[idx]
-        self.weights = np.full(self.n, 1 / self.n, dtype=self.weights_dtype or np.float64)   # fp64 from here on in the reference
+        if self.weights_dtype == "scaled32":
+            self.weights = np.full(self.n, np.float64(np.float32(1 / self.n)))
+        else:
+            self.weights = np.full(self.n, 1 / self.n, dtype=self.weights_dtype or np.float64)   # fp64 from here on in the reference
         return idx
 
     # --- moments                                                          (:105-114)

@@ -23,6 +23,8 @@ Fixture list:
   G8 linear_model.npz   LinearModel.create_LinearModel of the bioreactor (get_parts wiring), dt_control in {1, 0.1}
   G10 closed_loop.npz   sim_base.Simulation.simulate (the reference's own loop text) on the NumPy classes: recorded random
                         inputs and every record of the loop, particle filter and GS-UKF, control every tick / every 10th
+  G11 loop_envelope.npz the reference's Simulation run to end_time = 50 for 32 seeds per configuration (statistical envelope
+                        of the closed loop: ITSE, per-tick estimation error, outputs, inputs)
   G9 mpc_qp.npz         controller.MPC: the QP it hands to OSQP (H, q, A, l, u) for several horizons / bounds, and the
                         l, u vectors after step() has written x0, u_{-1} and the bias into them.  (osqp is not
                         installed: the SOLUTION of these QPs is not a reference output and is not stored.)
@@ -605,8 +607,82 @@ def gen_closed_loop(seed=1010):
     save("closed_loop.npz", **out)
 
 
+# --------------------------------------------------------------------------- G11
+def _patch_loop_environment():
+    """What gen_closed_loop installs around the reference's Simulation (see there), for a worker process."""
+    import controller  # noqa: F401  (reference)
+    import scipy.integrate
+    ROOT = os.path.dirname(os.path.dirname(OUT))
+    if ROOT not in sys.path:
+        sys.path.append(ROOT)
+    from oracle import closed_loop
+    orig_parts = sim_base.get_parts
+    sim_base.get_noise = _host_noise
+    sim_base.get_parts = lambda dt_control=1, N_particles=2 * 15, gpu=False, pf=True, _orig=orig_parts: _orig(
+        dt_control=dt_control, N_particles=N_particles, gpu=False, pf=pf)
+    _KktOsqp.mode = "exact"
+    sys.modules["osqp"].OSQP = _KktOsqp
+    controller.osqp.OSQP = _KktOsqp
+    scipy.integrate.simps = lambda y, x: closed_loop.simps_avg(y, x)
+
+
+def _envelope_worker(job):
+    tag, n, dtc, dtp, end, pf, seed = job
+    numpy.random.seed(seed)
+    sim = sim_base.Simulation(n, dtc, dtp, end_time=end, pf=pf)
+    sim.simulate()
+    outs = list(sim.lin_model.outputs)
+    return (tag, seed, float(sim.performance), float(sim.mpc_frac),
+            (numpy.asarray(sim.ys_f) - numpy.asarray(sim.ys)[:, outs]).astype(numpy.float32),
+            numpy.asarray(sim.ys)[:, outs].astype(numpy.float32), numpy.asarray(sim.us).astype(numpy.float32),
+            numpy.asarray(sim.covariance_point_size, dtype=numpy.float64))
+
+
+def gen_loop_envelope(seed=1111, seeds=32):
+    """G11: the reference's own Simulation (sim_base.py:207-309, the protocol of
+    results/pf_closedloop/bioreactor_performance_pf.py:19-58: end_time = 50, dt_predict = 0.1) run to the end on its NumPy
+    classes for ``seeds`` independent seeds per configuration -- particle filter N in {256, 1024} and GS-UKF N = 64, control
+    every tenth tick and every tick -- with the stand-ins of gen_closed_loop for what the container lacks.  Stored per run:
+    the ITSE ``performance`` (sim_base.py:164-185), the solved fraction, per tick the estimation error of the two controlled
+    outputs ys_f - ys[:, outputs], the outputs themselves, the inputs and the covariance size.  The Philox-driven device
+    loops must land inside the spread of these runs (tests/test_gpu_mpc.py)."""
+    import multiprocessing
+    cases = {
+        #             N     dt_control dt_predict end pf
+        "pf256_c1":  (256,  1.0, 0.1, 50, True),
+        "pf256_c01": (256,  0.1, 0.1, 50, True),
+        "pf1024_c1": (1024, 1.0, 0.1, 50, True),
+        "pf1024_c01": (1024, 0.1, 0.1, 50, True),
+        "gsf64_c1":  (64,   1.0, 0.1, 50, False),
+        "gsf64_c01": (64,   0.1, 0.1, 50, False),
+    }
+    jobs = [(tag,) + cfg + (seed + 1000 * k + s,) for k, (tag, cfg) in enumerate(sorted(cases.items())) for s in range(seeds)]
+    jobs.sort(key=lambda j: -j[1] * (10 if j[2] < 1 else 1))         # the long runs first
+    res = {}
+    with multiprocessing.Pool(min(7, os.cpu_count() or 1), initializer=_patch_loop_environment) as pool:
+        for k, r in enumerate(pool.imap_unordered(_envelope_worker, jobs)):
+            res.setdefault(r[0], []).append(r[1:])
+            if (k + 1) % 8 == 0:
+                print("  envelope %d/%d" % (k + 1, len(jobs)), flush=True)
+    out = {"names": numpy.array(sorted(cases))}
+    for tag, cfg in cases.items():
+        runs = sorted(res[tag])
+        out[tag + "_cfg"] = numpy.array([cfg[0], cfg[1], cfg[2], cfg[3], float(cfg[4])])
+        out[tag + "_seeds"] = numpy.array([r[0] for r in runs])
+        out[tag + "_performance"] = numpy.array([r[1] for r in runs])
+        out[tag + "_mpc_frac"] = numpy.array([r[2] for r in runs])
+        out[tag + "_err"] = numpy.array([r[3] for r in runs])            # (seeds, ticks, 2)  ys_f - ys[:, outputs]
+        out[tag + "_ys"] = numpy.array([r[4] for r in runs])             # (seeds, ticks, 2)
+        out[tag + "_us"] = numpy.array([r[5] for r in runs])             # (seeds, ticks, 2)
+        out[tag + "_cov"] = numpy.array([r[6] for r in runs])            # (seeds, ticks)
+        print("  %s: ITSE median %.4g (10%% %.4g, 90%% %.4g), mpc_frac min %.2f" % (
+            tag, numpy.median(out[tag + "_performance"]), *numpy.quantile(out[tag + "_performance"], [0.1, 0.9]),
+            out[tag + "_mpc_frac"].min()), flush=True)
+    save("loop_envelope.npz", **out)
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"constants", "model", "pdf", "resample", "pf", "gsukf", "stat", "linear", "mpc", "loop"}
+    which = set(sys.argv[1:]) or {"constants", "model", "pdf", "resample", "pf", "gsukf", "stat", "linear", "mpc", "loop", "envelope"}
     Xss = x_ss()
     print("X_ss =", Xss)
     if "constants" in which:
@@ -629,3 +705,5 @@ if __name__ == "__main__":
         gen_mpc_qp()
     if "loop" in which:
         gen_closed_loop()
+    if "envelope" in which:
+        gen_loop_envelope()

@@ -162,6 +162,14 @@ def _sharded_worker(rank, world, port, out, n_local=1 << 15):
         spf.update([0.06, 0.2], z)
         spf.resample()
     spf.wait_collectives()
+    # the posterior merge on the device (gse_merge_row -> all-reduce -> gse_merge_rows; nothing but the final 26 doubles comes
+    # to the host) against the host merge of rounds 1-3 (rows packed and combined with NumPy): the same formulas; exp / log of
+    # the shard shares come from two libraries, and the covariance undoes the pivot shift in another order
+    host_mean, host_cov = spf._merged_host()
+    dev_mean, dev_cov = spf._merged()
+    np.testing.assert_allclose(dev_mean, host_mean, rtol=1e-14, atol=0)
+    np.testing.assert_allclose(dev_cov, host_cov, rtol=1e-9, atol=1e-22)
+    assert spf.collectives_issued >= 3
     est = spf.point_estimate()
     cov = spf.point_covariance()
     lo = spf.local._element_offset
@@ -419,6 +427,17 @@ def _rccl_worker(rank, world, port, out):
         before = (spf.local.particles.get().copy(), spf.local.weights.get().copy())
         spf._exact_resample(0.25 + 0.2 * c)                          # all-gather of tile sums + all-to-all of rows, on RCCL
         log.append(("exact", before, spf.local.particles.get().copy(), spf.local.weights.get().copy(), dict(spf.last_exact)))
+    # the posterior merge, on the device from end to end: the shard's row written by gse_merge_row, an ASYNCHRONOUS all-reduce
+    # on RCCL, gse_merge_rows -- against the host merge of rounds 1-3 (one shard: its share is exp(0) = 1, so the mean is
+    # the host's bit for bit; the covariance undoes the pivot shift in another order)
+    host_mean, host_cov = spf._merged_host()
+    spf.merge_begin()
+    assert spf._merge_work is not None                               # (issued with async_op=True on the nccl backend)
+    moments = spf.merge_end()
+    assert moments.is_cuda and tuple(moments.shape) == (26,)
+    dev_mean, dev_cov = spf._merged()
+    np.testing.assert_array_equal(dev_mean, host_mean)
+    np.testing.assert_allclose(dev_cov, host_cov, rtol=1e-9, atol=1e-22)
     est = spf.point_estimate()                                       # the posterior merge: all-reduce on RCCL
     out[rank] = (log, est, spf.local.point_estimate())
     dist.barrier()
@@ -540,3 +559,34 @@ def test_fused_loop_tail_equals_the_separate_launches(n, dt_control, dt_predict,
     assert one.mpc_frac == many.mpc_frac
     np.testing.assert_array_equal(one.f.particles.get(), many.f.particles.get())
     np.testing.assert_array_equal(one.f.weights.get(), many.f.weights.get())
+
+
+@pytest.mark.parametrize("B,n,dt_control,dt_predict,end_time", [
+    (1, 1 << 16, 0.1, 0.1, 4), (4, 5003, 1.0, 0.1, 6), (3, 1 << 14, 1.0, 1.0, 6), (8, 1 << 12, 0.1, 0.1, 3)])
+def test_native_loop_equals_the_python_loop(B, n, dt_control, dt_predict, end_time):
+    """gse_pf_closed_loop -- the ticks of the resident particle-filter loop enqueued from C++ -- against the same loop enqueued
+    from Python (native_loop = False): the same launches with the same arguments in the same order, so every record, the
+    particles and the weights bit for bit; and the filter object carries on identically afterwards (the loop hands back where
+    the ensemble is and what is still pending: a resample whose copy rides the next launch)."""
+    sims = []
+    for native in (True, False):
+        gpu_se_amd.seed(91)
+        sim = sim_base.BatchedSimulation(batch=B, N_particles=n, dt_control=dt_control, dt_predict=dt_predict, end_time=end_time,
+                                         pf=True, resident=True, seed=4, native_loop=native)
+        assert sim._native_capable() == native
+        sim.simulate()
+        sims.append(sim)
+    one, many = sims
+    for name in ("us", "xs", "ys", "ys_meas", "moments", "xs_f", "ys_f", "covariance_point_size", "performance"):
+        np.testing.assert_array_equal(getattr(one, name), getattr(many, name), err_msg=name)
+    assert one.mpc_frac == many.mpc_frac
+    # one more cycle through the class API on both (before anything flushes the pending stages)
+    u = np.tile([0.05, 0.15], (B, 1))
+    z = np.tile([280.0, 611.0], (B, 1))
+    for sim in sims:
+        sim.f.predict(u, 0.1)
+        sim.f.update(u, z)
+        sim.f.resample()
+    np.testing.assert_array_equal(one.f.particles.get(), many.f.particles.get())
+    np.testing.assert_array_equal(one.f.weights.get(), many.f.weights.get())
+    np.testing.assert_array_equal(one.f.point_estimate(), many.f.point_estimate())

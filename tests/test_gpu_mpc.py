@@ -202,11 +202,58 @@ def test_loop_control_is_step_batch():
     assert np.any(np.abs(u_host) < 1e-9) or True
 
 
-def test_resident_loop_matches_the_host_loop_statistically():
-    """The loop with plant, controller and histories on the device: same structure of results as the host loop, the
-    controller's limit respected, and the closed-loop behaviour (set-point tracking, estimation error) of the same size."""
+ENVELOPE = ["pf256_c1", "pf256_c01", "pf1024_c1", "pf1024_c01", "gsf64_c1", "gsf64_c01"]
+
+
+@pytest.mark.parametrize("tag", ENVELOPE)
+def test_philox_resident_loops_land_inside_the_reference_envelope(golden, tag):
+    """G11 (tests/golden/loop_envelope.npz): the reference's OWN Simulation (sim_base.py:207-309; the protocol of
+    results/pf_closedloop/bioreactor_performance_pf.py:19-58: end_time = 50, dt_predict = 0.1) run to the end on its NumPy
+    classes for 32 seeds per configuration -- particle filter N = 256 / 1024, GS-UKF N = 64, control every tenth tick and every
+    tick.  The Philox-driven RESIDENT loop (the mode bench.py's closed_loop blocks and BASELINE config 5 run: plant, controller
+    and estimator on the device, Philox noise everywhere; the particle filter's ticks enqueued by gse_pf_closed_loop, the
+    GS-UKF's whole loop in the one persistent launch of gse_gsukf_closed_loop) cannot match those runs number for number --
+    other generators -- so 32 device rollouts are held to the reference's DISTRIBUTION:
+      * the ITSE ``performance`` (sim_base.py:164-185): the device median inside the reference's 10 % .. 90 % band, and the
+        device's own 10 % / 90 % quantiles within 30 % of the reference's;
+      * per window of 100 ticks and controlled output: the RMS estimation error ys_f - ys within a factor 0.75 .. 1.35 of the
+        reference's (measured: 0.85 .. 1.15); the mean output within 5 standard errors (+ 0.5 mg/L) of the reference's mean,
+        the standard error from the spread of the reference's per-seed window means; the mean input likewise (+ 0.002);
+      * every QP solved.
+    Ticks 0 .. 100 include the step to the set point (850 mg/L fatty acid): the controller's transient is part of the test."""
+    g = golden("loop_envelope.npz")
+    n, dtc, dtp, end, is_pf = g[tag + "_cfg"]
+    gpu_se_amd.seed(1234)
+    B = 32
+    sim = sim_base.BatchedSimulation(batch=B, N_particles=int(n), dt_control=float(dtc), dt_predict=float(dtp), end_time=int(end),
+                                     pf=bool(is_pf), resident=True)
+    sim.simulate()
+    assert sim.mpc_frac == 1.0 and np.all(g[tag + "_mpc_frac"] == 1.0)
+    perf_d, perf_r = np.asarray(sim.performance), g[tag + "_performance"]
+    qd, qr = np.quantile(perf_d, [0.1, 0.5, 0.9]), np.quantile(perf_r, [0.1, 0.5, 0.9])
+    assert qr[0] <= qd[1] <= qr[2], (qd, qr)
+    assert 0.7 * qr[0] <= qd[0] <= 1.3 * qr[0] and 0.7 * qr[2] <= qd[2] <= 1.3 * qr[2], (qd, qr)
+    err_d = sim.ys_f - sim.ys[:, :, [0, 2]]                      # (ticks, B, 2)
+    err_r = np.transpose(g[tag + "_err"], (1, 0, 2)).astype(np.float64)
+    ys_d, ys_r = sim.ys[:, :, [0, 2]], np.transpose(g[tag + "_ys"], (1, 0, 2)).astype(np.float64)
+    us_d, us_r = sim.us, np.transpose(g[tag + "_us"], (1, 0, 2)).astype(np.float64)
+    seeds = err_r.shape[1]
+    for lo in range(0, 500, 100):
+        sl = slice(max(lo, 1), lo + 100)
+        rms = lambda e: np.sqrt(np.mean(e[sl] ** 2, axis=(0, 1)))
+        ratio = rms(err_d) / rms(err_r)
+        assert np.all(ratio > 0.75) and np.all(ratio < 1.35), (tag, lo, ratio)
+        for dev_rec, ref_rec, slack in ((ys_d, ys_r, 0.5), (us_d, us_r, 0.002)):
+            se = ref_rec[sl].mean(axis=0).std(axis=0) * np.sqrt(1.0 / seeds + 1.0 / B)
+            gap = np.abs(dev_rec[sl].mean(axis=(0, 1)) - ref_rec[sl].mean(axis=(0, 1)))
+            assert np.all(gap <= 5.0 * se + slack), (tag, lo, gap, se)
+
+
+def test_resident_loop_has_the_records_of_the_host_loop():
+    """The loop with plant, controller and histories on the device returns the records of the host loop in the same shapes,
+    and respects the controller's limit."""
     gpu_se_amd.seed(12)
-    args = dict(batch=8, N_particles=1 << 12, dt_control=1, dt_predict=0.1, end_time=25)
+    args = dict(batch=4, N_particles=1 << 12, dt_control=1, dt_predict=0.1, end_time=5)
     host = sim_base.BatchedSimulation(seed=4, **args)
     host.simulate()
     res = sim_base.BatchedSimulation(seed=4, resident=True, **args)
@@ -214,15 +261,7 @@ def test_resident_loop_matches_the_host_loop_statistically():
     for name in ("us", "xs", "ys", "ys_meas", "xs_f", "ys_f", "covariance_point_size"):
         assert getattr(res, name).shape == getattr(host, name).shape, name
     assert res.mpc_frac == 1.0 and np.all(res.us >= -1e-12)
-    assert np.all(np.isfinite(res.performance)) and res.performance.shape == (8,)
-    # the estimator follows the plant equally well in both loops (the plant's noise comes from different generators)
-    err_res = np.abs(res.ys_f[5:] - res.ys[4:-1][:, :, [0, 2]])
-    err_host = np.abs(host.ys_f[5:] - host.ys[4:-1][:, :, [0, 2]])
-    assert np.median(err_res[..., 0]) < 2.0 * np.median(err_host[..., 0]) + 0.2
-    # and the controller takes the fatty-acid output the same way
-    rise_res, rise_host = res.ys[-1, :, 2] - res.ys[0, :, 2], host.ys[-1, :, 2] - host.ys[0, :, 2]
-    assert np.all(rise_res > 20) and abs(rise_res.mean() - rise_host.mean()) < 0.35 * abs(rise_host.mean())
-    np.testing.assert_allclose(res.us[1:].mean(axis=(0, 1)), host.us[1:].mean(axis=(0, 1)), rtol=0.25, atol=5e-3)
+    assert np.all(np.isfinite(res.performance)) and res.performance.shape == (4,)
 
 
 def test_moments_estimates_kernel_against_numpy():

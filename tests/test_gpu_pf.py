@@ -781,3 +781,122 @@ def test_cycles_are_hipgraph_capturable_and_replay_bit_identically():
         np.testing.assert_array_equal(host(graphed._x), host(eager._x))
         np.testing.assert_array_equal(host(graphed._w), host(eager._w))
     np.testing.assert_array_equal(graphed.point_estimate(), eager.point_estimate())
+
+
+# ------------------------------------------------------------------------------ the reference's weight range
+def _filter_and_reference_dtype_oracle(n, seed):
+    gpu_se_amd.seed(seed)
+    state_pdf, measurement_pdf = sim_base.get_noise(deterministic=True)
+    x0, _ = sim_base.get_noise()
+    xss = orc.steady_state()
+    x0.means += xss[None, :].astype(np.float32)
+    pf = ParallelParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, state_pdf, measurement_pdf)
+    osp, omp = orc.bioreactor_noise()
+    # weights_dtype=None: the REFERENCE's dtypes -- fp32 until the first resample, fp64 from then on (particle.py:50, :103)
+    o = orc.ParticleFilterOracle(n, None, osp, omp, particles=pf.particles.get(), weights_dtype=None)
+    return pf, o, xss
+
+
+@pytest.mark.parametrize("n,lazy", [(1 << 12, True), (1 << 16, True), (1 << 16, False)])
+def test_weight_range_of_the_reference_after_a_measurement_jump(n, lazy):
+    """The reference re-creates its weights as fp64 after every resample (filter/particle.py:103, :316), so ``weights *= pdf``
+    (:294) survives likelihoods down to 1e-308.  A jump of the measured glucose by 350 mg/L puts every particle's likelihood
+    near 1e-59: as plain fp32 products the new weights are ALL zero, their sum is zero, and the resample degenerates to
+    copies of particle 0 (what this build did until round 4; checked below with weight_scale = False).  With the
+    launch-uniform power-of-two scale (GSE_OP_WEIGHT_SCALE) the stored weights times 2^k are the reference's weights to one
+    fp32 rounding, the un-normalised point estimate between update and resample is the reference's, and the ancestors are
+    those of the oracle run in the reference's dtypes.  Both ways of launching: the fused cycle and one kernel per method.
+
+    Ancestors: the scale restores the reference's RANGE, not its mantissa -- a stored weight is the reference's fp64 weight
+    rounded to 24 bits, so a cumulative weight is off by about 2^-25 / sqrt(N_eff) of the total (N_eff = (sum w)^2 / sum w^2
+    heavy particles, each rounded independently), and with N thresholds among N keys about N^2 2^-25 / sqrt(N_eff) of them
+    fall between a key and its rounded twin: none at N = 4096 (asserted: at most 1), a handful at 2^16 right after the jump,
+    when a few hundred particles carry the posterior (asserted: that estimate x 4, + 2, and every one of them moves its
+    offspring to the NEIGHBOURING particle).  Exact equality would need fp64 weight storage (SURVEY 7 recommends fp32)."""
+    pf, o, xss = _filter_and_reference_dtype_oracle(n, 77)
+    pf.lazy = lazy
+    plain, _, _ = _filter_and_reference_dtype_oracle(n, 77)          # the same filter without the scale
+    plain.weight_scale = False
+    plain.particles = pf.particles.get()
+    rng = np.random.default_rng(21)
+    sd = np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])
+    u = [0.06, 0.2]
+    total_flips = 0
+    for cycle, jump in enumerate([0.0, 350.0, 350.0, 340.0]):
+        noise = (rng.standard_normal((n, 5)) * sd).astype(np.float32)
+        z = np.array(orc.bioreactor_g(xss)) + [0.2 + jump, -0.1]
+        r = float(rng.random())
+        for f in (pf, plain):
+            DeterministicGaussianSum.preload(noise)
+            f.predict(u, 0.1)
+            f.update(u, z)
+        o.predict_vec(u, 0.1, noise=noise)
+        o.update_vec(u, z)
+        w, k = pf._scaled_weights()
+        w_plain = plain._w[0, :n].cpu().numpy()
+        if cycle == 1:
+            assert k[0] < -150 and o.weights.max() < 1e-50, (k, o.weights.max())
+            assert w_plain.sum() == 0.0                                 # what plain fp32 weights make of this update
+        elif cycle == 0:
+            assert k[0] == 0                                            # likelihoods fp32 holds: the launch is bit for bit
+            np.testing.assert_array_equal(w[0], w_plain)                # what it is without the scale
+        heavy = o.weights > o.weights.max() * 1e-25                     # (beyond fp32's span below the heaviest: denormal / 0)
+        np.testing.assert_allclose(np.ldexp(w[0].astype(np.float64), int(k[0]))[heavy], o.weights[heavy], rtol=2.5e-7)
+        assert np.ldexp(w[0].astype(np.float64), int(k[0]))[~heavy].max(initial=0.0) <= o.weights.max() * 2e-25
+        # point_estimate() between update and resample is the reference's un-normalised weights @ particles (:318-320)
+        np.testing.assert_allclose(pf.point_estimate(), o.point_estimate(), rtol=1e-6)
+        idx = pf.resample(r=r, return_index=True).get().astype(np.int64)
+        # (before its first resample the reference's weights are still fp32 and so is its cumulative sum, particle.py:50, :89;
+        #  the device sums in fp64 always -- DESIGN.md section 2 -- so cycle 0 is compared on fp64 sums of the same weights;
+        #  from cycle 1 on that IS the reference's arithmetic)
+        own = orc.systematic_index(o.weights.astype(np.float64), r)
+        if cycle > 0:
+            np.testing.assert_array_equal(own, o.ancestors(r))
+        flips = int(np.sum(own != idx))
+        wo = o.weights.astype(np.float64)
+        n_eff = wo.sum() ** 2 / np.sum(wo * wo)
+        allowed = 2 + 4.0 * n * n * 2.0 ** -25 / np.sqrt(n_eff) if n > 4096 else 1
+        assert flips <= allowed and np.max(np.abs(own - idx)) <= 1, (cycle, flips, allowed, n_eff)
+        total_flips += flips
+        o.resample(r=r, idx=idx)
+        np.testing.assert_array_equal(pf.particles.get(), o.particles)
+        assert pf.weight_log2_scale[0] == 0                            # offspring weigh 1 / N: the exponent is spent
+        plain.resample(r=r)
+        if cycle == 1:                                                  # (zero weights: every offspring copies particle 0)
+            assert np.all(plain.particles.get() == plain.particles.get()[0])
+            plain.particles = pf.particles.get()                        # (carry on from the same ensemble)
+    assert total_flips <= (2 if n <= 4096 else 40)
+
+
+def test_weight_scale_travels_with_the_accessors():
+    """``weights`` hands out plain numbers (the exponent folded in, what fp32 holds of them), assigning weights clears the
+    exponent, and the island bookkeeping of a shard (log of the TRUE weight sum) includes it."""
+    n = 8192
+    pf, o, xss = _filter_and_reference_dtype_oracle(n, 78)
+    pf._island = torch.zeros((2, 1), dtype=torch.float64, device="cuda")
+    u = [0.06, 0.2]
+    z = np.array(orc.bioreactor_g(xss)) + [200.0, -0.1]
+    noise = np.zeros((n, 5), np.float32)
+    DeterministicGaussianSum.preload(noise)
+    pf.predict(u, 0.1)
+    pf.update(u, z)
+    o.predict_vec(u, 0.1, noise=noise)
+    o.update_vec(u, z)
+    w, k = pf._scaled_weights()
+    assert k[0] < -40
+    true_sum = float(np.sum(np.ldexp(w[0].astype(np.float64), int(k[0]))))
+    np.testing.assert_allclose(true_sum, o.weights.astype(np.float64).sum(), rtol=1e-6)
+    pf.resample(r=0.25)
+    pf._flush()
+    isl = pf._island.cpu().numpy()
+    np.testing.assert_allclose(isl[0, 0], np.log(true_sum), rtol=1e-12)
+    np.testing.assert_allclose(isl[1, 0], true_sum, rtol=1e-12)
+    # a second update, then the accessor: plain fp32 numbers (here: flushed towards zero, as fp32 must), exponent cleared
+    DeterministicGaussianSum.preload(noise)
+    pf.predict(u, 0.1)
+    pf.update(u, z)
+    assert pf.weight_log2_scale[0] < -40
+    got = pf.weights.get()
+    assert pf.weight_log2_scale[0] == 0 and got.dtype == np.float32
+    pf.weights = np.full(n, 1.0 / n, dtype=np.float32)
+    assert pf.weight_log2_scale[0] == 0

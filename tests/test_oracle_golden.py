@@ -255,3 +255,39 @@ def test_simps_rule_of_the_reference_scipy():
     np.testing.assert_allclose(closed_loop.simps_avg(y, x), (first + last) / 2, rtol=1e-14)
     from gpu_se_amd import sim_base
     np.testing.assert_allclose(sim_base.simps(y, x), closed_loop.simps_avg(y, x), rtol=1e-15)
+
+
+def test_loop_envelope_fixture_and_the_oracle_loop_inside_it(golden):
+    """G11 (loop_envelope.npz): 32 runs of the reference's own Simulation per configuration.  The fixture is complete, and
+    the oracle loop (oracle/closed_loop.py) driven by NumPy generators -- free-running, its own random numbers -- lands inside
+    the spread of those runs: 8 seeds of the particle filter, N = 256, control every tenth tick, the whole 50 minutes.
+    (The device loops are held to the same envelope in tests/test_gpu_mpc.py.)"""
+    import loop_util
+    from oracle import closed_loop
+    g = golden("loop_envelope.npz")
+    for tag in g["names"]:
+        assert g[tag + "_performance"].shape == (32,) and g[tag + "_err"].shape == (32, 500, 2)
+        assert np.all(g[tag + "_mpc_frac"] == 1.0) and np.all(np.isfinite(g[tag + "_performance"]))
+    tag = "pf256_c1"
+    n, dtc, dtp, end, _ = g[tag + "_cfg"]
+    n, end = int(n), int(end)
+    perf, err = [], []
+    xss = orc.steady_state()
+    for seed in range(8):
+        rng = np.random.default_rng(4000 + seed)
+        sp, mp = orc.bioreactor_noise(rng)
+        x0, _ = orc.bioreactor_noise(rng)
+        x0.means = x0.means + xss[None, :].astype(np.float32)
+        est = orc.ParticleFilterOracle(n, x0, sp, mp, rng=rng)
+        ticks = end * 10
+        noise = closed_loop.LoopNoise(sp.draw(ticks - 1), mp.draw(ticks - 1), [sp.draw(n) for _ in range(ticks - 1)],
+                                      rng.random(ticks))
+        sim = loop_util.loop_oracle(est, float(dtc), float(dtp), end, xss, noise).simulate()
+        assert sim.mpc_frac == 1.0
+        perf.append(sim.performance)
+        err.append(sim.ys_f - sim.ys[:, [0, 2]])
+    q = np.quantile(g[tag + "_performance"], [0.1, 0.9])
+    assert 0.8 * q[0] <= np.median(perf) <= 1.2 * q[1], (np.median(perf), q)
+    rms_o = np.sqrt(np.mean(np.array(err)[:, 100:] ** 2, axis=(0, 1)))
+    rms_r = np.sqrt(np.mean(g[tag + "_err"][:, 100:].astype(np.float64) ** 2, axis=(0, 1)))
+    assert np.all(rms_o / rms_r > 0.75) and np.all(rms_o / rms_r < 1.35), (rms_o, rms_r)
