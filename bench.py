@@ -308,6 +308,36 @@ def reference_itse(tag):
             "q90": float(q[2])}
 
 
+def run_cycles_block(torch, dt, sizes=(14, 16, 18, 20)):
+    """Open-loop cycles enqueued by ONE call (ParallelParticleFilter.run_cycles -> gse_pf_cycles: the loop over predict /
+    update / resample restated in C++, the same launches): device microseconds per cycle by HIP events and cycles per second
+    of wall time.  From Python the three method calls cost the host 11 us per cycle -- more than the device needs below 2^18
+    particles, so only this way does a mid-size filter run at the speed of its kernels (four workgroups per tile there)."""
+    import gpu_se_amd
+    from gpu_se_amd import sim_base
+    out = {}
+    for log2n in sizes:
+        n = 1 << log2n
+        io = make_inputs(700, dt, seed=5)
+        us, zs = np.array([u for u, _ in io]), np.array([z for _, z in io])
+        gpu_se_amd.seed(6)
+        _, _, _, f = sim_base.get_parts(N_particles=n)
+        f.run_cycles(us[:100], zs[:100], dt)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        f.run_cycles(us[100:], zs[100:], dt)
+        e1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        dev = e0.elapsed_time(e1) * 1e-3 / 600
+        assert np.all(np.isfinite(f.point_estimate()))
+        out["N=2^%d" % log2n] = {"device_us_per_cycle": round(dev * 1e6, 2), "cycles_per_s_wall": round(600 / wall, 1),
+                                 "kernels": "four workgroups per tile (GSE_OP_CLUSTER)" if f.cluster else "one workgroup per tile"}
+    return out
+
+
 def closed_loop_block(torch, B=32, log2n=18, end_time=50, pf=True):
     """BASELINE config 5 per GPU: 32 closed-loop rollouts x 2^18 particles, 499 ticks, MPC every tick, everything
     resident on the device (sim_base.BatchedSimulation(resident=True)).  pf=False: the same loop with banks of 2^log2n
@@ -595,6 +625,7 @@ def main():
         result["config"]["rccl"] = rccl_info
         if world == 1 and not args.no_extras:
             result["protocol_sum_us"] = protocol_sum(torch, n, io, dt)
+            result["run_cycles"] = run_cycles_block(torch, dt)
             result["gsukf"] = gsukf_block(torch)
             result["closed_loop"] = closed_loop_block(torch)
             # one real-time loop, and a few: the ticks are enqueued from C++ (gse_pf_closed_loop), so the wall time of a small

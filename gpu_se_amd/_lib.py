@@ -18,6 +18,9 @@ GSE_OP_SCAN_IN, GSE_OP_SCAN_OUT, GSE_OP_SCAN_IN_SLOT1, GSE_OP_SCAN_OUT_SLOT1 = 8
 GSE_OP_U_DEVICE, GSE_OP_Z_DEVICE = 128, 256
 GSE_OP_PREFIX_GLOBAL = 512
 GSE_OP_WEIGHT_SCALE = 1024
+GSE_OP_CLUSTER = 2048
+GSE_SLOT_QUARTERS = 2
+GSE_CLUSTER_MAX_TILES = 256        # policy: filters whose B x tiles stay within this run four workgroups per tile (GSE_OP_CLUSTER)
 GSE_RESAMPLE_WEIGHT_SCALE = 16
 GSE_IO_U_DEVICE, GSE_IO_Z_DEVICE = 1, 2
 GSE_SCAN_MAX_TILES = 2048      # policy: up to 2^21 particles every workgroup of the cycle kernel rebuilds the tile prefix in LDS
@@ -85,6 +88,7 @@ class PfLoopSpec(ctypes.Structure):
 
 
 GSE_PF_LOOP_WEIGHT_SCALE = 1
+GSE_PF_LOOP_CLUSTER = 2
 
 P_MIX = ctypes.POINTER(Mixture)
 P_RNG = ctypes.POINTER(Rng)
@@ -97,6 +101,7 @@ PROTOTYPES = {
     "gse_last_error": (ctypes.c_char_p, []),
     "gse_workspace_bytes": (c_i64, [ctypes.c_int, c_i64]),
     "gse_workspace_weight_scale_offset": (c_i64, [ctypes.c_int, c_i64]),
+    "gse_pf_slot_to_tiles": (ctypes.c_int, [ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_vp]),
     "gse_stream_synchronize": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "gse_pf_predict": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_d, P_MIX, P_RNG, c_vp]),
     "gse_pf_predict_injected": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_d, c_vp, c_vp]),
@@ -175,6 +180,7 @@ PROTOTYPES = {
     "gse_plant_step": (ctypes.c_int, [c_vp, c_vp, c_d, P_MIX, P_MIX, P_RNG, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "gse_gsukf_closed_loop": (ctypes.c_int, [ctypes.POINTER(LoopSpec), c_vp]),
     "gse_pf_closed_loop": (ctypes.c_int, [ctypes.POINTER(PfLoopSpec), c_vp]),
+    "gse_pf_cycles": (ctypes.c_int, [ctypes.POINTER(PfLoopSpec), ctypes.c_int, c_vp, c_vp, c_vp]),
     "gse_moments_estimates": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "gse_merge_row": (ctypes.c_int, [c_vp, c_vp, c_vp, P_D, c_vp, c_vp]),
     "gse_merge_rows": (ctypes.c_int, [c_vp, ctypes.c_int, P_D, c_vp, c_vp, c_vp]),

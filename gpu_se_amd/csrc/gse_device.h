@@ -376,11 +376,11 @@ __device__ __forceinline__ double mixture_pdf2(const Pdf2& m, double e0, double 
     return total;
 }
 
-// The same density times 2^-kexp, the power of two folded into the components' constants: a scaling by a power of two is
-// exact, so every term and the sum carry the mantissa of mixture_pdf2 (kexp = 0: the same bits) while the EXPONENT stays
-// inside what an fp32 weight can hold (GSE_OP_WEIGHT_SCALE, below).
+// The same density with the components' constants given by the caller -- cw_d 2^-k, the launch's power of two folded in ONCE
+// per thread (GSE_OP_WEIGHT_SCALE, below): a scaling by a power of two is exact, so every term and the sum carry the mantissa of
+// mixture_pdf2 (k = 0: the same bits) while the EXPONENT stays inside what an fp32 weight can hold.
 template <int kNd>
-__device__ __forceinline__ double mixture_pdf2_scaled(const Pdf2& m, double e0, double e1, int kexp) {
+__device__ __forceinline__ double mixture_pdf2_cw(const Pdf2& m, const double (&cw)[GSE_MAX_ND], double e0, double e1) {
 #pragma clang fp contract(off)
     double total = 0.0;
     const int nd = kNd > 0 ? kNd : m.nd;
@@ -389,10 +389,15 @@ __device__ __forceinline__ double mixture_pdf2_scaled(const Pdf2& m, double e0, 
         const double t0 = a0 * m.inv[d][0][0] + a1 * m.inv[d][1][0];
         const double t1 = a0 * m.inv[d][0][1] + a1 * m.inv[d][1][1];
         const double q = t0 * a0 + t1 * a1;
-        const double term = ldexp(m.cw[d], -kexp) * exp(-0.5 * q);
+        const double term = cw[d] * exp(-0.5 * q);
         total = (d == 0) ? term : total + term;
     }
     return total;
+}
+template <int kNd>
+__device__ __forceinline__ void scaled_constants(const Pdf2& m, int kexp, double (&cw)[GSE_MAX_ND]) {
+#pragma unroll
+    for (int d = 0; d < GSE_MAX_ND; ++d) cw[d] = (kNd > 0 && d >= kNd) ? 0.0 : ldexp(m.cw[d], -kexp);
 }
 
 // The reference keeps its weights in fp64 after the first resample (filter/particle.py:103, :316: numpy.full / cupy.full

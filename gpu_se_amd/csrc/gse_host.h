@@ -64,6 +64,7 @@ struct Workspace {
     double* scan[2];       // [B][T][256]  per-thread exclusive prefixes inside each tile (GSE_OP_SCAN_OUT / _IN), two slots
     double* cumsum;        // [B][N]       normalised cumulative weights
     double* wscale;        // [B]          GSE_OP_WEIGHT_SCALE: log2 of the factor between the stored and the true weights
+    double* qsums[2];      // [B][T][4]    GSE_OP_CLUSTER: the quarter sums that go with scan[slot] in quarter format
     int64_t bytes;
 };
 Workspace carve_workspace(void* base, int B, int64_t N);

@@ -107,6 +107,10 @@ Workspace carve_workspace(void* base, int B, int64_t N) {
     at += round256((int64_t)B * N * 8);
     ws.wscale = reinterpret_cast<double*>(p + at);
     at += round256((int64_t)B * 8);
+    for (int k = 0; k < 2; ++k) {
+        ws.qsums[k] = reinterpret_cast<double*>(p + at);
+        at += round256((int64_t)B * T * 4 * 8);
+    }
     ws.bytes = at;
     return ws;
 }

@@ -1,5 +1,6 @@
 // gse_pf.hip -- host side of the particle filter: launches and the C ABI.  The kernels are in gse_pf_kernels.h.
 #include "gse_pf_kernels.h"
+#include "gse_pf_cluster_kernels.h"
 #include "gse_rtc.h"
 
 #include <stdlib.h>
@@ -92,7 +93,9 @@ int launch_moments_resampled_partials(const char* fn, const float* x, const floa
     if (int rc = check_pf_geometry(fn, B, N, ld)) return rc;
     if (!(x && w && r && workspace)) return fail(GSE_ERR_ARG, "%s: null argument", fn);
     if (!(aligned16(x) && aligned16(w) && aligned16(workspace))) return fail(GSE_ERR_ARG, "%s: pointers must be 16-byte aligned", fn);
-    if (!(slot == 0 || slot == 1)) return fail(GSE_ERR_ARG, "%s: slot must be 0 or 1", fn);
+    const bool quarters = (slot & GSE_SLOT_QUARTERS) != 0;      // the slot is in quarter format (a GSE_OP_CLUSTER update wrote it)
+    slot &= ~GSE_SLOT_QUARTERS;
+    if (!(slot == 0 || slot == 1)) return fail(GSE_ERR_ARG, "%s: slot must be 0 or 1 (| GSE_SLOT_QUARTERS)", fn);
     const int T = (int)tiles_of(N);
     if (T > 2048) return fail(GSE_ERR_ARG, "%s: at most 2048 tiles (N <= 2^21)", fn);
     ResampleArgs ra;
@@ -102,8 +105,12 @@ int launch_moments_resampled_partials(const char* fn, const float* x, const floa
     }
     Workspace ws = carve_workspace(workspace, B, N);
     const int nblk = (int)std::min<int64_t>(std::min<int64_t>(kMomentBlocks, T), std::max<int64_t>(GSE_MOMRES_TOTAL_BLOCKS / B, GSE_MOMRES_MIN_BLOCKS));
-    hipLaunchKernelGGL(pf_moments_resampled_kernel, dim3(nblk, B), dim3(kBlock), (size_t)(T + 1) * sizeof(double), st, x, w,
-                       ws.scan_sums[slot], ws.scan[slot], ws.partials, N, ld, T, ra);
+    if (quarters)
+        hipLaunchKernelGGL(pf_moments_resampled_kernel<true>, dim3(nblk, B), dim3(kBlock), (size_t)(T + 1) * sizeof(double), st, x,
+                           w, ws.qsums[slot], ws.scan[slot], ws.partials, N, ld, T, ra);
+    else
+        hipLaunchKernelGGL(pf_moments_resampled_kernel<false>, dim3(nblk, B), dim3(kBlock), (size_t)(T + 1) * sizeof(double), st, x,
+                           w, ws.scan_sums[slot], ws.scan[slot], ws.partials, N, ld, T, ra);
     if (hipGetLastError() != hipSuccess) return fail(GSE_ERR_HIP, "%s: pf_moments_resampled_kernel did not launch", fn);
     return nblk;
 }
@@ -212,7 +219,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const bool G = ops & GSE_OP_GATHER, P = ops & GSE_OP_PREDICT, U = ops & GSE_OP_UPDATE;
     const uint32_t known = GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE | GSE_OP_SCAN_IN | GSE_OP_SCAN_OUT |
                            GSE_OP_SCAN_IN_SLOT1 | GSE_OP_SCAN_OUT_SLOT1 | GSE_OP_U_DEVICE | GSE_OP_Z_DEVICE |
-                           GSE_OP_PREFIX_GLOBAL | GSE_OP_WEIGHT_SCALE;
+                           GSE_OP_PREFIX_GLOBAL | GSE_OP_WEIGHT_SCALE | GSE_OP_CLUSTER;
     const bool prefix_global = (ops & GSE_OP_PREFIX_GLOBAL) != 0;
     GSE_REQUIRE((ops & (GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE)) != 0 && (ops & ~known) == 0,
                 "%s: bad ops mask 0x%x", fn, ops);
@@ -237,7 +244,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const bool u_on_device = (ops & GSE_OP_U_DEVICE) != 0, z_on_device = (ops & GSE_OP_Z_DEVICE) != 0;
     GSE_REQUIRE(!u_on_device || (P && u), "%s: GSE_OP_U_DEVICE needs GSE_OP_PREDICT and a device pointer u", fn);
     GSE_REQUIRE(!z_on_device || (U && z), "%s: GSE_OP_Z_DEVICE needs GSE_OP_UPDATE and a device pointer z", fn);
-    GSE_REQUIRE(!(u_on_device || z_on_device) || !G || (P && U && scan == 3),
+    GSE_REQUIRE(!(u_on_device || z_on_device) || !G || (P && U && scan == 3) || (ops & GSE_OP_CLUSTER),
                 "%s: with a gather, device-resident u / z need the whole single-launch cycle (gather + predict + update, scans "
                 "in and out)", fn);
     pack_io(a.io, B, ((P || U) && !u_on_device ? u : nullptr), (U && !z_on_device ? z : nullptr));   // (g may read u)
@@ -278,6 +285,9 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
         GSE_REQUIRE(G || (w_in && aligned16(w_in)), "%s: update without gather needs w_in", fn);
         if (int rc = check_mixture(fn, measurement_pdf, GSE_NY)) return rc;
         pack_pdf2(a.pdf, *measurement_pdf);
+        GSE_REQUIRE(!(ops & GSE_OP_WEIGHT_SCALE) || w_in != w_out,
+                    "%s: with GSE_OP_WEIGHT_SCALE an update writes its weights to another buffer (w_out != w_in): every workgroup "
+                    "of the launch scores the OLD weights of the scale's sample particles", fn);
     }
     a.dt = dt;
     const bool I = P && noise != nullptr;
@@ -285,6 +295,41 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const Workspace ws = carve_workspace(workspace, B, N);
     GSE_REQUIRE(!(ops & GSE_OP_WEIGHT_SCALE) || workspace, "%s: GSE_OP_WEIGHT_SCALE keeps the exponent in the workspace", fn);
     a.wscale = (ops & GSE_OP_WEIGHT_SCALE) ? ws.wscale : nullptr;
+    if (ops & GSE_OP_CLUSTER) {
+        // mid-size ensembles: four workgroups per tile, one particle per thread, scan slots in quarter format
+        // (gse_pf_cluster_kernels.h); the same particles, weights and ancestors as the kernels below
+        GSE_REQUIRE(!model, "%s: GSE_OP_CLUSTER is for the built-in model", fn);
+        GSE_REQUIRE(T <= kClusterMaxT, "%s: GSE_OP_CLUSTER takes at most %d tiles (N <= %d)", fn, kClusterMaxT, kClusterMaxT * kTile);
+        GSE_REQUIRE(!I, "%s: GSE_OP_CLUSTER draws its noise (no injected-noise variant)", fn);
+        GSE_REQUIRE(!prefix_global, "%s: GSE_OP_CLUSTER rebuilds the tile prefix itself", fn);
+        GSE_REQUIRE(!G || (scan & 1), "%s: GSE_OP_CLUSTER gathers from a quarter-format scan slot (GSE_OP_SCAN_IN)", fn);
+        GSE_REQUIRE(!U || ((scan & 2) && a.pdf.nd == 2), "%s: GSE_OP_CLUSTER updates leave a quarter-format slot (GSE_OP_SCAN_OUT) "
+                    "and take a 2-component measurement mixture", fn);
+        GSE_REQUIRE(G || x_out, "%s: null x_out", fn);
+        const int si = (ops & GSE_OP_SCAN_IN_SLOT1) ? 1 : 0, so = (ops & GSE_OP_SCAN_OUT_SLOT1) ? 1 : 0;
+        GSE_REQUIRE(!(G && U) || si != so, "%s: SCAN_IN and SCAN_OUT must use different slots", fn);
+        const bool dev_io = u_on_device || z_on_device;
+        const dim3 grid((unsigned)(4 * T), (unsigned)B);
+        hipStream_t st = (hipStream_t)stream;
+#define GSE_CLUSTER_GO(G_, P_, U_, D_)                                                                                          \
+        hipLaunchKernelGGL((pf_cluster_kernel<G_, P_, U_, D_>), grid, dim3(kBlock), 0, st, x_in, x_out, w_in, w_out, idx,        \
+                           ws.qsums[si], ws.scan[si], ws.qsums[so], ws.scan[so], island, N, ld, T, a)
+#define GSE_CLUSTER_PICK(D_)                                                       \
+        do {                                                                       \
+            if (G && P && U) GSE_CLUSTER_GO(true, true, true, D_);                 \
+            else if (G && P) GSE_CLUSTER_GO(true, true, false, D_);                \
+            else if (G && U) GSE_CLUSTER_GO(true, false, true, D_);                \
+            else if (G) GSE_CLUSTER_GO(true, false, false, D_);                    \
+            else if (P && U) GSE_CLUSTER_GO(false, true, true, D_);                \
+            else if (P) GSE_CLUSTER_GO(false, true, false, D_);                    \
+            else GSE_CLUSTER_GO(false, false, true, D_);                           \
+        } while (0)
+        if (dev_io) GSE_CLUSTER_PICK(true); else GSE_CLUSTER_PICK(false);
+#undef GSE_CLUSTER_PICK
+#undef GSE_CLUSTER_GO
+        GSE_LAUNCH_CHECK("pf_cluster_kernel");
+        return GSE_OK;
+    }
     StepLaunch L;
     L.grid = dim3((unsigned)T, (unsigned)B);
     L.st = (hipStream_t)stream;
@@ -350,6 +395,16 @@ int gse_pf_update(const float* x, float* w, int64_t ld, int B, int64_t N, const 
     GSE_REQUIRE(w, "gse_pf_update: null argument");      // (the bioreactor's g ignores u; a user model's may not)
     return pf_step(GSE_OP_UPDATE, x, nullptr, w, w, nullptr, ld, B, N, u, 0.0, z, nullptr, nullptr, nullptr, nullptr,
                    measurement_pdf, nullptr, workspace, stream, "gse_pf_update");
+}
+
+int gse_pf_slot_to_tiles(int B, int64_t N, int slot, void* workspace, void* stream) {
+    GSE_REQUIRE(B >= 1 && B <= GSE_MAX_B && N >= 1 && workspace && (slot == 0 || slot == 1), "gse_pf_slot_to_tiles: bad argument");
+    const int T = (int)tiles_of(N);
+    const Workspace ws = carve_workspace(workspace, B, N);
+    hipLaunchKernelGGL(quarters_to_tiles_kernel, dim3((unsigned)T, (unsigned)B), dim3(kBlock), 0, (hipStream_t)stream,
+                       ws.qsums[slot], ws.scan[slot], ws.scan_sums[slot], ws.scan[slot], T);
+    GSE_LAUNCH_CHECK("quarters_to_tiles_kernel");
+    return GSE_OK;
 }
 
 int64_t gse_workspace_weight_scale_offset(int B, int64_t N) {

@@ -207,7 +207,7 @@ __device__ __forceinline__ void store_out4(float* p, v4f_t v) {                 
 // 1024) is below 1024 raises mark[e] to k + 1 (LDS atomic max; a thread's equal neighbours are folded first).  No barrier.
 // kNeighbours: the lanes of the wavefront hold consecutive quads of one tile (t = threadIdx.x), so runs of equal slots are
 // folded across lanes too; false: the lanes hold unrelated quads (the work list of a wide ancestor range).
-template <bool kNeighbours>
+template <bool kNeighbours, int kSlots = kTile>      // kSlots: outputs the calling workgroup owns (marks it keeps)
 __device__ __forceinline__ void expand_quad(const OffspringCount& F, const double* pfx_s, uint32_t* mark, int64_t N,
                                             int32_t j0, int tq, int t, const float4 wv, double excl) {
     const int64_t k0 = (int64_t)tq * kTile + (int64_t)t * kPerThread;
@@ -233,7 +233,7 @@ __device__ __forceinline__ void expand_quad(const OffspringCount& F, const doubl
             if (near[p]) es[p] = F.settle(xs[p], es[p]);
     }
 #pragma unroll
-    for (int p = 0; p < kPerThread; ++p) es[p] = min(max(es[p] + 1 - j0, 0), (int32_t)kTile);
+    for (int p = 0; p < kPerThread; ++p) es[p] = min(max(es[p] + 1 - j0, 0), (int32_t)kSlots);
     // Only the LAST key of a run of equal slots needs to speak (it has the largest index).  Runs are folded inside the thread
     // and across the lanes of the wavefront (the next lane holds the next four keys): in a stretch of light particles
     // hundreds of consecutive keys share a slot, and their atomics on one LDS address would be served one by one.
@@ -243,7 +243,7 @@ __device__ __forceinline__ void expand_quad(const OffspringCount& F, const doubl
     for (int p = 0; p < kPerThread; ++p) {
         const bool last_of_run = k0 + p == tile_last ||
                                  ((p == kPerThread - 1) ? (next_first != (uint32_t)es[p] + 1u) : (es[(p + 1) % kPerThread] != es[p]));
-        if (k0 + p <= tile_last && es[p] < kTile && last_of_run) atomicMax(&mark[es[p]], (uint32_t)(k0 + p) + 1u);
+        if (k0 + p <= tile_last && es[p] < kSlots && last_of_run) atomicMax(&mark[es[p]], (uint32_t)(k0 + p) + 1u);
     }
 }
 
@@ -437,6 +437,47 @@ __device__ __forceinline__ void search_ancestors(const OffspringCount& F, const 
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// GSE_OP_WEIGHT_SCALE: the launch's binary exponent (gse_device.h, likelihood_exponent), by ONE wavefront: its 64 lanes score
+// the same 64 sample particles of x_in in every workgroup of the launch -- exponent of the old weight + exponent of the
+// likelihood under this launch's measurement -- and the best one fixes k.  In two halves so that the loads can be issued at
+// kernel entry and used much later (a wavefront that waits for them in one go keeps the rest of its workgroup at the next
+// barrier for a memory round trip): scale_samples_load, then scale_exponent_of.  wrow: the filter's weight row, or null (a
+// gather from materialised cumulative weights does not read the weights).
+struct ScaleSample {
+    float s[GSE_NX];
+    float w;
+};
+__device__ __forceinline__ void scale_samples_load(ScaleSample& q, const float* __restrict__ xin_b, const float* __restrict__ wrow,
+                                                   int64_t N, int64_t ld, int lane) {
+    const int64_t is = (int64_t)lane * N / kScaleSamples;
+#pragma unroll
+    for (int k = 0; k < GSE_NX; ++k) q.s[k] = xin_b[(int64_t)k * ld + is];
+    q.w = wrow ? wrow[is] : 1.f;
+}
+template <bool kGather, int kNd, bool kDevIO>
+__device__ __forceinline__ int scale_exponent_of(const ScaleSample& q, bool have_w, const StepArgs& a, int64_t N, int b) {
+    double fg0 = a.io.f[b].u0, fm0 = a.io.f[b].u1, za = a.io.f[b].z0, zb = a.io.f[b].z1;
+    if constexpr (kDevIO) {
+        if (a.u_dev) { fg0 = a.u_dev[2 * b]; fm0 = a.u_dev[2 * b + 1]; }
+        if (a.z_dev) { za = a.z_dev[2 * b]; zb = a.z_dev[2 * b + 1]; }
+    }
+    float o0[kObsKept], ya, yb;
+    model_keep(q.s, o0);
+    model_output_kept(o0, fg0, fm0, ya, yb);
+    // exponents, clamped to 15 bits each: score = old weight x likelihood (which sample matters most), cand = what k is made of
+    const int e_lik = min(max(likelihood_exponent<kNd>(a.pdf, za - (double)ya, zb - (double)yb), -16000), 2000);
+    const int e_w = have_w ? ((q.w > 0.f) ? max(ilogbf(q.w), -300) : -16000) : 0;
+    const int score = max(e_lik + e_w, -32000), cand = max(e_lik + (kGather ? 0 : e_w), -32000);
+    // the best score, with its cand, by ONE max-reduction of a packed key over the wavefront (DPP: no LDS round trips)
+    const uint32_t key = ((uint32_t)(score + 32768) << 16) | (uint32_t)(cand + 32768);
+    const uint32_t best = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(key), 63);
+    const int c = (int)(best & 0xffffu) - 32768;
+    // gather: the offspring weigh lik / N, so k = the anchor's likelihood exponent; otherwise its new weight w lik 2^-k is
+    // brought to about 1 / N  (ceil(log2 N) by a count of leading zeros)
+    const int k = kGather ? c : c + (N > 1 ? 64 - __clzll((unsigned long long)(N - 1)) : 0);
+    return (k < -kWeightScaleFrom) ? max(k, kWeightScaleMin) : 0;
+}
+
 template <bool kGather, bool kPredict, bool kInjected, bool kUpdate, int kNd, int kScan>
 __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     const float* __restrict__ x_in, float* __restrict__ x_out, const float* __restrict__ w_in, float* __restrict__ w_out,
@@ -465,7 +506,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     __shared__ __attribute__((aligned(16))) uint32_t mark[kInvMap ? kTile : 4];     // inverse map: see the gather stage
     __shared__ int32_t act_list[kInvMap ? kTile : 1];
     __shared__ int32_t act_n;
-    __shared__ __attribute__((aligned(16))) float wtile[(kStrided && kUpdate) ? kTile : 4];
+    __shared__ __attribute__((aligned(16))) double wtile[(kStrided && kUpdate) ? kTile : 2];    // the new weights, fp64 (see the update)
     __shared__ int64_t span[2];
     __shared__ double red[4];
     __shared__ int kexp_s;                    // GSE_OP_WEIGHT_SCALE: this launch's binary exponent
@@ -523,6 +564,11 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
         for (int i = 0; i < kMaxChunk; ++i) sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
     }
+    // ---- GSE_OP_WEIGHT_SCALE: the launch's binary exponent (scale_samples_load / scale_exponent_of above).  Wavefront 0 of
+    //      every workgroup requests the 64 samples HERE, with the tile sums, and turns them into k after the gather stage.
+    ScaleSample ssm;
+    const bool scale_w = (!kGather || kScanIn) && w_in != nullptr;
+    if (kUpdate && a.wscale && wv == 0) scale_samples_load(ssm, xin_b, scale_w ? w_in + (int64_t)b * ld : nullptr, N, ld, lane);
     if (kDraw) __syncthreads();                          // dp staged
     if (kDraw && draw_at == 0) draw_all();
     GSE_STAMP(1);
@@ -885,45 +931,30 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     }
     if (kDraw && draw_at == 2 && !drawn2) draw_all();      // (weights that do not sum to a positive number: no search)
     GSE_STAMP(4);
-    // ---- GSE_OP_WEIGHT_SCALE: the launch's binary exponent (gse_device.h, likelihood_exponent).  Wavefront 0 of every
-    //      workgroup scores the same 64 sample particles of x_in -- exponent of the old weight + exponent of the likelihood
-    //      under this launch's measurement -- and the best one fixes k; identical in every workgroup.
+    // GSE_OP_WEIGHT_SCALE: the launch's binary exponent, from the samples wavefront 0 requested at kernel entry.  The other
+    // wavefronts must not WAIT for it here: a barrier at this point lines the four wavefronts up again just before the state
+    // loads and costs the launch 2.7 % (A/B on one box: 67.5 us against 65.8 at 2^22, profiles/r04_scale_ab.txt; the arithmetic
+    // itself is free).  In the strided variants -- every launch that gathers or draws -- the update stage exchanges the new
+    // weights through LDS behind a barrier of its own: the likelihoods are formed UNSCALED, the fp64 products w pdf go through
+    // that exchange, and the power of two is applied behind its barrier (the reference's own order: weights *= pdf in fp64,
+    // particle.py:294 -- then one rounding to the stored fp32).  Variants without that exchange (a bare update, the
+    // injected-noise predict + update) take a barrier here.
     int kexp = 0;
+    constexpr bool kScaleBehindExchange = kStrided && kUpdate;
     if (kUpdate && a.wscale) {                               // (workgroup-uniform)
         if (wv == 0) {
-            double fg0 = a.io.f[b].u0, fm0 = a.io.f[b].u1, za = a.io.f[b].z0, zb = a.io.f[b].z1;
-            if constexpr (kDevIO) {
-                if (a.u_dev) { fg0 = a.u_dev[2 * b]; fm0 = a.u_dev[2 * b + 1]; }
-                if (a.z_dev) { za = a.z_dev[2 * b]; zb = a.z_dev[2 * b + 1]; }
-            }
-            const int64_t is = (int64_t)lane * N / kScaleSamples;
-            float s0[GSE_NX], o0[kObsKept], ya, yb;
-#pragma unroll
-            for (int k = 0; k < GSE_NX; ++k) s0[k] = xin_b[(int64_t)k * ld + is];
-            const bool have_w = (!kGather || kScanIn) && w_in != nullptr;
-            const float ws = have_w ? w_in[(int64_t)b * ld + is] : 1.f;
-            model_keep(s0, o0);
-            model_output_kept(o0, fg0, fm0, ya, yb);
-            const int e_lik = likelihood_exponent<kNd>(a.pdf, za - (double)ya, zb - (double)yb);
-            const int e_w = (ws > 0.f) ? ilogbf(ws) : -1000000;            // (no weight: out of the running)
-            int score = e_lik + (have_w ? e_w : 0), cand = e_lik + ((have_w && !kGather) ? e_w : 0);
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                const int s2 = __shfl_xor(score, m, 64), c2 = __shfl_xor(cand, m, 64);
-                if (s2 > score || (s2 == score && c2 > cand)) { score = s2; cand = c2; }
-            }
-            // gather: the offspring weigh lik / N, so k = the anchor's likelihood exponent; otherwise its new weight
-            // w lik 2^-k is brought to about 1 / N
-            int k = kGather ? cand : cand + (int)ceil(log2((double)N));
-            k = (k < -kWeightScaleFrom) ? max(k, kWeightScaleMin) : 0;
+            const int k = scale_exponent_of<kGather, kNd, kDevIO>(ssm, scale_w, a, N, b);
             if (lane == 0) kexp_s = k;
         }
-        __syncthreads();
-        kexp = kexp_s;
+        if (!kScaleBehindExchange) {
+            __syncthreads();
+            kexp = kexp_s;
+        }
     }
     // a thread is live if it owns at least one particle (its first one)
     const bool live = jp[0] < Nu;
     float wnew[kPerThread] = {w_uniform, w_uniform, w_uniform, w_uniform};
+    double wd[kPerThread] = {0.0, 0.0, 0.0, 0.0};            // strided update: the new weights before their rounding to fp32
     if (live) {
         // ---- issue every load now; the RNG arithmetic below needs no memory and hides their latency.  (Plain loads
         //      get sunk below the RNG by the compiler to save registers, which serialises "RNG, then wait for HBM";
@@ -1055,15 +1086,13 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             for (int p = 0; p < kPerThread; ++p) wnew[p] = (jp[p] < Nu) ? wb[jp[p]] : 0.f;
         }
         if (kUpdate) {
-            // GSE_OP_WEIGHT_SCALE: kexp (above) taken out of every likelihood of the launch; the accumulated exponent
-            if (a.wscale && tile_id == 0 && tid == 0) a.wscale[b] = (kGather ? 0.0 : a.wscale[b]) + (double)kexp;
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p) {
                 float y0, y1;
                 model_output_kept(obs[p], fg, fm, y0, y1);
-                const double lik = mixture_pdf2_scaled<kNd>(a.pdf, z0 - (double)y0, z1 - (double)y1, kexp);
-                // (with a scale: saturate instead of overflowing -- a particle 2^127 heavier than the anchor)
-                wnew[p] = (float)(a.wscale ? fmin((double)wnew[p] * lik, 3.4028234663852886e38) : (double)wnew[p] * lik);
+                const double lik = mixture_pdf2<kNd>(a.pdf, z0 - (double)y0, z1 - (double)y1);
+                if (kScaleBehindExchange) wd[p] = (double)wnew[p] * lik;             // (rounded behind the exchange below)
+                else wnew[p] = (float)ldexp((double)wnew[p] * lik, -kexp);            // (kexp = 0: the product itself)
             }
         } else if (kGather) {
             if (a.wscale && tile_id == 0 && tid == 0) a.wscale[b] = 0.0;     // (the offspring weigh 1 / N each)
@@ -1088,11 +1117,16 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         // tree) so that fused and separate launches leave bit-identical sums; the strided mapping goes through LDS.
         if (kStrided) {
 #pragma unroll
-            for (int p = 0; p < kPerThread; ++p) wtile[tid + p * kBlock] = wnew[p];
+            for (int p = 0; p < kPerThread; ++p) wtile[tid + p * kBlock] = wd[p];
             __syncthreads();
-            const float4 t4 = *reinterpret_cast<const float4*>(&wtile[tid * kPerThread]);
-            wnew[0] = t4.x; wnew[1] = t4.y; wnew[2] = t4.z; wnew[3] = t4.w;
+            if (a.wscale) kexp = kexp_s;                    // (written by wavefront 0 before it came to this barrier)
+            const double2 t01 = *reinterpret_cast<const double2*>(&wtile[tid * kPerThread]);
+            const double2 t23 = *reinterpret_cast<const double2*>(&wtile[tid * kPerThread + 2]);
+            wnew[0] = (float)ldexp(t01.x, -kexp); wnew[1] = (float)ldexp(t01.y, -kexp);
+            wnew[2] = (float)ldexp(t23.x, -kexp); wnew[3] = (float)ldexp(t23.y, -kexp);
         }
+        // GSE_OP_WEIGHT_SCALE: the exponent the stored weights now carry (an update on top of an update accumulates)
+        if (a.wscale && tile_id == 0 && tid == 0) a.wscale[b] = (kGather ? 0.0 : a.wscale[b]) + (double)kexp;
         // the new weights, four consecutive ones per thread: one dwordx4 store (rows are padded to a multiple of 4)
         if (i0 < N) {
             const v4f w4o = {wnew[0], wnew[1], wnew[2], wnew[3]};
@@ -1854,6 +1888,9 @@ __global__ __launch_bounds__(kBlock) void pf_moments_kernel(const float* __restr
 #ifndef GSE_MOMRES_COMPACT
 #define GSE_MOMRES_COMPACT 1
 #endif
+// kQuarters: the slot is in QUARTER FORMAT (gse_pf_cluster_kernels.h): tile_sums = [B][T][4] quarter sums, qx_all the quads'
+// exclusive prefixes inside their quarter; the tile sum and the tile-level prefix are formed as block_exclusive_scan forms them.
+template <bool kQuarters>
 __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                       const double* __restrict__ tile_sums,
                                                                       const double* __restrict__ qx_all,
@@ -1870,12 +1907,19 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
     const double* qx = qx_all + (int64_t)b * T * kBlock;
     // tile prefix (the arithmetic of the step kernel's gather stage)
     {
-        const double* sums = tile_sums + (int64_t)b * T;
+        const double* sums = tile_sums + (int64_t)b * T * (kQuarters ? 4 : 1);
         const int m = (T + kBlock - 1) / kBlock;
         const int qlo = tid * m;
         double sv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
+        for (int i = 0; i < 8; ++i) {
+            if (kQuarters) {
+                const double* q = sums + 4 * (qlo + i);
+                sv[i] = (i < m && qlo + i < T) ? ((q[0] + q[1]) + q[2]) + q[3] : 0.0;
+            } else {
+                sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
+            }
+        }
         double chunk = 0.0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) chunk += sv[i];
@@ -1914,7 +1958,15 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
             const int t = sub * 64 + lane;
             const int64_t k0 = (int64_t)tq * kTile + (int64_t)t * kPerThread;
             const float4 wq = load_weights4(wb, k0, N, ld);
-            const double excl = qx[tq * kBlock + t];
+            double excl = qx[tq * kBlock + t];
+            if (kQuarters) {                           // (+ the quarters before this one, as block_exclusive_scan adds them)
+                const double* q = tile_sums + ((int64_t)b * T + tq) * 4;
+                double base = 0.0;
+                if (sub > 0) base = q[0];
+                if (sub > 1) base += q[1];
+                if (sub > 2) base += q[2];
+                excl = base + excl;
+            }
             double sc[kPerThread];
             sc[0] = (k0 + 0 < N) ? (double)wq.x : 0.0;
             sc[1] = sc[0] + ((k0 + 1 < N) ? (double)wq.y : 0.0);

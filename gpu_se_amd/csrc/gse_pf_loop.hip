@@ -17,6 +17,8 @@ namespace {
 
 struct PfLoopState {
     const gse_pf_loop_spec* s;
+    const double *u_cur = nullptr, *z_cur = nullptr;    // this launch's inputs / measurements; io_dev: device pointers [B][2]
+    bool io_dev = true;
     float *x, *x_alt, *w, *w_alt;
     bool pend_gather = false, pend_predict = false;
     int gather_slot = -1, scan_slot = -1;
@@ -26,8 +28,10 @@ struct PfLoopState {
 
     // filter/particle.py _launch_step for inputs that live on the device, Philox noise, the built-in model
     int launch_step(bool update) {
+        const bool cluster = (s->flags & GSE_PF_LOOP_CLUSTER) != 0;
+        if (cluster) return launch_cluster(update);
         const bool whole = pend_gather && gather_slot >= 0 && pend_predict && update;
-        if (pend_gather && !whole && (pend_predict || update)) {
+        if (io_dev && pend_gather && !whole && (pend_predict || update)) {
             // device-resident u / z are read by the single-launch cycle or by the variants without gather: copy the ancestors first
             const bool keep = pend_predict;
             pend_predict = false;
@@ -38,29 +42,58 @@ struct PfLoopState {
         const bool gather = pend_gather;
         const bool swap_x = gather || (ops && update && pend_predict);
         float* x_out = swap_x ? x_alt : x;
-        float* w_out = gather ? w_alt : w;
+        const bool swap_w = gather || (ops && update);
+        float* w_out = swap_w ? w_alt : w;
         if (gather) {
             ops |= GSE_OP_GATHER;
             if (gather_slot >= 0) ops |= GSE_OP_SCAN_IN | (gather_slot ? GSE_OP_SCAN_IN_SLOT1 : 0u);
         }
-        if (pend_predict) ops |= GSE_OP_PREDICT | GSE_OP_U_DEVICE;
+        if (pend_predict) ops |= GSE_OP_PREDICT | (io_dev ? GSE_OP_U_DEVICE : 0u);
         int scan_out = -1;
         if (update) {
             scan_out = (gather && gather_slot == 0) ? 1 : 0;
-            ops |= GSE_OP_UPDATE | GSE_OP_Z_DEVICE | GSE_OP_SCAN_OUT | (scan_out ? GSE_OP_SCAN_OUT_SLOT1 : 0u);
+            ops |= GSE_OP_UPDATE | (io_dev ? GSE_OP_Z_DEVICE : 0u) | GSE_OP_SCAN_OUT | (scan_out ? GSE_OP_SCAN_OUT_SLOT1 : 0u);
         }
-        if (int rc = gse_pf_step(ops, x, x_out, w, w_out, nullptr, s->ld, s->B, s->N, s->u, s->dt, s->z, r_cur, s->state_pdf, &rng,
+        if (int rc = gse_pf_step(ops, x, x_out, w, w_out, nullptr, s->ld, s->B, s->N, u_cur, s->dt, z_cur, r_cur, s->state_pdf, &rng,
                                  nullptr, s->measurement_pdf, nullptr, s->workspace, st))
             return rc;
         if (pend_predict) rng.step += 1;
         if (swap_x) std::swap(x, x_alt);
-        if (gather) std::swap(w, w_alt);
+        if (swap_w) std::swap(w, w_alt);
         pend_gather = false;
         gather_slot = -1;
         pend_predict = false;
         if (update) scan_slot = scan_out;
         return GSE_OK;
     }
+    // filter/particle.py _launch_cluster: four workgroups per tile (GSE_OP_CLUSTER), any stage combination in one launch
+    int launch_cluster(bool update) {
+        const bool gather = pend_gather;
+        uint32_t ops = GSE_OP_CLUSTER | (((s->flags & GSE_PF_LOOP_WEIGHT_SCALE) && (update || gather)) ? GSE_OP_WEIGHT_SCALE : 0u);
+        const bool swap_x = gather || ((ops & GSE_OP_WEIGHT_SCALE) && update && pend_predict);
+        float* x_out = swap_x ? x_alt : x;
+        const bool swap_w = gather || ((ops & GSE_OP_WEIGHT_SCALE) && update);
+        float* w_out = swap_w ? w_alt : w;
+        if (gather) ops |= GSE_OP_GATHER | GSE_OP_SCAN_IN | (gather_slot ? GSE_OP_SCAN_IN_SLOT1 : 0u);
+        if (pend_predict) ops |= GSE_OP_PREDICT | (io_dev ? GSE_OP_U_DEVICE : 0u);
+        int scan_out = -1;
+        if (update) {
+            scan_out = (gather && gather_slot == 0) ? 1 : 0;
+            ops |= GSE_OP_UPDATE | (io_dev ? GSE_OP_Z_DEVICE : 0u) | GSE_OP_SCAN_OUT | (scan_out ? GSE_OP_SCAN_OUT_SLOT1 : 0u);
+        }
+        if (int rc = gse_pf_step(ops, x, x_out, w, w_out, nullptr, s->ld, s->B, s->N, u_cur, s->dt, z_cur, r_cur, s->state_pdf, &rng,
+                                 nullptr, s->measurement_pdf, nullptr, s->workspace, st))
+            return rc;
+        if (pend_predict) rng.step += 1;
+        if (swap_x) std::swap(x, x_alt);
+        if (swap_w) std::swap(w, w_alt);
+        pend_gather = false;
+        gather_slot = -1;
+        pend_predict = false;
+        if (update) scan_out_slot(scan_out);
+        return GSE_OK;
+    }
+    void scan_out_slot(int slot) { scan_slot = slot; }
     int flush() { return (pend_gather || pend_predict) ? launch_step(false) : GSE_OK; }
 };
 
@@ -70,6 +103,8 @@ extern "C" int gse_pf_closed_loop(gse_pf_loop_spec* s, void* stream) {
     GSE_REQUIRE(s, "gse_pf_closed_loop: null spec");
     GSE_REQUIRE(s->B >= 1 && s->B <= GSE_MAX_B && s->ticks >= 2, "gse_pf_closed_loop: bad B / ticks");
     GSE_REQUIRE(s->N >= 1 && s->N <= ((int64_t)1 << 21), "gse_pf_closed_loop: 1 <= N <= 2^21 (the single-launch cycle's range)");
+    GSE_REQUIRE(!(s->flags & GSE_PF_LOOP_CLUSTER) || s->N <= ((int64_t)256 * GSE_TILE),
+                "gse_pf_closed_loop: GSE_PF_LOOP_CLUSTER takes at most 256 tiles (N <= 2^18)");
     GSE_REQUIRE(s->x[0] && s->x[1] && s->w[0] && s->w[1] && s->workspace && s->state_pdf && s->measurement_pdf,
                 "gse_pf_closed_loop: null filter argument");
     GSE_REQUIRE(s->measurement_pdf->nd == 2, "gse_pf_closed_loop: the single-launch cycle needs a 2-component measurement mixture");
@@ -85,6 +120,8 @@ extern "C" int gse_pf_closed_loop(gse_pf_loop_spec* s, void* stream) {
     f.x = s->x[0]; f.x_alt = s->x[1]; f.w = s->w[0]; f.w_alt = s->w[1];
     f.rng = s->rng;
     f.r_cur = s->r;
+    f.u_cur = s->u;
+    f.z_cur = s->z;
     f.st = (hipStream_t)stream;
     gse_rng plant_rng = s->plant_rng;
     gse_loop_tail tail = {};
@@ -119,7 +156,8 @@ extern "C" int gse_pf_closed_loop(gse_pf_loop_spec* s, void* stream) {
             tail.y_meas_out = s->ys_meas + (int64_t)t * B * 5;
             tail.log_x = s->xs + (int64_t)t * B * 5;
             tail.log_u = s->us + (int64_t)t * B * 2;
-            if (int rc = gse_pf_moments_resampled_tail(f.x, f.w, s->ld, B, s->N, f.r_cur, f.gather_slot,
+            const int slot_arg = f.gather_slot | ((s->flags & GSE_PF_LOOP_CLUSTER) ? GSE_SLOT_QUARTERS : 0);
+            if (int rc = gse_pf_moments_resampled_tail(f.x, f.w, s->ld, B, s->N, f.r_cur, slot_arg,
                                                        s->moments + (int64_t)t * B * 26, s->workspace, &tail, stream))
                 return rc;
             control_done = true;
@@ -144,5 +182,51 @@ extern "C" int gse_pf_closed_loop(gse_pf_loop_spec* s, void* stream) {
     s->rng.step = f.rng.step;
     if (f.pend_gather)
         for (int b = 0; b < B; ++b) s->r_pending[b] = f.r_cur[b];
+    return GSE_OK;
+}
+
+// K open-loop cycles predict(u_k, dt) -> update(u_k, z_k) -> resample(r_k) of B filters, enqueued from C++: the class's deferred
+// stages restated as above (one launch per cycle: the pending resample's copy + predict + update), inputs and measurements HOST
+// arrays.  What results/pf_openloop/pf_run_seq.py loops over from Python, 11 us of host time per cycle -- more than the device
+// needs for a mid-size filter.  The same launches as K rounds of the three class methods: the same particles and weights.
+extern "C" int gse_pf_cycles(gse_pf_loop_spec* s, int K, const double* u /* host [K][B][2] */, const double* z /* host [K][B][2] */,
+                             void* stream) {
+    GSE_REQUIRE(s && u && z && K >= 1, "gse_pf_cycles: bad argument");
+    GSE_REQUIRE(s->B >= 1 && s->B <= GSE_MAX_B && s->N >= 1 && s->N <= ((int64_t)1 << 21), "gse_pf_cycles: bad B / N (N <= 2^21)");
+    GSE_REQUIRE(s->x[0] && s->x[1] && s->w[0] && s->w[1] && s->workspace && s->state_pdf && s->measurement_pdf && s->r,
+                "gse_pf_cycles: null filter argument");
+    GSE_REQUIRE(s->measurement_pdf->nd == 2, "gse_pf_cycles: the single-launch cycle needs a 2-component measurement mixture");
+    GSE_REQUIRE(!(s->flags & GSE_PF_LOOP_CLUSTER) || s->N <= ((int64_t)256 * GSE_TILE),
+                "gse_pf_cycles: GSE_PF_LOOP_CLUSTER takes at most 256 tiles (N <= 2^18)");
+    const int B = s->B;
+    PfLoopState f;
+    f.s = s;
+    f.io_dev = false;
+    f.x = s->x[0]; f.x_alt = s->x[1]; f.w = s->w[0]; f.w_alt = s->w[1];
+    f.rng = s->rng;
+    f.r_cur = s->r;
+    f.st = (hipStream_t)stream;
+    f.pend_gather = s->pend_gather != 0;                    // (a resample the caller left pending rides the first launch)
+    f.gather_slot = s->gather_slot;
+    if (f.pend_gather) f.r_cur = s->r_pending;
+    for (int k = 0; k < K; ++k) {
+        f.u_cur = u + (int64_t)k * B * 2;
+        f.z_cur = z + (int64_t)k * B * 2;
+        f.pend_predict = true;
+        if (int rc = f.launch_step(true)) return rc;
+        GSE_REQUIRE(f.scan_slot >= 0, "gse_pf_cycles: internal: no scan slot after an update");
+        f.r_cur = s->r + (int64_t)k * B;
+        f.gather_slot = f.scan_slot;
+        f.scan_slot = -1;
+        f.pend_gather = true;
+    }
+    s->x_current = (f.x == s->x[0]) ? 0 : 1;
+    s->w_current = (f.w == s->w[0]) ? 0 : 1;
+    s->pend_gather = 1;
+    s->pend_predict = 0;
+    s->gather_slot = f.gather_slot;
+    s->scan_slot = -1;
+    s->rng.step = f.rng.step;
+    for (int b = 0; b < B; ++b) s->r_pending[b] = f.r_cur[b];
     return GSE_OK;
 }

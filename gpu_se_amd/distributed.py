@@ -135,14 +135,16 @@ class ShardedParticleFilter:
     collectives_issued = 0                                  # all-reduces / all-gathers / all-to-alls issued by this object
 
     def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, group=None, merge_device=None,
-                 reduce_every=32):
+                 reduce_every=32, even_split=False):
         self.group = group
         self.world = dist.get_world_size(group) if group is not None else 1
         self.rank = dist.get_rank(group) if group is not None else 0
         self.N_particles = int(N_particles)
         # shards on tile boundaries whenever every rank can have a tile of its own: exact resampling (and with it the
         # island policy below) needs that of every shard but the last
-        self._align = _lib.GSE_TILE
+        # (even_split: the plain contiguous split, equal shards up to one particle -- what from_get_parts(n_local) promises;
+        #  exact resampling then needs n_local to be a multiple of the tile)
+        self._align = 1 if even_split else _lib.GSE_TILE
         self._spans = [shard_bounds(self.N_particles, self.world, q, self._align) for q in range(self.world)]
         self._exact_capable = not any(cnt % _lib.GSE_TILE for _, cnt in self._spans[:-1])
         lo, n_local = self._spans[self.rank]
@@ -168,11 +170,12 @@ class ShardedParticleFilter:
         # so every rank takes the same decision).  ess_fraction = 0 switches the policy off.
         self.ess_fraction = 0.5
         if not self._exact_capable:
-            # fewer than one tile per rank: the shards cannot sit on tile boundaries, so no exact resample and no policy that
-            # would call for one in the middle of a run (resample(exact=True) still raises)
+            # the shards do not sit on tile boundaries (fewer than one tile per rank, or an even split of a count that is no
+            # multiple of the tile): no exact resample and no policy that would call for one in the middle of a run
+            # (resample(exact=True) still raises)
             import warnings
-            warnings.warn("ShardedParticleFilter: %d particles on %d ranks are less than one tile of %d per rank; the island "
-                          "policy is off (ess_fraction = 0)" % (self.N_particles, self.world, _lib.GSE_TILE))
+            warnings.warn("ShardedParticleFilter: the shards of %d particles on %d ranks do not end on tile boundaries (%d "
+                          "particles); the island policy is off (ess_fraction = 0)" % (self.N_particles, self.world, _lib.GSE_TILE))
             self.ess_fraction = 0.0
         self._shares = torch.zeros(self.world, dtype=torch.float64, device=self._merge_device)
         self._shares_cycle = None                           # resample count at which the pending exchange was issued
@@ -202,7 +205,7 @@ class ShardedParticleFilter:
         x0, _ = sim_base.get_noise()
         x0.means += numpy.asarray(xss[None, :], dtype=numpy.float32)
         return cls(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n_local * world, x0, state_pdf,
-                   measurement_pdf, group=group)
+                   measurement_pdf, group=group, even_split=True)
 
     # ------------------------------------------------------------------ the cycle (all local)
     def predict(self, u, dt):

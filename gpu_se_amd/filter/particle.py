@@ -119,6 +119,11 @@ class ParallelParticleFilter:
         self._scan_slot = None                              # slot holding scans of the CURRENT weights, if any
         self._scan_capable = True                           # the cycle kernel resamples from tile sums + per-thread prefixes
         self._prefix_global = (-(-n // _lib.GSE_TILE)) > _lib.GSE_SCAN_MAX_TILES    # ... beyond 2^21 from a scanned tile prefix
+        # Mid-size filters (B x tiles <= 256, i.e. less than one generation of workgroups): four workgroups per tile, one
+        # particle per thread (GSE_OP_CLUSTER) -- the same results, a shorter chain of dependent latencies.  The scan slots such
+        # launches write are in quarter format; _slot_fmt remembers which kind of launch wrote a slot ('q' / 't').
+        self.cluster = self._model is None and B * (-(-n // _lib.GSE_TILE)) <= _lib.GSE_CLUSTER_MAX_TILES
+        self._slot_fmt = [None, None]
         self._pend_predict = None
         self._want_index = False
         self._last_index = None
@@ -194,6 +199,16 @@ class ParallelParticleFilter:
         """Run the pending gather / predict stages, plus an update if ``update`` = (u, z) is given."""
         injected = self._pend_predict is not None and self._pend_predict[2] is not None
         scan_ok = self._scan_capable and self.measurement_pdf._Nd == 2
+        # which family of kernels: a pending gather reads its slot with the kind of launch that wrote it; otherwise the policy
+        gather_q = self._pend_gather and self._gather_slot is not None and self._slot_fmt[self._gather_slot] == "q"
+        if gather_q and injected:
+            pend, self._pend_predict = self._pend_predict, None         # (the cluster kernels draw their noise: copy first)
+            self._launch_step(update=None)
+            self._pend_predict, gather_q = pend, False
+        use_cluster = bool(gather_q or (self.cluster and self._model is None and scan_ok and not injected and
+                                        not self._pend_gather and not self._prefix_global))
+        if use_cluster:
+            return self._launch_cluster(update)
         whole = lambda: (self._pend_gather and self._gather_slot is not None and self._pend_predict is not None and
                          update is not None and scan_ok and     # gather + predict + update in ONE launch, scans in and out
                          not (injected and self._prefix_global))  # (no injected-noise variant of the scanned-prefix mode)
@@ -225,7 +240,9 @@ class ParallelParticleFilter:
         x_in = self._x
         x_out = self._x_alt if swap_x else self._x
         w_in = self._w
-        w_out = self._w_alt if gather else self._w
+        # (... and an update writes its weights to the other buffer: every workgroup scores the OLD weights of the samples)
+        swap_w = gather or (bool(ops) and update is not None)
+        w_out = self._w_alt if swap_w else self._w
         idx_ptr = None
         if gather:
             ops |= _lib.GSE_OP_GATHER
@@ -284,7 +301,7 @@ class ParallelParticleFilter:
             self._check(rc)
         if swap_x:
             self._x, self._x_alt = self._x_alt, self._x
-        if gather:
+        if swap_w:
             self._w, self._w_alt = self._w_alt, self._w
         self._pend_gather = False
         self._gather_slot = None
@@ -293,6 +310,76 @@ class ParallelParticleFilter:
         if update is not None:
             self._tiles_valid = True
             self._scan_slot = scan_out
+            if scan_out is not None:
+                self._slot_fmt[scan_out] = "t"
+
+    def _launch_cluster(self, update):
+        """_launch_step with four workgroups per tile (GSE_OP_CLUSTER): any combination of the pending gather (from a
+        quarter-format slot), the pending predict (Philox) and an update, host or device-resident inputs, one launch."""
+        n, gather = self.N_particles, self._pend_gather
+        ops = _lib.GSE_OP_CLUSTER | (_lib.GSE_OP_WEIGHT_SCALE if (self.weight_scale and (update is not None or gather)) else 0)
+        # (predict + update without a gather: out of place when the weights are scaled -- the scale's anchor is read from x_in)
+        swap_x = gather or (bool(ops & _lib.GSE_OP_WEIGHT_SCALE) and update is not None and self._pend_predict is not None)
+        x_out = self._x_alt if swap_x else self._x
+        swap_w = gather or (bool(ops & _lib.GSE_OP_WEIGHT_SCALE) and update is not None)      # (see _launch_step)
+        w_out = self._w_alt if swap_w else self._w
+        idx_ptr = None
+        if gather:
+            ops |= _lib.GSE_OP_GATHER | _lib.GSE_OP_SCAN_IN | (_lib.GSE_OP_SCAN_IN_SLOT1 if self._gather_slot else 0)
+            if self._want_index or self.record_ancestors:
+                self._last_index = torch.empty((self._B, self._ld), dtype=torch.int32, device=self._x.device)
+                idx_ptr = self._last_index.data_ptr()
+                if self.record_ancestors:
+                    self.ancestor_log.append(self._last_index)
+        pod_state = rng_ref = pod_meas = None
+        dt, cu, cz = 0.0, self._c_u, self._c_z
+        if self._pend_predict is not None:
+            ops |= _lib.GSE_OP_PREDICT
+            u, dt, _ = self._pend_predict
+            if torch.is_tensor(u):
+                ops |= _lib.GSE_OP_U_DEVICE
+                cu = ctypes.cast(ctypes.c_void_p(u.data_ptr()), _lib.P_D)
+            else:
+                self._fill(cu, u, _lib.GSE_NU)
+            pod_state = ctypes.byref(self.state_pdf._pod())
+            self._c_rng.step = self._step
+            self._step += 1
+            rng_ref = self._c_rng_ref
+        scan_out = None
+        if update is not None:
+            ops |= _lib.GSE_OP_UPDATE
+            if torch.is_tensor(update[1]):
+                ops |= _lib.GSE_OP_Z_DEVICE
+                cz = ctypes.cast(ctypes.c_void_p(self._device_io(update[1], _lib.GSE_NY).data_ptr()), _lib.P_D)
+            else:
+                self._fill(cz, update[1], _lib.GSE_NY)
+            if self._pend_predict is None and torch.is_tensor(update[0]):        # (nothing reads u here; keep the flags consistent)
+                pass
+            pod_meas = ctypes.byref(self.measurement_pdf._pod())
+            scan_out = 1 if (gather and self._gather_slot == 0) else 0
+            ops |= _lib.GSE_OP_SCAN_OUT | (_lib.GSE_OP_SCAN_OUT_SLOT1 if scan_out else 0)
+        rc = self._fn_step(ops, self._x.data_ptr(), x_out.data_ptr(), self._w.data_ptr(), w_out.data_ptr(), idx_ptr, self._ld,
+                           self._B, n, cu, dt, cz, self._c_r, pod_state, rng_ref, None, pod_meas,
+                           self._island.data_ptr() if self._island is not None else None, self._ws.data_ptr(),
+                           stream_ptr(self._dev_index))
+        if rc:
+            self._check(rc)
+        if swap_x:
+            self._x, self._x_alt = self._x_alt, self._x
+        if swap_w:
+            self._w, self._w_alt = self._w_alt, self._w
+        self._pend_gather = False
+        self._gather_slot = None
+        self._pend_predict = None
+        self._moments_host = None
+        if update is not None:
+            self._tiles_valid = False                           # (the workspace's tile sums are not written by these launches)
+            self._scan_slot = scan_out
+            self._slot_fmt[scan_out] = "q"
+
+    def _slot_arg(self, slot):
+        """A scan slot as gse_pf_moments_resampled takes it: | GSE_SLOT_QUARTERS when a cluster launch wrote it."""
+        return int(slot) | (_lib.GSE_SLOT_QUARTERS if self._slot_fmt[slot] == "q" else 0)
 
     # ------------------------------------------------------------------ attributes
     def _handed_out(self):
@@ -453,6 +540,62 @@ class ParallelParticleFilter:
             v = self._last_index[:, :self.N_particles]
             return DevArray.wrap(v[0] if self._B == 1 else v)
 
+    def run_cycles(self, us, zs, dt, rs=None):
+        """K cycles predict(us[k], dt) -> update(us[k], zs[k]) -> resample() enqueued by ONE call (gse_pf_cycles: the loop over
+        the three methods that results/pf_openloop/pf_run_seq.py:15-130 runs from Python, restated in C++): the same launches,
+        hence the same particles, weights and ancestors as K rounds of the methods, without the interpreter's 11 us per cycle
+        between them -- which is more than the device needs for a filter of up to 2^18 particles.  us, zs: (K, 2) host arrays
+        ((K, B, 2) for a batch); rs: optional (K,) / (K, B) uniform numbers (default: the filter's own host stream, in the order
+        resample() would draw them).  Philox noise, the built-in model, a 2-component measurement mixture, N <= 2^21."""
+        if self._model is not None or isinstance(self.state_pdf, DeterministicGaussianSum) or self.measurement_pdf._Nd != 2 \
+                or self.N_particles > (1 << 21) or not self.lazy or self._island is not None or self.record_ancestors:
+            for k in range(len(us)):                        # (whatever gse_pf_cycles does not take: the methods themselves)
+                self.predict(us[k], dt)
+                self.update(us[k], zs[k])
+                self.resample(r=None if rs is None else rs[k])
+            return
+        B, K = self._B, len(us)
+        if self._pend_predict is not None or (self._pend_gather and self._gather_slot is None):
+            self._flush()
+        u = numpy.ascontiguousarray(numpy.broadcast_to(numpy.asarray(us, dtype=numpy.float64).reshape(K, -1, 2), (K, B, 2)))
+        z = numpy.ascontiguousarray(numpy.broadcast_to(numpy.asarray(zs, dtype=numpy.float64).reshape(K, -1, 2), (K, B, 2)))
+        if rs is None:
+            r = numpy.array([self._host_rng.random(B) if B > 1 else [self._host_rng.random()] for _ in range(K)])
+        else:
+            r = numpy.broadcast_to(numpy.asarray(rs, dtype=numpy.float64).reshape(K, -1), (K, B))
+        r = numpy.ascontiguousarray(r, dtype=numpy.float64)
+        # which kernel family: a pending copy reads its slot with the kind of launch that wrote it, otherwise the policy
+        if self._pend_gather:
+            clustered = self._slot_fmt[self._gather_slot] == "q"
+        else:
+            clustered = bool(self.cluster and not self._prefix_global)
+        addr = lambda obj: ctypes.cast(ctypes.pointer(obj), ctypes.c_void_p).value
+        spec = _lib.PfLoopSpec()
+        spec.B, spec.ticks, spec.N, spec.ld, spec.dt = B, K, self.N_particles, self._ld, float(dt)
+        spec.flags = (_lib.GSE_PF_LOOP_WEIGHT_SCALE if self.weight_scale else 0) | (_lib.GSE_PF_LOOP_CLUSTER if clustered else 0)
+        spec.x[0], spec.x[1], spec.w[0], spec.w[1] = (t.data_ptr() for t in (self._x, self._x_alt, self._w, self._w_alt))
+        spec.workspace = self._ws.data_ptr()
+        spec.state_pdf, spec.measurement_pdf = addr(self.state_pdf._pod()), addr(self.measurement_pdf._pod())
+        spec.rng = _lib.Rng(seed=self._seed, step=self._step, element_offset=self._element_offset)
+        spec.r = r.ctypes.data
+        spec.pend_gather = 1 if self._pend_gather else 0
+        spec.gather_slot = self._gather_slot if self._pend_gather else -1
+        for b in range(B):
+            spec.r_pending[b] = self._c_r[b]
+        rc = self._lib.gse_pf_cycles(ctypes.byref(spec), K, u.ctypes.data, z.ctypes.data, stream_ptr(self._dev_index))
+        if rc:
+            self._check(rc)
+        if spec.x_current:
+            self._x, self._x_alt = self._x_alt, self._x
+        if spec.w_current:
+            self._w, self._w_alt = self._w_alt, self._w
+        self._step = int(spec.rng.step)
+        self._pend_gather, self._gather_slot, self._scan_slot = True, int(spec.gather_slot), None
+        self._slot_fmt[self._gather_slot] = "q" if clustered else "t"
+        self._tiles_valid, self._moments_host, self._want_index = False, None, False
+        for b in range(B):
+            self._c_r[b] = spec.r_pending[b]
+
     # ------------------------------------------------------------------ estimates
     def _raw_moments_arrays(self):
         """(S0 (B,), S1 (B, 5), S2 (B, 5, 5), pivot (B, 5)) with d = x - pivot, from the device (synchronises)."""
@@ -482,7 +625,7 @@ class ParallelParticleFilter:
                 self.N_particles > (1 << 21):
             return False
         self._call("gse_pf_moments_resampled", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
-                   self._c_r, int(self._gather_slot), out.data_ptr(), self._ws.data_ptr(), stream_ptr(self._dev_index))
+                   self._c_r, self._slot_arg(self._gather_slot), out.data_ptr(), self._ws.data_ptr(), stream_ptr(self._dev_index))
         return True
 
     def _resampled_moments_tail(self, out, tail):
@@ -494,7 +637,7 @@ class ParallelParticleFilter:
                 self.N_particles > (1 << 21):
             return False
         self._call("gse_pf_moments_resampled_tail", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
-                   self._c_r, int(self._gather_slot), out.data_ptr(), self._ws.data_ptr(), ctypes.byref(tail),
+                   self._c_r, self._slot_arg(self._gather_slot), out.data_ptr(), self._ws.data_ptr(), ctypes.byref(tail),
                    stream_ptr(self._dev_index))
         return True
 

@@ -3,7 +3,7 @@ drivers: plant + estimator + MPC, one rollout (Simulation)
 """
 import numpy
 
-from gpu_se_amd import controller
+from gpu_se_amd import _lib, controller
 from gpu_se_amd import filter as _filter
 from gpu_se_amd import gaussian_sum_dist, model
 
@@ -550,7 +550,8 @@ class BatchedSimulation:
         f = self.f
         return (self.native_loop and self.pf and self.fused_tail and self.noise is None and self.controller is None and
                 f._model is None and f.N_particles <= (1 << 21) and f.measurement_pdf._Nd == 2 and f.lazy and
-                f._island is None and not f.record_ancestors)
+                f._island is None and not f.record_ancestors and
+                (not f.cluster or f.N_particles <= _lib.GSE_CLUSTER_MAX_TILES * _lib.GSE_TILE))
 
     def _launch_native(self, lib, f, K, X, u, z, y_pred, known, status, us, xs, ys, ys_meas, moments, rng, stream):
         import ctypes
@@ -567,7 +568,8 @@ class BatchedSimulation:
         addr = lambda obj: ctypes.cast(ctypes.pointer(obj), ctypes.c_void_p).value
         spec = _lib.PfLoopSpec()
         spec.B, spec.ticks, spec.N, spec.ld, spec.dt = B, len(self.ts), f.N_particles, f._ld, float(self.dt)
-        spec.flags = _lib.GSE_PF_LOOP_WEIGHT_SCALE if f.weight_scale else 0
+        clustered = bool(f.cluster)                       # (the filter's policy: four workgroups per tile for mid-size ensembles)
+        spec.flags = (_lib.GSE_PF_LOOP_WEIGHT_SCALE if f.weight_scale else 0) | (_lib.GSE_PF_LOOP_CLUSTER if clustered else 0)
         spec.x[0], spec.x[1], spec.w[0], spec.w[1] = f._x.data_ptr(), f._x_alt.data_ptr(), f._w.data_ptr(), f._w_alt.data_ptr()
         spec.workspace = f._ws.data_ptr()
         spec.state_pdf, spec.measurement_pdf = addr(f.state_pdf._pod()), addr(f.measurement_pdf._pod())
@@ -589,6 +591,9 @@ class BatchedSimulation:
         f._pend_gather = bool(spec.pend_gather)
         f._gather_slot = int(spec.gather_slot) if spec.gather_slot >= 0 else None
         f._scan_slot = int(spec.scan_slot) if spec.scan_slot >= 0 else None
+        for slot in (f._gather_slot, f._scan_slot):
+            if slot is not None:
+                f._slot_fmt[slot] = "q" if clustered else "t"
         f._tiles_valid = False
         f._moments_host = None
         if spec.pend_predict:

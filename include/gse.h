@@ -194,9 +194,23 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
  *                    weight * 2^scale[b].  The CALLER zeroes it when it sets the weights itself; UPDATE adds its k, GATHER
  *                    resets it (offspring weigh 1 / N); the island bookkeeping includes it.  Everything normalised (resampling,
  *                    offspring counts, S1 / S0) is invariant; the un-normalised sums of gse_pf_moments are those of the STORED
- *                    weights: multiply by 2^scale[b].  A PREDICT | UPDATE launch without GATHER must then be out of place
- *                    (x_out != x_in): the anchor is read from x_in while other workgroups write x_out. */
+ *                    weights: multiply by 2^scale[b].  The scale's anchor is read from x_in and w_in while other workgroups
+ *                    write: an UPDATE then needs w_out != w_in, and PREDICT | UPDATE without GATHER x_out != x_in. */
 #define GSE_OP_WEIGHT_SCALE 1024u
+/* Mid-size ensembles (N <= 2^18: at most 256 tiles; Philox noise, 2-component measurement mixture):
+ *   GSE_OP_CLUSTER   the same stages by FOUR workgroups per tile of 1024 particles, one particle per thread -- below one
+ *                    generation of workgroups the cycle is a chain of dependent latencies (11-12 us from 2^14 to 2^18
+ *                    particles), and a lane that walks it for one particle instead of four on four times the CUs is through
+ *                    sooner.  Same particles, weights and ancestors, bit for bit.  The scan slots such a launch writes
+ *                    (SCAN_OUT) and reads (SCAN_IN; a GATHER needs it) are in QUARTER FORMAT -- per tile the four sums of its
+ *                    quarters and per 4 particles the exclusive prefix inside the quarter, which the consumer combines as the
+ *                    one-workgroup-per-tile kernel combines its four wavefronts -- so a slot is read by the kind of launch that
+ *                    wrote it; gse_pf_moments_resampled takes such a slot as  slot | GSE_SLOT_QUARTERS,  and
+ *                    gse_pf_slot_to_tiles converts one in place (tile sums + tile-level prefixes) for everything else.
+ *                    Device-resident u / z with any stage combination. */
+#define GSE_OP_CLUSTER 2048u
+#define GSE_SLOT_QUARTERS 2
+int gse_pf_slot_to_tiles(int B, int64_t N, int slot, void *workspace, void *stream);
 int64_t gse_workspace_weight_scale_offset(int B, int64_t N);   /* byte offset of scale[B] inside the workspace; < 0: bad B / N */
 int gse_pf_step(uint32_t ops, const float *x_in, float *x_out, const float *w_in, float *w_out, int32_t *idx,
                 int64_t ld, int B, int64_t N, const double *u, double dt, const double *z, const double *r,
@@ -540,6 +554,7 @@ int gse_gsukf_closed_loop(const gse_loop_spec *spec /* host */, void *stream);
  * N <= 2^21, a 2-component measurement mixture.  Pointers are device memory unless marked host.  On return the spec's
  * trailing fields say where the ensemble is and what is still pending (a resample's copy rides the NEXT launch). */
 #define GSE_PF_LOOP_WEIGHT_SCALE 1u              /* launches carry GSE_OP_WEIGHT_SCALE */
+#define GSE_PF_LOOP_CLUSTER 2u                   /* launches carry GSE_OP_CLUSTER (N <= 2^18; the slots are in quarter format) */
 typedef struct gse_pf_loop_spec {
     int32_t B, ticks;
     int64_t N, ld;
@@ -566,6 +581,12 @@ typedef struct gse_pf_loop_spec {
     double r_pending[GSE_MAX_B];                 /* the uniform numbers of the pending resample */
 } gse_pf_loop_spec;
 int gse_pf_closed_loop(gse_pf_loop_spec *spec /* host, in / out */, void *stream);
+/* K open-loop cycles predict(u_k, dt) -> update(u_k, z_k) -> resample(r_k) of the B filters in `spec` (its filter fields:
+ * B, N, ld, dt, flags, x, w, workspace, state_pdf, measurement_pdf, rng, r = HOST [K][B]; on entry pend_gather / gather_slot /
+ * r_pending may describe a resample whose copy is still pending -- in tile or quarter format as flags say), enqueued from
+ * C++: one gse_pf_step per cycle (the previous cycle's resample copy + predict + update), the loops of
+ * results/pf_openloop/pf_run_seq.py:15-130 without the host's time between the calls.  u, z: HOST [K][B][2]. */
+int gse_pf_cycles(gse_pf_loop_spec *spec /* host, in / out */, int K, const double *u, const double *z, void *stream);
 
 /* Rows of estimator moments (26 doubles each: gse_pf_moments / gse_gsukf_moments26) -> per row [mean (5), largest singular
  * value of the covariance]: point_estimate() and point_covariance() (filter/particle.py:318-327) for every tick and rollout of a

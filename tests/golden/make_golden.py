@@ -638,6 +638,30 @@ def _envelope_worker(job):
             numpy.asarray(sim.covariance_point_size, dtype=numpy.float64))
 
 
+def gen_loop_envelope_large(seed=2222, seeds=16):
+    """G11b: the same for ONE larger ensemble, N = 16384 particles, control every tick -- 16 seeds of the reference's own
+    Simulation (four minutes of its per-particle Python loops each): what the ITSE does as N grows (the device loops run
+    2^18 particles per rollout in BASELINE config 5; the reference cannot, but its trend from 256 over 1024 to 16384 can be
+    checked).  Stored like G11, in loop_envelope_large.npz."""
+    import multiprocessing
+    tag, cfg = "pf16384_c01", (16384, 0.1, 0.1, 50, True)
+    jobs = [(tag,) + cfg + (seed + s,) for s in range(seeds)]
+    runs = []
+    with multiprocessing.Pool(min(7, os.cpu_count() or 1), initializer=_patch_loop_environment) as pool:
+        for k, r in enumerate(pool.imap_unordered(_envelope_worker, jobs)):
+            runs.append(r[1:])
+            print("  large envelope %d/%d: ITSE %.4g" % (k + 1, len(jobs), r[2]), flush=True)
+    runs.sort()
+    out = {"names": numpy.array([tag]), tag + "_cfg": numpy.array([cfg[0], cfg[1], cfg[2], cfg[3], float(cfg[4])]),
+           tag + "_seeds": numpy.array([r[0] for r in runs]), tag + "_performance": numpy.array([r[1] for r in runs]),
+           tag + "_mpc_frac": numpy.array([r[2] for r in runs]), tag + "_err": numpy.array([r[3] for r in runs]),
+           tag + "_ys": numpy.array([r[4] for r in runs]), tag + "_us": numpy.array([r[5] for r in runs]),
+           tag + "_cov": numpy.array([r[6] for r in runs])}
+    print("  %s: ITSE median %.4g (10%% %.4g, 90%% %.4g)" % (tag, numpy.median(out[tag + "_performance"]),
+                                                         *numpy.quantile(out[tag + "_performance"], [0.1, 0.9])), flush=True)
+    save("loop_envelope_large.npz", **out)
+
+
 def gen_loop_envelope(seed=1111, seeds=32):
     """G11: the reference's own Simulation (sim_base.py:207-309, the protocol of
     results/pf_closedloop/bioreactor_performance_pf.py:19-58: end_time = 50, dt_predict = 0.1) run to the end on its NumPy
@@ -682,7 +706,7 @@ def gen_loop_envelope(seed=1111, seeds=32):
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"constants", "model", "pdf", "resample", "pf", "gsukf", "stat", "linear", "mpc", "loop", "envelope"}
+    which = set(sys.argv[1:]) or {"constants", "model", "pdf", "resample", "pf", "gsukf", "stat", "linear", "mpc", "loop", "envelope", "envelope_large"}
     Xss = x_ss()
     print("X_ss =", Xss)
     if "constants" in which:
@@ -707,3 +731,5 @@ if __name__ == "__main__":
         gen_closed_loop()
     if "envelope" in which:
         gen_loop_envelope()
+    if "envelope_large" in which:
+        gen_loop_envelope_large()

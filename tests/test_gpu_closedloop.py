@@ -590,3 +590,24 @@ def test_native_loop_equals_the_python_loop(B, n, dt_control, dt_predict, end_ti
     np.testing.assert_array_equal(one.f.particles.get(), many.f.particles.get())
     np.testing.assert_array_equal(one.f.weights.get(), many.f.weights.get())
     np.testing.assert_array_equal(one.f.point_estimate(), many.f.point_estimate())
+
+
+@pytest.mark.parametrize("B,n,dt_control", [(1, 1 << 16, 0.1), (2, 50000, 1.0)])
+def test_resident_loop_with_cluster_launches_equals_the_tile_launches(B, n, dt_control):
+    """The resident particle-filter loop of a mid-size ensemble runs four workgroups per tile (GSE_OP_CLUSTER; the deferred
+    moments read the quarter-format slot): every record bit for bit those of the same loop on the one-workgroup-per-tile
+    kernels, enqueued from C++ and from Python."""
+    sims = []
+    for cluster, native in ((True, True), (False, True), (True, False)):
+        gpu_se_amd.seed(92)
+        sim = sim_base.BatchedSimulation(batch=B, N_particles=n, dt_control=dt_control, dt_predict=0.1, end_time=4, pf=True,
+                                         resident=True, seed=4, native_loop=native)
+        assert sim.f.cluster
+        sim.f.cluster = cluster
+        sim.simulate()
+        sims.append(sim)
+    for other in sims[1:]:
+        for name in ("us", "xs", "ys", "ys_meas", "moments", "xs_f", "ys_f", "covariance_point_size", "performance"):
+            np.testing.assert_array_equal(getattr(sims[0], name), getattr(other, name), err_msg=name)
+    np.testing.assert_array_equal(sims[0].f.particles.get(), sims[1].f.particles.get())
+    np.testing.assert_array_equal(sims[0].f.particles.get(), sims[2].f.particles.get())

@@ -96,7 +96,7 @@ PF_CASES = [
 
 
 @pytest.mark.parametrize("driver,B,n,dt_control,dt_predict,end_time", PF_CASES)
-def test_particle_filter_loops_tick_by_tick_against_the_oracle_loop(driver, B, n, dt_control, dt_predict, end_time):
+def test_particle_filter_loops_tick_by_tick_following_the_devices_ancestors(driver, B, n, dt_control, dt_predict, end_time):
     """Over the whole run, no state re-seeded: the drivers' records against the oracle loop fed the same random inputs.
     Ancestors: the contract on the device's likelihoods is one fp32 ulp of the oracle's (device exp against NumPy's; in the
     runs examined they were bit-equal), and with N thresholds among N cumulative weights a shift of 1e-7 would move a
@@ -147,7 +147,7 @@ GSF_CASES = [
 
 
 @pytest.mark.parametrize("driver,B,n,dt_control,dt_predict,end_time", GSF_CASES)
-def test_gaussian_sum_filter_loops_tick_by_tick_against_the_oracle_loop(driver, B, n, dt_control, dt_predict, end_time):
+def test_gaussian_sum_filter_loops_tick_by_tick_following_the_devices_ancestors(driver, B, n, dt_control, dt_predict, end_time):
     """The same with the GS-UKF as the estimator.  Its covariances are fp32 sums of eleven outer products (the device keeps
     another order than NumPy: 2e-5 per step, tests/test_gpu_gsukf.py), so weights agree to 1e-4 and a Gaussian whose
     cumulative weight sits that close to a threshold may go either way: the oracle copies the device's ancestors and counts

@@ -900,3 +900,142 @@ def test_weight_scale_travels_with_the_accessors():
     assert pf.weight_log2_scale[0] == 0 and got.dtype == np.float32
     pf.weights = np.full(n, 1.0 / n, dtype=np.float32)
     assert pf.weight_log2_scale[0] == 0
+
+
+# ------------------------------------------------------------------------------ four workgroups per tile (mid-size ensembles)
+def _pair_of_filters(n, seed, batch=None):
+    out = []
+    for cluster in (True, False):
+        gpu_se_amd.seed(seed)
+        state_pdf, measurement_pdf = sim_base.get_noise()
+        x0, _ = sim_base.get_noise()
+        x0.means += orc.steady_state()[None, :].astype(np.float32)
+        if batch is None:
+            f = ParallelParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, state_pdf, measurement_pdf)
+        else:
+            from gpu_se_amd.filter import BatchedParticleFilter
+            f = BatchedParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, state_pdf, measurement_pdf,
+                                      batch=batch)
+        assert f.cluster                                        # (the policy takes these sizes)
+        f.cluster = cluster
+        out.append(f)
+    return out
+
+
+@pytest.mark.parametrize("n,lazy", [(5003, True), (1 << 14, True), ((1 << 16) + 17, True), (1 << 18, True), (1 << 15, False)])
+def test_cluster_cycle_equals_the_tile_cycle(n, lazy):
+    """GSE_OP_CLUSTER (gse_pf_cluster_kernels.h: four workgroups per tile, one particle per thread, scan slots in quarter
+    format) against the one-workgroup-per-tile kernels on the same filter: Philox noise, 12 cycles from the prior (the first
+    ones have the wide ancestor ranges that take the look-up path), a measurement jump in between (the weight scale) --
+    particles, weights, ancestors and estimates bit for bit after every cycle, fused launches and one launch per method.  The
+    policy switch between the two kernel families changes the time of a cycle, not its result."""
+    a, b_ = _pair_of_filters(n, 61)
+    rng = np.random.default_rng(5)
+    xss = orc.steady_state()
+    for f in (a, b_):
+        f.lazy = lazy
+    for c in range(12):
+        u = [float(rng.uniform(0.03, 0.09)), float(rng.uniform(0.1, 0.3))]
+        # (the inputs wander and every third step is a whole minute: the cloud drifts 50 .. 150 mg/L from the measurements, wide
+        #  ancestor ranges in most cycles; at cycle 7 the measurement is another 500 mg/L away: likelihoods near 2^-600)
+        z = np.array(orc.bioreactor_g(xss)) + rng.normal(0, 0.3, 2) + ([-500.0, 0.0] if c == 7 else [0.0, 0.0])
+        r = float(rng.random())
+        idx = []
+        for f in (a, b_):
+            f.predict(u, 0.1 if c % 3 else 1.0)
+            f.update(u, z)
+            if c in (2, 7):                                     # between update and resample: stored weights and their exponent
+                idx.append(f._scaled_weights())
+                continue
+            idx.append(f.resample(r=r, return_index=True).get())
+        if c in (2, 7):
+            np.testing.assert_array_equal(idx[0][0], idx[1][0])
+            np.testing.assert_array_equal(idx[0][1], idx[1][1])
+            if c == 7:
+                assert idx[0][1][0] < -400 and idx[0][0].max() > 1e-30, (idx[0][1], idx[0][0].max())
+            for f in (a, b_):
+                f.resample(r=r)
+        else:
+            np.testing.assert_array_equal(idx[0], idx[1], err_msg="ancestors, cycle %d" % c)
+        if c % 4 == 3:
+            np.testing.assert_array_equal(a.particles.get(), b_.particles.get(), err_msg="particles, cycle %d" % c)
+            np.testing.assert_array_equal(a.point_estimate(), b_.point_estimate())
+    assert a._slot_fmt.count("q") >= 1 and "q" not in b_._slot_fmt
+    np.testing.assert_array_equal(a.particles.get(), b_.particles.get())
+    np.testing.assert_array_equal(a.weights.get(), b_.weights.get())
+
+
+def test_cluster_cycle_on_adversarial_weights_and_in_batches():
+    """The same on weight patterns built to hurt a systematic resample (assigned through the attribute: the resample that
+    follows forms its cumulative weights itself, the update after it leaves a quarter-format slot again), and with several
+    filters per launch."""
+    n = 1 << 15
+    a, b_ = _pair_of_filters(n, 62)
+    rng = np.random.default_rng(6)
+    xss = orc.steady_state()
+    z = np.array(orc.bioreactor_g(xss)) + [0.2, -0.1]
+    for name, w in adversarial_weights(n, rng).items():
+        if name in ("zero_sum", "nan"):
+            continue
+        r = float(rng.random())
+        got = []
+        for f in (a, b_):
+            f.weights = (w / w.sum()).astype(np.float32)
+            f.resample(r=r)
+            f.predict([0.06, 0.2], 0.1)
+            f.update([0.06, 0.2], z)
+            got.append(f.resample(r=0.5 * r, return_index=True).get())
+        np.testing.assert_array_equal(got[0], got[1], err_msg=name)
+        np.testing.assert_array_equal(a.particles.get(), b_.particles.get(), err_msg=name)
+    B, n = 3, 40000
+    a, b_ = _pair_of_filters(n, 63, batch=B)
+    u = np.tile([0.06, 0.2], (B, 1))
+    zb = np.tile(z, (B, 1)) + np.arange(B)[:, None] * 0.3
+    for c in range(5):
+        rr = rng.random(B)
+        got = []
+        for f in (a, b_):
+            f.predict(u, 0.1)
+            f.update(u, zb)
+            got.append(f.resample(r=rr, return_index=True).get())
+        np.testing.assert_array_equal(got[0], got[1])
+    np.testing.assert_array_equal(a.particles.get(), b_.particles.get())
+    np.testing.assert_array_equal(a.point_estimate(), b_.point_estimate())
+
+
+@pytest.mark.parametrize("n,batch", [(1 << 14, None), (70001, None), (1 << 20, None), (9000, 3)])
+def test_run_cycles_equals_the_three_methods(n, batch):
+    """ParallelParticleFilter.run_cycles (gse_pf_cycles: K cycles enqueued from C++) against K rounds of predict / update /
+    resample from Python: the same launches, so particles, weights and estimates bit for bit -- mid-size filters (cluster
+    launches), 2^20 (the tile kernels), a batch; and the filter carries on identically afterwards."""
+    fs = []
+    for _ in range(2):
+        gpu_se_amd.seed(44)
+        state_pdf, measurement_pdf = sim_base.get_noise()
+        x0, _ = sim_base.get_noise()
+        x0.means += orc.steady_state()[None, :].astype(np.float32)
+        if batch is None:
+            fs.append(ParallelParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, state_pdf, measurement_pdf))
+        else:
+            from gpu_se_amd.filter import BatchedParticleFilter
+            fs.append(BatchedParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, state_pdf,
+                                            measurement_pdf, batch=batch))
+    a, b_ = fs
+    rng = np.random.default_rng(3)
+    xss = orc.steady_state()
+    K, B = 9, batch or 1
+    us = np.stack([rng.uniform(0.03, 0.09, (K, B)), rng.uniform(0.1, 0.3, (K, B))], axis=-1)
+    zs = np.array(orc.bioreactor_g(xss))[None, None, :] + rng.normal(0, 0.3, (K, B, 2))
+    shape = (lambda v: v[0]) if batch is None else (lambda v: v)
+    for part in (slice(0, 4), slice(4, 9)):                 # (the second call starts from a pending resample)
+        a.run_cycles(us[part] if batch else us[part, 0], zs[part] if batch else zs[part, 0], 0.1)
+        for k in range(part.start, part.stop):
+            b_.predict(shape(us[k]), 0.1)
+            b_.update(shape(us[k]), shape(zs[k]))
+            b_.resample()
+    np.testing.assert_array_equal(a.particles.get(), b_.particles.get())
+    np.testing.assert_array_equal(a.weights.get(), b_.weights.get())
+    for f in (a, b_):
+        f.predict(shape(us[0]), 0.1)
+        f.update(shape(us[0]), shape(zs[0]))
+    np.testing.assert_array_equal(a.point_estimate(), b_.point_estimate())
