@@ -202,7 +202,7 @@ def test_loop_control_is_step_batch():
     assert np.any(np.abs(u_host) < 1e-9) or True
 
 
-ENVELOPE = ["pf256_c1", "pf256_c01", "pf1024_c1", "pf1024_c01", "gsf64_c1", "gsf64_c01"]
+ENVELOPE = ["pf256_c1", "pf256_c01", "pf1024_c1", "pf1024_c01", "gsf64_c1", "gsf64_c01", "pf16384_c01"]
 
 
 @pytest.mark.parametrize("tag", ENVELOPE)
@@ -221,7 +221,9 @@ def test_philox_resident_loops_land_inside_the_reference_envelope(golden, tag):
         the standard error from the spread of the reference's per-seed window means; the mean input likewise (+ 0.002);
       * every QP solved.
     Ticks 0 .. 100 include the step to the set point (850 mg/L fatty acid): the controller's transient is part of the test."""
-    g = golden("loop_envelope.npz")
+    # (G11b, 16 seeds at N = 16384: the reference's ITSE grows with the ensemble -- 4.37e5, 4.53e5, 5.11e5 at 256, 1024, 16384,
+    #  its estimate lags the plant by a tick -- and so does the device's: 4.5e5 at 2^10, 5.1e5 at 2^14, 5.4e5 at 2^18)
+    g = golden("loop_envelope_large.npz" if tag == "pf16384_c01" else "loop_envelope.npz")
     n, dtc, dtp, end, is_pf = g[tag + "_cfg"]
     gpu_se_amd.seed(1234)
     B = 32

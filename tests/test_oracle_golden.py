@@ -268,6 +268,10 @@ def test_loop_envelope_fixture_and_the_oracle_loop_inside_it(golden):
     for tag in g["names"]:
         assert g[tag + "_performance"].shape == (32,) and g[tag + "_err"].shape == (32, 500, 2)
         assert np.all(g[tag + "_mpc_frac"] == 1.0) and np.all(np.isfinite(g[tag + "_performance"]))
+    big = golden("loop_envelope_large.npz")                       # G11b: 16 seeds at N = 16384
+    assert big["pf16384_c01_performance"].shape == (16,) and np.all(big["pf16384_c01_mpc_frac"] == 1.0)
+    # the reference's own trend: its ITSE does not fall as the ensemble grows (the estimate lags the plant by one tick)
+    assert np.median(big["pf16384_c01_performance"]) > np.median(g["pf256_c01_performance"])
     tag = "pf256_c1"
     n, dtc, dtp, end, _ = g[tag + "_cfg"]
     n, end = int(n), int(end)
