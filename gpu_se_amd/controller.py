@@ -29,7 +29,8 @@ import numpy
 
 from gpu_se_amd import _lib
 
-MAX_ROWS = 64            # GSE_MPC_MAX_ROWS
+MAX_ROWS = 2048          # GSE_MPC_MAX_ROWS_TOTAL: bounded rows in all (beyond 64 a working set of at most 64 rows, GSE_MPC_MAX_ROWS)
+MAX_ACTIVE = 64          # GSE_MPC_MAX_ROWS: rows that can be active together; the most the fused loop kernels take at all
 
 
 class _Law(ctypes.Structure):
@@ -138,8 +139,9 @@ class MPC:
             rows.append(("u", 0, i, self._u_lim[0][i], self._u_lim[1][i]))
         rows = [r for r in rows if numpy.isfinite(r[3]) or numpy.isfinite(r[4])]
         if len(rows) > MAX_ROWS:
-            raise NotImplementedError("this MPC has %d bounded rows; the device solver takes at most %d "
-                                      "(bound fewer outputs / moves, or shorten the horizons)" % (len(rows), MAX_ROWS))
+            raise NotImplementedError("this MPC has %d bounded rows; the device solver takes at most %d (of which %d active "
+                                      "together): bound fewer outputs / moves, or shorten the horizons"
+                                      % (len(rows), MAX_ROWS, MAX_ACTIVE))
         return rows
 
     def _build(self):
@@ -315,6 +317,11 @@ class MPC:
             self._dev = (lib, law, keep)
         self._dev[1].report_unsolved = 1 if self.report_unsolved else 0
         return self._dev
+
+    @property
+    def n_bounded_rows(self):
+        """Bounded rows of the law (beyond 64 the fused loop kernels do not take it: gse_mpc_step / gse_loop_control do)."""
+        return len(self._law["lo"])
 
     def step_device(self, theta, du0=None, y1=None, status=None):
         """theta: device tensor [B, Nx+Ni+No] fp64 -> (du0 [B, Ni], y1 [B, No], status [B] int32), all on the device,

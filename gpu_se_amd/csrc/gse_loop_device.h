@@ -36,9 +36,128 @@ __device__ __forceinline__ void per_iteration_uniform(MpcLawDev& l) {
     asm volatile("" : "+s"(l.Gu), "+s"(l.gu0), "+s"(l.Tu), "+s"(l.Gy), "+s"(l.gy0), "+s"(l.Ty));
 }
 
+// More bounded rows than a wavefront has lanes (controller.py:180-207 bounds every output over the whole horizon: P x No rows):
+// the dual is solved over a WORKING SET of at most 64 rows, one per lane, grown one row at a time --
+//   1. with the multipliers of the working set, every row's value c_i = c0_i - sum_j S[i][W_j] nu_j is formed (each lane takes
+//      every 64th row; c0_i = gc0_i + Gc_i theta) and the row that violates its bounds the most is found;
+//   2. none does (beyond the stopping tolerance): the multipliers are optimal -- rows outside the set are feasible with zero
+//      multipliers, rows inside satisfy the KKT conditions by 3 -- done;
+//   3. otherwise that row joins the set (lane |W|) and the dual coordinate sweeps (Hildreth, as below) run over the set from
+//      the multipliers they had, until the stopping rule of the small solver holds;
+// and so on: every pass adds a row the previous optimum violated, so the dual objective rises strictly and no set repeats.
+// Not converged (status 1, the caller's fallback): more than 64 rows active together, or sweeps exhausted.  Nothing is kept
+// in LDS (the callers have none to spare): the rows are re-formed from the law's matrices in every pass -- a few thousand
+// independent loads per rollout and pass, served by the L2.
+__device__ __noinline__ int mpc_solve_large(const MpcLawDev& law, double theta_lane, int lane, double& out) {
+    const int m = law.n_rows, nt = law.n_theta;
+    int nW = 0;
+    int myrow = -1;                                   // lane j < nW: the row it holds
+    double nu = 0.0, c = 0.0, c0 = 0.0, lo = -INFINITY, hi = INFINITY, sii = 1.0;
+    int converged = 0;
+    double th[GSE_MPC_MAX_THETA];
+#pragma unroll
+    for (int k = 0; k < GSE_MPC_MAX_THETA; ++k) th[k] = __shfl(theta_lane, k, 64);
+    for (int pass = 0; pass <= 64; ++pass) {
+        // 1. the most violated row outside the working set
+        double worst = 0.0, worst_c = 0.0, worst_c0 = 0.0;
+        int worst_row = -1;
+        for (int base = 0; base < m; base += 64) {        // (every lane runs every trip: the shuffles below need them all)
+            const int i = min(base + lane, m - 1);
+            const bool valid = base + lane < m;
+            double ci0 = law.gc0[i];
+#pragma unroll
+            for (int k = 0; k < GSE_MPC_MAX_THETA; ++k)
+                if (k < nt) ci0 += law.Gc[i * nt + k] * th[k];
+            double ci = ci0;
+            bool inside = !valid;
+            for (int j = 0; j < nW; ++j) {
+                const int wj = __shfl(myrow, j, 64);
+                const double nj = __shfl(nu, j, 64);
+                inside = inside || (wj == i);
+                if (nj != 0.0) ci -= law.S[(int64_t)i * m + wj] * nj;
+            }
+            if (inside) continue;
+            const double l = law.lo[i], h = law.hi[i];
+            const double over = ci - h, under = l - ci;
+            const double viol = fmax(over, under);
+            const double tol = law.eps_abs + law.eps_rel * (fabs(ci0) + (over > under ? fabs(h) : fabs(l)));
+            if (viol > tol && viol - tol > worst) { worst = viol - tol; worst_row = i; worst_c = ci; worst_c0 = ci0; }
+        }
+        double best = worst;
+        int best_lane = lane;
+#pragma unroll
+        for (int s2 = 32; s2 >= 1; s2 >>= 1) {
+            const double ob = __shfl_xor(best, s2, 64);
+            const int ol = __shfl_xor(best_lane, s2, 64);
+            if (ob > best || (ob == best && ol < best_lane)) { best = ob; best_lane = ol; }
+        }
+        if (!(best > 0.0)) { converged = 1; break; }
+        if (nW == 64) break;
+        // 2. that row joins the working set on lane nW
+        const int r = __shfl(worst_row, best_lane, 64);
+        const double rc = __shfl(worst_c, best_lane, 64), rc0 = __shfl(worst_c0, best_lane, 64);
+        if (lane == nW) {
+            myrow = r; nu = 0.0; c = rc; c0 = rc0;
+            lo = law.lo[r]; hi = law.hi[r]; sii = law.S[(int64_t)r * m + r];
+        }
+        ++nW;
+        // 3. dual coordinate sweeps over the set (the small solver's, with S gathered through the set's row numbers)
+        const bool row = lane < nW;
+        int inner = 0;
+        for (int sweep = 0; sweep < law.max_sweeps && !inner; ++sweep) {
+            for (int i = 0; i < nW; ++i) {
+                const int wi = __shfl(myrow, i, 64);
+                double delta = 0.0;
+                if (lane == i && sii > 0.0) {
+                    const double rr = c + sii * nu;
+                    const double want = (rr > hi) ? (rr - hi) / sii : ((rr < lo) ? (rr - lo) / sii : 0.0);
+                    delta = want - nu;
+                    nu = want;
+                }
+                delta = __shfl(delta, i, 64);
+                if (row && delta != 0.0) c -= law.S[(int64_t)myrow * m + wi] * delta;
+            }
+            double res = 0.0, scale = fabs(c0);
+            if (row) {
+                if (nu > 0.0) { res = fabs(c - hi); scale += fabs(hi); }
+                else if (nu < 0.0) { res = fabs(c - lo); scale += fabs(lo); }
+                else {
+                    res = fmax(fmax(c - hi, lo - c), 0.0);
+                    if (c > hi) scale += fabs(hi);
+                    if (c < lo) scale += fabs(lo);
+                }
+            }
+            const bool ok = !row || (res <= law.eps_abs + law.eps_rel * scale);
+            inner = __all(ok) ? 1 : 0;
+        }
+        if (!inner) break;                            // sweeps exhausted
+    }
+    // outputs: lane k < n_u forms du0[k], lane 32 + k forms y1[k]
+    const bool for_u = lane < law.n_u, for_y = lane >= 32 && lane - 32 < law.n_y;
+    const bool mine = for_u || for_y;
+    const int k = for_u ? lane : lane - 32;
+    const double* G = for_u ? law.Gu : law.Gy;
+    double acc = 0.0;
+    if (mine) {
+        acc = for_u ? law.gu0[k] : law.gy0[k];
+        for (int q = 0; q < nt; ++q) acc += G[k * nt + q] * th[q];
+    }
+    for (int j = 0; j < nW; ++j) {
+        const int wj = __shfl(myrow, j, 64);
+        const double nj = __shfl(nu, j, 64);
+        if (mine && nj != 0.0) acc -= (for_u ? law.Tu : law.Ty)[(int64_t)k * m + wj] * nj;
+    }
+    out = acc;
+    return law.report_unsolved ? 0 : converged;
+}
+
 // The law for one rollout, by one wavefront.  theta_lane: lane k < n_theta holds theta[k].  On return lane k < n_u holds
 // du0[k] in out, lane 32 + k (k < n_y) holds y1[k]; the return value (uniform) is 1 if the sweeps converged.
+template <bool kManyRows = false>     // kManyRows: the caller takes laws with more than 64 bounded rows (mpc_solve_large)
 __device__ __forceinline__ int mpc_solve(const MpcLawDev& law, double theta_lane, int lane, double& out) {
+    if constexpr (kManyRows) {
+        if (law.n_rows > 64) return mpc_solve_large(law, theta_lane, lane, out);
+    }
     const int m = law.n_rows, nt = law.n_theta;
     // this lane's row at the unconstrained optimum
     const bool row = lane < m;
@@ -173,6 +292,7 @@ struct LoopGlue {
 
 // The controller call of the closed loop for rollout b, by ONE wavefront (lane = its lane): the filter's moments -> point
 // estimate -> deviation variables -> MPC -> next input, bias bookkeeping included (sim_base.py:253-274).
+template <bool kManyRows = false>
 __device__ __forceinline__ void loop_control_wave(const MpcLawDev& law, const LoopGlue& g, const double* __restrict__ moments,
                                                   const double* __restrict__ y_meas, double* __restrict__ u,
                                                   double* __restrict__ y_pred, int32_t* __restrict__ known,
@@ -200,7 +320,7 @@ __device__ __forceinline__ void loop_control_wave(const MpcLawDev& law, const Lo
     if (lane < nx + ni) th = fmax(fmin(th, 1e10), -1e10);
     if (theta_out && lane < law.n_theta) theta_out[b * law.n_theta + lane] = th;
     double out;
-    const int converged = mpc_solve(law, th, lane, out);
+    const int converged = mpc_solve<kManyRows>(law, th, lane, out);
     // next input: the first move on top of u_-1 (controller.py:272-275); when the QP is not solved the reference puts
     // [0.06, 0.2] where the DEVIATION input goes (sim_base.py:271-274), the operating point is added either way
     const double um1_i = __shfl(um1, nx + (lane < ni ? lane : 0), 64);
@@ -275,7 +395,7 @@ __device__ __forceinline__ void plant_step_one(double* __restrict__ X, const dou
 }
 
 #ifndef __HIPCC_RTC__
-int pack_mpc_law(const char* fn, const gse_mpc_law* law, MpcLawDev& d);                          // (gse_mpc.hip)
+int pack_mpc_law(const char* fn, const gse_mpc_law* law, MpcLawDev& d, int max_rows = GSE_MPC_MAX_ROWS);   // (gse_mpc.hip)
 int pack_loop_glue(const char* fn, const gse_loop_glue* glue, const MpcLawDev& d, LoopGlue& g);
 #endif
 

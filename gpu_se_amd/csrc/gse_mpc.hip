@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64 * kMpcWavesPerBlock) void mpc_step_kernel(const 
     if (b >= B) return;                                   // whole wavefronts leave; no barrier below
     const double th = lane < law.n_theta ? theta[b * law.n_theta + lane] : 0.0;
     double out;
-    const int converged = mpc_solve(law, th, lane, out);
+    const int converged = mpc_solve<true>(law, th, lane, out);
     if (lane < law.n_u) du0[b * law.n_u + lane] = out;
     if (lane >= 32 && lane - 32 < law.n_y) y1[b * law.n_y + lane - 32] = out;
     if (lane == 0) status[b] = converged ? 0 : 1;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64 * kMpcWavesPerBlock) void loop_control_kernel(
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * kMpcWavesPerBlock + (threadIdx.x >> 6);
     if (b >= B) return;
-    loop_control_wave(law, g, moments, y_meas, u, y_pred, known, status, theta_out, b, lane);
+    loop_control_wave<true>(law, g, moments, y_meas, u, y_pred, known, status, theta_out, b, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -256,10 +256,10 @@ using namespace gse;
 
 namespace gse {
 
-int pack_mpc_law(const char* fn, const gse_mpc_law* law, MpcLawDev& d) {
+int pack_mpc_law(const char* fn, const gse_mpc_law* law, MpcLawDev& d, int max_rows) {
     GSE_REQUIRE(law, "%s: null law", fn);
-    GSE_REQUIRE(law->n_rows >= 0 && law->n_rows <= GSE_MPC_MAX_ROWS,
-                "%s: %d bounded rows; the device solver takes at most %d", fn, law->n_rows, GSE_MPC_MAX_ROWS);
+    GSE_REQUIRE(law->n_rows >= 0 && law->n_rows <= max_rows,
+                "%s: %d bounded rows; this entry point takes at most %d", fn, law->n_rows, max_rows);
     GSE_REQUIRE(law->n_theta >= 1 && law->n_theta <= GSE_MPC_MAX_THETA && law->n_u >= 1 && law->n_u <= GSE_MPC_MAX_OUT &&
                     law->n_y >= 1 && law->n_y <= GSE_MPC_MAX_OUT,
                 "%s: law dimensions (n_theta %d, n_u %d, n_y %d) out of range", fn, law->n_theta, law->n_u, law->n_y);
@@ -306,7 +306,7 @@ int gse_mpc_step(const gse_mpc_law* law, const double* theta, int64_t B, double*
                  void* stream) {
     GSE_REQUIRE(theta && du0 && y1 && status && B >= 1, "gse_mpc_step: bad argument");
     MpcLawDev d;
-    if (int rc = pack_mpc_law("gse_mpc_step", law, d)) return rc;
+    if (int rc = pack_mpc_law("gse_mpc_step", law, d, GSE_MPC_MAX_ROWS_TOTAL)) return rc;
     const unsigned blocks = (unsigned)((B + kMpcWavesPerBlock - 1) / kMpcWavesPerBlock);
     hipLaunchKernelGGL(mpc_step_kernel, dim3(blocks), dim3(64 * kMpcWavesPerBlock), 0, (hipStream_t)stream, d, theta, B, du0,
                        y1, status);
@@ -319,7 +319,7 @@ int gse_loop_control(const gse_mpc_law* law, const gse_loop_glue* glue, const do
                      void* stream) {
     GSE_REQUIRE(glue && moments && y_meas && u && y_pred && known && status && B >= 1, "gse_loop_control: bad argument");
     MpcLawDev d;
-    if (int rc = pack_mpc_law("gse_loop_control", law, d)) return rc;
+    if (int rc = pack_mpc_law("gse_loop_control", law, d, GSE_MPC_MAX_ROWS_TOTAL)) return rc;
     LoopGlue g;
     if (int rc = pack_loop_glue("gse_loop_control", glue, d, g)) return rc;
     const unsigned blocks = (unsigned)((B + kMpcWavesPerBlock - 1) / kMpcWavesPerBlock);

@@ -466,7 +466,7 @@ class BatchedSimulation:
         # the rest of a control tick behind the particle filter's deferred moments -- their reduction, the controller call, the
         # plant -- rides ONE launch (gse_pf_moments_resampled_tail) where it can: two launches for what were five
         tail = None
-        if self.pf and self.fused_tail:
+        if self.pf and self.fused_tail and K.n_bounded_rows <= controller.MAX_ACTIVE:
             _, law, _keep_law = K._device_law()
             glue = K.loop_glue(_U_FALLBACK)
             addr = lambda obj: ctypes.cast(ctypes.pointer(obj), ctypes.c_void_p).value
@@ -549,6 +549,7 @@ class BatchedSimulation:
         model, the fused tail, up to 2^21 particles.  ``native_loop = False`` keeps the Python loop below (the same launches)."""
         f = self.f
         return (self.native_loop and self.pf and self.fused_tail and self.noise is None and self.controller is None and
+                self.K.n_bounded_rows <= controller.MAX_ACTIVE and
                 f._model is None and f.N_particles <= (1 << 21) and f.measurement_pdf._Nd == 2 and f.lazy and
                 f._island is None and not f.record_ancestors and
                 (not f.cluster or f.N_particles <= _lib.GSE_CLUSTER_MAX_TILES * _lib.GSE_TILE))
@@ -608,6 +609,7 @@ class BatchedSimulation:
         Gaussians on the built-in model, Philox noise.  ``persistent = False`` keeps the launch-per-piece loop."""
         from gpu_se_amd import _lib
         return (self.persistent and not self.pf and self.noise is None and self.f._model is None and
+                self.K.n_bounded_rows <= controller.MAX_ACTIVE and
                 self.f.N_particles <= _lib.GSE_GSUKF_CYCLE_MAX and self.controller is None)
 
     def _launch_persistent(self, lib, f, K, X, u, z, y_pred, known, status, us, xs, ys, ys_meas, moments, state_pod, meas_pod, rng,

@@ -442,7 +442,11 @@ int gse_rng_raw(uint32_t *out, int64_t M, const gse_rng *rng, uint32_t purpose, 
  * kernel and the next predict without a host round trip.  status[b] = 0 converged, 1 not converged within
  * max_sweeps (infeasible or ill-conditioned bounds: the caller falls back as sim_base.py:271-273 does).
  */
-#define GSE_MPC_MAX_ROWS 64      /* bounded rows (finite y / u / du limits) the device solver takes */
+#define GSE_MPC_MAX_ROWS 64      /* bounded rows (finite y / u / du limits) that may be ACTIVE together: one per lane; the most
+                                    the fused entry points (gse_pf_moments_resampled_tail, gse_gsukf_closed_loop) take at all */
+#define GSE_MPC_MAX_ROWS_TOTAL 2048 /* bounded rows gse_mpc_step / gse_loop_control take (controller.py:180-207 bounds every output
+                                    over the whole horizon): beyond 64 the dual is solved over a working set of at most 64 rows,
+                                    grown by the most violated row until no row outside it is violated (exact: KKT) */
 #define GSE_MPC_MAX_THETA 16     /* Nx + Ni + No of the controller's (sub-selected) linear model     */
 #define GSE_MPC_MAX_OUT 8        /* Ni, No                                                            */
 typedef struct gse_mpc_law {

@@ -244,8 +244,9 @@ class KKTSolver:
         self.Aeq = self.A[np.flatnonzero(self.eq)]
         ineq = np.flatnonzero(~self.eq)
         self.sides = [(int(i), -1) for i in ineq if np.isfinite(l[i])] + [(int(i), +1) for i in ineq if np.isfinite(u[i])]
-        if len(self.sides) > self.MAX_SIDES:
-            raise NotImplementedError("KKTSolver enumerates active sets: %d finite inequality sides are too many" % len(self.sides))
+        # (more sides than can be enumerated -- every output bounded over the whole horizon, controller.py:180-207: solve()
+        #  then walks active sets instead, see _solve_by_active_sets; the KKT conditions it ends on are the same proof)
+        self.enumerate = len(self.sides) <= self.MAX_SIDES
         self._lu = {}
 
     def _factor(self, subset):
@@ -259,9 +260,56 @@ class KKTSolver:
             self._lu[subset] = (scipy.sparse.linalg.splu(K), K)
         return self._lu[subset]
 
+    def _solve_by_active_sets(self, l, u, max_steps=2000):
+        """Many bounded rows: a walk over active sets instead of their enumeration -- solve the KKT system of the current set;
+        drop the active side whose multiplier has the wrong sign most; otherwise add the most violated side; stop when
+        neither exists.  What is returned satisfies the KKT conditions of the convex QP (checked here, to the tolerances of
+        solve()), which is the proof of optimality whatever the walk was; a walk that does not end raises."""
+        import scipy.sparse
+        import scipy.sparse.linalg
+        n, n_eq = self.H.shape[0], int(self.eq.sum())
+        beq = l[self.eq]
+        active = []                                                      # [(row, sign)]
+        for _ in range(max_steps):
+            rows = [self.Aeq] + [self.A[i] for i, _ in active]
+            Ar = scipy.sparse.vstack(rows).tocsc()
+            m = Ar.shape[0]
+            K = scipy.sparse.bmat([[self.H, Ar.T], [Ar, scipy.sparse.csc_matrix((m, m))]], format="csc")
+            rhs = np.concatenate([-self.q, beq, [l[i] if sgn < 0 else u[i] for i, sgn in active]])
+            try:
+                lu = scipy.sparse.linalg.splu(K)
+            except RuntimeError:
+                # active rows that depend on each other through the equalities (a move limit and an output limit that say the
+                # same thing): factor with a whiff of dual regularisation, refine against the true system
+                reg = scipy.sparse.diags(np.concatenate([np.zeros(n), np.full(m, -1e-11)]))
+                lu = scipy.sparse.linalg.splu((K + reg).tocsc())
+            sol = lu.solve(rhs)
+            for _ in range(3):
+                sol += lu.solve(rhs - K @ sol)
+            z, lam = sol[:n], sol[n + n_eq:]
+            wrong = [(lam[k] if sgn < 0 else -lam[k]) for k, (i, sgn) in enumerate(active)]     # > 0: wrong sign
+            if wrong and max(wrong) > 1e-12:
+                active.pop(int(np.argmax(wrong)))
+                continue
+            Az = self.A @ z
+            scale = 1e-9 * (1.0 + np.abs(Az))
+            low, high = (l - scale) - Az, Az - (u + scale)
+            low[self.eq], high[self.eq] = -np.inf, -np.inf
+            worst_low, worst_high = int(np.argmax(low)), int(np.argmax(high))
+            if low[worst_low] <= 0 and high[worst_high] <= 0:
+                return z
+            taken = {i for i, _ in active}
+            pick = (worst_low, -1) if low[worst_low] >= high[worst_high] else (worst_high, +1)
+            if pick[0] in taken:
+                raise ValueError("the QP's bounds on row %d contradict each other" % pick[0])
+            active.append(pick)
+        raise ValueError("the active-set walk did not end in %d steps" % max_steps)
+
     def solve(self, l, u):
         import itertools
         l, u = np.asarray(l, dtype=float), np.asarray(u, dtype=float)
+        if not self.enumerate:
+            return self._solve_by_active_sets(l, u)
         n = self.H.shape[0]
         n_eq = int(self.eq.sum())
         beq = l[self.eq]

@@ -60,8 +60,52 @@ def test_step_follows_the_reference_contract():
     with pytest.raises(ValueError):
         boxed.step(np.array([2.5, 0.0]), um1 * 0, y0)
     assert boxed.y_predicted is None
-    with pytest.raises(NotImplementedError):            # 600 bounded output rows: more than the device solver takes
-        controller.MPC(Q=Q, R=R, lin_model=lin_model(), ysp=LIN["dt1_ysp"], P=300, M=200, y_bounds=[(-3, 3), (-400, 400)])._law
+    with pytest.raises(NotImplementedError):            # 6000 bounded output rows: more than the device solver takes
+        controller.MPC(Q=Q, R=R, lin_model=lin_model(), ysp=LIN["dt1_ysp"], P=3000, M=200, y_bounds=[(-3, 3), (-400, 400)])._law
+
+
+def test_outputs_bounded_over_the_whole_horizon():
+    """controller.py:180-207 bounds every output at every step of the horizon: P x No rows -- 600 for get_parts' horizons with
+    y_bounds given, far more than a wavefront has lanes.  The device law solves the dual over a working set of at most 64 rows
+    grown by the most violated row (mpc_solve_large: exact, the KKT conditions of the reference's QP hold when it stops);
+    against the oracle's solve of the reference's QP (a walk over active sets that ends on the same KKT conditions): first
+    input and predicted output to 1e-9 over states that leave every bound slack and states that press on some, one rollout at
+    a time and as a batch.  More than 64 rows active TOGETHER (bounds that exclude the set point: all 300 rows of an output)
+    is reported as not solved -- the loop's fallback branch, as for an OSQP failure."""
+    lm = lin_model()
+    kw = dict(P=300, M=200, y_bounds=[(-0.004, 0.004), (-400.0, 400.0)])
+    K = controller.MPC(Q=Q, R=R, lin_model=lm, ysp=LIN["dt1_ysp"], **kw)
+    assert K.n_bounded_rows == 600
+    O = orc.MPCOracle(300, 200, Q, R, lm.A, lm.B, lm.C, lm.D, LIN["dt1_ysp"], y_bounds=kw["y_bounds"])
+    rng = np.random.default_rng(8)
+    cases = [(np.zeros(2), np.zeros(2), np.zeros(2))]
+    for scale in (1.0, 3.0, 6.0):
+        for _ in range(3):
+            cases.append((rng.normal(size=2) * np.array([0.5, 5.0]) * scale, rng.normal(size=2) * 0.02,
+                          rng.normal(size=2) * np.array([1.0, 100.0]) * scale))
+    active_counts = []
+    lo, hi = np.array([-0.004, -400.0]), np.array([0.004, 400.0])
+    for x0, um1, y0 in cases:
+        O.y_predicted = K.y_predicted = None
+        want = O.step(x0, um1, y0)
+        got = K.step(x0, um1, y0)
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(K.y_predicted, O.y_predicted, rtol=1e-9, atol=1e-8)
+        l, u = orc.write_step(O.l0, O.u0, O.P, O.Nx, O.Ni, O.No, x0, um1, np.zeros(2))
+        ys = O.solver.solve(l, u)[(O.P + 1) * O.Nx:(O.P + 1) * O.Nx + O.P * O.No].reshape(O.P, O.No)
+        active_counts.append(int(np.sum((np.abs(ys - lo) < 1e-9) | (np.abs(ys - hi) < 1e-9))))
+    assert max(active_counts) >= 2 and min(active_counts) == 0, active_counts
+    x0s, um1s, y0s = (np.array([c[k] for c in cases]) for k in range(3))
+    K.y_predicted = None
+    ctrl, ok = K.step_batch(x0s, um1s, y0s)
+    assert ok.all()
+    for b in range(len(cases)):
+        O.y_predicted = None
+        np.testing.assert_allclose(ctrl[b], O.step(x0s[b], um1s[b], y0s[b]), rtol=1e-9, atol=1e-9)
+    # the set point outside the bounds: 300 rows active together
+    tight = controller.MPC(Q=Q, R=R, lin_model=lm, ysp=LIN["dt1_ysp"], P=300, M=200, y_bounds=[(-1.0, 1.0), (-150.0, 150.0)])
+    with pytest.raises(ValueError):
+        tight.step(np.zeros(2), np.zeros(2), np.zeros(2))
 
 
 def test_closed_loop_with_mpc_drives_the_outputs_to_the_setpoint():
