@@ -46,11 +46,24 @@ __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) 
 
 // Cholesky factor of a symmetric 5x5 matrix given by its packed lower triangle (fp32, like LAPACK spotrf on
 // the fp32 covariances).  Returns false when a pivot is not positive.
+// Round 4: the factorisation uses the hardware's square root and reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp each) and multiplies by
+// 1 / L_jj -- five reciprocals for ten divisions.  The correctly rounded sqrtf and division are long sequences on this
+// hardware (range scaling, Newton steps, fix-up: ~35 instructions each with their branches), 685 of the 3 937 vector
+// instructions of the one-lane-per-Gaussian cycle kernel, which is bound by exactly that count.  An entry of L moves by at
+// most 2 ulp against LAPACK's spotrf -- the reference's own two Cholesky routes (numpy.linalg.cholesky on the CPU class,
+// torch.cholesky on the GPU class, gs_ukf.py:72, :335) differ by as much, and every tolerance of the G5 tests was set for a
+// factor that is not LAPACK's bit for bit.  One definition for every kernel, so they still agree with each other to the bit.
+#ifndef GSE_CHOL_FAST
+#define GSE_CHOL_FAST 1          // 0: correctly rounded sqrtf and division (rounds 1-3)
+#endif
 __device__ __forceinline__ bool chol5(const float (&A)[kTri], float (&L)[kTri]) {
     // (no contraction into FMAs left to the compiler: the same source inlined into different kernels must give the same
     //  bits, and whether `s - a * b` is fused depends on the surrounding code)
 #pragma clang fp contract(off)
     bool ok = true;
+#if GSE_CHOL_FAST
+    float inv[kNx];                                  // 1 / L_jj, once per column (five reciprocals for ten divisions)
+#endif
 #pragma unroll
     for (int i = 0; i < kNx; ++i) {
 #pragma unroll
@@ -60,9 +73,18 @@ __device__ __forceinline__ bool chol5(const float (&A)[kTri], float (&L)[kTri]) 
             for (int k = 0; k < j; ++k) s -= L[tri(i, k)] * L[tri(j, k)];
             if (i == j) {
                 ok = ok && (s > 0.0f);
+#if GSE_CHOL_FAST
+                L[tri(i, i)] = __builtin_amdgcn_sqrtf(s);
+                inv[i] = __builtin_amdgcn_rcpf(L[tri(i, i)]);
+#else
                 L[tri(i, i)] = sqrtf(s);
+#endif
             } else {
+#if GSE_CHOL_FAST
+                L[tri(i, j)] = s * inv[j];
+#else
                 L[tri(i, j)] = s / L[tri(j, j)];
+#endif
             }
         }
     }
