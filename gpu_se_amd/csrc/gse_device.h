@@ -338,6 +338,33 @@ __device__ __forceinline__ void model_output(const float (&x)[5], double, double
 }
 #endif
 
+// The state after this launch's model step, APPROXIMATELY, for the weight scale's anchor (gse_pf_kernels.h: only the binary
+// exponent of a likelihood is taken from it): the bioreactor's increment restated in fp32 with hardware reciprocals -- a
+// third of the dependent latency of the fp64 evaluation, and the wavefront that computes the anchor is on its workgroup's
+// critical path.  A user model takes its exact step.
+__device__ __forceinline__ void model_step_anchor(float (&x)[5], double u0, double u1, double dt) {
+#ifdef GSE_USER_MODEL
+    double dx[5];
+    model_increment(x, u0, u1, dt, dx);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) x[k] = (float)((double)x[k] + dx[k]);
+#else
+    const float fg = (float)u0, f_out = (float)(u0 + u1), h = (float)dt;
+    const float cg = fmaxf(x[0], 0.f), cx = fmaxf(x[1], 0.f), cfa = fmaxf(x[2], 0.f), ch = x[4];
+    const float r_h = (float)(280.0 / 180.0) - cg;
+    const float monod = cg * __builtin_amdgcn_rcpf(1e-2f + cg);
+    const float r_fa = (float)(0.25 / 116.0 * 24.6) * cx * monod;
+    const float th1_max = (float)((0.4 - 0.25) / 180.0 * 24.6) * cx;
+    const float th1_req = th1_max - (th1_max * (float)(1.0 / 2000.0 / (0.28 / 180.0)) * r_h + 0.01f * ch);
+    const float th1 = fminf(th1_max, fmaxf(0.f, th1_req)) * monod;
+    const float r_e = fminf((float)(0.025 / 46.0 * 24.6) * cx, fmaxf(0.f, th1_req - th1_max));
+    const float th2 = fminf((float)((0.1 - 0.025) / 180.0 * 24.6) * cx, fmaxf(0.f, th1_req - th1_max - r_e));
+    const float r_g = -r_fa * (float)(116.0 / 180.0) - th1 - r_e * (float)(46.0 / 180.0) - th2;
+    x[0] += (fg * (float)(5000.0 / 180.0) - f_out * cg + r_g) * h;
+    x[2] += (-f_out * cfa + r_fa) * h;
+#endif
+}
+
 // x += f(x): one rounding of the fp64 sum to fp32 (what "row_f32 += tuple_f64" does in NumPy).
 __device__ __forceinline__ void model_step(float (&x)[5], double u0, double u1, double dt) {
     double dx[5];

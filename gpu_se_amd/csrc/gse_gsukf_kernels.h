@@ -46,15 +46,16 @@ __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) 
 
 // Cholesky factor of a symmetric 5x5 matrix given by its packed lower triangle (fp32, like LAPACK spotrf on
 // the fp32 covariances).  Returns false when a pivot is not positive.
-// Round 4: the factorisation uses the hardware's square root and reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp each) and multiplies by
-// 1 / L_jj -- five reciprocals for ten divisions.  The correctly rounded sqrtf and division are long sequences on this
-// hardware (range scaling, Newton steps, fix-up: ~35 instructions each with their branches), 685 of the 3 937 vector
-// instructions of the one-lane-per-Gaussian cycle kernel, which is bound by exactly that count.  An entry of L moves by at
-// most 2 ulp against LAPACK's spotrf -- the reference's own two Cholesky routes (numpy.linalg.cholesky on the CPU class,
-// torch.cholesky on the GPU class, gs_ukf.py:72, :335) differ by as much, and every tolerance of the G5 tests was set for a
-// factor that is not LAPACK's bit for bit.  One definition for every kernel, so they still agree with each other to the bit.
+// Round 4: the factorisation starts from the hardware's square root and reciprocal (v_sqrt_f32, v_rcp_f32) and CORRECTS them
+// -- the root by one residual step, the reciprocal of L_jj by one Newton step, every quotient s / L_jj by one residual step
+// (Markstein) -- five reciprocals for ten divisions.  The general sqrtf and division are long sequences on this hardware
+// (range scaling, Newton steps, fix-up, with their branches: ~35 instructions each), 685 of the 3 937 vector instructions of
+// the one-lane-per-Gaussian cycle kernel, which is bound by exactly that count; the corrected estimates keep 550 of the
+// saving and give the correctly rounded results but for rare last-bit cases (GSE_CHOL_FAST = 1, the raw estimates, moves
+// one weight in a thousand by 1e-4: the update of the mean amplifies an ulp of L).  One definition for every kernel, so
+// they agree with each other to the bit whatever the setting.
 #ifndef GSE_CHOL_FAST
-#define GSE_CHOL_FAST 1          // 0: correctly rounded sqrtf and division (rounds 1-3)
+#define GSE_CHOL_FAST 2          // 0: sqrtf and division (rounds 1-3); 1: the hardware's estimates as they are; 2: corrected
 #endif
 __device__ __forceinline__ bool chol5(const float (&A)[kTri], float (&L)[kTri]) {
     // (no contraction into FMAs left to the compiler: the same source inlined into different kernels must give the same
@@ -73,14 +74,30 @@ __device__ __forceinline__ bool chol5(const float (&A)[kTri], float (&L)[kTri]) 
             for (int k = 0; k < j; ++k) s -= L[tri(i, k)] * L[tri(j, k)];
             if (i == j) {
                 ok = ok && (s > 0.0f);
-#if GSE_CHOL_FAST
+#if GSE_CHOL_FAST == 2
+                // the hardware's estimates, corrected: sqrt by one residual step (g + (s - g g) / (2 g)), the reciprocal by one
+                // Newton step -- correctly rounded but for rare last-bit cases, without the general routines' range handling
+                {
+                    const float g0 = __builtin_amdgcn_sqrtf(s);
+                    const float r0 = __builtin_amdgcn_rcpf(g0);
+                    const float g1 = fmaf(fmaf(-g0, g0, s), 0.5f * r0, g0);
+                    L[tri(i, i)] = (s > 0.0f) ? g1 : g0;
+                    const float rr = __builtin_amdgcn_rcpf(L[tri(i, i)]);
+                    inv[i] = fmaf(rr, fmaf(-L[tri(i, i)], rr, 1.0f), rr);
+                }
+#elif GSE_CHOL_FAST
                 L[tri(i, i)] = __builtin_amdgcn_sqrtf(s);
                 inv[i] = __builtin_amdgcn_rcpf(L[tri(i, i)]);
 #else
                 L[tri(i, i)] = sqrtf(s);
 #endif
             } else {
-#if GSE_CHOL_FAST
+#if GSE_CHOL_FAST == 2
+                {                                    // q = s / d from the refined reciprocal, one residual correction (Markstein)
+                    const float q0 = s * inv[j];
+                    L[tri(i, j)] = fmaf(fmaf(-L[tri(j, j)], q0, s), inv[j], q0);
+                }
+#elif GSE_CHOL_FAST
                 L[tri(i, j)] = s * inv[j];
 #else
                 L[tri(i, j)] = s / L[tri(j, j)];

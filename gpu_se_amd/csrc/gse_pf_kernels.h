@@ -443,6 +443,12 @@ __device__ __forceinline__ void search_ancestors(const OffspringCount& F, const 
 // kernel entry and used much later (a wavefront that waits for them in one go keeps the rest of its workgroup at the next
 // barrier for a memory round trip): scale_samples_load, then scale_exponent_of.  wrow: the filter's weight row, or null (a
 // gather from materialised cumulative weights does not read the weights).
+#ifndef GSE_SCALE_WAVE
+#define GSE_SCALE_WAVE 3
+#endif
+#ifndef GSE_SCALE_FN_ATTR
+#define GSE_SCALE_FN_ATTR __forceinline__
+#endif
 struct ScaleSample {
     float s[GSE_NX];
     float w;
@@ -454,15 +460,22 @@ __device__ __forceinline__ void scale_samples_load(ScaleSample& q, const float* 
     for (int k = 0; k < GSE_NX; ++k) q.s[k] = xin_b[(int64_t)k * ld + is];
     q.w = wrow ? wrow[is] : 1.f;
 }
-template <bool kGather, int kNd, bool kDevIO>
-__device__ __forceinline__ int scale_exponent_of(const ScaleSample& q, bool have_w, const StepArgs& a, int64_t N, int b) {
+template <bool kGather, bool kPredict, int kNd, bool kDevIO>
+__device__ GSE_SCALE_FN_ATTR int scale_exponent_of(const ScaleSample& q, bool have_w, const StepArgs& a, int64_t N, int b) {
     double fg0 = a.io.f[b].u0, fm0 = a.io.f[b].u1, za = a.io.f[b].z0, zb = a.io.f[b].z1;
     if constexpr (kDevIO) {
         if (a.u_dev) { fg0 = a.u_dev[2 * b]; fm0 = a.u_dev[2 * b + 1]; }
         if (a.z_dev) { za = a.z_dev[2 * b]; zb = a.z_dev[2 * b + 1]; }
     }
+    // the sample as the update will find it: through this launch's model step (without its noise).  The benchmark protocol
+    // moves the plant -- and with it the measurement -- by a hundred mg/L per cycle (dt = 1, random inputs,
+    // results/pf_openloop/pf_run_seq.py:48): judged where it stood BEFORE the step every sample looks 2^-90 unlikely.
+    float st[GSE_NX];
+#pragma unroll
+    for (int k = 0; k < GSE_NX; ++k) st[k] = q.s[k];
+    if (kPredict) model_step_anchor(st, fg0, fm0, a.dt);
     float o0[kObsKept], ya, yb;
-    model_keep(q.s, o0);
+    model_keep(st, o0);
     model_output_kept(o0, fg0, fm0, ya, yb);
     // exponents, clamped to 15 bits each: score = old weight x likelihood (which sample matters most), cand = what k is made of
     const int e_lik = min(max(likelihood_exponent<kNd>(a.pdf, za - (double)ya, zb - (double)yb), -16000), 2000);
@@ -567,8 +580,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     // ---- GSE_OP_WEIGHT_SCALE: the launch's binary exponent (scale_samples_load / scale_exponent_of above).  Wavefront 0 of
     //      every workgroup requests the 64 samples HERE, with the tile sums, and turns them into k after the gather stage.
     ScaleSample ssm;
+    constexpr int kScaleWave = GSE_SCALE_WAVE;       // which wavefront evaluates the anchor (wavefront 0 has thread 0's chores already)
     const bool scale_w = (!kGather || kScanIn) && w_in != nullptr;
-    if (kUpdate && a.wscale && wv == 0) scale_samples_load(ssm, xin_b, scale_w ? w_in + (int64_t)b * ld : nullptr, N, ld, lane);
+    if (kUpdate && a.wscale && wv == kScaleWave) scale_samples_load(ssm, xin_b, scale_w ? w_in + (int64_t)b * ld : nullptr, N, ld, lane);
     if (kDraw) __syncthreads();                          // dp staged
     if (kDraw && draw_at == 0) draw_all();
     GSE_STAMP(1);
@@ -942,8 +956,8 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     int kexp = 0;
     constexpr bool kScaleBehindExchange = kStrided && kUpdate;
     if (kUpdate && a.wscale) {                               // (workgroup-uniform)
-        if (wv == 0) {
-            const int k = scale_exponent_of<kGather, kNd, kDevIO>(ssm, scale_w, a, N, b);
+        if (wv == kScaleWave) {
+            const int k = scale_exponent_of<kGather, kPredict, kNd, kDevIO>(ssm, scale_w, a, N, b);
             if (lane == 0) kexp_s = k;
         }
         if (!kScaleBehindExchange) {
