@@ -19,6 +19,7 @@ GSE_OP_U_DEVICE, GSE_OP_Z_DEVICE = 128, 256
 GSE_OP_PREFIX_GLOBAL = 512
 GSE_OP_WEIGHT_SCALE = 1024
 GSE_OP_CLUSTER = 2048
+GSE_OP_SAMPLES = 4096
 GSE_SLOT_QUARTERS = 2
 GSE_CLUSTER_MAX_TILES = 256        # policy: filters whose B x tiles stay within this run four workgroups per tile (GSE_OP_CLUSTER)
 GSE_RESAMPLE_WEIGHT_SCALE = 16
@@ -77,7 +78,7 @@ class LoopTail(ctypes.Structure):
 
 class PfLoopSpec(ctypes.Structure):
     """struct gse_pf_loop_spec (include/gse.h)."""
-    _fields_ = [("B", c_i32), ("ticks", c_i32), ("N", c_i64), ("ld", c_i64), ("dt", c_d), ("flags", c_u32), ("reserved", c_u32),
+    _fields_ = [("B", c_i32), ("ticks", c_i32), ("N", c_i64), ("ld", c_i64), ("dt", c_d), ("flags", c_u32), ("samples_ok", c_u32),
                 ("x", c_vp * 2), ("w", c_vp * 2), ("workspace", c_vp), ("state_pdf", c_vp), ("measurement_pdf", c_vp),
                 ("rng", Rng), ("law", c_vp), ("glue", c_vp), ("X", c_vp), ("u", c_vp), ("z", c_vp), ("y_pred", c_vp),
                 ("known", c_vp), ("plant_state_noise", c_vp), ("plant_meas_noise", c_vp), ("plant_rng", Rng),

@@ -342,6 +342,27 @@ __device__ __forceinline__ void model_output(const float (&x)[5], double, double
 // exponent of a likelihood is taken from it): the bioreactor's increment restated in fp32 with hardware reciprocals -- a
 // third of the dependent latency of the fp64 evaluation, and the wavefront that computes the anchor is on its workgroup's
 // critical path.  A user model takes its exact step.
+#ifndef GSE_USER_MODEL
+// the two rates the observed states' increments are made of -- functions of the state alone (no input, no step length)
+__device__ __forceinline__ void anchor_rates(const float (&x)[5], float& r_g, float& r_fa) {
+    const float cg = fmaxf(x[0], 0.f), cx = fmaxf(x[1], 0.f), ch = x[4];
+    const float r_h = (float)(280.0 / 180.0) - cg;
+    const float monod = cg * __builtin_amdgcn_rcpf(1e-2f + cg);
+    r_fa = (float)(0.25 / 116.0 * 24.6) * cx * monod;
+    const float th1_max = (float)((0.4 - 0.25) / 180.0 * 24.6) * cx;
+    const float th1_req = th1_max - (th1_max * (float)(1.0 / 2000.0 / (0.28 / 180.0)) * r_h + 0.01f * ch);
+    const float th1 = fminf(th1_max, fmaxf(0.f, th1_req)) * monod;
+    const float r_e = fminf((float)(0.025 / 46.0 * 24.6) * cx, fmaxf(0.f, th1_req - th1_max));
+    const float th2 = fminf((float)((0.1 - 0.025) / 180.0 * 24.6) * cx, fmaxf(0.f, th1_req - th1_max - r_e));
+    r_g = -r_fa * (float)(116.0 / 180.0) - th1 - r_e * (float)(46.0 / 180.0) - th2;
+}
+// ... and the step of the two observed states from them
+__device__ __forceinline__ void anchor_advance(float& cg_s, float& cfa_s, float r_g, float r_fa, double u0, double u1, double dt) {
+    const float fg = (float)u0, f_out = (float)(u0 + u1), h = (float)dt;
+    cg_s += (fg * (float)(5000.0 / 180.0) - f_out * fmaxf(cg_s, 0.f) + r_g) * h;
+    cfa_s += (-f_out * fmaxf(cfa_s, 0.f) + r_fa) * h;
+}
+#endif
 __device__ __forceinline__ void model_step_anchor(float (&x)[5], double u0, double u1, double dt) {
 #ifdef GSE_USER_MODEL
     double dx[5];
@@ -349,19 +370,9 @@ __device__ __forceinline__ void model_step_anchor(float (&x)[5], double u0, doub
 #pragma unroll
     for (int k = 0; k < 5; ++k) x[k] = (float)((double)x[k] + dx[k]);
 #else
-    const float fg = (float)u0, f_out = (float)(u0 + u1), h = (float)dt;
-    const float cg = fmaxf(x[0], 0.f), cx = fmaxf(x[1], 0.f), cfa = fmaxf(x[2], 0.f), ch = x[4];
-    const float r_h = (float)(280.0 / 180.0) - cg;
-    const float monod = cg * __builtin_amdgcn_rcpf(1e-2f + cg);
-    const float r_fa = (float)(0.25 / 116.0 * 24.6) * cx * monod;
-    const float th1_max = (float)((0.4 - 0.25) / 180.0 * 24.6) * cx;
-    const float th1_req = th1_max - (th1_max * (float)(1.0 / 2000.0 / (0.28 / 180.0)) * r_h + 0.01f * ch);
-    const float th1 = fminf(th1_max, fmaxf(0.f, th1_req)) * monod;
-    const float r_e = fminf((float)(0.025 / 46.0 * 24.6) * cx, fmaxf(0.f, th1_req - th1_max));
-    const float th2 = fminf((float)((0.1 - 0.025) / 180.0 * 24.6) * cx, fmaxf(0.f, th1_req - th1_max - r_e));
-    const float r_g = -r_fa * (float)(116.0 / 180.0) - th1 - r_e * (float)(46.0 / 180.0) - th2;
-    x[0] += (fg * (float)(5000.0 / 180.0) - f_out * cg + r_g) * h;
-    x[2] += (-f_out * cfa + r_fa) * h;
+    float r_g, r_fa;
+    anchor_rates(x, r_g, r_fa);
+    anchor_advance(x[0], x[2], r_g, r_fa, u0, u1, dt);
 #endif
 }
 

@@ -65,6 +65,7 @@ struct Workspace {
     double* cumsum;        // [B][N]       normalised cumulative weights
     double* wscale;        // [B]          GSE_OP_WEIGHT_SCALE: log2 of the factor between the stored and the true weights
     double* qsums[2];      // [B][T][4]    GSE_OP_CLUSTER: the quarter sums that go with scan[slot] in quarter format
+    float* samples[2];     // [B][64][8]   GSE_OP_SAMPLES: the weight scale's sample particles of the launch that filled scan[slot]
     int64_t bytes;
 };
 Workspace carve_workspace(void* base, int B, int64_t N);

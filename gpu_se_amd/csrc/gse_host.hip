@@ -111,6 +111,10 @@ Workspace carve_workspace(void* base, int B, int64_t N) {
         ws.qsums[k] = reinterpret_cast<double*>(p + at);
         at += round256((int64_t)B * T * 4 * 8);
     }
+    for (int k = 0; k < 2; ++k) {
+        ws.samples[k] = reinterpret_cast<float*>(p + at);
+        at += round256((int64_t)B * 64 * 8 * 4);
+    }
     ws.bytes = at;
     return ws;
 }

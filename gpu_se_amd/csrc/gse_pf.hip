@@ -219,7 +219,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const bool G = ops & GSE_OP_GATHER, P = ops & GSE_OP_PREDICT, U = ops & GSE_OP_UPDATE;
     const uint32_t known = GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE | GSE_OP_SCAN_IN | GSE_OP_SCAN_OUT |
                            GSE_OP_SCAN_IN_SLOT1 | GSE_OP_SCAN_OUT_SLOT1 | GSE_OP_U_DEVICE | GSE_OP_Z_DEVICE |
-                           GSE_OP_PREFIX_GLOBAL | GSE_OP_WEIGHT_SCALE | GSE_OP_CLUSTER;
+                           GSE_OP_PREFIX_GLOBAL | GSE_OP_WEIGHT_SCALE | GSE_OP_CLUSTER | GSE_OP_SAMPLES;
     const bool prefix_global = (ops & GSE_OP_PREFIX_GLOBAL) != 0;
     GSE_REQUIRE((ops & (GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE)) != 0 && (ops & ~known) == 0,
                 "%s: bad ops mask 0x%x", fn, ops);
@@ -295,6 +295,13 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const Workspace ws = carve_workspace(workspace, B, N);
     GSE_REQUIRE(!(ops & GSE_OP_WEIGHT_SCALE) || workspace, "%s: GSE_OP_WEIGHT_SCALE keeps the exponent in the workspace", fn);
     a.wscale = (ops & GSE_OP_WEIGHT_SCALE) ? ws.wscale : nullptr;
+    // the scale's sample particles travel beside the scan slots (gse_pf_kernels.h, scale_samples_carried)
+    const bool samples_fit = (ops & GSE_OP_WEIGHT_SCALE) && !(ops & GSE_OP_CLUSTER) && N >= kSamplesMinN && N % kScaleSamples == 0;
+    a.smp_out = (samples_fit && U && (scan & 2)) ? ws.samples[(ops & GSE_OP_SCAN_OUT_SLOT1) ? 1 : 0] : nullptr;
+    a.smp_in = (samples_fit && U && (scan & 1) && (ops & GSE_OP_SAMPLES)) ? ws.samples[(ops & GSE_OP_SCAN_IN_SLOT1) ? 1 : 0] : nullptr;
+    a.smp_stride = (uint32_t)(N / kScaleSamples);
+    a.smp_magic = a.smp_stride ? (uint32_t)((((uint64_t)1 << 32) + a.smp_stride - 1) / a.smp_stride) : 0u;
+    GSE_REQUIRE(!(a.smp_in && a.smp_out) || a.smp_in != a.smp_out, "%s: SCAN_IN and SCAN_OUT must use different slots", fn);
     if (ops & GSE_OP_CLUSTER) {
         // mid-size ensembles: four workgroups per tile, one particle per thread, scan slots in quarter format
         // (gse_pf_cluster_kernels.h); the same particles, weights and ancestors as the kernels below

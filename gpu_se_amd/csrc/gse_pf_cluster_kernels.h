@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void pf_cluster_kernel(
     // the barrier of the quarter scan below (pf_step_kernel does the same behind its weight exchange)
     int kexp = 0;
     if (kUpdate && a.wscale && wv == 0) {
-        const int k = scale_exponent_of<kGather, kPredict, kNd, kDevIO>(ssm, w_in != nullptr, a, N, b);
+        const int k = scale_exponent_of<kGather, kPredict, kNd, kDevIO>(ssm, w_in != nullptr, false, a, N, b);
         if (lane == 0) kexp_s = k;
     }
 

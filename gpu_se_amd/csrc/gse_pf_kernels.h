@@ -50,6 +50,11 @@ struct StepArgs {
     const double* u_dev;   // GSE_OP_U_DEVICE / GSE_OP_Z_DEVICE: [B][2] in device memory instead of io (a closed loop
     const double* z_dev;   // whose controller and plant run on the device never brings them to the host)
     double* wscale;        // GSE_OP_WEIGHT_SCALE: [B] accumulated binary exponent of the stored weights (workspace), or null
+    // the scale's sample particles, carried from launch to launch beside the scan slots (see scale_samples_load):
+    const float* smp_in;   // [B][kScaleSamples][kSampleRow] of the slot this launch resamples from (GSE_OP_SAMPLES), or null
+    float* smp_out;        // ... of the slot this launch's update fills, or null
+    uint32_t smp_stride;   // N / kScaleSamples: sample l is particle l * smp_stride
+    uint32_t smp_magic;    // ceil(2^32 / smp_stride)
 };
 
 #ifndef GSE_STEP_MIN_WAVES
@@ -460,8 +465,48 @@ __device__ __forceinline__ void scale_samples_load(ScaleSample& q, const float* 
     for (int k = 0; k < GSE_NX; ++k) q.s[k] = xin_b[(int64_t)k * ld + is];
     q.w = wrow ? wrow[is] : 1.f;
 }
+// The same samples CARRIED from the launch that wrote these particles (round 4).  Read where they lie they cost a
+// wavefront 64 cache lines per row -- 384 line requests per workgroup, as many as the launch's whole particle traffic has
+// (A/B on one box, profiles/r04_scale_ab.txt: +1.5 % at 2^20 ... 2^22) -- and the model step that follows sits on the
+// workgroup's critical path (+2 %).  A launch whose update fills a scan slot therefore leaves the 64 sample particles of its
+// OUTPUT beside the slot, one row of kSampleRow floats each, written by the threads that own them (at most one per tile:
+// the launches that do this have N / 64 >= one tile): two 16-byte loads per lane of one wavefront bring them back.  For the
+// bioreactor a row holds what the anchor needs of the particle and nothing else -- the two observed states and the two rates
+// their increments are made of, which depend on the state alone -- so that the consumer's "model step" is four FMAs:
+//     { Cg, r_g, Cfa, r_fa, -, w, -, - }          (a user model: { x0 .. x4, w, -, - } and its own exact step)
+// GSE_OP_SAMPLES (include/gse.h) is the caller's word that x_in is still what that launch wrote.
+constexpr int kSampleRow = 8;
+constexpr int64_t kSamplesMinN = (int64_t)kScaleSamples * kTile;
+__device__ __forceinline__ void scale_samples_carried(ScaleSample& q, const float* __restrict__ smp_b, int lane) {
+    const float4 lo = *reinterpret_cast<const float4*>(smp_b + lane * kSampleRow);
+    const float2 hi = *reinterpret_cast<const float2*>(smp_b + lane * kSampleRow + 4);
+    q.s[0] = lo.x; q.s[1] = lo.y; q.s[2] = lo.z; q.s[3] = lo.w; q.s[4] = hi.x;
+    q.w = hi.y;
+}
+// the state half of a row, by the thread that holds the sample's new state
+__device__ __forceinline__ void scale_sample_store_state(float* __restrict__ row, const float (&s)[GSE_NX]) {
+#ifdef GSE_USER_MODEL
+    *reinterpret_cast<float4*>(row) = make_float4(s[0], s[1], s[2], s[3]);
+    row[4] = s[4];
+#else
+    float r_g, r_fa;
+    anchor_rates(s, r_g, r_fa);
+    *reinterpret_cast<float4*>(row) = make_float4(s[0], r_g, s[2], r_fa);
+#endif
+}
+// Which particle of tile [tile0, tile0 + kTile) is a sample, if any: l * stride with l = ceil(tile0 / stride) < 64.  Uniform
+// over the workgroup (scalar arithmetic): the quotient by a multiplication with the host's reciprocal, put right by a comparison.
+__device__ __forceinline__ bool scale_sample_of_tile(const StepArgs& a, uint32_t tile0, uint32_t& index, int& l) {
+    const uint32_t stride = a.smp_stride;
+    uint32_t q = __umulhi(tile0, a.smp_magic);           // floor(tile0 / stride) or one more (magic = ceil(2^32 / stride), tile0 < 2^31)
+    if (q * stride > tile0) --q;
+    if (q * stride != tile0) ++q;                        // ceil
+    l = (int)q;
+    index = q * stride;
+    return q < (uint32_t)kScaleSamples && index - tile0 < (uint32_t)kTile;
+}
 template <bool kGather, bool kPredict, int kNd, bool kDevIO>
-__device__ GSE_SCALE_FN_ATTR int scale_exponent_of(const ScaleSample& q, bool have_w, const StepArgs& a, int64_t N, int b) {
+__device__ GSE_SCALE_FN_ATTR int scale_exponent_of(const ScaleSample& q, bool have_w, bool carried, const StepArgs& a, int64_t N, int b) {
     double fg0 = a.io.f[b].u0, fm0 = a.io.f[b].u1, za = a.io.f[b].z0, zb = a.io.f[b].z1;
     if constexpr (kDevIO) {
         if (a.u_dev) { fg0 = a.u_dev[2 * b]; fm0 = a.u_dev[2 * b + 1]; }
@@ -473,6 +518,12 @@ __device__ GSE_SCALE_FN_ATTR int scale_exponent_of(const ScaleSample& q, bool ha
     float st[GSE_NX];
 #pragma unroll
     for (int k = 0; k < GSE_NX; ++k) st[k] = q.s[k];
+#ifndef GSE_USER_MODEL
+    if (carried) {                                       // (uniform) a carried row: { Cg, r_g, Cfa, r_fa }
+        const float r_g = st[1], r_fa = st[3];
+        if (kPredict) anchor_advance(st[0], st[2], r_g, r_fa, fg0, fm0, a.dt);
+    } else
+#endif
     if (kPredict) model_step_anchor(st, fg0, fm0, a.dt);
     float o0[kObsKept], ya, yb;
     model_keep(st, o0);
@@ -582,7 +633,11 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     ScaleSample ssm;
     constexpr int kScaleWave = GSE_SCALE_WAVE;       // which wavefront evaluates the anchor (wavefront 0 has thread 0's chores already)
     const bool scale_w = (!kGather || kScanIn) && w_in != nullptr;
-    if (kUpdate && a.wscale && wv == kScaleWave) scale_samples_load(ssm, xin_b, scale_w ? w_in + (int64_t)b * ld : nullptr, N, ld, lane);
+    const bool carried = kScanIn && a.smp_in != nullptr;                   // (uniform)
+    if (kUpdate && a.wscale && wv == kScaleWave) {
+        if (carried) scale_samples_carried(ssm, a.smp_in + (int64_t)b * kScaleSamples * kSampleRow, lane);
+        else scale_samples_load(ssm, xin_b, scale_w ? w_in + (int64_t)b * ld : nullptr, N, ld, lane);
+    }
     if (kDraw) __syncthreads();                          // dp staged
     if (kDraw && draw_at == 0) draw_all();
     GSE_STAMP(1);
@@ -957,7 +1012,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     constexpr bool kScaleBehindExchange = kStrided && kUpdate;
     if (kUpdate && a.wscale) {                               // (workgroup-uniform)
         if (wv == kScaleWave) {
-            const int k = scale_exponent_of<kGather, kPredict, kNd, kDevIO>(ssm, scale_w, a, N, b);
+            const int k = scale_exponent_of<kGather, kPredict, kNd, kDevIO>(ssm, scale_w, carried, a, N, b);
             if (lane == 0) kexp_s = k;
         }
         if (!kScaleBehindExchange) {
@@ -1167,6 +1222,23 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
             double* qo = scan_out + ((int64_t)b * T + tile_id) * kBlock + tid;
             if constexpr ((GSE_WT_STORES & 4) != 0) __hip_atomic_store(qo, excl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else *qo = excl;
+        }
+        if (kScanOut && a.smp_out) {
+            // the scale's sample particle of this tile, if it has one (scale_samples_carried), by the thread that holds its new
+            // weight.  Its new state is read back from x_out: another thread of this workgroup stored it, ahead of the
+            // barriers above.  One scalar test in the tiles without a sample -- all but 64 of them.
+            uint32_t index;
+            int l;
+            if (scale_sample_of_tile(a, (uint32_t)tile0, index, l) && (index >> 2) == (uint32_t)(i0 >> 2)) {
+                const float* xs = ((kGather || kPredict) ? x_out : x_in) + (int64_t)b * GSE_NX * ld + index;
+                float sn[GSE_NX];
+#pragma unroll
+                for (int k = 0; k < GSE_NX; ++k) sn[k] = xs[(int64_t)k * ld];
+                float* row = a.smp_out + ((int64_t)b * kScaleSamples + l) * kSampleRow;
+                scale_sample_store_state(row, sn);
+                const int q = (int)(index & 3u);
+                row[5] = q == 0 ? wnew[0] : q == 1 ? wnew[1] : q == 2 ? wnew[2] : wnew[3];
+            }
         }
     }
     GSE_STAMP(10);

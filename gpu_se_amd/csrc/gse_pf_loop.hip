@@ -22,6 +22,7 @@ struct PfLoopState {
     float *x, *x_alt, *w, *w_alt;
     bool pend_gather = false, pend_predict = false;
     int gather_slot = -1, scan_slot = -1;
+    bool samples_ok = false;                            // GSE_OP_SAMPLES: the slot's sample rows describe the particles
     gse_rng rng;
     const double* r_cur;
     hipStream_t st;
@@ -46,7 +47,7 @@ struct PfLoopState {
         float* w_out = swap_w ? w_alt : w;
         if (gather) {
             ops |= GSE_OP_GATHER;
-            if (gather_slot >= 0) ops |= GSE_OP_SCAN_IN | (gather_slot ? GSE_OP_SCAN_IN_SLOT1 : 0u);
+            if (gather_slot >= 0) ops |= GSE_OP_SCAN_IN | (gather_slot ? GSE_OP_SCAN_IN_SLOT1 : 0u) | (samples_ok ? GSE_OP_SAMPLES : 0u);
         }
         if (pend_predict) ops |= GSE_OP_PREDICT | (io_dev ? GSE_OP_U_DEVICE : 0u);
         int scan_out = -1;
@@ -60,6 +61,7 @@ struct PfLoopState {
         if (pend_predict) rng.step += 1;
         if (swap_x) std::swap(x, x_alt);
         if (swap_w) std::swap(w, w_alt);
+        samples_ok = update && (ops & GSE_OP_WEIGHT_SCALE);      // (nothing but these launches touches the particles while the loop runs)
         pend_gather = false;
         gather_slot = -1;
         pend_predict = false;
@@ -179,6 +181,7 @@ extern "C" int gse_pf_closed_loop(gse_pf_loop_spec* s, void* stream) {
     s->pend_predict = f.pend_predict ? 1 : 0;
     s->gather_slot = f.gather_slot;
     s->scan_slot = f.scan_slot;
+    s->samples_ok = f.samples_ok ? 1u : 0u;
     s->rng.step = f.rng.step;
     if (f.pend_gather)
         for (int b = 0; b < B; ++b) s->r_pending[b] = f.r_cur[b];
@@ -208,6 +211,7 @@ extern "C" int gse_pf_cycles(gse_pf_loop_spec* s, int K, const double* u /* host
     f.st = (hipStream_t)stream;
     f.pend_gather = s->pend_gather != 0;                    // (a resample the caller left pending rides the first launch)
     f.gather_slot = s->gather_slot;
+    f.samples_ok = f.pend_gather && s->samples_ok != 0;
     if (f.pend_gather) f.r_cur = s->r_pending;
     for (int k = 0; k < K; ++k) {
         f.u_cur = u + (int64_t)k * B * 2;
@@ -226,6 +230,7 @@ extern "C" int gse_pf_cycles(gse_pf_loop_spec* s, int K, const double* u /* host
     s->pend_predict = 0;
     s->gather_slot = f.gather_slot;
     s->scan_slot = -1;
+    s->samples_ok = f.samples_ok ? 1u : 0u;
     s->rng.step = f.rng.step;
     for (int b = 0; b < B; ++b) s->r_pending[b] = f.r_cur[b];
     return GSE_OK;

@@ -117,6 +117,7 @@ class ParallelParticleFilter:
         self._pend_gather = False
         self._gather_slot = None                            # slot of the scans a pending gather reads (None: cumsum array)
         self._scan_slot = None                              # slot holding scans of the CURRENT weights, if any
+        self._samples_ok = False                            # ... and the weight scale's samples of the CURRENT particles beside it
         self._scan_capable = True                           # the cycle kernel resamples from tile sums + per-thread prefixes
         self._prefix_global = (-(-n // _lib.GSE_TILE)) > _lib.GSE_SCAN_MAX_TILES    # ... beyond 2^21 from a scanned tile prefix
         # Mid-size filters (B x tiles <= 256, i.e. less than one generation of workgroups): four workgroups per tile, one
@@ -248,6 +249,8 @@ class ParallelParticleFilter:
             ops |= _lib.GSE_OP_GATHER
             if self._gather_slot is not None:
                 ops |= _lib.GSE_OP_SCAN_IN | (_lib.GSE_OP_SCAN_IN_SLOT1 if self._gather_slot else 0)
+                if self._samples_ok:
+                    ops |= _lib.GSE_OP_SAMPLES
                 if self._prefix_global:
                     ops |= _lib.GSE_OP_PREFIX_GLOBAL
             if self._want_index or self.record_ancestors:
@@ -307,6 +310,9 @@ class ParallelParticleFilter:
         self._gather_slot = None
         self._pend_predict = None
         self._moments_host = None
+        # GSE_OP_SAMPLES: this launch left the weight scale's sample particles beside the slot it filled; they describe the
+        # particles until somebody else touches them (the accessors, a launch of another kind)
+        self._samples_ok = bool(update is not None and scan_out is not None and (ops & _lib.GSE_OP_WEIGHT_SCALE))
         if update is not None:
             self._tiles_valid = True
             self._scan_slot = scan_out
@@ -372,6 +378,7 @@ class ParallelParticleFilter:
         self._gather_slot = None
         self._pend_predict = None
         self._moments_host = None
+        self._samples_ok = False
         if update is not None:
             self._tiles_valid = False                           # (the workspace's tile sums are not written by these launches)
             self._scan_slot = scan_out
@@ -388,6 +395,7 @@ class ParallelParticleFilter:
         cached moments, the tile sums and tile prefixes a deferred resample would use -- is therefore dropped the moment a
         view leaves: the next estimate / resample recomputes it (one small kernel) instead of using stale values."""
         self._moments_host = None
+        self._samples_ok = False
         self._tiles_valid = False
         self._scan_slot = None
 
@@ -395,6 +403,7 @@ class ParallelParticleFilter:
     def particles(self):
         self._flush()
         self._moments_host = None
+        self._samples_ok = False
         v = self._x[:, :self._nx, :self.N_particles].transpose(1, 2)   # (B, N, Nx) strided view
         return DevArray.wrap(v[0] if self._B == 1 else v)
 
@@ -404,6 +413,7 @@ class ParallelParticleFilter:
         self._flush()
         self._x[:, :self._nx, :self.N_particles] = v.transpose(1, 2)
         self._moments_host = None
+        self._samples_ok = False
 
     def _fold_weight_scale(self):
         """Bring the stored weights to the scale 1 (what fp32 can hold of the true weights) and clear the exponent: a
@@ -443,6 +453,7 @@ class ParallelParticleFilter:
         self._tiles_valid = False
         self._scan_slot = None
         self._moments_host = None
+        self._samples_ok = False
 
     # ------------------------------------------------------------------ the cycle
     def predict(self, u, dt):
@@ -493,7 +504,7 @@ class ParallelParticleFilter:
             self._w, self._w_alt = self._w_alt, self._w
         if self.weight_scale:
             self._wscale.zero_()
-        self._tiles_valid, self._scan_slot, self._moments_host = False, None, None
+        self._tiles_valid, self._scan_slot, self._moments_host, self._samples_ok = False, None, None, False
         self._last_index = idx
         if self.record_ancestors:
             self.ancestor_log.append(idx)
@@ -580,6 +591,7 @@ class ParallelParticleFilter:
         spec.r = r.ctypes.data
         spec.pend_gather = 1 if self._pend_gather else 0
         spec.gather_slot = self._gather_slot if self._pend_gather else -1
+        spec.samples_ok = 1 if (self._pend_gather and self._samples_ok) else 0
         for b in range(B):
             spec.r_pending[b] = self._c_r[b]
         rc = self._lib.gse_pf_cycles(ctypes.byref(spec), K, u.ctypes.data, z.ctypes.data, stream_ptr(self._dev_index))
@@ -593,6 +605,7 @@ class ParallelParticleFilter:
         self._pend_gather, self._gather_slot, self._scan_slot = True, int(spec.gather_slot), None
         self._slot_fmt[self._gather_slot] = "q" if clustered else "t"
         self._tiles_valid, self._moments_host, self._want_index = False, None, False
+        self._samples_ok = bool(spec.samples_ok)
         for b in range(B):
             self._c_r[b] = spec.r_pending[b]
 

@@ -597,6 +597,7 @@ class BatchedSimulation:
                 f._slot_fmt[slot] = "q" if clustered else "t"
         f._tiles_valid = False
         f._moments_host = None
+        f._samples_ok = bool(spec.samples_ok)
         if spec.pend_predict:
             f._pend_predict = (u, float(self.dt), None)
         for b in range(B):

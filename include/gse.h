@@ -209,6 +209,12 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
  *                    gse_pf_slot_to_tiles converts one in place (tile sums + tile-level prefixes) for everything else.
  *                    Device-resident u / z with any stage combination. */
 #define GSE_OP_CLUSTER 2048u
+/*   GSE_OP_SAMPLES   (with WEIGHT_SCALE, SCAN_IN) the caller's word that x_in is exactly what the launch that filled the slot
+ *                    left in its x_out: that launch (WEIGHT_SCALE | UPDATE | SCAN_OUT, N >= 65536 a multiple of 64, not
+ *                    CLUSTER) put the scale's 64 sample particles beside the slot, and this one takes them from there instead
+ *                    of fetching them from x_in / w_in (64 cache lines per row and a model step on the critical path of every
+ *                    workgroup: 3-4 % of the launch).  Speed only; ignored where no samples can have been left. */
+#define GSE_OP_SAMPLES 4096u
 #define GSE_SLOT_QUARTERS 2
 int gse_pf_slot_to_tiles(int B, int64_t N, int slot, void *workspace, void *stream);
 int64_t gse_workspace_weight_scale_offset(int B, int64_t N);   /* byte offset of scale[B] inside the workspace; < 0: bad B / N */
@@ -563,7 +569,9 @@ typedef struct gse_pf_loop_spec {
     int32_t B, ticks;
     int64_t N, ld;
     double dt;
-    uint32_t flags, reserved;
+    uint32_t flags;
+    uint32_t samples_ok;                         /* in / out: the pending copy may carry GSE_OP_SAMPLES (the particles are what the launch
+                                                    that filled gather_slot wrote); 0 if in doubt */
     float *x[2], *w[2];                          /* the filter's buffer pairs [B][5][ld], [B][ld]; [0] holds the ensemble */
     void *workspace;                             /* gse_workspace_bytes(B, N) */
     const gse_mixture *state_pdf, *measurement_pdf;          /* host */

@@ -868,6 +868,78 @@ def test_weight_range_of_the_reference_after_a_measurement_jump(n, lazy):
     assert total_flips <= (2 if n <= 4096 else 40)
 
 
+@pytest.mark.parametrize("n,batch", [(1 << 17, None), (1 << 16, 2), (3 * (1 << 16), None)])
+def test_carried_scale_samples_give_what_the_fetched_ones_give(n, batch):
+    """GSE_OP_SAMPLES (round 4): a launch whose update fills a scan slot leaves the weight scale's 64 sample particles beside
+    it and the next launch takes them from there instead of fetching them from x_in / w_in.  Speed only: with and without,
+    the particles are the same bits and so are the true weights (stored weight x 2^scale), through a jump of the measurement
+    that engages the scale; the three methods and run_cycles (whose second call inherits the samples of the first through the
+    spec); touching the particles in between withdraws the word."""
+    from gpu_se_amd import _lib
+    from gpu_se_amd.filter import BatchedParticleFilter
+    fs = []
+    for _ in range(3):
+        gpu_se_amd.seed(91)
+        state_pdf, measurement_pdf = sim_base.get_noise()
+        x0, _ = sim_base.get_noise()
+        x0.means += orc.steady_state()[None, :].astype(np.float32)
+        if batch is None:
+            f = ParallelParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, state_pdf, measurement_pdf)
+        else:
+            f = BatchedParticleFilter(Bioreactor.homeostatic_DEs, Bioreactor.static_outputs, n, x0, state_pdf, measurement_pdf,
+                                      batch=batch)
+        f.cluster = False                                   # (the tile kernels are the ones that carry samples)
+        fs.append(f)
+    carried, fetched, looped = fs
+    seen = {id(f): [] for f in fs}
+    for f in (carried, fetched):
+        def spy(ops, *args, _f=f, _inner=f._fn_step):
+            seen[id(_f)].append(int(ops))
+            return _inner(ops, *args)
+        f._fn_step = spy
+    rng = np.random.default_rng(8)
+    xss = orc.steady_state()
+    K, B = 10, batch or 1
+    us = np.stack([rng.uniform(0.03, 0.09, (K, B)), rng.uniform(0.1, 0.3, (K, B))], axis=-1)
+    zs = np.array(orc.bioreactor_g(xss))[None, None, :] + rng.normal(0, 0.3, (K, B, 2))
+    zs[6:, :, 0] -= 500.0                                   # the measured glucose jumps: likelihoods around 1e-100
+    rs = rng.random((K, B))
+    shape = (lambda v: v[0]) if batch is None else (lambda v: v)
+    true_weights = lambda f: np.ldexp(f._w[:, :n].cpu().numpy().astype(np.float64), f._wscale.cpu().numpy().astype(int)[:, None])
+    engaged = False
+    for k in range(K):
+        for f in (carried, fetched):
+            f.predict(shape(us[k]), 0.1)
+            if f is fetched:
+                f._samples_ok = False
+            f.update(shape(us[k]), shape(zs[k]))
+        engaged = engaged or bool(np.any(carried._wscale.cpu().numpy() < -100))
+        np.testing.assert_array_equal(carried._x.cpu().numpy(), fetched._x.cpu().numpy())
+        np.testing.assert_array_equal(true_weights(carried), true_weights(fetched))
+        assert np.all(np.abs(carried._wscale.cpu().numpy() - fetched._wscale.cpu().numpy()) <= 1)
+        for f in (carried, fetched):
+            f.resample(r=shape(rs[k]))
+    assert engaged
+    with_word = [bool(o & _lib.GSE_OP_SAMPLES) for o in seen[id(carried)] if o & _lib.GSE_OP_SCAN_IN]
+    assert len(with_word) == K - 1 and all(with_word), seen[id(carried)]
+    assert not any(o & _lib.GSE_OP_SAMPLES for o in seen[id(fetched)])
+    # run_cycles: two calls, the second starting from the first's pending resample and its samples
+    for part in (slice(0, 4), slice(4, K)):
+        looped.run_cycles(us[part] if batch else us[part, 0], zs[part] if batch else zs[part, 0], 0.1,
+                          rs=rs[part] if batch else rs[part, 0])
+        assert looped._samples_ok
+    for f in (carried, looped):
+        f._flush()
+    np.testing.assert_array_equal(looped._x.cpu().numpy(), carried._x.cpu().numpy())
+    np.testing.assert_array_equal(looped._w.cpu().numpy(), carried._w.cpu().numpy())
+    # the accessors withdraw the word (a caller may write through the view they hand out)
+    carried.predict(shape(us[0]), 0.1)
+    carried.update(shape(us[0]), shape(zs[0]))
+    assert carried._samples_ok
+    carried.particles
+    assert not carried._samples_ok
+
+
 def test_weight_scale_travels_with_the_accessors():
     """``weights`` hands out plain numbers (the exponent folded in, what fp32 holds of them), assigning weights clears the
     exponent, and the island bookkeeping of a shard (log of the TRUE weight sum) includes it."""
