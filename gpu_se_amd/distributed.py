@@ -133,6 +133,8 @@ class ShardedParticleFilter:
     """
 
     collectives_issued = 0                                  # all-reduces / all-gathers / all-to-alls issued by this object
+    _shares_host = _side_stream = _shares_event = None      # (device groups only: see __init__)
+    _shares_recorded = False
 
     def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, group=None, merge_device=None,
                  reduce_every=32, even_split=False):
@@ -179,6 +181,16 @@ class ShardedParticleFilter:
             self.ess_fraction = 0.0
         self._shares = torch.zeros(self.world, dtype=torch.float64, device=self._merge_device)
         self._shares_cycle = None                           # resample count at which the pending exchange was issued
+        # On the device the exchanged log-weights come back to the host BESIDE the cycles (round 4): a side stream waits for the
+        # collective and copies them to pinned memory; the policy reads them `shares_lag` resamples after the exchange, when
+        # the copy has long landed -- every rank at the same resample count, so every rank decides alike -- and the stream
+        # the cycles run on never waits for the collective nor the host for the stream.  (Reading them one cycle later through
+        # .cpu() drained the launch queue at every exchange: ~60 us without work per rank, four times in the driver's K = 20.)
+        self._shares_host = self._side_stream = self._shares_event = None
+        if self._merge_device.type == "cuda" and self.group is not None:
+            self._shares_host = torch.zeros(self.world, dtype=torch.float64).pin_memory()
+            self._side_stream = torch.cuda.Stream(device=self._merge_device)
+            self._shares_event = torch.cuda.Event()
         self._force_exact = False
         self._islands_apart = False                         # an island resample has run since the last exact one
         self.exact_resamples = 0
@@ -237,11 +249,16 @@ class ShardedParticleFilter:
         """One cycle after the shards' log-weights were exchanged: read them (the only synchronisation of the island
         mode, once per reduce_every cycles) and decide, identically on every rank, whether the islands have drifted
         apart far enough for an exact resample."""
-        if self._shares_cycle is None or self._resamples <= self._shares_cycle:
+        if self._shares_cycle is None or self._resamples < self._shares_cycle + self.shares_lag:
             return
-        self.wait_collectives()
         self._shares_cycle = None
-        self.last_island_ess = island_ess(self._shares.cpu().numpy())
+        if self._shares_event is not None:
+            self._shares_event.synchronize()                # (the copy landed cycles ago: nothing to wait for)
+            shares = self._shares_host.numpy().copy()
+        else:
+            self.wait_collectives()
+            shares = self._shares.cpu().numpy()
+        self.last_island_ess = island_ess(shares)
         if self.ess_fraction > 0 and self.last_island_ess < self.ess_fraction * self.world:
             self._force_exact = True
 
@@ -339,6 +356,8 @@ class ShardedParticleFilter:
         """Asynchronous all-reduce of the shards' accumulated log-weights (slot p = rank p's island[0], zeros elsewhere):
         the global weight bookkeeping of SURVEY 8e.  Nothing waits for it until the next resample() / an estimate."""
         self.wait_collectives()
+        if self._shares_event is not None and self._shares_recorded:
+            torch.cuda.current_stream().wait_event(self._shares_event)     # (the side stream's copy of the previous exchange)
         # a buffer of its own: later launches keep updating island[0] while the collective may still be in flight
         self._shares.zero_()
         if self._merge_device.type == "cuda":
@@ -348,6 +367,17 @@ class ShardedParticleFilter:
         self._pending = dist.all_reduce(self._shares, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.collectives_issued += 1
         self._shares_cycle = self._resamples
+        if self._shares_event is not None:
+            with torch.cuda.stream(self._side_stream):
+                self._pending.wait()                        # the SIDE stream waits for the collective ...
+                self._shares_host.copy_(self._shares, non_blocking=True)
+                self._shares_event.record(self._side_stream)
+            self._shares_recorded = True
+
+    @property
+    def shares_lag(self):
+        """Resamples between an exchange of the shards' log-weights and the policy's look at them (the same on every rank)."""
+        return 1 if self._shares_event is None else max(1, min(4, self.reduce_every - 1))
 
     def wait_collectives(self):
         if self._pending is not None:

@@ -423,6 +423,18 @@ def _rccl_worker(rank, world, port, out):
             spf._exchange_shares()                                   # the policy's all-reduce, asynchronous on RCCL
             spf.wait_collectives()
             log.append(("shares", spf._shares.cpu().numpy().copy(), float(spf.local._island[0, 0].item())))
+            # ... and the policy's look at them: a side stream brought them to pinned memory behind the collective, the policy
+            # reads that copy shares_lag resamples later without waiting for the stream the cycles run on
+            assert spf._shares_event is not None and spf._shares_cycle is not None and spf.shares_lag == 4
+            spf.last_island_ess = -1.0
+            for extra in range(spf.shares_lag):
+                assert spf._shares_cycle is not None and spf.last_island_ess == -1.0
+                spf.predict([0.06, 0.2], 0.1)
+                spf.update([0.06, 0.2], z)                           # (the launch that copies counts the resample)
+                spf.resample()
+                spf._consider_shares()                               # (resample() calls it when there is more than one rank)
+            assert spf._shares_cycle is None and spf.last_island_ess == 1.0
+            np.testing.assert_array_equal(spf._shares_host.numpy(), log[-1][1])
             continue
         before = (spf.local.particles.get().copy(), spf.local.weights.get().copy())
         spf._exact_resample(0.25 + 0.2 * c)                          # all-gather of tile sums + all-to-all of rows, on RCCL
