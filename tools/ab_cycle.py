@@ -20,7 +20,7 @@ at = [0]
 def cycle(_i):
     u, z = io[at[0] % len(io)]; at[0] += 1
     pf.predict(u, 1.0); pf.update(u, z); pf.resample()
-for i in range(10): cycle(i)
+for i in range(int(os.environ.get("GSE_AB_BURN", "10"))): cycle(i)
 import time
 out, host = [], []
 for rep in range(4):
