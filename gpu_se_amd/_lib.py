@@ -24,6 +24,9 @@ GSE_SLOT_QUARTERS = 2
 GSE_CLUSTER_MAX_TILES = 256        # policy: filters whose B x tiles stay within this run four workgroups per tile (GSE_OP_CLUSTER)
 GSE_RESAMPLE_WEIGHT_SCALE = 16
 GSE_IO_U_DEVICE, GSE_IO_Z_DEVICE = 1, 2
+GSE_IO_SUMS_SLOT1 = 4
+GSE_CYCLE_LANES_MAX_TILES = 256     # gse_gsukf_cycle_lanes: banks of up to this many tiles of 1024 Gaussians
+GSE_CYCLE_LANES_MAX_WORKGROUPS = 512   # ... and the class's policy: while the launch is one generation of two workgroups per CU
 GSE_SCAN_MAX_TILES = 2048      # policy: up to 2^21 particles every workgroup of the cycle kernel rebuilds the tile prefix in LDS
                                # (one launch per cycle); beyond, a one-workgroup scan of the tile sums runs first and the
                                # cycle kernel stages windows of ITS prefix (GSE_OP_PREFIX_GLOBAL: two launches, the second
@@ -148,6 +151,9 @@ PROTOTYPES = {
     "gse_gsukf_predict_update_sums": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d, c_vp, P_F,
                                                      P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_vp, c_u32, c_vp]),
     "gse_gsukf_resample_begin_sums": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_vp, c_vp]),
+    "gse_gsukf_resample_begin_slot": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_vp, ctypes.c_int, c_vp]),
+    "gse_gsukf_cycle_lanes": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d, c_vp, P_D, P_F,
+                                             P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_vp, c_u32, c_vp]),
     "gse_gsukf_gather_rows_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp]),
     "gse_gsukf_predict_update_from_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d,
                                                            c_vp, P_F, P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_u32, c_vp]),

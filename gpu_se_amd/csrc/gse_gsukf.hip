@@ -127,6 +127,9 @@ static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w,
                                 const float* noise, const gse_mixture* measurement_pdf, int32_t* status, void* stream,
                                 uint32_t where = 0, const float* mu_in = nullptr, const float* P_in = nullptr,
                                 const int32_t* anc = nullptr, void* workspace = nullptr) {
+    const int slot = (where & GSE_IO_SUMS_SLOT1) ? 1 : 0;
+    GSE_REQUIRE(!(where & GSE_IO_SUMS_SLOT1) || workspace, "gse_gsukf_predict_update: GSE_IO_SUMS_SLOT1 belongs to the calls that leave sums");
+    where &= ~GSE_IO_SUMS_SLOT1;
     if (int rc = check_gsukf("gse_gsukf_predict_update", B, N)) return rc;
     GSE_REQUIRE(mu && P && w && u && z && w_sigma && measurement_pdf, "gse_gsukf_predict_update: null argument");
     GSE_REQUIRE(!anc || (mu_in && P_in && mu_in != mu && P_in != P),
@@ -143,12 +146,18 @@ static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w,
     const dim3 grid((unsigned)((N + kLaneBank - 1) / kLaneBank), B), block(kLaneBank);
     hipStream_t st = (hipStream_t)stream;
     // with a workspace the launch also leaves the quarter sums of the new weights there (gse_gsukf_resample_begin_sums)
-    double* quarters = workspace ? gsukf_quarter_sums(carve_workspace(workspace, B, N)) : nullptr;
+    // (... and the quads' prefixes inside their quarters: what gse_gsukf_cycle_lanes resamples from)
+    double *quarters = nullptr, *quads = nullptr;
+    if (workspace) {
+        const Workspace ws = carve_workspace(workspace, B, N);
+        quarters = gsukf_quarter_sums(ws, slot);
+        quads = gsukf_quad_prefix(ws, slot);
+    }
     if (noise) {
         a.pred.draw = DrawParams{};
         a.pred.rng = RngKey{};
         return launch(model, "gse::gsukf_predict_update_lanes_kernel<true>", gsukf_predict_update_lanes_kernel<true>, grid, block, st,
-                      mu, P, w, noise, N, status, mu_in, P_in, anc, quarters, a);
+                      mu, P, w, noise, N, status, mu_in, P_in, anc, quarters, quads, a);
     }
     if (int rc = check_mixture("gse_gsukf_predict_update", state_pdf, nx)) return rc;
     pack_draw(a.pred.draw, *state_pdf);
@@ -156,9 +165,9 @@ static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w,
     const float* none = nullptr;
     if (a.pred.draw.diagonal)
         return launch(model, "gse::gsukf_predict_update_lanes_kernel<false, 1>", gsukf_predict_update_lanes_kernel<false, 1>, grid,
-                      block, st, mu, P, w, none, N, status, mu_in, P_in, anc, quarters, a);
+                      block, st, mu, P, w, none, N, status, mu_in, P_in, anc, quarters, quads, a);
     return launch(model, "gse::gsukf_predict_update_lanes_kernel<false, 0>", gsukf_predict_update_lanes_kernel<false, 0>, grid, block,
-                  st, mu, P, w, none, N, status, mu_in, P_in, anc, quarters, a);
+                  st, mu, P, w, none, N, status, mu_in, P_in, anc, quarters, quads, a);
 }
 
 static int gsukf_cycle(UserModel* model, float* mu, float* P, float* w, int32_t* idx, int B, int64_t N, const double* u,
@@ -228,7 +237,7 @@ static int gsukf_resample(UserModel* model, const float* mu_in, const float* P_i
 // The first half of a resample: cumulative weights and ANCESTORS (idx), weights reset to 1 / N -- no row is copied; the copy
 // rides the next gse_gsukf_predict_update_from, or gse_gsukf_gather_rows does it on its own.
 static int gsukf_resample_begin(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const double* r, void* workspace,
-                                void* stream, bool quarter_sums_valid = false) {
+                                void* stream, int sums_slot = -1) {
     if (int rc = check_gsukf("gse_gsukf_resample_begin", B, N)) return rc;
     GSE_REQUIRE(w && w_out && idx && r && workspace && w != w_out, "gse_gsukf_resample_begin: null or aliasing argument");
     ResampleArgs ra;
@@ -242,7 +251,7 @@ static int gsukf_resample_begin(const float* w, float* w_out, int32_t* idx, int 
         GSE_LAUNCH_CHECK("small_resample_kernel");
         return GSE_OK;
     }
-    if (launch_ancestors(w, w_out, idx, B, N, ra, ws, st, quarter_sums_valid)) {   // up to 2^21: tile sums, then the ancestors
+    if (launch_ancestors(w, w_out, idx, B, N, ra, ws, st, sums_slot)) {   // up to 2^21: tile sums, then the ancestors
         GSE_LAUNCH_CHECK("ancestors_scatter_kernel");
         return GSE_OK;
     }
@@ -375,7 +384,60 @@ int gse_gsukf_predict_update_sums(const float* mu_in, const float* P_in, const i
 }
 int gse_gsukf_resample_begin_sums(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const double* r, void* workspace,
                                   void* stream) {
-    return gsukf_resample_begin(w, w_out, idx, B, N, r, workspace, stream, true);
+    return gsukf_resample_begin(w, w_out, idx, B, N, r, workspace, stream, 0);
+}
+int gse_gsukf_resample_begin_slot(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const double* r, void* workspace,
+                                  int slot, void* stream) {
+    GSE_REQUIRE(slot == 0 || slot == 1, "gse_gsukf_resample_begin_slot: slot must be 0 or 1");
+    return gsukf_resample_begin(w, w_out, idx, B, N, r, workspace, stream, slot);
+}
+// Resample + predict + update of a large bank in ONE launch (gse_gsukf_cycle_lanes.h): the resample is the one the sums of
+// slot s describe (s = 1 with GSE_IO_SUMS_SLOT1, else 0: left by gse_gsukf_predict_update_sums or by this function, on w_in),
+// the new sums go to the other slot.
+int gse_gsukf_cycle_lanes(const float* mu_in, const float* P_in, const float* w_in, float* mu, float* P, float* w_out,
+                          int32_t* idx, int B, int64_t N, const double* u, double dt, const double* z, const double* r,
+                          const float* w_sigma, const gse_mixture* state_pdf, const gse_rng* rng, const float* noise,
+                          const gse_mixture* measurement_pdf, int32_t* status, void* workspace, uint32_t where, void* stream) {
+    const char* fn = "gse_gsukf_cycle_lanes";
+    if (int rc = check_gsukf(fn, B, N)) return rc;
+    GSE_REQUIRE(mu_in && P_in && w_in && mu && P && w_out && u && z && r && w_sigma && measurement_pdf && workspace,
+                "%s: null argument", fn);
+    GSE_REQUIRE(mu != mu_in && P != P_in && w_out != w_in, "%s: the outputs must be other arrays than the inputs", fn);
+    GSE_REQUIRE(aligned16(workspace) && aligned16(w_in), "%s: workspace and w_in must be 16-byte aligned", fn);
+    const int T = (int)tiles_of(N);
+    GSE_REQUIRE(N % 4 == 0 && T <= kCycleLanesMaxT && lane_per_gaussian(B, N),
+                "%s: for banks of 4097 .. %d Gaussians, N a multiple of 4 (otherwise gse_gsukf_resample_begin_slot + "
+                "gse_gsukf_predict_update_sums)", fn, kCycleLanesMaxT * kTile);
+    GSE_REQUIRE(noise || (state_pdf && rng), "%s: need either noise or (state_pdf, rng)", fn);
+    if (int rc = check_mixture(fn, measurement_pdf, GSE_NY)) return rc;
+    ResampleArgs ra;
+    for (int b = 0; b < B; ++b) {
+        GSE_REQUIRE(r[b] >= 0.0 && r[b] < 1.0, "%s: r[%d] = %g is outside [0, 1)", fn, b, r[b]);
+        ra.r[b] = r[b];
+    }
+    const int slot_in = (where & GSE_IO_SUMS_SLOT1) ? 1 : 0;
+    where &= ~GSE_IO_SUMS_SLOT1;
+    GsukfPredictUpdateArgs a;
+    pack_bank_io(a.pred.io, a.pred.u_dev, a.pred.z_dev, B, u, z, where);
+    pack_sigma_weights(a.pred.sw, w_sigma, 2 * kNx + 1);
+    a.pred.dt = dt;
+    pack_pdf2(a.pdf, *measurement_pdf);
+    const Workspace ws = carve_workspace(workspace, B, N);
+    hipStream_t st = (hipStream_t)stream;
+    int variant;                                            // 0 injected noise, 1 Philox with diagonal factors, 2 Philox
+    if (noise) {
+        a.pred.draw = DrawParams{};
+        a.pred.rng = RngKey{};
+        variant = 0;
+    } else {
+        if (int rc = check_mixture(fn, state_pdf, kNx)) return rc;
+        pack_draw(a.pred.draw, *state_pdf);
+        a.pred.rng = make_rng_key(*rng, kPurposeGsukf);
+        variant = a.pred.draw.diagonal ? 1 : 2;
+    }
+    launch_gsukf_cycle_lanes(variant, mu_in, P_in, w_in, mu, P, w_out, idx, noise, B, N, status, ws, slot_in, ra, a, st);
+    GSE_LAUNCH_CHECK("gsukf_cycle_lanes_kernel");
+    return GSE_OK;
 }
 // gse_gsukf_moments in the particle filter's layout (rows of 26 doubles: S0, S1[5], S2[15] + C[15], pivot[5]): what
 // gse_loop_control and the host post-processing of a closed loop take from either estimator

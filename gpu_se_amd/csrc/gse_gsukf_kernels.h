@@ -823,6 +823,25 @@ __global__ __launch_bounds__(kLaneBank) void gsukf_update_lanes_kernel(float* __
 // predict and update of a large bank in ONE launch (the class defers predict() until update()): what predict leaves in
 // the staged rows is what update picks up -- the same fp32 values the separate launches pass through memory, so the same
 // bits, without writing 120 bytes per Gaussian and reading them back, and one launch less.
+// What a workgroup of the one-lane-per-Gaussian kernels leaves of its 256 new weights (wq, in LDS) for the resample that
+// follows: they are one QUARTER of a tile of 1024, and wavefront 0 forms of them what wavefront `quarter` of the tile-sum /
+// cumulative-sum kernels forms -- 64 lanes x 4 consecutive weights, masked_sum4, the wavefront scan: the quarter's sum
+// ([B][T][4]) and, if asked for, every quad's exclusive prefix inside the quarter ([B][T][256]; the scan slot format of the
+// particle filter's cluster kernels, gse_pf_cluster_kernels.h).  Called by the 64 lanes of wavefront 0; q: the quarter's index
+// among the bank's quarters (4 tile + quarter).
+__device__ __forceinline__ void lanes_quarter_scan(const float* wq, int64_t g0, int64_t N, int b, int q, int lane,
+                                                   double* __restrict__ quarter_sums, double* __restrict__ quad_prefix) {
+    const int64_t T = (N + kTile - 1) / kTile;
+    const float4 q4 = *reinterpret_cast<const float4*>(&wq[4 * lane]);
+    const double mine4 = masked_sum4(q4.x, q4.y, q4.z, q4.w, g0 + 4 * lane, N);
+    const double inc = wave_inclusive_scan(mine4, lane);
+    if (quad_prefix) {
+        const double ex = wave_shift_up1(inc);
+        quad_prefix[((int64_t)b * T + (q >> 2)) * kBlock + (q & 3) * 64 + lane] = ex;
+    }
+    if (lane == 63) quarter_sums[(int64_t)b * (4 * T) + q] = inc;
+}
+
 struct GsukfPredictUpdateArgs {
     GsukfPredictArgs pred;      // (its io carries u and z)
     Pdf2 pdf;
@@ -835,10 +854,13 @@ template <bool kInjected, int kDiagonal = -1>
 __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict_update_lanes_kernel(
     float* __restrict__ mu, float* __restrict__ P, float* __restrict__ w, const float* __restrict__ noise, int64_t N,
     int32_t* __restrict__ status, const float* __restrict__ mu_in, const float* __restrict__ P_in,
-    const int32_t* __restrict__ anc, double* __restrict__ quarter_sums, const GsukfPredictUpdateArgs a) {
+    const int32_t* __restrict__ anc, double* __restrict__ quarter_sums, double* __restrict__ quad_prefix,
+    const GsukfPredictUpdateArgs a) {
     __shared__ DrawParams dp;
     __shared__ float stage[kLaneBank * kStageStride];
+#if !GSE_GSUKF_DIRECT_ROWS
     __shared__ int anc_s[kLaneBank];
+#endif
     __shared__ __attribute__((aligned(16))) float wq[kLaneBank];
     const int t = threadIdx.x, b = blockIdx.y;
     const int64_t g0 = (int64_t)blockIdx.x * kLaneBank;
@@ -886,12 +908,7 @@ __global__ __launch_bounds__(kLaneBank, GSE_GSUKF_PRED_WAVES) void gsukf_predict
         // consumer is the next kernel on the stream.
         wq[t] = w_new;
         __syncthreads();
-        if (t < 64) {
-            const float4 q4 = *reinterpret_cast<const float4*>(&wq[4 * t]);
-            const double mine4 = masked_sum4(q4.x, q4.y, q4.z, q4.w, g0 + 4 * t, N);
-            const double inc = wave_inclusive_scan(mine4, t);
-            if (t == 63) quarter_sums[(int64_t)b * (4 * ((N + kTile - 1) / kTile)) + blockIdx.x] = inc;
-        }
+        if (t < 64) lanes_quarter_scan(wq, g0, N, b, (int)blockIdx.x, t, quarter_sums, quad_prefix);
     }
 #if GSE_GSUKF_DIRECT_ROWS
     if (t < nloc) lane_row_out(stage + t * kStageStride, mu_b + t * kNx, P_b + t * kNxx);

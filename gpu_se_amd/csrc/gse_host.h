@@ -147,10 +147,18 @@ int launch_index_gather(float* w_out, int32_t* idx, int B, int64_t N, const Resa
 // ... of a bank of up to 2048 tiles from its weights and tile sums, no cumulative weights written (ancestors_scatter_kernel;
 // GSE_ANCESTORS_BY_SEARCH=1 in the environment: round 2's ancestors_kernel)
 bool launch_ancestors(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, const Workspace& ws,
-                      hipStream_t st, bool quarter_sums_valid = false);
+                      hipStream_t st, int sums_slot);   // sums_slot: the slot whose quarter sums describe w, or -1
 // where the one-lane-per-Gaussian update launch leaves the quarter sums of its new weights ([B][4 T] doubles): the
 // workspace's first slot of per-thread tile prefixes, which only the particle filter uses
-inline double* gsukf_quarter_sums(const Workspace& ws) { return ws.scan[0]; }
+// resample + predict + update of a large GS-UKF bank in one launch (gse_gsukf_cycle_lanes.h; the kernel lives in gse_pf.hip's
+// translation unit, beside the gather stage it shares with the particle filter's cluster kernels)
+struct GsukfPredictUpdateArgs;
+constexpr int kCycleLanesMaxT = 256;
+void launch_gsukf_cycle_lanes(int variant, const float* mu_in, const float* P_in, const float* w_in, float* mu, float* P, float* w_out,
+                              int32_t* idx, const float* noise, int B, int64_t N, int32_t* status, const Workspace& ws, int slot_in,
+                              const ResampleArgs& ra, const GsukfPredictUpdateArgs& a, hipStream_t st);
+inline double* gsukf_quarter_sums(const Workspace& ws, int slot = 0) { return ws.qsums[slot]; }    // [B][T][4]
+inline double* gsukf_quad_prefix(const Workspace& ws, int slot = 0) { return ws.scan[slot]; }      // [B][T][256]
 // the partial sums of gse_pf_moments_resampled without the reduction that finishes them (gse_pf.hip); returns the number of
 // partials per filter, or a negative error code
 int launch_moments_resampled_partials(const char* fn, const float* x, const float* w, int64_t ld, int B, int64_t N, const double* r,

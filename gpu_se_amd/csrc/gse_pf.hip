@@ -1,6 +1,7 @@
 // gse_pf.hip -- host side of the particle filter: launches and the C ABI.  The kernels are in gse_pf_kernels.h.
 #include "gse_pf_kernels.h"
 #include "gse_pf_cluster_kernels.h"
+#include "gse_gsukf_cycle_lanes.h"
 #include "gse_rtc.h"
 
 #include <stdlib.h>
@@ -55,17 +56,18 @@ int launch_index_gather(float* w_out, int32_t* idx, int B, int64_t N, const Resa
 }
 
 bool launch_ancestors(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, const Workspace& ws,
-                      hipStream_t st, bool quarter_sums_valid) {
+                      hipStream_t st, int sums_slot) {
+    const bool quarter_sums_valid = sums_slot >= 0;
     const int T = (int)tiles_of(N);
     if (T > kAncestorsMaxT) return false;
     const size_t lds = ((size_t)(T + 1) * sizeof(double) + (size_t)T + 7) & ~(size_t)7;
     static const bool by_search = getenv("GSE_ANCESTORS_BY_SEARCH") != nullptr;     // (the round-2 kernel, kept for A/B runs)
     if (quarter_sums_valid) {           // the update launch left the quarter sums of these weights in the workspace
         if (by_search)
-            hipLaunchKernelGGL(ancestors_kernel<1>, dim3(T, B), dim3(kBlock), lds, st, w, gsukf_quarter_sums(ws), w_out, idx, N, T, ra);
+            hipLaunchKernelGGL(ancestors_kernel<1>, dim3(T, B), dim3(kBlock), lds, st, w, gsukf_quarter_sums(ws, sums_slot), w_out, idx, N, T, ra);
         else
-            hipLaunchKernelGGL(ancestors_scatter_kernel<1>, dim3(T, B), dim3(kBlock), lds, st, w, gsukf_quarter_sums(ws), w_out, idx,
-                               N, T, ra);
+            hipLaunchKernelGGL(ancestors_scatter_kernel<1>, dim3(T, B), dim3(kBlock), lds, st, w, gsukf_quarter_sums(ws, sums_slot), w_out,
+                               idx, N, T, ra);
         return true;
     }
     hipLaunchKernelGGL(tile_sum_kernel, dim3(T, B), dim3(kBlock), 0, st, w, ws.tile_sums, N, N, T);
@@ -74,6 +76,23 @@ bool launch_ancestors(const float* w, float* w_out, int32_t* idx, int B, int64_t
     else
         hipLaunchKernelGGL(ancestors_scatter_kernel<0>, dim3(T, B), dim3(kBlock), lds, st, w, ws.tile_sums, w_out, idx, N, T, ra);
     return true;
+}
+
+void launch_gsukf_cycle_lanes(int variant, const float* mu_in, const float* P_in, const float* w_in, float* mu, float* P, float* w_out,
+                              int32_t* idx, const float* noise, int B, int64_t N, int32_t* status, const Workspace& ws, int slot_in,
+                              const ResampleArgs& ra, const GsukfPredictUpdateArgs& a, hipStream_t st) {
+    static_assert(kCycleLanesMaxT == kClusterMaxT, "the gather stage's LDS is laid out for this many tiles");
+    const int T = (int)tiles_of(N), slot_out = 1 - slot_in;
+    const dim3 grid((unsigned)(4 * T), (unsigned)B), block(kLaneBank);
+    const float* none = nullptr;
+#define GSE_CYCLE_LANES_GO(I_, D_, noise_)                                                                                          \
+    hipLaunchKernelGGL((gsukf_cycle_lanes_kernel<I_, D_>), grid, block, 0, st, mu_in, P_in, w_in, mu, P, w_out, idx, noise_, N, T,     \
+                       status, gsukf_quarter_sums(ws, slot_in), gsukf_quad_prefix(ws, slot_in), gsukf_quarter_sums(ws, slot_out),    \
+                       gsukf_quad_prefix(ws, slot_out), ra, a)
+    if (variant == 0) GSE_CYCLE_LANES_GO(true, -1, noise);
+    else if (variant == 1) GSE_CYCLE_LANES_GO(false, 1, none);
+    else GSE_CYCLE_LANES_GO(false, 0, none);
+#undef GSE_CYCLE_LANES_GO
 }
 
 bool launch_small_resample(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, hipStream_t st) {

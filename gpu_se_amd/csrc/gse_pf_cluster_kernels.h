@@ -115,6 +115,130 @@ __device__ __forceinline__ int32_t cluster_lookup(const OffspringCount& F, const
     return min(max(below + 1, tl0 * kTile), N - 1);
 }
 
+// The gather stage of a cluster workgroup as a function of its own -- the ancestor of output j0 + tid, for the 256 outputs
+// j0 .. j0 + 255 of one quarter of a tile -- because the GS-UKF's one-lane-per-Gaussian kernel runs the same stage for its 256
+// Gaussians (gse_gsukf_kernels.h, round 4).  qv: this thread's tile's four quarter sums (thread t < T holds tile t's; requested
+// by the caller at kernel entry so that something else covers their latency); wrow: the weights the sums were taken from
+// (rows of ld floats, 16-byte aligned); qx: [T][256] the quads' exclusive prefixes inside their quarters.  Must be called by
+// all 256 threads; W: the total weight (not positive and finite: every output's ancestor is 0, particle.py:98).
+struct ClusterGatherLds {
+    uint32_t mark[kQuarterSlots];
+    int32_t act_list[kClusterMaxT];
+    int32_t act_n;
+    double red[4];
+    double pfx_s[kClusterMaxT + 1];
+    double qs_s[4 * kClusterMaxT];
+};
+__device__ __forceinline__ int32_t cluster_gather(ClusterGatherLds& L, const double (&qv)[4], const float* __restrict__ wrow,
+                                                  const double* __restrict__ qx, int64_t N, int64_t ld, int T, double r, int64_t j0,
+                                                  int tid, double& W) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const uint32_t jme = (uint32_t)(j0 + tid);
+    if (tid < T) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) L.qs_s[4 * tid + i] = qv[i];
+    }
+    L.mark[tid] = 0u;
+    if (tid == 0) L.act_n = 0;
+    // tile prefix: one tile sum per thread (the chunks of pf_step_kernel's prefix are one tile long up to 256 tiles)
+    const double chunk = (tid < T) ? quarters_total(qv) : 0.0;
+    double total;
+    const double run = block_exclusive_scan(chunk, L.red, total);
+    if (tid < T) L.pfx_s[tid] = run;
+    if (tid == 0) L.pfx_s[T] = total;
+    __syncthreads();
+    W = L.pfx_s[T];
+    int32_t anc = 0;
+    const int32_t j1 = (int32_t)min(j0 + kQuarterSlots, N);
+    if ((W > 0.0) && (W < INFINITY) && j0 < N) {                       // (workgroup-uniform)
+        OffspringCount F;
+        F.init(N, r, W);
+        const int32_t jf = (int32_t)j0;
+        auto slot_of = [&](double x) -> int32_t { return min(max(F(x) - jf, 0), (int32_t)kQuarterSlots); };
+        const double p_lo = (F.u_of(jf) * W) * (1.0 - 0x1p-50);
+        const double p_hi = (F.u_of(j1 - 1) * W) * (1.0 + 0x1p-50);
+        int tl0, tl1;
+        wave_search_ge_pair([&](int q) { return L.pfx_s[q + 1]; }, T, p_lo, p_hi, lane, tl0, tl1);
+        // the thresholds' range with a margin far above the rounding of a key (2^-52 W) and far below the distance of two
+        // thresholds (W / N): what lies outside it marks nothing
+        const double g_lo = p_lo - 0x1p-40 * W, g_hi = p_hi + 0x1p-40 * W;
+        // ... and the first key that can be anybody's ancestor here: the first key of the first quarter of tile tl0 whose end
+        // reaches g_lo (tl0 is the first TILE whose end does).  An output whose slot nobody marked descends from it: the key
+        // that would have marked the slot is the last one below the first threshold, in a quarter nobody counted.
+        int32_t floor_key = tl0 * kTile;
+        {
+            const double P0 = L.pfx_s[tl0];
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+                if (P0 + quarters_base(L.qs_s + 4 * tl0, v + 1) < g_lo) floor_key = tl0 * kTile + (v + 1) * (kTile / 4);
+        }
+        const bool direct = tl1 - tl0 < 2;
+        int n_act = tl1 - tl0 + 1;
+        if (!direct) {
+            // census of the range: a tile whose two ends fall into one slot is spoken for by its last key (pf_step_kernel)
+            for (int q0 = tl0; q0 <= tl1; q0 += kBlock) {
+                const int q = q0 + tid;
+                const bool have = q <= tl1;
+                const int32_t e0 = have ? slot_of(L.pfx_s[q]) : 0, e1 = have ? slot_of(L.pfx_s[q + 1]) : -1;
+                const uint32_t next_e1 = wave_shift_down1((uint32_t)(e1 + 2));
+                if (!have) continue;
+                if (e0 == e1) {
+                    if (e1 < kQuarterSlots && next_e1 != (uint32_t)(e1 + 2))
+                        atomicMax(&L.mark[e1], (uint32_t)(min((int64_t)(q + 1) * kTile, N) - 1) + 1u);
+                } else {
+                    L.act_list[atomicAdd(&L.act_n, 1)] = q;
+                }
+            }
+            __syncthreads();
+            n_act = L.act_n;
+        }
+        const bool wide = !direct && n_act > GSE_SEARCH_FROM;          // workgroup-uniform
+        if (wide) {
+            anc = cluster_lookup(F, L.pfx_s, L.qs_s, wrow, qx, (int32_t)N, (int32_t)ld, tl0, tl1, min((int32_t)jme, j1 - 1));
+        } else {
+            // (loads unconditional, indices clamped, the next tile's in flight while this one is expanded: pf_step_kernel)
+            auto tile_at = [&](int i) { return direct ? tl0 + i : L.act_list[i]; };
+            auto weights_of = [&](int tq) {
+                const int64_t k0 = min((int64_t)tq * kTile + (int64_t)tid * kPerThread, ld - kPerThread);
+                return *reinterpret_cast<const float4*>(wrow + k0);
+            };
+            const int last = max(n_act - 1, 0);
+            int t0 = tile_at(0);
+            float4 c0 = weights_of(t0);
+            double x0 = qx[t0 * kBlock + tid];
+            for (int i = 0; i < n_act; ++i) {
+                const int t1 = tile_at(min(i + 1, last));
+                const float4 c1 = weights_of(t1);
+                const double x1 = qx[t1 * kBlock + tid];
+                // A wavefront holds one QUARTER of the tile's keys.  The 256 outputs of this workgroup descend from a stretch of
+                // about 256 keys -- one or two quarters of the one or two listed tiles -- so most wavefronts hold keys that lie all
+                // below the first threshold or all above the last: they mark nothing and need not count (a key marks the slot of
+                // the first output ABOVE it; see `floor` below for the last key below the first threshold).  The counting is
+                // most of what this stage issues: skipped per wavefront, the stage costs the one-lane-per-Gaussian kernel of the
+                // GS-UKF, bound by its instruction count, 2 us instead of 5 at 2^18 Gaussians.
+                const double qb = quarters_base(L.qs_s + 4 * t0, wv);
+                const double q_lo = L.pfx_s[t0] + qb, q_hi = q_lo + L.qs_s[4 * t0 + wv];
+                if (q_hi >= g_lo && q_lo <= g_hi)                         // (wavefront-uniform)
+                    expand_quad<true, kQuarterSlots>(F, L.pfx_s, L.mark, N, jf, t0, tid, c0, qb + x0);
+                t0 = t1; c0 = c1; x0 = x1;
+            }
+            __syncthreads();
+            // inclusive max-scan of the 256 marks, one slot per thread
+            const uint32_t m0 = L.mark[tid];
+            const uint32_t inc = wave_inclusive_max(m0);
+            uint32_t* wmax = reinterpret_cast<uint32_t*>(L.red);          // (free since the tile prefix)
+            if (lane == 63) wmax[wv] = inc;
+            __syncthreads();
+            uint32_t best = inc;
+            if (wv > 0) best = max(best, wmax[0]);
+            if (wv > 1) best = max(best, wmax[1]);
+            if (wv > 2) best = max(best, wmax[2]);
+            anc = (int32_t)min(max(best, (uint32_t)floor_key), (uint32_t)N - 1u);
+        }
+    }
+    return anc;
+}
+
 // grid (4 T, B): workgroup (tile, quarter) = (blockIdx.x >> 2, blockIdx.x & 3).  qsum_*: [B][T][4], qx_*: [B][T][256].
 template <bool kGather, bool kPredict, bool kUpdate, bool kDevIO>
 __global__ __launch_bounds__(kBlock) void pf_cluster_kernel(
@@ -124,14 +248,9 @@ __global__ __launch_bounds__(kBlock) void pf_cluster_kernel(
     const StepArgs a) {
     constexpr int kNd = 2;
     __shared__ DrawParams dp;
-    __shared__ uint32_t mark[kQuarterSlots];
-    __shared__ int32_t act_list[kClusterMaxT];
-    __shared__ int32_t act_n;
+    __shared__ ClusterGatherLds gl;
     __shared__ __attribute__((aligned(16))) double wq[kQuarterSlots];      // the new weights before their rounding (fp64)
-    __shared__ double red[4];
     __shared__ int kexp_s;
-    __shared__ double pfx_s[kClusterMaxT + 1];
-    __shared__ double qs_s[4 * kClusterMaxT];
 
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tile_id = (int)(blockIdx.x >> 2), quarter = (int)(blockIdx.x & 3u);
@@ -173,92 +292,12 @@ __global__ __launch_bounds__(kBlock) void pf_cluster_kernel(
     // ---- gather: the ancestor of this thread's output -----------------------------------------------------------------
     int32_t anc = (int32_t)min(jme, Nu - 1u);
     if (kGather) {
-        if (tid < T) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) qs_s[4 * tid + i] = qv[i];
-        }
-        mark[tid] = 0u;
-        if (tid == 0) act_n = 0;
-        // tile prefix: one tile sum per thread (the chunks of pf_step_kernel's prefix are one tile long up to 256 tiles)
-        const double chunk = (tid < T) ? quarters_total(qv) : 0.0;
-        double total;
-        const double run = block_exclusive_scan(chunk, red, total);
-        if (tid < T) pfx_s[tid] = run;
-        if (tid == 0) pfx_s[T] = total;
-        __syncthreads();
-        const double W = pfx_s[T];
+        double W;
+        anc = cluster_gather(gl, qv, w_in + (int64_t)b * ld, qx_in + (int64_t)b * T * kBlock, N, ld, T, a.ra.r[b], j0, tid, W);
         if (island && blockIdx.x == 0 && tid == 0) {                     // shard bookkeeping (see gse_pf_resample)
             const double ws_b = a.wscale ? a.wscale[b] : 0.0;
             island[b] += log(W) + ws_b * 0.69314718055994530942;
             island[gridDim.y + b] = ldexp(W, (int)ws_b);
-        }
-        anc = 0;       // weights that do not sum to a positive finite number: every offspring copies particle 0 (particle.py:98)
-        const int32_t j1 = (int32_t)min(j0 + kQuarterSlots, N);
-        if ((W > 0.0) && (W < INFINITY) && j0 < N) {                       // (workgroup-uniform)
-            OffspringCount F;
-            F.init(N, a.ra.r[b], W);
-            const int32_t jf = (int32_t)j0;
-            auto slot_of = [&](double x) -> int32_t { return min(max(F(x) - jf, 0), (int32_t)kQuarterSlots); };
-            const double p_lo = (F.u_of(jf) * W) * (1.0 - 0x1p-50);
-            const double p_hi = (F.u_of(j1 - 1) * W) * (1.0 + 0x1p-50);
-            int tl0, tl1;
-            wave_search_ge_pair([&](int q) { return pfx_s[q + 1]; }, T, p_lo, p_hi, lane, tl0, tl1);
-            const float* wrow = w_in + (int64_t)b * ld;
-            const double* qx = qx_in + (int64_t)b * T * kBlock;
-            const bool direct = tl1 - tl0 < 2;
-            int n_act = tl1 - tl0 + 1;
-            if (!direct) {
-                // census of the range: a tile whose two ends fall into one slot is spoken for by its last key (pf_step_kernel)
-                for (int q0 = tl0; q0 <= tl1; q0 += kBlock) {
-                    const int q = q0 + tid;
-                    const bool have = q <= tl1;
-                    const int32_t e0 = have ? slot_of(pfx_s[q]) : 0, e1 = have ? slot_of(pfx_s[q + 1]) : -1;
-                    const uint32_t next_e1 = wave_shift_down1((uint32_t)(e1 + 2));
-                    if (!have) continue;
-                    if (e0 == e1) {
-                        if (e1 < kQuarterSlots && next_e1 != (uint32_t)(e1 + 2))
-                            atomicMax(&mark[e1], (uint32_t)(min((int64_t)(q + 1) * kTile, N) - 1) + 1u);
-                    } else {
-                        act_list[atomicAdd(&act_n, 1)] = q;
-                    }
-                }
-                __syncthreads();
-                n_act = act_n;
-            }
-            const bool wide = !direct && n_act > GSE_SEARCH_FROM;          // workgroup-uniform
-            if (wide) {
-                anc = cluster_lookup(F, pfx_s, qs_s, wrow, qx, (int32_t)N, (int32_t)ld, tl0, tl1, min((int32_t)jme, j1 - 1));
-            } else {
-                // (loads unconditional, indices clamped, the next tile's in flight while this one is expanded: pf_step_kernel)
-                auto tile_at = [&](int i) { return direct ? tl0 + i : act_list[i]; };
-                auto weights_of = [&](int tq) {
-                    const int64_t k0 = min((int64_t)tq * kTile + (int64_t)tid * kPerThread, ld - kPerThread);
-                    return *reinterpret_cast<const float4*>(wrow + k0);
-                };
-                const int last = max(n_act - 1, 0);
-                int t0 = tile_at(0);
-                float4 c0 = weights_of(t0);
-                double x0 = qx[t0 * kBlock + tid];
-                for (int i = 0; i < n_act; ++i) {
-                    const int t1 = tile_at(min(i + 1, last));
-                    const float4 c1 = weights_of(t1);
-                    const double x1 = qx[t1 * kBlock + tid];
-                    expand_quad<true, kQuarterSlots>(F, pfx_s, mark, N, jf, t0, tid, c0, quarters_base(qs_s + 4 * t0, wv) + x0);
-                    t0 = t1; c0 = c1; x0 = x1;
-                }
-                __syncthreads();
-                // inclusive max-scan of the 256 marks, one slot per thread
-                const uint32_t m0 = mark[tid];
-                const uint32_t inc = wave_inclusive_max(m0);
-                uint32_t* wmax = reinterpret_cast<uint32_t*>(red);          // (free since the tile prefix)
-                if (lane == 63) wmax[wv] = inc;
-                __syncthreads();
-                uint32_t best = inc;
-                if (wv > 0) best = max(best, wmax[0]);
-                if (wv > 1) best = max(best, wmax[1]);
-                if (wv > 2) best = max(best, wmax[2]);
-                anc = (int32_t)min(max(best, (uint32_t)tl0 * (uint32_t)kTile), (uint32_t)N - 1u);
-            }
         }
     }
 

@@ -78,6 +78,16 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._pend_gather = None                      # ancestors [B, N] int32 of a resample whose row copy is still to come
         self._replay = None                           # noise a DeterministicGaussianSum handed out at predict() time
         self._sums_valid = False                      # the workspace holds the quarter sums of the current weights
+        self._sums_slot = 0                           # ... in this slot (gse_gsukf_cycle_lanes alternates between the two)
+        # a resample of a large bank whose ANCESTORS are still to be found: the next predict + update launch finds them itself
+        # (gse_gsukf_cycle_lanes: one launch per cycle); holds the resample's uniform numbers [B]
+        self._pend_resample = None
+        self._c_r_pend = (_lib.c_d * B)()
+        # (policy: while the launch leaves the chip room -- at most 512 workgroups of 256 Gaussians, two per CU; beyond, the
+        #  kernel is bound by its instruction count and the two launches are faster: gse_gsukf_cycle_lanes.h)
+        tiles = (n + _lib.GSE_TILE - 1) // _lib.GSE_TILE
+        self._cycle_lanes = (self._model is None and n > _lib.GSE_SMALL_RESAMPLE_MAX and n % 4 == 0 and
+                             tiles <= _lib.GSE_CYCLE_LANES_MAX_TILES and 4 * tiles * B <= _lib.GSE_CYCLE_LANES_MAX_WORKGROUPS)
         self._sums_ok = True                          # ... may be used at all: not once a writable view of the weights is out
         self.record_ancestors = False                 # True: every resample's ancestors [B, N] int32 are kept in
         self.ancestor_log = []                        # ancestor_log (device tensors; parity tests of whole loops)
@@ -108,6 +118,15 @@ class ParallelGaussianSumUnscentedKalmanFilter:
     # ------------------------------------------------------------------ attributes
     def _flush(self):
         """Run whatever is pending with the one-kernel-per-method calls: the row copy of a deferred resample, predict, update."""
+        if self._pend_resample is not None:
+            # the ancestors nobody has found yet: by the resample's own kernel, from the sums the update left
+            self._pend_resample = None
+            if self._idx_buf is None:
+                self._idx_buf = torch.empty((self._B, self.N_particles), dtype=torch.int32, device=self._w.device)
+            self._call("gse_gsukf_resample_begin_slot", self._w.data_ptr(), self._w_alt.data_ptr(), self._idx_buf.data_ptr(),
+                       self._B, self.N_particles, self._c_r_pend, self._ws.data_ptr(), self._sums_slot, stream_ptr())
+            self._w, self._w_alt = self._w_alt, self._w
+            self._pend_gather = self._idx_buf
         if self._pend_gather is not None:
             idx, self._pend_gather = self._pend_gather, None
             self._call("gse_gsukf_gather_rows", self._means.data_ptr(), self._covs.data_ptr(), idx.data_ptr(),
@@ -291,6 +310,21 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         """predict(u, dt) and update(., z) of a large bank in one launch (gse_gsukf_predict_update): same bits as the two."""
         pod, rng, noise = self._draw_args()
         u_arg, z_arg, where = self._io(u, z)
+        if self._pend_resample is not None:
+            # ... and the whole resample in front of them, ancestors included (gse_gsukf_cycle_lanes): from the sums of one
+            # slot of the workspace, leaving those of the new weights in the other
+            self._pend_resample = None
+            slot = self._sums_slot
+            self._call("gse_gsukf_cycle_lanes", self._means.data_ptr(), self._covs.data_ptr(), self._w.data_ptr(),
+                       self._means_alt.data_ptr(), self._covs_alt.data_ptr(), self._w_alt.data_ptr(), None, self._B,
+                       self.N_particles, u_arg, float(dt), z_arg, self._c_r_pend, self._w_sigma_c, pod, rng, noise,
+                       ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr(), self._ws.data_ptr(),
+                       where | (_lib.GSE_IO_SUMS_SLOT1 if slot else 0), stream_ptr())
+            self._means, self._means_alt = self._means_alt, self._means
+            self._covs, self._covs_alt = self._covs_alt, self._covs
+            self._w, self._w_alt = self._w_alt, self._w
+            self._sums_valid, self._sums_slot = True, 1 - slot
+            return
         # ... and, if a resample left it to this launch, its row copy: every Gaussian is read from its ancestor's row, the
         # results go to the other pair of arrays.
         idx, self._pend_gather = self._pend_gather, None
@@ -302,7 +336,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
             # ... and leaves the quarter sums of the new weights in the workspace: the resample that follows needs no
             # tile-sum launch (valid until anything else touches the weights or the workspace)
             self._call("gse_gsukf_predict_update_sums", *args, self._ws.data_ptr(), where, stream_ptr())
-            self._sums_valid = True
+            self._sums_valid, self._sums_slot = True, 0
         else:
             self._call("gse_gsukf_predict_update_from", *args, where, stream_ptr())
         if idx is not None:
@@ -379,13 +413,23 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         elif self.lazy and self._fuse_pu and self._pend_predict is None and self._pend_update is None:
             # large banks: ancestors and weights now, the rows with the next predict + update (one launch, _predict_update_now)
             self._flush()
+            if self._cycle_lanes and self._sums_valid and idx is None:
+                # ... or nothing now: the update left the sums the resample needs, and the next predict + update launch
+                # finds the ancestors of its own Gaussians (any accessor in between: _flush runs the resample's kernels)
+                for b in range(B):
+                    self._c_r_pend[b] = rr[b]
+                self._pend_resample = True
+                return
             if idx is None:                          # (a buffer of the filter's own unless the caller keeps the ancestors)
                 if self._idx_buf is None:
                     self._idx_buf = torch.empty((B, n), dtype=torch.int32, device=self._w.device)
                 idx = self._idx_buf
-            sums = self._sums_valid                  # (read before _call clears it: the resample replaces the weights)
-            self._call("gse_gsukf_resample_begin_sums" if sums else "gse_gsukf_resample_begin", self._w.data_ptr(),
-                       self._w_alt.data_ptr(), idx.data_ptr(), B, n, rr, self._ws.data_ptr(), stream_ptr())
+            if self._sums_valid:                     # (the resample replaces the weights: _call clears the flag)
+                self._call("gse_gsukf_resample_begin_slot", self._w.data_ptr(), self._w_alt.data_ptr(), idx.data_ptr(), B, n, rr,
+                           self._ws.data_ptr(), self._sums_slot, stream_ptr())
+            else:
+                self._call("gse_gsukf_resample_begin", self._w.data_ptr(), self._w_alt.data_ptr(), idx.data_ptr(), B, n, rr,
+                           self._ws.data_ptr(), stream_ptr())
             self._w, self._w_alt = self._w_alt, self._w
             self._pend_gather = idx
         else:

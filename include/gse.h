@@ -296,6 +296,7 @@ int gse_gsukf_moments(const float *mu, const float *P, const float *w, int B, in
  * of GSE_OP_U_DEVICE / GSE_OP_Z_DEVICE of gse_pf_step).  Otherwise as the calls without `_dev`. */
 #define GSE_IO_U_DEVICE 1u
 #define GSE_IO_Z_DEVICE 2u
+#define GSE_IO_SUMS_SLOT1 4u   /* (calls that leave or take quarter sums) slot 1 of the workspace instead of slot 0 */
 int gse_gsukf_predict_dev(float *mu, float *P, int B, int64_t N, const double *u, double dt, const float *w_sigma,
                           const gse_mixture *state_pdf, const gse_rng *rng, const float *noise, int32_t *status,
                           uint32_t where, void *stream);
@@ -336,6 +337,21 @@ int gse_gsukf_predict_update_sums(const float *mu_in, const float *P_in, const i
                                   void *stream);
 int gse_gsukf_resample_begin_sums(const float *w, float *w_out, int32_t *idx, int B, int64_t N, const double *r, void *workspace,
                                   void *stream);
+/* Two slots for those sums (with every quad's exclusive prefix inside its quarter beside them), so that ONE launch can resample
+ * from the sums of the previous update while it leaves those of its own: gse_gsukf_predict_update_sums takes
+ * GSE_IO_SUMS_SLOT1 in `where`; gse_gsukf_resample_begin_slot reads the slot it is told; and
+ * gse_gsukf_cycle_lanes is resample(r) + predict(u, dt) + update(u, z) of a bank of 4097 .. 2^18 Gaussians (N a multiple of 4,
+ * the built-in model) in one launch: the ancestors are found by the workgroups of the predict + update kernel themselves
+ * (the gather stage of the particle filter's cluster kernels), from w_in and the sums of slot 0 (1 with GSE_IO_SUMS_SLOT1);
+ * the bank is read from (mu_in, P_in) at its ancestors' rows, results and new weights go to (mu, P, w_out), the new sums to
+ * the OTHER slot, the ancestors to idx if it is not NULL.  Same bits as gse_gsukf_resample_begin_slot +
+ * gse_gsukf_predict_update_sums, one launch and 4-5 us less per cycle at 2^18 Gaussians (filter/gs_ukf.py:348-436). */
+int gse_gsukf_resample_begin_slot(const float *w, float *w_out, int32_t *idx, int B, int64_t N, const double *r, void *workspace,
+                                  int slot, void *stream);
+int gse_gsukf_cycle_lanes(const float *mu_in, const float *P_in, const float *w_in, float *mu, float *P, float *w_out,
+                          int32_t *idx, int B, int64_t N, const double *u, double dt, const double *z, const double *r /* host [B] */,
+                          const float *w_sigma, const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,
+                          const gse_mixture *measurement_pdf, int32_t *status, void *workspace, uint32_t where, void *stream);
 
 /* gse_gsukf_moments in the particle filter's layout -- rows of 26 doubles { S0, S1[5], S2[15] + C[15], p[5] }, so that
  * S2 - S1 e^T - e S1^T + S0 e e^T is the whole covariance (filter/gs_ukf.py:442-449): what gse_loop_control and the host

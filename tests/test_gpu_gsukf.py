@@ -403,6 +403,59 @@ def test_large_bank_deferred_resample_equals_the_eager_calls():
     np.testing.assert_array_equal(banks[0].weights.get(), banks[1].weights.get())
 
 
+@pytest.mark.parametrize("n,batch,deterministic", [((1 << 16) + 100, None, False), (12 * 1024 + 4, 2, False),
+                                                   (1 << 18, None, False), (20 * 1024, None, True)])
+def test_one_launch_cycle_of_a_large_bank_equals_the_two_launches(n, batch, deterministic):
+    """gse_gsukf_cycle_lanes (round 4): resample + predict + update of a large bank in ONE launch -- the workgroups of the
+    one-lane-per-Gaussian kernel find the ancestors of their own 256 Gaussians with the gather stage of the particle filter's
+    cluster kernels, from the quarter sums and quad prefixes the previous launch left -- against the two launches it replaces
+    (ancestors_scatter_kernel, then predict + update reading every Gaussian from its ancestor's row): the same means,
+    covariances and weights bit for bit over whole cycles, on ragged banks, a batch, Philox and injected noise, through a
+    measurement that leaves a handful of Gaussians with all the weight (ancestor ranges many tiles wide: the look-up path),
+    and with accessors in between (the pending resample then runs through its own kernels)."""
+    xss = orc.steady_state()
+    rng = np.random.default_rng(11)
+    B = batch or 1
+    means = (xss[None, :] + rng.standard_normal((n, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+    banks = []
+    for one_launch in (True, False):
+        if batch is None:
+            gf = make(n, means, deterministic=deterministic)
+        else:
+            gf = make_batch(batch, n, np.stack([means, means[::-1]][:batch]), deterministic=deterministic)
+        # (the class's policy: while the launch is at most 512 workgroups -- here the entry point is exercised up to its limit)
+        assert gf._cycle_lanes == (4 * ((n + 1023) // 1024) * B <= 512)
+        gf._cycle_lanes = one_launch
+        banks.append(gf)
+    banks[1]._seed = banks[0]._seed
+    z0 = np.array(orc.bioreactor_g(xss))
+    shape = (lambda v: v[0]) if batch is None else (lambda v: v)
+    for c in range(7):
+        u = np.repeat([[0.05 + 0.005 * c, 0.2]], B, axis=0)
+        z = z0[None, :] + rng.normal(0, 0.3, (B, 2))
+        if c == 3:
+            z[:, 0] += 60.0                           # far out: a few Gaussians carry the weight afterwards
+        r = rng.random(B)
+        noise = (rng.standard_normal((n, 11, 5)) * np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])).astype(np.float32)
+        for gf in banks:
+            if deterministic:
+                DeterministicGaussianSum.preload(noise)
+            gf.predict(shape(u), 0.1)
+            gf.update(shape(u), shape(z))
+            gf.resample(r=shape(r))
+        assert banks[0]._pend_resample is not None and banks[0]._pend_gather is None       # nothing has run for the resample yet
+        assert banks[1]._pend_resample is None and banks[1]._pend_gather is not None       # the ancestors are there already
+        if c == 4:                                    # an accessor in between: the pending resample runs through its own kernels
+            np.testing.assert_array_equal(banks[0].means.get(), banks[1].means.get())
+            assert banks[0]._pend_resample is None
+        if c == 5:
+            np.testing.assert_array_equal(banks[0].point_estimate(), banks[1].point_estimate())
+    np.testing.assert_array_equal(banks[0].means.get(), banks[1].means.get())
+    np.testing.assert_array_equal(banks[0].covariances.get(), banks[1].covariances.get())
+    np.testing.assert_array_equal(banks[0].weights.get(), banks[1].weights.get())
+    assert int(banks[0]._status.item()) == int(banks[1]._status.item())
+
+
 @pytest.mark.parametrize("n", [1, 7, 33, 64])
 def test_fused_cycle_equals_separate_launches(n):
     """predict + update + resample of a small bank in ONE launch (gse_gsukf_cycle) vs the three methods run one kernel

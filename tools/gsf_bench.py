@@ -10,6 +10,8 @@ z = np.array(Bioreactor.static_outputs(xss, None))
 for n in [int(a) for a in sys.argv[1:]] or [64, 1024, 16384, 262144]:
     gpu_se_amd.seed(3)
     _, _, _, gf = sim_base.get_parts(N_particles=n, pf=False)
+    if os.environ.get("GSE_GSF_TWO_LAUNCHES") == "1":
+        gf._cycle_lanes = False           # (A/B: ancestors by their own kernel, as until round 4)
     u = [0.06, 0.2]
     def cycle():
         gf.predict(u, 0.1); gf.update(u, z); gf.resample()
