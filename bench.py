@@ -254,7 +254,7 @@ def protocol_sum(torch, n, io, dt, runs=100):
                                   "`value` instead times back-to-back cycles without synchronisation"}
 
 
-def gsukf_block(torch, sizes=(64, 4096, 1 << 18)):
+def gsukf_block(torch, sizes=(64, 4096, 1 << 16, 1 << 18)):
     """BASELINE config 3 and the large-bank end of results/gsf_openloop/gsf_run_seq.py:483-484: device time per GS-UKF
     cycle (HIP events), 760 algorithmic bytes per Gaussian."""
     import gpu_se_amd
@@ -288,7 +288,8 @@ def gsukf_block(torch, sizes=(64, 4096, 1 << 18)):
         else:
             gbs = GSUKF_ALG_BYTES * n / dev / 1e9
             entry.update({"achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
-                          "algorithmic_bytes_per_gaussian": GSUKF_ALG_BYTES})
+                          "algorithmic_bytes_per_gaussian": GSUKF_ALG_BYTES,
+                          "launches_per_cycle": 1 if getattr(gf, "_cycle_lanes", False) else 2})
         out["N=%d" % n] = entry
     return out
 
