@@ -443,6 +443,10 @@ def main():
     io = io[burn_in:]
     for i in range(warmup):
         cycle(i)
+    if world > 1:
+        # (one untimed exchange of the shards' log-weights: the first collective on a buffer sets its channels up -- warm-up,
+        #  as the W cycles are for the kernels; the timed region issues its own, counted below)
+        pf._exchange_shares()
     pf.wait_collectives()
     torch.cuda.synchronize()
     if world > 1:
