@@ -114,6 +114,44 @@ def test_user_model_with_philox_noise_and_fused_cycle():
     assert np.all(np.isfinite(est)) and abs(est[1] - truth[1]) < 0.6 and abs(est[0] * est[1] - truth[0] * truth[1]) < 2.5
 
 
+def test_user_model_with_carried_scale_samples():
+    """GSE_OP_SAMPLES with a user model (tests/test_gpu_pf.py has the built-in one): the rows left beside the scan slot hold the
+    sample particles' whole state and the consumer takes the model's exact step -- the same particles and true weights as with
+    the samples fetched from x_in / w_in, through an update whose likelihoods need the power-of-two scale."""
+    from gpu_se_amd import _lib
+    n = 1 << 16
+    fs = []
+    for _ in range(2):
+        gpu_se_amd.seed(5)
+        x0, state, meas = _two_state_parts()
+        fs.append(ParallelParticleFilter(um.two_state_f, um.two_state_g, n, x0, state, meas))
+    carried, fetched = fs
+    ops_seen = []
+
+    def spy(ops, *args, _inner=carried._fn_step):
+        ops_seen.append(int(ops))
+        return _inner(ops, *args)
+    carried._fn_step = spy
+    truth = np.array([9.0, 0.5])
+    true_weights = lambda f: np.ldexp(f._w[:, :n].cpu().numpy().astype(np.float64), f._wscale.cpu().numpy().astype(int)[:, None])
+    engaged = False
+    for c in range(8):
+        truth = truth + np.array(um.two_state_f(truth, [1.0], 0.01))
+        z = np.array(um.two_state_g(truth, [1.0])) + [0.7, -0.3] + ([6.0, 0.0] if c >= 5 else [0.0, 0.0])
+        for f in fs:
+            f.predict([1.0], 0.01)
+            if f is fetched:
+                f._samples_ok = False
+            f.update([1.0], z)
+        engaged = engaged or bool(carried._wscale.cpu().numpy()[0] < -50)
+        np.testing.assert_array_equal(carried._x.cpu().numpy(), fetched._x.cpu().numpy())
+        np.testing.assert_array_equal(true_weights(carried), true_weights(fetched))
+        for f in fs:
+            f.resample(r=0.05 + 0.1 * c)
+    assert engaged
+    assert sum(bool(o & _lib.GSE_OP_SAMPLES) for o in ops_seen) == 7
+
+
 def test_a_model_nobody_prebuilt_is_compiled_in_the_process_and_both_backends_agree():
     """Run-time compilation where the model is first seen: a model defined HERE (nothing on disk, nothing built by
     __graft_entry__.build()), kernels compiled by hiprtc in this process when the launches ask for them -- and, bit for bit,
