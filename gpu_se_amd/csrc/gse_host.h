@@ -66,6 +66,7 @@ struct Workspace {
     double* wscale;        // [B]          GSE_OP_WEIGHT_SCALE: log2 of the factor between the stored and the true weights
     double* qsums[2];      // [B][T][4]    GSE_OP_CLUSTER: the quarter sums that go with scan[slot] in quarter format
     float* samples[2];     // [B][64][8]   GSE_OP_SAMPLES: the weight scale's sample particles of the launch that filled scan[slot]
+    uint32_t* kexact;      // [B]          GSE_OP_WEIGHT_SCALE, updates without a resample in front: scale_exact_kernel's maximum
     int64_t bytes;
 };
 Workspace carve_workspace(void* base, int B, int64_t N);

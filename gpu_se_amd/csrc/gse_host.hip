@@ -115,6 +115,8 @@ Workspace carve_workspace(void* base, int B, int64_t N) {
         ws.samples[k] = reinterpret_cast<float*>(p + at);
         at += round256((int64_t)B * 64 * 8 * 4);
     }
+    ws.kexact = reinterpret_cast<uint32_t*>(p + at);
+    at += round256((int64_t)B * 4);
     ws.bytes = at;
     return ws;
 }

@@ -321,6 +321,32 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     a.smp_stride = (uint32_t)(N / kScaleSamples);
     a.smp_magic = a.smp_stride ? (uint32_t)((((uint64_t)1 << 32) + a.smp_stride - 1) / a.smp_stride) : 0u;
     GSE_REQUIRE(!(a.smp_in && a.smp_out) || a.smp_in != a.smp_out, "%s: SCAN_IN and SCAN_OUT must use different slots", fn);
+    a.k_exact = nullptr;
+    if ((ops & GSE_OP_WEIGHT_SCALE) && U && !G) {
+        // an update without a resample in front of it: the scale's anchor over ALL particles, by a pass of its own
+        // (scale_exact_kernel: the weights may span any number of binades by now, and 64 samples need not see the heavy ones)
+        hipStream_t st = (hipStream_t)stream;
+        GSE_HIP_CHECK(hipMemsetAsync(ws.kexact, 0, (size_t)B * sizeof(uint32_t), st));
+        a.k_exact = ws.kexact;
+        const dim3 grid((unsigned)std::min<int64_t>((N + kBlock - 1) / kBlock, 2048), (unsigned)B);
+        const bool dev_io = u_on_device || z_on_device;
+        if (model) {
+            char name[96];
+            snprintf(name, sizeof name, "gse::scale_exact_kernel<%s, %s>", P ? "true" : "false", dev_io ? "true" : "false");
+            uint32_t* kx = ws.kexact;
+            void* params[] = {(void*)&x_in, (void*)&w_in, (void*)&N, (void*)&ld, (void*)&kx, (void*)&a};
+            if (int rc = launch_user_kernel(model, name, grid, dim3(kBlock), 0, st, params)) return rc;
+        } else if (P && dev_io) {
+            hipLaunchKernelGGL((scale_exact_kernel<true, true>), grid, dim3(kBlock), 0, st, x_in, w_in, N, ld, ws.kexact, a);
+        } else if (P) {
+            hipLaunchKernelGGL((scale_exact_kernel<true, false>), grid, dim3(kBlock), 0, st, x_in, w_in, N, ld, ws.kexact, a);
+        } else if (dev_io) {
+            hipLaunchKernelGGL((scale_exact_kernel<false, true>), grid, dim3(kBlock), 0, st, x_in, w_in, N, ld, ws.kexact, a);
+        } else {
+            hipLaunchKernelGGL((scale_exact_kernel<false, false>), grid, dim3(kBlock), 0, st, x_in, w_in, N, ld, ws.kexact, a);
+        }
+        GSE_LAUNCH_CHECK("scale_exact_kernel");
+    }
     if (ops & GSE_OP_CLUSTER) {
         // mid-size ensembles: four workgroups per tile, one particle per thread, scan slots in quarter format
         // (gse_pf_cluster_kernels.h); the same particles, weights and ancestors as the kernels below

@@ -276,7 +276,8 @@ __global__ __launch_bounds__(kBlock) void pf_cluster_kernel(
     // GSE_OP_WEIGHT_SCALE: this launch's binary exponent (the same 64 samples in every workgroup of the launch): requested
     // here, with the quarter sums, turned into k after the gather stage
     ScaleSample ssm;
-    if (kUpdate && a.wscale && wv == 0) scale_samples_load(ssm, xin_b, w_in ? w_in + (int64_t)b * ld : nullptr, N, ld, lane);
+    if (kUpdate && a.wscale && wv == 0 && (kGather || !a.k_exact))
+        scale_samples_load(ssm, xin_b, w_in ? w_in + (int64_t)b * ld : nullptr, N, ld, lane);
     if (kPredict) __syncthreads();                                       // dp staged
     float e[GSE_NX] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (kPredict) {

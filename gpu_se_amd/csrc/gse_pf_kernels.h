@@ -55,7 +55,11 @@ struct StepArgs {
     float* smp_out;        // ... of the slot this launch's update fills, or null
     uint32_t smp_stride;   // N / kScaleSamples: sample l is particle l * smp_stride
     uint32_t smp_magic;    // ceil(2^32 / smp_stride)
+    // ... and for launches that update WITHOUT a resample in front (the weights may be anything by then): the best exponent over
+    // ALL particles, left by scale_exact_kernel just before this launch ([B], biased by kExactBias; null: the samples decide)
+    const uint32_t* k_exact;
 };
+constexpr int32_t kExactBias = 1 << 20;
 
 #ifndef GSE_STEP_MIN_WAVES
 #define GSE_STEP_MIN_WAVES 4     // waves per SIMD the register allocator must leave room for (tuning knob)
@@ -507,6 +511,12 @@ __device__ __forceinline__ bool scale_sample_of_tile(const StepArgs& a, uint32_t
 }
 template <bool kGather, bool kPredict, int kNd, bool kDevIO>
 __device__ GSE_SCALE_FN_ATTR int scale_exponent_of(const ScaleSample& q, bool have_w, bool carried, const StepArgs& a, int64_t N, int b) {
+    if (!kGather && a.k_exact) {                         // (uniform) the exact maximum is there: scale_exact_kernel
+        const uint32_t stored = a.k_exact[b];
+        if (stored == 0u) return 0;                       // (no particle with a positive weight)
+        const int k = ((int)stored - kExactBias) + (N > 1 ? 64 - __clzll((unsigned long long)(N - 1)) : 0);
+        return (k < -kWeightScaleFrom) ? max(k, kWeightScaleMin) : 0;
+    }
     double fg0 = a.io.f[b].u0, fm0 = a.io.f[b].u1, za = a.io.f[b].z0, zb = a.io.f[b].z1;
     if constexpr (kDevIO) {
         if (a.u_dev) { fg0 = a.u_dev[2 * b]; fm0 = a.u_dev[2 * b + 1]; }
@@ -540,6 +550,43 @@ __device__ GSE_SCALE_FN_ATTR int scale_exponent_of(const ScaleSample& q, bool ha
     // brought to about 1 / N  (ceil(log2 N) by a count of leading zeros)
     const int k = kGather ? c : c + (N > 1 ? 64 - __clzll((unsigned long long)(N - 1)) : 0);
     return (k < -kWeightScaleFrom) ? max(k, kWeightScaleMin) : 0;
+}
+
+// The anchor of a launch that updates WITHOUT a resample in front of it, exactly (round 4).  After a resample every weight is
+// 1 / N and 64 samples say all there is to know about where the likelihood is large; after updates that were NOT followed by a
+// resample the weights themselves span any number of binades, the heaviest particle need not stand anywhere near a sample, and
+// a k taken from light samples would scale the heavy ones past the end of fp32.  Such launches are rare (the first cycle of a
+// run; callers that skip resamples) and pay for certainty with a pass of their own: the maximum over ALL particles of
+// (exponent of the weight + exponent of the likelihood after the launch's model step), one atomic per wavefront.
+template <bool kPredict, bool kDevIO>
+__global__ __launch_bounds__(kBlock) void scale_exact_kernel(const float* __restrict__ x_in, const float* __restrict__ w_in,
+                                                             int64_t N, int64_t ld, uint32_t* __restrict__ k_out,
+                                                             const StepArgs a) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    double fg0 = a.io.f[b].u0, fm0 = a.io.f[b].u1, za = a.io.f[b].z0, zb = a.io.f[b].z1;
+    if constexpr (kDevIO) {
+        if (a.u_dev) { fg0 = a.u_dev[2 * b]; fm0 = a.u_dev[2 * b + 1]; }
+        if (a.z_dev) { za = a.z_dev[2 * b]; zb = a.z_dev[2 * b + 1]; }
+    }
+    const float* xb = x_in + (int64_t)b * GSE_NX * ld;
+    const float* wb = w_in + (int64_t)b * ld;
+    uint32_t best = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
+        const float w = wb[i];
+        float st[GSE_NX];
+#pragma unroll
+        for (int k = 0; k < GSE_NX; ++k) st[k] = xb[(int64_t)k * ld + i];
+        if (!(w > 0.f)) continue;
+        if (kPredict) model_step_anchor(st, fg0, fm0, a.dt);
+        float o0[kObsKept], ya, yb;
+        model_keep(st, o0);
+        model_output_kept(o0, fg0, fm0, ya, yb);
+        const int e_lik = min(max(likelihood_exponent<0>(a.pdf, za - (double)ya, zb - (double)yb), -16000), 2000);
+        const int e = max(e_lik + max(ilogbf(w), -300), -32000);
+        best = max(best, (uint32_t)(e + kExactBias));
+    }
+    best = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(best), 63);
+    if (lane == 0 && best != 0u) atomicMax(k_out + b, best);
 }
 
 template <bool kGather, bool kPredict, bool kInjected, bool kUpdate, int kNd, int kScan>
@@ -636,7 +683,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     const bool carried = kScanIn && a.smp_in != nullptr;                   // (uniform)
     if (kUpdate && a.wscale && wv == kScaleWave) {
         if (carried) scale_samples_carried(ssm, a.smp_in + (int64_t)b * kScaleSamples * kSampleRow, lane);
-        else scale_samples_load(ssm, xin_b, scale_w ? w_in + (int64_t)b * ld : nullptr, N, ld, lane);
+        else if (kGather || !a.k_exact) scale_samples_load(ssm, xin_b, scale_w ? w_in + (int64_t)b * ld : nullptr, N, ld, lane);
     }
     if (kDraw) __syncthreads();                          // dp staged
     if (kDraw && draw_at == 0) draw_all();

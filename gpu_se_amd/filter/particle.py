@@ -621,11 +621,9 @@ class ParallelParticleFilter:
                 # the kernel sums the STORED weights; the reference's quantities are un-normalised sums of the true ones
                 k = self._wscale.cpu().numpy()
                 if numpy.any(numpy.isposinf(self._moments_host[:, 0])):
-                    # (the scale's one failure mode, said loudly: DESIGN.md section 3 -- updates without a resample in between can
-                    #  concentrate the weight where none of the scale's 64 sample particles stands)
-                    raise FloatingPointError("the stored weights overflowed the launch's power-of-two scale (weight sum = inf): "
-                                             "updates without a resample in between left the scale's sample particles more than "
-                                             "2^100 below the heaviest particle; resample after the update, as sim_base's loop does")
+                    # (not expected: after a resample the scale's samples are within 2 log2 N binades of the heaviest particle,
+                    #  and updates without one take their anchor from all particles -- but never silently)
+                    raise FloatingPointError("the stored weights overflowed the launch's power-of-two scale (weight sum = inf)")
                 if numpy.any(k != 0):
                     self._moments_host[:, :21] = numpy.ldexp(self._moments_host[:, :21], k.astype(numpy.int64)[:, None])
         m = self._moments_host

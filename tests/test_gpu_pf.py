@@ -940,6 +940,48 @@ def test_carried_scale_samples_give_what_the_fetched_ones_give(n, batch):
     assert not carried._samples_ok
 
 
+@pytest.mark.parametrize("n,cluster,lazy", [(1 << 13, True, True), (1 << 13, False, True), (1 << 13, False, False),
+                                            (1 << 16, False, True)])
+def test_scale_of_an_update_without_a_resample_looks_at_every_particle(n, cluster, lazy):
+    """An update that is NOT preceded by a resample finds weights that may span any number of binades, and the heaviest
+    particle need not stand anywhere near one of the 64 sample particles the scale's anchor looks at after a resample: with
+    all but one particle at the bottom of fp32 (2^-149) and the one heavy particle between two samples, a k taken from the
+    samples would scale the heavy one past the end of fp32 (inf; round 4 until this test).  Such launches take the anchor
+    from a pass over ALL particles (scale_exact_kernel): the new weights are the reference's fp64 products to one fp32
+    rounding -- with likelihoods fp32 can hold (k = 0) and through a measurement jump (k far below)."""
+    pf, o, xss = _filter_and_reference_dtype_oracle(n, 83)
+    pf.cluster, pf.lazy = cluster, lazy
+    rng = np.random.default_rng(4)
+    sd = np.sqrt([1e-4, 1e-7, 1e-3, 1e-3, 1e-7])
+    u = [0.06, 0.2]
+    heavy_at = 5 + 3 * (n // 64)                           # (between the samples, which stand at multiples of n / 64)
+    x = pf.particles.get().copy()
+    for jump in (0.0, 350.0):
+        w0 = np.full(n, np.float32(2.0 ** -149))
+        w0[heavy_at] = 1.0
+        pf.weights = w0
+        noise = (rng.standard_normal((n, 5)) * sd).astype(np.float32)
+        z = np.array(orc.bioreactor_g(xss)) + [0.2 + jump, -0.1]
+        DeterministicGaussianSum.preload(noise)
+        pf.predict(u, 0.1)
+        pf.update(u, z)
+        w, k = pf._scaled_weights()
+        stored = w[0].astype(np.float64)
+        assert np.all(np.isfinite(stored)), (jump, int(k[0]))
+        # the reference's arithmetic on the same particles: fp64 products of the fp32 weights with the fp64 likelihoods
+        o.particles = x.copy()
+        o.predict_vec(u, 0.1, noise=noise)
+        e = z[None, :] - orc.bioreactor_g_vec(o.particles).astype(np.float64)
+        want = w0.astype(np.float64) * o.measurement_pdf.pdf(e)
+        got = np.ldexp(stored, int(k[0]))
+        np.testing.assert_allclose(got[heavy_at], want[heavy_at], rtol=2.5e-7)
+        assert (k[0] == 0) == (jump == 0.0) and (jump == 0.0 or k[0] < -100), (jump, k)
+        light = np.arange(n) != heavy_at
+        assert got[light].max() <= want[heavy_at] * 2.0 ** -120           # (the light ones: denormal or zero, as they should be)
+        x = pf.particles.get().copy()
+        np.testing.assert_array_equal(x, o.particles)
+
+
 def test_weight_scale_travels_with_the_accessors():
     """``weights`` hands out plain numbers (the exponent folded in, what fp32 holds of them), assigning weights clears the
     exponent, and the island bookkeeping of a shard (log of the TRUE weight sum) includes it."""
