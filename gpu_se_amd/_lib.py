@@ -20,6 +20,7 @@ GSE_OP_PREFIX_GLOBAL = 512
 GSE_OP_WEIGHT_SCALE = 1024
 GSE_OP_CLUSTER = 2048
 GSE_OP_SAMPLES = 4096
+GSE_OP_UNIFORM_WEIGHTS = 8192
 GSE_SLOT_QUARTERS = 2
 GSE_CLUSTER_MAX_TILES = 256        # policy: filters whose B x tiles stay within this run four workgroups per tile (GSE_OP_CLUSTER)
 GSE_RESAMPLE_WEIGHT_SCALE = 16

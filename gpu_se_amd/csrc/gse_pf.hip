@@ -238,7 +238,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     const bool G = ops & GSE_OP_GATHER, P = ops & GSE_OP_PREDICT, U = ops & GSE_OP_UPDATE;
     const uint32_t known = GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE | GSE_OP_SCAN_IN | GSE_OP_SCAN_OUT |
                            GSE_OP_SCAN_IN_SLOT1 | GSE_OP_SCAN_OUT_SLOT1 | GSE_OP_U_DEVICE | GSE_OP_Z_DEVICE |
-                           GSE_OP_PREFIX_GLOBAL | GSE_OP_WEIGHT_SCALE | GSE_OP_CLUSTER | GSE_OP_SAMPLES;
+                           GSE_OP_PREFIX_GLOBAL | GSE_OP_WEIGHT_SCALE | GSE_OP_CLUSTER | GSE_OP_SAMPLES | GSE_OP_UNIFORM_WEIGHTS;
     const bool prefix_global = (ops & GSE_OP_PREFIX_GLOBAL) != 0;
     GSE_REQUIRE((ops & (GSE_OP_GATHER | GSE_OP_PREDICT | GSE_OP_UPDATE)) != 0 && (ops & ~known) == 0,
                 "%s: bad ops mask 0x%x", fn, ops);
@@ -322,7 +322,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     a.smp_magic = a.smp_stride ? (uint32_t)((((uint64_t)1 << 32) + a.smp_stride - 1) / a.smp_stride) : 0u;
     GSE_REQUIRE(!(a.smp_in && a.smp_out) || a.smp_in != a.smp_out, "%s: SCAN_IN and SCAN_OUT must use different slots", fn);
     a.k_exact = nullptr;
-    if ((ops & GSE_OP_WEIGHT_SCALE) && U && !G) {
+    if ((ops & GSE_OP_WEIGHT_SCALE) && U && !G && !(ops & GSE_OP_UNIFORM_WEIGHTS)) {
         // an update without a resample in front of it: the scale's anchor over ALL particles, by a pass of its own
         // (scale_exact_kernel: the weights may span any number of binades by now, and 64 samples need not see the heavy ones)
         hipStream_t st = (hipStream_t)stream;

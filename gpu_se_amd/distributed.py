@@ -331,6 +331,7 @@ class ShardedParticleFilter:
             f._wscale.zero_()
         f._island[0, 0] = float(numpy.log(n / self.N_particles))     # the shard's share is its share of the particles
         f._tiles_valid, f._scan_slot, f._moments_host, f._samples_ok = False, None, None, False
+        f._w_uniform = True
         self._islands_apart = False
         self.exact_resamples += 1
         self.last_exact = dict(r=r, J=J, send=send, recv=recv)

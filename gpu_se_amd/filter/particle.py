@@ -118,6 +118,7 @@ class ParallelParticleFilter:
         self._gather_slot = None                            # slot of the scans a pending gather reads (None: cumsum array)
         self._scan_slot = None                              # slot holding scans of the CURRENT weights, if any
         self._samples_ok = False                            # ... and the weight scale's samples of the CURRENT particles beside it
+        self._w_uniform = True                              # every weight is 1 / N (the constructor's, or a resample's since)
         self._scan_capable = True                           # the cycle kernel resamples from tile sums + per-thread prefixes
         self._prefix_global = (-(-n // _lib.GSE_TILE)) > _lib.GSE_SCAN_MAX_TILES    # ... beyond 2^21 from a scanned tile prefix
         # Mid-size filters (B x tiles <= 256, i.e. less than one generation of workgroups): four workgroups per tile, one
@@ -235,6 +236,8 @@ class ParallelParticleFilter:
         ops = _lib.GSE_OP_WEIGHT_SCALE if (self.weight_scale and (update is not None or self._pend_gather)) else 0
         n = self.N_particles
         gather = self._pend_gather
+        if ops and update is not None and not gather and self._w_uniform:
+            ops |= _lib.GSE_OP_UNIFORM_WEIGHTS              # (the scale's samples say enough: no pass over all particles first)
         # (predict + update without a gather is out of place too when the weights are scaled: the launch reads the scale's
         #  anchor, particle 0, from x_in while other workgroups write their new states)
         swap_x = gather or (bool(ops) and update is not None and self._pend_predict is not None)
@@ -314,6 +317,10 @@ class ParallelParticleFilter:
         # particles until somebody else touches them (the accessors, a launch of another kind)
         self._samples_ok = bool(update is not None and scan_out is not None and (ops & _lib.GSE_OP_WEIGHT_SCALE))
         if update is not None:
+            self._w_uniform = False
+        elif gather:
+            self._w_uniform = True
+        if update is not None:
             self._tiles_valid = True
             self._scan_slot = scan_out
             if scan_out is not None:
@@ -329,6 +336,8 @@ class ParallelParticleFilter:
         x_out = self._x_alt if swap_x else self._x
         swap_w = gather or (bool(ops & _lib.GSE_OP_WEIGHT_SCALE) and update is not None)      # (see _launch_step)
         w_out = self._w_alt if swap_w else self._w
+        if (ops & _lib.GSE_OP_WEIGHT_SCALE) and update is not None and not gather and self._w_uniform:
+            ops |= _lib.GSE_OP_UNIFORM_WEIGHTS
         idx_ptr = None
         if gather:
             ops |= _lib.GSE_OP_GATHER | _lib.GSE_OP_SCAN_IN | (_lib.GSE_OP_SCAN_IN_SLOT1 if self._gather_slot else 0)
@@ -380,6 +389,10 @@ class ParallelParticleFilter:
         self._moments_host = None
         self._samples_ok = False
         if update is not None:
+            self._w_uniform = False
+        elif gather:
+            self._w_uniform = True
+        if update is not None:
             self._tiles_valid = False                           # (the workspace's tile sums are not written by these launches)
             self._scan_slot = scan_out
             self._slot_fmt[scan_out] = "q"
@@ -398,6 +411,7 @@ class ParallelParticleFilter:
         self._samples_ok = False
         self._tiles_valid = False
         self._scan_slot = None
+        self._w_uniform = False
 
     @property
     def particles(self):
@@ -454,6 +468,7 @@ class ParallelParticleFilter:
         self._scan_slot = None
         self._moments_host = None
         self._samples_ok = False
+        self._w_uniform = False
 
     # ------------------------------------------------------------------ the cycle
     def predict(self, u, dt):
@@ -505,6 +520,7 @@ class ParallelParticleFilter:
         if self.weight_scale:
             self._wscale.zero_()
         self._tiles_valid, self._scan_slot, self._moments_host, self._samples_ok = False, None, None, False
+        self._w_uniform = True                              # (index_gather_kernel wrote 1 / N everywhere)
         self._last_index = idx
         if self.record_ancestors:
             self.ancestor_log.append(idx)
@@ -606,6 +622,7 @@ class ParallelParticleFilter:
         self._slot_fmt[self._gather_slot] = "q" if clustered else "t"
         self._tiles_valid, self._moments_host, self._want_index = False, None, False
         self._samples_ok = bool(spec.samples_ok)
+        self._w_uniform = False
         for b in range(B):
             self._c_r[b] = spec.r_pending[b]
 

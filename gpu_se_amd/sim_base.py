@@ -598,6 +598,7 @@ class BatchedSimulation:
         f._tiles_valid = False
         f._moments_host = None
         f._samples_ok = bool(spec.samples_ok)
+        f._w_uniform = False
         if spec.pend_predict:
             f._pend_predict = (u, float(self.dt), None)
         for b in range(B):

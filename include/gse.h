@@ -215,6 +215,11 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
  *                    of fetching them from x_in / w_in (64 cache lines per row and a model step on the critical path of every
  *                    workgroup: 3-4 % of the launch).  Speed only; ignored where no samples can have been left. */
 #define GSE_OP_SAMPLES 4096u
+/*   GSE_OP_UNIFORM_WEIGHTS  (with WEIGHT_SCALE | UPDATE, no GATHER) the caller's word that w_in holds 1 / N everywhere (a
+ *                    resample wrote it and nothing has touched it since): the scale's 64 samples then say enough, and the
+ *                    pass over all particles that such a launch otherwise runs first for its anchor (weights of any spread:
+ *                    scale_exact_kernel, one more kernel inside this call) is left out.  Speed only. */
+#define GSE_OP_UNIFORM_WEIGHTS 8192u
 #define GSE_SLOT_QUARTERS 2
 int gse_pf_slot_to_tiles(int B, int64_t N, int slot, void *workspace, void *stream);
 int64_t gse_workspace_weight_scale_offset(int B, int64_t N);   /* byte offset of scale[B] inside the workspace; < 0: bad B / N */
