@@ -414,44 +414,22 @@ __device__ __forceinline__ double mixture_pdf2(const Pdf2& m, double e0, double 
     return total;
 }
 
-// The same density with the components' constants given by the caller -- cw_d 2^-k, the launch's power of two folded in ONCE
-// per thread (GSE_OP_WEIGHT_SCALE, below): a scaling by a power of two is exact, so every term and the sum carry the mantissa of
-// mixture_pdf2 (k = 0: the same bits) while the EXPONENT stays inside what an fp32 weight can hold.
-template <int kNd>
-__device__ __forceinline__ double mixture_pdf2_cw(const Pdf2& m, const double (&cw)[GSE_MAX_ND], double e0, double e1) {
-#pragma clang fp contract(off)
-    double total = 0.0;
-    const int nd = kNd > 0 ? kNd : m.nd;
-    for (int d = 0; d < nd; ++d) {
-        const double a0 = e0 - m.mean[d][0], a1 = e1 - m.mean[d][1];
-        const double t0 = a0 * m.inv[d][0][0] + a1 * m.inv[d][1][0];
-        const double t1 = a0 * m.inv[d][0][1] + a1 * m.inv[d][1][1];
-        const double q = t0 * a0 + t1 * a1;
-        const double term = cw[d] * exp(-0.5 * q);
-        total = (d == 0) ? term : total + term;
-    }
-    return total;
-}
-template <int kNd>
-__device__ __forceinline__ void scaled_constants(const Pdf2& m, int kexp, double (&cw)[GSE_MAX_ND]) {
-#pragma unroll
-    for (int d = 0; d < GSE_MAX_ND; ++d) cw[d] = (kNd > 0 && d >= kNd) ? 0.0 : ldexp(m.cw[d], -kexp);
-}
 
 // The reference keeps its weights in fp64 after the first resample (filter/particle.py:103, :316: numpy.full / cupy.full
 // without a dtype), so ``w *= pdf`` survives likelihoods down to 1e-308; fp32 storage flushes everything below 1e-38 N to
 // zero -- after a jump of the measurement EVERY particle, the weights sum to zero and the run forks from the reference's.
-// GSE_OP_WEIGHT_SCALE restores the range with a launch-uniform power of two: the update multiplies by pdf * 2^-k.  k comes
+// GSE_OP_WEIGHT_SCALE restores the range with a launch-uniform power of two: the update stores fp32(w pdf 2^-k).  k comes
 // from an ANCHOR every workgroup of the launch evaluates identically: 64 particles spread evenly over the ensemble as the
-// launch found it (x_in, which such a launch does not write), each scored by the binary exponent of its OLD weight plus that
-// of its likelihood under the new measurement -- estimated without an exponential as max_d (log2 cw_d - q_d / (2 ln 2)) --
-// and the best-scoring one (the sample that matters most to the posterior) fixes k so that ITS new weight is about 1 / N.
-// Resampling, normalised estimates and the offspring counts are invariant under the scale; what is not (the un-normalised
-// sums of point_estimate between update and resample, the island weight of a shard) reads the accumulated exponent from the
-// workspace.  While the anchor's likelihood is 2^-kWeightScaleFrom or more nothing is scaled (k = 0): every launch whose
-// weights fp32 holds anyway produces the bits it produced before.  Limits: fp32 spans 2^-149 .. 2^127 around the anchor;
-// particles lighter than that flush (harmless), heavier ones saturate at the largest finite fp32 value instead of
-// overflowing (an ensemble whose modes lie hundreds of standard deviations apart can hold both ends only in fp64).
+// launch found it, each scored by the binary exponent of its OLD weight plus that of its likelihood under the new measurement
+// after this launch's model step -- estimated without an exponential as max_d (log2 cw_d - q_d / (2 ln 2)) -- and the
+// best-scoring one (the sample that matters most to the posterior) fixes k so that ITS new weight is about 1 / N.  (The
+// samples travel from launch to launch beside the scan slots, GSE_OP_SAMPLES; a launch that updates without a resample in
+// front of it, where 64 samples need not see the heavy particles, takes the maximum over ALL particles from a pass of its
+// own: gse_pf_kernels.h.)  Resampling, normalised estimates and the offspring counts are invariant under the scale; what is
+// not (the un-normalised sums of point_estimate between update and resample, the island weight of a shard) reads the
+// accumulated exponent from the workspace.  While the anchor's likelihood is 2^-kWeightScaleFrom or more nothing is scaled
+// (k = 0): every launch whose weights fp32 holds anyway produces the bits it produced before.  fp32 spans 2^-149 .. 2^127
+// around the anchor: particles lighter than that flush (harmless -- they are that far below the posterior's mass).
 constexpr int kWeightScaleFrom = 40;
 constexpr int kWeightScaleMin = -1000;      // (2^1000 cw still finite; fp64 exp() has underflowed long before)
 constexpr int kScaleSamples = 64;

@@ -285,7 +285,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
                     "%s: without gather the step is in place: x_out must equal x_in (except predict + update with "
                     "GSE_OP_WEIGHT_SCALE, which must NOT be in place)", fn);
         GSE_REQUIRE(!((ops & GSE_OP_WEIGHT_SCALE) && U) || x_out != x_in,
-                    "%s: with GSE_OP_WEIGHT_SCALE a launch that predicts and updates reads the scale's anchor (particle 0) from "
+                    "%s: with GSE_OP_WEIGHT_SCALE a launch that predicts and updates reads the scale's sample particles from "
                     "x_in while other workgroups write x_out: the two must be separate buffers", fn);
         if (noise) {
             GSE_REQUIRE(aligned16(noise), "%s: noise must be 16-byte aligned", fn);

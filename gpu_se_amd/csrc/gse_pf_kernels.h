@@ -675,7 +675,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
         for (int i = 0; i < kMaxChunk; ++i) sv[i] = (i < m && qlo + i < T) ? sums[qlo + i] : 0.0;
     }
-    // ---- GSE_OP_WEIGHT_SCALE: the launch's binary exponent (scale_samples_load / scale_exponent_of above).  Wavefront 0 of
+    // ---- GSE_OP_WEIGHT_SCALE: the launch's binary exponent (scale_samples_load / scale_exponent_of above).  One wavefront (kScaleWave) of
     //      every workgroup requests the 64 samples HERE, with the tile sums, and turns them into k after the gather stage.
     ScaleSample ssm;
     constexpr int kScaleWave = GSE_SCALE_WAVE;       // which wavefront evaluates the anchor (wavefront 0 has thread 0's chores already)
@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
     }
     if (kDraw && draw_at == 2 && !drawn2) draw_all();      // (weights that do not sum to a positive number: no search)
     GSE_STAMP(4);
-    // GSE_OP_WEIGHT_SCALE: the launch's binary exponent, from the samples wavefront 0 requested at kernel entry.  The other
+    // GSE_OP_WEIGHT_SCALE: the launch's binary exponent, from the samples wavefront kScaleWave requested at kernel entry.  The other
     // wavefronts must not WAIT for it here: a barrier at this point lines the four wavefronts up again just before the state
     // loads and costs the launch 2.7 % (A/B on one box: 67.5 us against 65.8 at 2^22, profiles/r04_scale_ab.txt; the arithmetic
     // itself is free).  In the strided variants -- every launch that gathers or draws -- the update stage exchanges the new
@@ -1235,7 +1235,7 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
 #pragma unroll
             for (int p = 0; p < kPerThread; ++p) wtile[tid + p * kBlock] = wd[p];
             __syncthreads();
-            if (a.wscale) kexp = kexp_s;                    // (written by wavefront 0 before it came to this barrier)
+            if (a.wscale) kexp = kexp_s;                    // (written by wavefront kScaleWave before it came to this barrier)
             const double2 t01 = *reinterpret_cast<const double2*>(&wtile[tid * kPerThread]);
             const double2 t23 = *reinterpret_cast<const double2*>(&wtile[tid * kPerThread + 2]);
             wnew[0] = (float)ldexp(t01.x, -kexp); wnew[1] = (float)ldexp(t01.y, -kexp);
