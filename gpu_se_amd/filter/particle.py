@@ -239,7 +239,7 @@ class ParallelParticleFilter:
         if ops and update is not None and not gather and self._w_uniform:
             ops |= _lib.GSE_OP_UNIFORM_WEIGHTS              # (the scale's samples say enough: no pass over all particles first)
         # (predict + update without a gather is out of place too when the weights are scaled: the launch reads the scale's
-        #  anchor, particle 0, from x_in while other workgroups write their new states)
+        #  sample particles from x_in while other workgroups write their new states)
         swap_x = gather or (bool(ops) and update is not None and self._pend_predict is not None)
         x_in = self._x
         x_out = self._x_alt if swap_x else self._x

@@ -186,10 +186,12 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
                                  /*  GATHER | PREDICT | UPDATE | SCAN_IN | SCAN_OUT)                             */
 /* The reference's weight RANGE (filter/particle.py:103, :316 re-create the weights as fp64 after every resample, so
  * ``weights *= pdf`` at :294 survives likelihoods down to 1e-308; fp32 storage flushes below 1e-38 N):
- *   GSE_OP_WEIGHT_SCALE  (with UPDATE: multiplies by pdf * 2^-k instead of pdf, k = the binary exponent of the likelihood at
- *                    particle 0 of the filter as the launch found it -- one value per filter and launch, a power of two, so no
- *                    mantissa bit of any weight changes; k = 0 unless that likelihood is below 2^-40, i.e. launches whose
- *                    weights fp32 holds anyway are bit for bit what they are without the flag) the accumulated exponent
+ *   GSE_OP_WEIGHT_SCALE  (with UPDATE: stores fp32(w * pdf * 2^-k) instead of fp32(w * pdf), k = the binary exponent that
+ *                    brings the best of 64 sample particles of the filter -- old weight x likelihood after this launch's model
+ *                    step -- to about 1 / N: one value per filter and launch, a power of two, so no mantissa bit of any weight
+ *                    changes; k = 0 unless that likelihood is below 2^-40, i.e. launches whose weights fp32 holds anyway are
+ *                    bit for bit what they are without the flag; an UPDATE without GATHER looks at ALL particles first, see
+ *                    GSE_OP_UNIFORM_WEIGHTS) the accumulated exponent
  *                    lives in the workspace at gse_workspace_weight_scale_offset(B, N): [B] doubles, true weight = stored
  *                    weight * 2^scale[b].  The CALLER zeroes it when it sets the weights itself; UPDATE adds its k, GATHER
  *                    resets it (offspring weigh 1 / N); the island bookkeeping includes it.  Everything normalised (resampling,
