@@ -160,6 +160,10 @@ class ParallelParticleFilter:
     def _fill(self, buf, values, width):
         B = self._B
         if B == 1:
+            if type(values) in (list, tuple) and len(values) == width:     # (the common call: a short list of Python floats)
+                for i in range(width):
+                    buf[i] = values[i]
+                return
             flat = numpy.asarray(values, dtype=numpy.float64).reshape(-1)
             for i in range(width):
                 buf[i] = flat[i]
@@ -172,6 +176,8 @@ class ParallelParticleFilter:
 
     def _host_u(self, u):
         """Inputs as the kernels take them: two per filter (a user model with one input gets a zero for the other)."""
+        if self._B == 1 and self._model is None and type(u) in (list, tuple) and len(u) == 2:
+            return (float(u[0]), float(u[1]))
         a = numpy.asarray(u, dtype=numpy.float64)
         if self._model is not None and self._model.nu < _lib.GSE_NU:
             a = a.reshape(-1, self._model.nu) if self._B > 1 else a.reshape(1, -1)
