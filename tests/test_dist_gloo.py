@@ -228,3 +228,34 @@ def test_exact_resample_exchange_over_gloo():
         assert same.mean() > 0.999
         moved += int(np.sum((anc[lo:lo + cnt] < lo) | (anc[lo:lo + cnt] >= lo + cnt)))
     assert moved > 0                                                # particles did cross ranks
+
+
+def test_island_policy_reads_the_shares_at_a_fixed_lag():
+    """On device groups the exchanged log-weights come back through pinned memory and the policy looks at them
+    ``shares_lag`` resamples after the exchange -- a function of the resample COUNT alone, so every rank decides at the same
+    resample whatever its side stream has or has not finished (host logic only: the event is a stand-in)."""
+    class Event:
+        waited = 0
+
+        def synchronize(self):
+            Event.waited += 1
+
+    shard = object.__new__(gd.ShardedParticleFilter)
+    shard.world, shard.reduce_every, shard.ess_fraction = 4, 8, 0.5
+    shard._shares_event, shard._shares_host = Event(), torch.tensor([0.0, -50.0, -50.0, -50.0], dtype=torch.float64)
+    shard._force_exact, shard.last_island_ess = False, 4.0
+    assert shard.shares_lag == 4
+    shard._shares_cycle, shard._resamples = 16, 16
+    for count in range(16, 20):                              # nothing is read before the lag has passed
+        shard._resamples = count
+        shard._consider_shares()
+        assert shard._shares_cycle == 16 and Event.waited == 0 and not shard._force_exact
+    shard._resamples = 20
+    shard._consider_shares()
+    assert shard._shares_cycle is None and Event.waited == 1
+    assert shard.last_island_ess < 0.5 * 4 and shard._force_exact      # one island carries everything: the next resample is exact
+    for every, lag in ((1, 1), (2, 1), (5, 4), (32, 4)):
+        shard.reduce_every = every
+        assert shard.shares_lag == lag
+    shard._shares_event = None                                # host groups (gloo): the old one-cycle lag
+    assert shard.shares_lag == 1
