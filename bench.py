@@ -284,7 +284,8 @@ def gsukf_block(torch, sizes=(64, 4096, 1 << 16, 1 << 18)):
         if n <= 64:
             entry["bound"] = "launch latency (one launch, one workgroup): no roofline fraction"
         elif n <= 4096:
-            entry["bound"] = "launch latency (two launches per cycle): no roofline fraction"
+            entry["bound"] = "launch latency (%s per cycle): no roofline fraction" % (
+                "one launch" if getattr(gf, "_cycle_lanes", False) else "two launches")
         else:
             gbs = GSUKF_ALG_BYTES * n / dev / 1e9
             entry.update({"achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),

@@ -148,15 +148,19 @@ static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w,
     // with a workspace the launch also leaves the quarter sums of the new weights there (gse_gsukf_resample_begin_sums)
     // (... and the quads' prefixes inside their quarters: what gse_gsukf_cycle_lanes resamples from)
     double *quarters = nullptr, *quads = nullptr;
+    dim3 grid_sums = grid;
     if (workspace) {
         const Workspace ws = carve_workspace(workspace, B, N);
         quarters = gsukf_quarter_sums(ws, slot);
         quads = gsukf_quad_prefix(ws, slot);
+        // every quarter of every tile gets its sum, also the quarters of the last tile that hold no Gaussian (0): the consumers
+        // read four per tile
+        grid_sums.x = (unsigned)(4 * tiles_of(N));
     }
     if (noise) {
         a.pred.draw = DrawParams{};
         a.pred.rng = RngKey{};
-        return launch(model, "gse::gsukf_predict_update_lanes_kernel<true>", gsukf_predict_update_lanes_kernel<true>, grid, block, st,
+        return launch(model, "gse::gsukf_predict_update_lanes_kernel<true>", gsukf_predict_update_lanes_kernel<true>, grid_sums, block, st,
                       mu, P, w, noise, N, status, mu_in, P_in, anc, quarters, quads, a);
     }
     if (int rc = check_mixture("gse_gsukf_predict_update", state_pdf, nx)) return rc;
@@ -164,9 +168,9 @@ static int gsukf_predict_update(UserModel* model, float* mu, float* P, float* w,
     a.pred.rng = make_rng_key(*rng, kPurposeGsukf);
     const float* none = nullptr;
     if (a.pred.draw.diagonal)
-        return launch(model, "gse::gsukf_predict_update_lanes_kernel<false, 1>", gsukf_predict_update_lanes_kernel<false, 1>, grid,
+        return launch(model, "gse::gsukf_predict_update_lanes_kernel<false, 1>", gsukf_predict_update_lanes_kernel<false, 1>, grid_sums,
                       block, st, mu, P, w, none, N, status, mu_in, P_in, anc, quarters, quads, a);
-    return launch(model, "gse::gsukf_predict_update_lanes_kernel<false, 0>", gsukf_predict_update_lanes_kernel<false, 0>, grid, block,
+    return launch(model, "gse::gsukf_predict_update_lanes_kernel<false, 0>", gsukf_predict_update_lanes_kernel<false, 0>, grid_sums, block,
                   st, mu, P, w, none, N, status, mu_in, P_in, anc, quarters, quads, a);
 }
 
@@ -406,7 +410,7 @@ int gse_gsukf_cycle_lanes(const float* mu_in, const float* P_in, const float* w_
     GSE_REQUIRE(aligned16(workspace) && aligned16(w_in), "%s: workspace and w_in must be 16-byte aligned", fn);
     const int T = (int)tiles_of(N);
     GSE_REQUIRE(N % 4 == 0 && T <= kCycleLanesMaxT && lane_per_gaussian(B, N),
-                "%s: for banks of 4097 .. %d Gaussians, N a multiple of 4 (otherwise gse_gsukf_resample_begin_slot + "
+                "%s: for banks of 65 .. %d Gaussians, N a multiple of 4 (otherwise gse_gsukf_resample_begin_slot + "
                 "gse_gsukf_predict_update_sums)", fn, kCycleLanesMaxT * kTile);
     GSE_REQUIRE(noise || (state_pdf && rng), "%s: need either noise or (state_pdf, rng)", fn);
     if (int rc = check_mixture(fn, measurement_pdf, GSE_NY)) return rc;

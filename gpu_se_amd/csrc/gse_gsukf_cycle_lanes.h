@@ -9,8 +9,8 @@
 // look-up path for wide ranges) on the weights, quarter sums and quad prefixes of the previous launch: the launch of its own,
 // and the gap in front of it, are gone.  Same ancestors as ancestors_scatter_kernel bit for bit (both re-form cumsum_kernel's
 // keys), hence the same bank.  It pays while the bank leaves the chip room -- up to 2^17 Gaussians, two workgroups per CU in one
-// generation: 14.1 / 14.3 / 16.6 / 22.4 us per cycle at 5 000 / 2^14 / 2^16 / 2^17 Gaussians for 16.4 / 16.2 / 18.3 / 23.6 of
-// the two launches -- and not beyond: this kernel is bound by its instruction count at two wavefronts per SIMD, and while one
+// generation: 13.1 / 13.6 / 14.3 / 16.6 / 22.4 us per cycle at 300 / 4096 / 2^14 / 2^16 / 2^17 Gaussians for 16.2 / 18.6 /
+// 16.2 / 18.3 / 23.6 of the two launches -- and not beyond: this kernel is bound by its instruction count at two wavefronts per SIMD, and while one
 // of the two waits through the gather stage's chain of latencies the SIMD issues at half its rate (2^18: 40.0 us for 37.9;
 // 43 / 35 us with / without the stage under the profiler, whichever order the workgroups of a CU take noise and gather in).
 // The class therefore uses it for banks of at most 512 workgroups (filter/gs_ukf.py).

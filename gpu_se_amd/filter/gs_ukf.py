@@ -86,8 +86,9 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         # (policy: while the launch leaves the chip room -- at most 512 workgroups of 256 Gaussians, two per CU; beyond, the
         #  kernel is bound by its instruction count and the two launches are faster: gse_gsukf_cycle_lanes.h)
         tiles = (n + _lib.GSE_TILE - 1) // _lib.GSE_TILE
-        self._cycle_lanes = (self._model is None and n > _lib.GSE_SMALL_RESAMPLE_MAX and n % 4 == 0 and
-                             tiles <= _lib.GSE_CYCLE_LANES_MAX_TILES and 4 * tiles * B <= _lib.GSE_CYCLE_LANES_MAX_WORKGROUPS)
+        self._cycle_lanes = (self._model is None and B * n >= _lib.GSE_GSUKF_LANES_MIN and n > _lib.GSE_GSUKF_CYCLE_MAX and
+                             n % 4 == 0 and tiles <= _lib.GSE_CYCLE_LANES_MAX_TILES and
+                             4 * tiles * B <= _lib.GSE_CYCLE_LANES_MAX_WORKGROUPS)
         self._sums_ok = True                          # ... may be used at all: not once a writable view of the weights is out
         self.record_ancestors = False                 # True: every resample's ancestors [B, N] int32 are kept in
         self.ancestor_log = []                        # ancestor_log (device tensors; parity tests of whole loops)
@@ -332,7 +333,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         args = (self._means.data_ptr(), self._covs.data_ptr(), idx.data_ptr() if idx is not None else None, out_m.data_ptr(),
                 out_c.data_ptr(), self._w.data_ptr(), self._B, self.N_particles, u_arg, float(dt), z_arg, self._w_sigma_c, pod, rng,
                 noise, ctypes.byref(self.measurement_pdf._pod()), self._status.data_ptr())
-        if self._model is None and self.N_particles > _lib.GSE_SMALL_RESAMPLE_MAX and self._sums_ok:
+        if self._model is None and (self.N_particles > _lib.GSE_SMALL_RESAMPLE_MAX or self._cycle_lanes) and self._sums_ok:
             # ... and leaves the quarter sums of the new weights in the workspace: the resample that follows needs no
             # tile-sum launch (valid until anything else touches the weights or the workspace)
             self._call("gse_gsukf_predict_update_sums", *args, self._ws.data_ptr(), where, stream_ptr())

@@ -347,7 +347,7 @@ int gse_gsukf_resample_begin_sums(const float *w, float *w_out, int32_t *idx, in
 /* Two slots for those sums (with every quad's exclusive prefix inside its quarter beside them), so that ONE launch can resample
  * from the sums of the previous update while it leaves those of its own: gse_gsukf_predict_update_sums takes
  * GSE_IO_SUMS_SLOT1 in `where`; gse_gsukf_resample_begin_slot reads the slot it is told; and
- * gse_gsukf_cycle_lanes is resample(r) + predict(u, dt) + update(u, z) of a bank of 4097 .. 2^18 Gaussians (N a multiple of 4,
+ * gse_gsukf_cycle_lanes is resample(r) + predict(u, dt) + update(u, z) of a bank of 65 .. 2^18 Gaussians (N a multiple of 4,
  * the built-in model) in one launch: the ancestors are found by the workgroups of the predict + update kernel themselves
  * (the gather stage of the particle filter's cluster kernels), from w_in and the sums of slot 0 (1 with GSE_IO_SUMS_SLOT1);
  * the bank is read from (mu_in, P_in) at its ancestors' rows, results and new weights go to (mu, P, w_out), the new sums to

@@ -404,7 +404,8 @@ def test_large_bank_deferred_resample_equals_the_eager_calls():
 
 
 @pytest.mark.parametrize("n,batch,deterministic", [((1 << 16) + 100, None, False), (12 * 1024 + 4, 2, False),
-                                                   (1 << 18, None, False), (20 * 1024, None, True)])
+                                                   (1 << 18, None, False), (20 * 1024, None, True), (300, None, False),
+                                                   (2048 + 4, 2, False)])
 def test_one_launch_cycle_of_a_large_bank_equals_the_two_launches(n, batch, deterministic):
     """gse_gsukf_cycle_lanes (round 4): resample + predict + update of a large bank in ONE launch -- the workgroups of the
     one-lane-per-Gaussian kernel find the ancestors of their own 256 Gaussians with the gather stage of the particle filter's
