@@ -272,7 +272,7 @@ def gsukf_block(torch, sizes=(64, 4096, 1 << 16, 1 << 18)):
             gf.predict(u, 0.1); gf.update(u, z); gf.resample()
         # (setting a bank up leaves the device idle for a while: 200 untimed cycles -- 9 ms at 2^18 -- clock it up again, as
         #  device_warm_up does for the particle filter's figure; tools/gsf_bench.py has always measured this way)
-        for i in range(200):
+        for i in range(200 if n > 4096 else 2000):          # (small banks: 2000 x 11 us, or the clocks are still on their way up)
             cycle(i)
         reps = 300
         t0 = time.perf_counter()
