@@ -8,10 +8,12 @@ API -> ctypes C ABI -> HIP kernels.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
          bench.py --gpus N --steps K --warmup W          (the driver's form: RANK / WORLD_SIZE come from the env)
 
-N > 1: one process per GPU, each rank owns a contiguous shard of ONE big ensemble (weak scaling: 2^20 particles per
-rank; at N = 8 the default is 2^21 per rank = 2^24 in total, BASELINE config 4), independent Philox sub-streams, island
-resampling; the only collective is a small asynchronous RCCL all-reduce of the shards' log-weights every 32nd cycle and
-the posterior merge at estimates.  Rank 0 prints ONE JSON line.
+N > 1: one process per GPU, each rank owns a contiguous shard of ONE big ensemble (weak scaling: 2^20 particles per rank for
+EVERY N, so that the driver's 1 / 2 / 4 / 8 series is one workload), independent Philox sub-streams, island resampling; the only
+collective is a small asynchronous RCCL all-reduce of the shards' log-weights every 32nd cycle and the posterior merge at
+estimates.  Beside `value` the line of an N > 1 run carries `config4_shape` (2^21 particles per rank: BASELINE
+config 4 at N = 8) and `config5` (32 closed-loop rollouts x 2^18 particles per rank: BASELINE config 5 at N = 8).  Rank 0 prints
+ONE JSON line.
 
 `value` is the whole job's throughput in the metric's unit: particle-cycles per second over all ranks divided by 2^20,
 i.e. "cycles per second of 2^20-particle filters" -- at N = 1 with 2^20 particles exactly the cycles per second of
@@ -43,7 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log2-particles", type=float, default=None,
-                    help="particles per GPU = 2^this (default 20; 21 with --gpus 8: BASELINE config 4)")
+                    help="particles per GPU = 2^this (default 20 for every --gpus N)")
     ap.add_argument("--burn-in", type=int, default=0,
                     help="extra untimed cycles before the W warm-up steps (default 0: `value` is measured on a filter drawn "
                          "from its prior, SURVEY 8d; the running-estimator figure is reported beside it as `steady_state`)")
@@ -55,7 +57,7 @@ def parse():
                          "all-to-all of particles over xGMI) instead of the default island resampling")
     args = ap.parse_args()
     if args.log2_particles is None:
-        args.log2_particles = 21.0 if args.gpus == 8 else 20.0
+        args.log2_particles = 20.0
     return args
 
 
@@ -134,11 +136,14 @@ def device_warm_up(torch, n, dt, cycles=500):
     return cycles
 
 
+CYCLE_KERNEL_SOURCES = ("gse_pf_kernels.h", "gse_device.h", "gse_host.h", "gse_merge_device.h", "gse_pf.hip")
+
+
 def csrc_hash():
-    """sha256 over the kernel sources and the ABI header: ties a committed profile to the build it was taken on."""
+    """sha256 over the sources the cycle kernel is compiled from and the ABI header: ties a committed PMC profile to the build
+    it was taken on (the other translation units do not touch that kernel)."""
     h = hashlib.sha256()
-    files = sorted(os.listdir(os.path.join(ROOT, "gpu_se_amd", "csrc")))
-    for name in files:
+    for name in sorted(CYCLE_KERNEL_SOURCES):
         with open(os.path.join(ROOT, "gpu_se_amd", "csrc", name), "rb") as fh:
             h.update(name.encode() + b"\0" + fh.read())
     with open(os.path.join(ROOT, "include", "gse.h"), "rb") as fh:
@@ -148,13 +153,17 @@ def csrc_hash():
 
 def pmc_traffic(n):
     """HBM bytes per launch of the cycle kernel from the committed PMC profile (rocprofv3 cannot run inside this
-    process): profiles/pmc_traffic.json, valid for N = 2^20 and for the sources whose hash it records."""
+    process): profiles/pmc_traffic.json, per size (N = 2^20, 2^21), with the hash of the sources it was taken on."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if n != 1 << 20 or not os.path.exists(path):
+    if not os.path.exists(path):
         return None, None
     with open(path) as fh:
         d = json.load(fh)
-    return d.get("traffic_bytes_per_launch"), d.get("csrc_sha256_16")
+    by_n = d.get("by_n") or ({str(1 << 20): d} if "traffic_bytes_per_launch" in d else {})
+    e = by_n.get(str(n))
+    if e is None:
+        return None, None
+    return e.get("traffic_bytes_per_launch"), e.get("csrc_sha256_16")
 
 
 def time_method_events(torch, fn, reps):
@@ -381,6 +390,54 @@ def closed_loop_block(torch, B=32, log2n=18, end_time=50, pf=True):
             "reference_ITSE": reference_itse(pf, 1 << log2n)}
 
 
+def config5_block(torch, dist, world, rank, rehearsal, B=32, log2n=18, end_time=50, base_seed=1000):
+    """BASELINE config 5 (256 stochastic closed-loop rollouts x 2^18 particles on 8 GPUs) at its per-rank shape: every rank runs
+    BatchedSimulation(batch=32, N=2^18, resident=True) with seed = base + rank -- independent replicas, no collective until the
+    gather of the ITSE scalars -- between a barrier + synchronize on both sides; wall = max over the ranks.  Protocol:
+    results/pf_closedloop/bioreactor_performance_pf.py:19-58, :104-118 (Monte-Carlo repetitions of the closed loop)."""
+    import gpu_se_amd
+    from gpu_se_amd import sim_base
+    gpu_se_amd.seed(base_seed + rank)
+    sim = sim_base.BatchedSimulation(batch=B, N_particles=1 << log2n, dt_control=0.1, dt_predict=0.1, end_time=end_time,
+                                     seed=base_seed + rank, resident=True, pf=True)
+    sim.K._device_law()
+    warm = sim_base.BatchedSimulation(batch=B, N_particles=1 << 10, dt_control=0.1, dt_predict=0.1, end_time=2,
+                                      seed=base_seed + 500 + rank, resident=True, pf=True)
+    warm.K = sim.K
+    warm.simulate()                                 # (loads every kernel of the loop before the clock starts)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sim.simulate()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev = "cpu" if rehearsal else "cuda"
+    worst = torch.tensor([wall, float(sim.timing["device_loop"])], dtype=torch.float64, device=dev)
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    scores = [torch.zeros(B, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(scores, torch.as_tensor(np.asarray(sim.performance, dtype=np.float64), device=dev))
+    solved = torch.tensor([float(sim.mpc_frac)], dtype=torch.float64, device=dev)
+    dist.all_reduce(solved, op=dist.ReduceOp.MIN)
+    allp = torch.cat(scores).cpu().numpy()
+    ticks = len(sim.ts) - 1
+    wall, dev_s = float(worst[0].item()), float(worst[1].item())
+    return {"workload": "closed-loop MPC + PF: %d rollouts x 2^%d particles on %d ranks (%d per rank%s), %d ticks, MPC every tick, "
+                        "resident on the device" % (world * B, log2n, world, B, ": BASELINE config 5" if world == 8 else "", ticks),
+            "rollouts": world * B, "rollouts_per_rank": B, "particles_per_rollout": 1 << log2n, "ticks": ticks,
+            "wall_s": round(wall, 4), "device_s_slowest_rank": round(dev_s, 4),
+            "rollout_ticks_per_s": round(world * B * ticks / wall, 1),
+            "particle_cycles_per_s": round(world * B * ticks * float(1 << log2n) / wall, 1),
+            "seeds": "base %d + rank (gpu_se_amd.seed and the simulation's own)" % base_seed,
+            "median_ITSE": float(np.median(allp)), "ITSE_q10_q90": [float(q) for q in np.quantile(allp, [0.1, 0.9])],
+            "distinct_ITSE_values": int(len(np.unique(allp))),
+            "mpc_solved_fraction_min_over_ranks": round(float(solved.item()), 4),
+            "collectives": "none in the loops; one all-gather of %d ITSE scalars per rank at the end" % B,
+            "reference_ITSE": reference_itse(True, 1 << log2n)}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -426,6 +483,32 @@ def main():
     dt = 1.0                                                    # pf_run_seq.py:48
     io = make_inputs(burn_in + steps + warmup, dt)
 
+    def bracket(fn, first, count, spf):
+        """`count` calls fn(first), fn(first + 1), ... bracketed by barrier + synchronize on both sides; seconds, max over ranks."""
+        spf.wait_collectives()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        before = spf.collectives_issued
+        t0 = time.perf_counter()
+        for i in range(first, first + count):
+            fn(i)
+        spf.wait_collectives()
+        # (the stream is polled until the last cycle has ended, then the bracket's synchronisations find nothing left to wait for:
+        #  a blocking wait alone adds its wake-up latency -- 20-40 us, a tenth of the driver's K = 20 cycles -- to the timed region)
+        gpu_se_amd.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, spf.collectives_issued - before
+
     def cycle(i):
         u, z = io[i]
         pf.predict(u, dt)
@@ -448,39 +531,20 @@ def main():
         # (one untimed exchange of the shards' log-weights: the first collective on a buffer sets its channels up -- warm-up,
         #  as the W cycles are for the kernels; the timed region issues its own, counted below)
         pf._exchange_shares()
-    pf.wait_collectives()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    collectives_before = pf.collectives_issued
-    t0 = time.perf_counter()
-    for i in range(warmup, warmup + steps):
-        cycle(i)
-    pf.wait_collectives()
-    # (the stream is polled until the last cycle has ended, then the bracket's synchronisations find nothing left to wait for:
-    #  a blocking wait alone adds its wake-up latency -- 20-40 us, a tenth of the driver's K = 20 cycles -- to the timed region)
-    gpu_se_amd.synchronize()
-    if world > 1:
-        torch.cuda.synchronize()
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    collectives_timed = pf.collectives_issued - collectives_before
+    elapsed, collectives_timed = bracket(cycle, warmup, steps, pf)
     est = pf.point_estimate()                                   # merges the shards (all-reduce of the moments)
     assert np.all(np.isfinite(est)), est
 
     # ---- the same cycles, each ENDING IN THE POSTERIOR MERGE (the reference's loop asks for an estimate every tick,
-    #      sim_base.py:262, :287-295): moments of the shard, its row of the merge buffer, the all-reduce of [P][22] doubles
-    #      (asynchronous on RCCL), the combination -- all on the device, stream-ordered, nothing comes to the host
-    #      (ShardedParticleFilter.merge_begin / merge_end).  Same bracket as above: barrier + synchronize on both sides, max
-    #      over the ranks.
+    #      sim_base.py:262, :287-295).  Round 5: nothing is flushed -- the cycle's ONE launch, then ONE more (gse_pf_merge_begin:
+    #      the moments of the ensemble the pending resample will produce, its last workgroup finishes them and writes the
+    #      shard's row), the all-reduce of [P][22] doubles (asynchronous on RCCL), and with more than one rank gse_merge_end
+    #      (combination + estimate); a single shard is combined by the first launch.  The merged moments of every cycle go to
+    #      a record row; the covariance sizes of all rows come from one gse_moments_estimates call at the end of the region, as
+    #      in the resident closed loops.  Stream-ordered, nothing comes to the host.  Same bracket as above.
     io2 = make_inputs(steps + 5, dt, seed=11)
-    sink = torch.zeros((1, 6), dtype=torch.float64, device="cuda")
+    record = torch.zeros((steps + 5, 26), dtype=torch.float64, device="cuda")
+    sizes = torch.zeros((steps + 5, 6), dtype=torch.float64, device="cuda")
     from gpu_se_amd import _lib as _gl
 
     def cycle_with_estimate(i):
@@ -488,33 +552,52 @@ def main():
         pf.predict(u, dt)
         pf.update(u, z)
         pf.resample()
-        pf.merge_begin()
-        m = pf.merge_end()
-        _gl.call("gse_moments_estimates", m.data_ptr(), 1, sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        pf.merge_begin(into=record[i])
+        pf.merge_end()
+        if i == steps + 4:
+            _gl.call("gse_moments_estimates", record.data_ptr(), steps + 5, sizes.data_ptr(), torch.cuda.current_stream().cuda_stream)
     for i in range(5):
         cycle_with_estimate(i)
-    pf.wait_collectives()
-    torch.cuda.synchronize()
+    elapsed_est, collectives_est = bracket(cycle_with_estimate, 5, steps, pf)
+    est_rows = sizes.cpu().numpy()
+    assert np.all(np.isfinite(est_rows)) and np.all(est_rows[:, 5] > 0), "merged estimates are not finite"
+    assert np.allclose(est_rows[-1, :5], pf.estimate_device.cpu().numpy()[:5], rtol=1e-12)
+
+    # ---- N > 1 only: the two multi-GPU configurations of BASELINE.json at their per-rank shapes, as blocks of the same line
+    config4 = config5 = None
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    collectives_before = pf.collectives_issued
-    t1 = time.perf_counter()
-    for i in range(5, 5 + steps):
-        cycle_with_estimate(i)
-    pf.wait_collectives()
-    gpu_se_amd.synchronize()
-    if world > 1:
-        torch.cuda.synchronize()
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed_est = time.perf_counter() - t1
-    if world > 1:
-        tt = torch.tensor([elapsed_est], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed_est = float(tt.item())
-    collectives_est = pf.collectives_issued - collectives_before
-    assert np.all(np.isfinite(sink.cpu().numpy())), "merged estimate is not finite"
+        # config 4: 2^24 particles over 8 GPUs = 2^21 per rank (here: 2^21 per rank on however many ranks there are)
+        n4 = 1 << 21
+        gpu_se_amd.seed(4321)
+        pf4 = ShardedParticleFilter.from_get_parts(n_local=n4, group=dist.group.WORLD)
+        pf4.reduce_every = pf.reduce_every
+        io4 = make_inputs(steps + warmup, dt, seed=21)
+
+        def cycle4(i):
+            u, z = io4[i]
+            pf4.predict(u, dt)
+            pf4.update(u, z)
+            pf4.resample()
+        for i in range(warmup):
+            cycle4(i)
+        pf4._exchange_shares()
+        el4, coll4 = bracket(cycle4, warmup, steps, pf4)
+        est4 = pf4.point_estimate()
+        assert np.all(np.isfinite(est4)), est4
+        config4 = {"workload": "PF N=2^%d particles sharded over %d ranks (2^21 per rank%s), island resampling, posterior merge at "
+                               "the end" % (21 + int(np.log2(world)) if (world & (world - 1)) == 0 else 0, world,
+                                            ": BASELINE config 4" if world == 8 else ""),
+                   "particles_per_rank": n4, "total_particles": n4 * world, "steps": steps, "warmup": warmup,
+                   "ms_per_step": round(el4 / steps * 1e3, 5), "ensemble_cycles_per_s": round(steps / el4, 2),
+                   "value": round(float(world) * n4 * steps / el4 / UNIT_PARTICLES, 2), "unit": "cycles/s per 2^20 particles",
+                   "collectives_in_timed_region": int(coll4), "exact_resamples": pf4.exact_resamples,
+                   "frac_vs_reference_passes": round(140.0 * n4 * steps / el4 / 1e9 / HBM_PEAK_GBS, 4)}
+        del pf4
+        # config 5: 256 closed-loop rollouts x 2^18 particles on 8 GPUs = 32 rollouts per rank, independent replicas (seed =
+        # base + rank), no collective until the final gather of the ITSE scalars
+        # (results/pf_closedloop/bioreactor_performance_pf.py:19-58, :104-118)
+        config5 = config5_block(torch, dist, world, rank, rehearsal)
+
     # what torch.distributed / RCCL saw (so that a multi-GPU line can be checked against the launcher's own record)
     rccl_info = {"initialised": bool(use_dist), "world_size": world, "backend": None, "devices": [local_rank]}
     if use_dist:
@@ -569,36 +652,43 @@ def main():
         traffic, traffic_hash = pmc_traffic(n)
         sources = csrc_hash()
         single_launch = not lp._prefix_global
-        measured = (traffic / per["cycle"] / 1e9) if (traffic and traffic_hash == sources) else None
-        roofline = {"bound": "hbm",
-                    "limited_by": "vector-instruction issue + fixed launch cost (the fused launch moves 0.38 of the algorithmic "
-                                  "bytes; see hbm_measured)",
-                    "hbm_measured": None if measured is None else
-                    {"GBps": round(measured, 1), "frac_of_peak": round(measured / HBM_PEAK_GBS, 4),
-                     "note": "PMC bytes of the committed profile / this run's device time per launch: what the launch really "
-                             "moves through HBM"},
+        current = bool(traffic) and traffic_hash == sources
+        measured = (traffic / per["cycle"] / 1e9) if traffic else None
+        # Round 5: `frac` is what the launch really moves through HBM (PMC bytes of the committed profile of
+        # THIS kernel at THIS size) / this run's device time per launch / peak -- a bandwidth, which cannot pass 1.  The figure
+        # against the reference's five passes over a particle (SURVEY 8d's 140 bytes), which CAN pass 1 because the fused launch
+        # moves 0.38 of those bytes, is `vs_reference_passes`.
+        roofline = {"bound": "valu-issue",
+                    "roofline_of": "hbm (1.8 flop/B is far below the vector ridge, SURVEY 8d): `peak`; the fused launch is limited "
+                                   "by vector-instruction issue (437 wave-instructions per particle, profiles/r04_pmc_sq.txt) and "
+                                   "its fixed launch cost, which is why it reaches `frac` of that peak with no wasted traffic "
+                                   "(traffic / algorithmic bytes = %s)" % (round(traffic / (140.0 * n), 3) if traffic else "n/a"),
                     "kernel": "pf_step_kernel<gather,predict,update,scan>" if single_launch
                     else "tile_scan_kernel (one workgroup) + pf_step_kernel<gather,predict,update,scan from the scanned tile "
                          "prefix> (two launches per cycle beyond 2^21 particles)",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic if traffic_hash == sources else None,
+                    "achieved": None if measured is None else round(measured, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": None if measured is None else round(measured / HBM_PEAK_GBS, 4),
+                    "traffic": traffic,
+                    "traffic_is_of_these_sources": current,
                     "traffic_profiled_on_csrc": traffic_hash, "csrc_sha256_16": sources,
-                    "algorithmic_bytes_per_particle": 140,
+                    "vs_reference_passes": {"algorithmic_bytes_per_particle": 140, "GBps": round(achieved, 1),
+                                            "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                            "note": "140 B x N / device time per cycle / 8 TB/s: the reference's passes (predict 40 + "
+                                                    "update 28 + resample 72 B) priced at HBM peak against ONE fused launch -- a "
+                                                    "speed-up over a pass-per-method design, not a bandwidth; may pass 1"},
                     "device_us": {k: round(v * 1e6, 2) for k, v in per.items()},
                     "measured_on": "a filter drawn from its prior, 10 warm-up cycles, %d timed cycles" % reps,
-                    "note": "achieved = 140 B x N / average launch-to-launch device time of one cycle (HIP events on "
-                            "the launch stream); traffic = PMC bytes of the committed profile, null when the kernel "
-                            "sources changed since it was taken.  The 140 bytes are the reference's five passes over a "
-                            "particle (SURVEY 8d); the fused launch really moves `traffic` (about 56 MB at 2^20, 0.38 of the "
-                            "algorithmic bytes), which is why `frac` can pass 1: the kernel is bound by its instruction count "
-                            "and fixed cost, not by HBM"}
+                    "note": "achieved = HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2-corrected + WRITE_SIZE, separate passes: "
+                            "profiles/pmc_traffic.json) / average launch-to-launch device time of one cycle (HIP events on the launch "
+                            "stream, this run); null when no profile of this size is committed; traffic_is_of_these_sources says "
+                            "whether the kernel's sources have changed since the profile was taken"}
         fresh_prior = {"cycles_per_s": round(1.0 / fresh_wall, 1), "device_us_per_cycle": round(per["cycle"] * 1e6, 2),
-                       "frac": round(achieved / HBM_PEAK_GBS, 4), "warmup": 10, "timed_cycles": reps,
+                       "frac_vs_reference_passes": round(achieved / HBM_PEAK_GBS, 4), "warmup": 10, "timed_cycles": reps,
                        "note": "SURVEY 8d protocol: particles ~ prior, 10 warm-ups, then the timed cycles back to back (one "
                                "synchronisation at the end); `value` above is the same workload at the driver's K and W"}
         steady_state = {"cycles_per_s": round(1.0 / steady_wall, 1), "device_us_per_cycle": round(steady * 1e6, 2),
-                        "achieved_GBps": round(steady_gbs, 1), "frac": round(steady_gbs / HBM_PEAK_GBS, 4),
+                        "frac_vs_reference_passes": round(steady_gbs / HBM_PEAK_GBS, 4),
+                        "hbm_frac": None if not traffic else round(traffic / steady / 1e9 / HBM_PEAK_GBS, 4),
                         "after_cycles": 2000, "timed_cycles": reps,
                         "note": "the same filter after 2000 cycles of tracking the plant (the posterior is narrow, ancestor "
                                 "ranges are 1-2 tiles): what round 2 reported as `value`"}
@@ -613,9 +703,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "ParallelParticleFilter HIP, N=2^%g particles per GPU, systematic resample (%s)"
                                    % (args.log2_particles,
-                                      "BASELINE config 4: 2^24 particles over 8 GPUs" if (world == 8 and n == 1 << 21)
-                                      else "BASELINE config 2" if (world == 1 and n == 1 << 20)
-                                      else "weak scaling of BASELINE config 2"),
+                                      "BASELINE config 2" if (world == 1 and n == 1 << 20)
+                                      else "weak scaling of BASELINE config 2: the same 2^20 particles per GPU at every N"),
                        "particles_per_gpu": n, "particles_per_rank": [cnt for _, cnt in pf._spans],
                        "total_particles": n * world, "dt": dt, "burn_in_cycles": burn_in, "reduce_every": pf.reduce_every,
                        "device_warmup_cycles": device_warmup,
@@ -634,13 +723,23 @@ def main():
                 "value": round(float(world) * n * steps / elapsed_est / UNIT_PARTICLES, 2),
                 "unit": "cycles/s per 2^20 particles", "ms_per_step": round(elapsed_est / steps * 1e3, 5),
                 "collectives_in_timed_region": int(collectives_est),
-                "note": "every cycle ends in the posterior merge over all ranks: shard moments -> merge row (device) -> all-reduce "
-                        "of [P][22] doubles (RCCL, async) -> combination (device); stream-ordered, no host copy"},
+                "launches_per_cycle": 2 if world == 1 else 3,
+                "frac_of_164B_per_particle": round(164.0 * n * steps / elapsed_est / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "every cycle ends in the posterior merge over all ranks, nothing flushed: the cycle's one launch, then "
+                        "gse_pf_merge_begin (moments of the ensemble the pending resample will produce; the launch's last workgroup "
+                        "finishes them and writes the shard's row), all-reduce of [P][22] doubles (RCCL, async), gse_merge_end "
+                        "(combination + mean; a single shard: inside the first launch); merged moments recorded per cycle, the "
+                        "covariance sizes of all rows from one gse_moments_estimates call at the end of the timed region; "
+                        "stream-ordered, no host copy.  164 B = 140 + the 24 B of a moments pass (SURVEY 8d)"},
             "roofline": roofline,
             "fresh_prior": fresh_prior,
             "steady_state": steady_state,
         }
         result["config"]["rccl"] = rccl_info
+        if config4 is not None:
+            result["config4_shape"] = config4
+        if config5 is not None:
+            result["config5"] = config5
         if world == 1 and not args.no_extras:
             result["protocol_sum_us"] = protocol_sum(torch, n, io, dt)
             result["run_cycles"] = run_cycles_block(torch, dt)

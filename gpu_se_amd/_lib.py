@@ -89,11 +89,24 @@ class PfLoopSpec(ctypes.Structure):
                 ("schedule", c_vp), ("r", c_vp), ("us", c_vp), ("xs", c_vp), ("ys", c_vp), ("ys_meas", c_vp), ("moments", c_vp),
                 ("status", c_vp),
                 ("x_current", c_i32), ("w_current", c_i32), ("pend_gather", c_i32), ("pend_predict", c_i32),
-                ("gather_slot", c_i32), ("scan_slot", c_i32), ("r_pending", c_d * GSE_MAX_B)]
+                ("gather_slot", c_i32), ("scan_slot", c_i32), ("r_pending", c_d * GSE_MAX_B),
+                ("island", c_vp), ("w_uniform", c_i32), ("reserved2", c_i32)]
 
 
 GSE_PF_LOOP_WEIGHT_SCALE = 1
 GSE_PF_LOOP_CLUSTER = 2
+
+
+class MergeSpec(ctypes.Structure):
+    """struct gse_merge_spec (include/gse.h)."""
+    _fields_ = [("P", c_i32), ("rank", c_i32), ("flags", c_i32), ("slot", c_i32), ("r", c_d), ("island", c_vp), ("wscale", c_vp),
+                ("common_pivot", c_d * GSE_NX), ("rows", c_vp), ("moments26", c_vp), ("merged26", c_vp), ("estimate6", c_vp),
+                ("status", c_vp)]
+
+
+GSE_MERGE_STATUS_NO_WEIGHT, GSE_MERGE_STATUS_OVERFLOW = 1, 2
+GSE_MERGE_PENDING, GSE_MERGE_COV_SIZE = 1, 2
+GSE_WSTATUS_SUM_NOT_FINITE = 1
 
 P_MIX = ctypes.POINTER(Mixture)
 P_RNG = ctypes.POINTER(Rng)
@@ -106,6 +119,7 @@ PROTOTYPES = {
     "gse_last_error": (ctypes.c_char_p, []),
     "gse_workspace_bytes": (c_i64, [ctypes.c_int, c_i64]),
     "gse_workspace_weight_scale_offset": (c_i64, [ctypes.c_int, c_i64]),
+    "gse_workspace_status_offset": (c_i64, [ctypes.c_int, c_i64]),
     "gse_pf_slot_to_tiles": (ctypes.c_int, [ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_vp]),
     "gse_stream_synchronize": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "gse_pf_predict": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, P_D, c_d, P_MIX, P_RNG, c_vp]),
@@ -192,6 +206,8 @@ PROTOTYPES = {
     "gse_moments_estimates": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "gse_merge_row": (ctypes.c_int, [c_vp, c_vp, c_vp, P_D, c_vp, c_vp]),
     "gse_merge_rows": (ctypes.c_int, [c_vp, ctypes.c_int, P_D, c_vp, c_vp, c_vp]),
+    "gse_pf_merge_begin": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.POINTER(MergeSpec), c_vp, c_vp]),
+    "gse_merge_end": (ctypes.c_int, [ctypes.POINTER(MergeSpec), c_vp]),
     "gse_plant_step_injected": (ctypes.c_int, [c_vp, c_vp, c_d, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
 }
 

@@ -67,6 +67,9 @@ struct Workspace {
     double* qsums[2];      // [B][T][4]    GSE_OP_CLUSTER: the quarter sums that go with scan[slot] in quarter format
     float* samples[2];     // [B][64][8]   GSE_OP_SAMPLES: the weight scale's sample particles of the launch that filled scan[slot]
     uint32_t* kexact;      // [B]          GSE_OP_WEIGHT_SCALE, updates without a resample in front: scale_exact_kernel's maximum
+    uint32_t* wstatus;     // [B]          sticky status of each filter (GSE_WSTATUS_*), raised by the kernels, cleared by the caller
+    uint32_t* counters;    // [B]          tickets of the workgroups of a launch whose last one finishes the job (gse_pf_merge_begin);
+                           //              zero between launches: the workspace is zero-initialised ONCE by its owner
     int64_t bytes;
 };
 Workspace carve_workspace(void* base, int B, int64_t N);
@@ -162,8 +165,11 @@ inline double* gsukf_quarter_sums(const Workspace& ws, int slot = 0) { return ws
 inline double* gsukf_quad_prefix(const Workspace& ws, int slot = 0) { return ws.scan[slot]; }      // [B][T][256]
 // the partial sums of gse_pf_moments_resampled without the reduction that finishes them (gse_pf.hip); returns the number of
 // partials per filter, or a negative error code
+// merge (optional): the launch's last workgroup finishes the sums and runs the tail of gse_pf_merge_begin (B = 1)
 int launch_moments_resampled_partials(const char* fn, const float* x, const float* w, int64_t ld, int B, int64_t N, const double* r,
-                                      int slot, void* workspace, hipStream_t st);
+                                      int slot, void* workspace, hipStream_t st, const gse_merge_spec* merge = nullptr);
+int launch_moments_partials(const char* fn, const float* x, const float* w, int64_t ld, int B, int64_t N, void* workspace,
+                            hipStream_t st);
 bool launch_small_resample(const float* w, float* w_out, int32_t* idx, int B, int64_t N, const ResampleArgs& ra, hipStream_t st);
 void launch_moments_finish(const double* partials, int nblk, int width, double* out, int out_stride, int B,
                            const float* pivot_src, int64_t pfs, int64_t pes, int pivot_at, int pivot_count, hipStream_t st);

@@ -116,6 +116,10 @@ Workspace carve_workspace(void* base, int B, int64_t N) {
         at += round256((int64_t)B * 64 * 8 * 4);
     }
     ws.kexact = reinterpret_cast<uint32_t*>(p + at);
+    ws.wstatus = ws.kexact + GSE_MAX_B;                  // (the same 256 bytes: 2 x 32 words)
+    static_assert(2 * GSE_MAX_B * 4 <= 256, "kexact and wstatus share one 256-byte block");
+    at += round256((int64_t)B * 4);
+    ws.counters = reinterpret_cast<uint32_t*>(p + at);
     at += round256((int64_t)B * 4);
     ws.bytes = at;
     return ws;
@@ -147,6 +151,13 @@ int gse_stream_synchronize(void* stream, int spin) {
     }
     const hipError_t e = hipStreamSynchronize(st);
     return e == hipSuccess ? GSE_OK : gse::fail(GSE_ERR_HIP, "gse_stream_synchronize: %s", hipGetErrorString(e));
+}
+
+int64_t gse_workspace_status_offset(int B, int64_t N) {
+    if (B < 1 || B > GSE_MAX_B || N < 1)
+        return gse::fail(GSE_ERR_ARG, "gse_workspace_status_offset: bad B = %d or N = %lld", B, (long long)N);
+    gse::Workspace ws = gse::carve_workspace(nullptr, B, N);
+    return (int64_t)(reinterpret_cast<char*>(ws.wstatus) - static_cast<char*>(nullptr));
 }
 
 int64_t gse_workspace_bytes(int B, int64_t N) {

@@ -21,6 +21,7 @@
 // between the moments kernel and the next predict, so that the closed loop never waits for the host.
 #include "gse_host.h"
 #include "gse_loop_device.h"
+#include "gse_merge_device.h"
 
 namespace gse {
 
@@ -194,60 +195,92 @@ __global__ __launch_bounds__(256) void moments_estimates_kernel(const double* __
 // domain (distributed.merge_rows / shard_shares).  One thread each: a few hundred flops between a moments kernel and the
 // controller, so that a sharded closed loop never brings an estimate to the host.
 // ------------------------------------------------------------------------------------------------
-struct Pivot5 { double p[GSE_NX]; };
-
 __global__ void merge_row_kernel(const double* __restrict__ m, const double* __restrict__ log_island,
                                  const double* __restrict__ wscale, const Pivot5 common, double* __restrict__ row) {
-#pragma clang fp contract(off)                            // (the host formulas of distributed.pack_merge_row, operation by operation)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int ws = wscale ? (int)wscale[0] : 0;           // (GSE_OP_WEIGHT_SCALE: the sums are those of the stored weights)
-    const double s0 = ldexp(m[0], ws);
-    double s1[GSE_NX], delta[GSE_NX];
-#pragma unroll
-    for (int k = 0; k < GSE_NX; ++k) {
-        s1[k] = ldexp(m[1 + k], ws);
-        delta[k] = m[21 + k] - common.p[k];
-    }
-    row[0] = log_island[0];
-    row[1] = s0;
-#pragma unroll
-    for (int k = 0; k < GSE_NX; ++k) row[2 + k] = s1[k] + delta[k] * s0;
-    int c = 0;
-#pragma unroll
-    for (int r = 0; r < GSE_NX; ++r)
-#pragma unroll
-        for (int q = r; q < GSE_NX; ++q, ++c)
-            row[7 + c] = ((ldexp(m[6 + c], ws) + s1[r] * delta[q]) + delta[r] * s1[q]) + s0 * (delta[r] * delta[q]);
+    // (GSE_OP_WEIGHT_SCALE: the sums are those of the stored weights)
+    merge_row_thread(m, log_island[0], wscale ? (int)wscale[0] : 0, common, row);
 }
 
 __global__ void merge_rows_kernel(const double* __restrict__ rows, int P, const Pivot5 common, double* __restrict__ out,
                                   int32_t* __restrict__ status) {
-#pragma clang fp contract(off)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double top = -INFINITY;
-    for (int p = 0; p < P; ++p) {
-        const double la = rows[p * 22], s0 = rows[p * 22 + 1];
-        const bool live = (s0 > 0.0) && (fabs(la) < INFINITY) && (s0 < INFINITY);
-        if (live) top = fmax(top, la + log(s0));
+    merge_rows_thread(rows, P, common, out, status);
+}
+
+// The tail of gse_pf_merge_begin for the LIVE particles and weights (no resample pending): ONE workgroup finishes the shard's
+// moment partials (moments_finish_block's arithmetic, all loads requested at once), its first wavefront runs merge_tail_wave.
+// (With a resample pending the resampled-moments kernel's last workgroup does all this itself: gse_pf_kernels.h.)
+struct MergeFinishArgs {
+    const double* partials;          // [kMomentBlocks][kMomentWidth] of filter 0
+    int nblk;
+    const float* pivot_src;
+    int64_t pivot_elem_stride;
+    MergeTail tail;
+};
+
+__global__ __launch_bounds__(64 * kFinishGroups) void merge_finish_kernel(const MergeFinishArgs a) {
+    __shared__ double part[kFinishGroups][64];
+    __shared__ double sm[32];                          // the shard's moments (26)
+    __shared__ double sx[32];                          // its row (22)
+    const int tid = threadIdx.x;
+    {   // moments_finish_block (same order of additions), the <= 32 partials of a thread in flight together
+        const int c = tid & 63, g = tid >> 6;
+        constexpr int kPer = kMomentBlocks / kFinishGroups;       // 32
+        double v[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int q = g + j * kFinishGroups;
+            v[j] = (c < 21 && q < a.nblk) ? a.partials[(int64_t)q * kMomentWidth + c] : 0.0;
+        }
+        double acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[j] = 0.0 + v[j];
+#pragma unroll
+            for (int i = 1; i < kPer / 8; ++i) acc[j] += v[j + 8 * i];
+        }
+        part[g][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        __syncthreads();
+        if (g == 0 && c < 21) {
+            double t[kFinishGroups];
+#pragma unroll
+            for (int k = 0; k < kFinishGroups; ++k) t[k] = part[k][c];
+#pragma unroll
+            for (int span = 1; span < kFinishGroups; span *= 2)
+#pragma unroll
+                for (int k = 0; k < kFinishGroups; k += 2 * span) t[k] += t[k + span];
+            sm[c] = t[0];
+            a.tail.moments26[c] = t[0];
+        }
+        if (g == 1 && c < GSE_NX) {
+            const double pvt = (double)a.pivot_src[c * a.pivot_elem_stride];
+            sm[21 + c] = pvt;
+            a.tail.moments26[21 + c] = pvt;
+        }
     }
-    double acc[20], total = 0.0;
-#pragma unroll
-    for (int k = 0; k < 20; ++k) acc[k] = 0.0;
-    if (status) status[0] = (top > -INFINITY) ? 0 : 1;   // 1: every shard has zero weight (all likelihoods underflowed)
-    for (int p = 0; p < P; ++p) {
-        const double la = rows[p * 22], s0 = rows[p * 22 + 1];
-        const bool live = (s0 > 0.0) && (fabs(la) < INFINITY) && (s0 < INFINITY);
-        if (!live) continue;
-        const double a = exp((la + log(s0)) - top);
-        total += a;
-#pragma unroll
-        for (int k = 0; k < 20; ++k) acc[k] += a * rows[p * 22 + 2 + k] / s0;
-    }
-    out[0] = 1.0;
-#pragma unroll
-    for (int k = 0; k < 20; ++k) out[1 + k] = acc[k] / total;
-#pragma unroll
-    for (int k = 0; k < GSE_NX; ++k) out[21 + k] = common.p[k];
+    for (int i = tid; i < a.tail.P * 22; i += 64 * kFinishGroups)
+        if (i / 22 != a.tail.rank) a.tail.rows[i] = 0.0;
+    __syncthreads();
+    if (tid < 64) merge_tail_wave(a.tail, sm, sx, 1.0, tid);
+}
+
+__global__ __launch_bounds__(64) void merge_end_kernel(const double* __restrict__ rows, int P, const Pivot5 common, int flags,
+                                                       double* __restrict__ merged26, double* __restrict__ estimate6,
+                                                       int32_t* __restrict__ status) {
+    __shared__ double sm[32];
+    const int lane = threadIdx.x;
+    double mine;
+    const int st = merge_rows_wave(rows, P, common, lane, mine);
+    if (lane == 0) status[0] = st;
+    if (lane < 26) merged26[lane] = mine;
+    if (!estimate6) return;
+    if (lane < 32) sm[lane] = (lane < 26) ? mine : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (flags & GSE_MERGE_COV_SIZE) estimates_wave(sm, estimate6, lane);
+    else if (lane < GSE_NX) estimate6[lane] = sm[1 + lane] + sm[21 + lane] * sm[0];
 }
 
 }  // namespace gse
@@ -398,6 +431,41 @@ int gse_merge_rows(const double* rows, int P, const double* common_pivot, double
     for (int k = 0; k < GSE_NX; ++k) pv.p[k] = common_pivot[k];
     hipLaunchKernelGGL(merge_rows_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rows, P, pv, moments26_out, status);
     GSE_LAUNCH_CHECK("merge_rows_kernel");
+    return GSE_OK;
+}
+
+int gse_pf_merge_begin(const float* x, const float* w, int64_t ld, int64_t N, const gse_merge_spec* spec, void* workspace,
+                       void* stream) {
+    GSE_REQUIRE(spec, "gse_pf_merge_begin: null spec");
+    GSE_REQUIRE(spec->P >= 1 && spec->P <= 4096 && spec->rank >= 0 && spec->rank < spec->P, "gse_pf_merge_begin: bad P / rank");
+    GSE_REQUIRE(spec->rows && spec->moments26 && spec->merged26 && spec->status, "gse_pf_merge_begin: null output");
+    GSE_REQUIRE((spec->flags & ~(GSE_MERGE_PENDING | GSE_MERGE_COV_SIZE)) == 0, "gse_pf_merge_begin: bad flags 0x%x", spec->flags);
+    hipStream_t st = (hipStream_t)stream;
+    if (spec->flags & GSE_MERGE_PENDING) {
+        // ONE launch: the resampled-moments kernel, whose last workgroup to finish runs the tail (gse_pf_kernels.h)
+        const double r = spec->r;
+        const int nblk = launch_moments_resampled_partials("gse_pf_merge_begin", x, w, ld, 1, N, &r, spec->slot, workspace, st, spec);
+        return nblk < 0 ? nblk : GSE_OK;
+    }
+    const int nblk = launch_moments_partials("gse_pf_merge_begin", x, w, ld, 1, N, workspace, st);
+    if (nblk < 0) return nblk;
+    MergeFinishArgs a;
+    a.partials = carve_workspace(workspace, 1, N).partials;
+    a.nblk = nblk;
+    a.pivot_src = x; a.pivot_elem_stride = ld;
+    pack_merge_tail(spec, a.tail);
+    hipLaunchKernelGGL(merge_finish_kernel, dim3(1), dim3(64 * kFinishGroups), 0, st, a);
+    GSE_LAUNCH_CHECK("merge_finish_kernel");
+    return GSE_OK;
+}
+
+int gse_merge_end(const gse_merge_spec* spec, void* stream) {
+    GSE_REQUIRE(spec && spec->rows && spec->merged26 && spec->status && spec->P >= 1 && spec->P <= 4096, "gse_merge_end: bad argument");
+    Pivot5 pv;
+    for (int k = 0; k < GSE_NX; ++k) pv.p[k] = spec->common_pivot[k];
+    hipLaunchKernelGGL(merge_end_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)spec->rows, spec->P, pv,
+                       (int)spec->flags, spec->merged26, spec->estimate6, spec->status);
+    GSE_LAUNCH_CHECK("merge_end_kernel");
     return GSE_OK;
 }
 

@@ -108,7 +108,7 @@ bool launch_small_resample(const float* w, float* w_out, int32_t* idx, int B, in
 #define GSE_MOMRES_MIN_BLOCKS 32
 #endif
 int launch_moments_resampled_partials(const char* fn, const float* x, const float* w, int64_t ld, int B, int64_t N, const double* r,
-                                      int slot, void* workspace, hipStream_t st) {
+                                      int slot, void* workspace, hipStream_t st, const gse_merge_spec* merge) {
     if (int rc = check_pf_geometry(fn, B, N, ld)) return rc;
     if (!(x && w && r && workspace)) return fail(GSE_ERR_ARG, "%s: null argument", fn);
     if (!(aligned16(x) && aligned16(w) && aligned16(workspace))) return fail(GSE_ERR_ARG, "%s: pointers must be 16-byte aligned", fn);
@@ -117,20 +117,57 @@ int launch_moments_resampled_partials(const char* fn, const float* x, const floa
     if (!(slot == 0 || slot == 1)) return fail(GSE_ERR_ARG, "%s: slot must be 0 or 1 (| GSE_SLOT_QUARTERS)", fn);
     const int T = (int)tiles_of(N);
     if (T > 2048) return fail(GSE_ERR_ARG, "%s: at most 2048 tiles (N <= 2^21)", fn);
+    if (merge && B != 1) return fail(GSE_ERR_ARG, "%s: the merge is that of ONE filter (a shard)", fn);
     ResampleArgs ra;
     for (int b = 0; b < B; ++b) {
         if (!(r[b] >= 0.0 && r[b] < 1.0)) return fail(GSE_ERR_ARG, "%s: r[%d] = %g is outside [0, 1)", fn, b, r[b]);
         ra.r[b] = r[b];
     }
     Workspace ws = carve_workspace(workspace, B, N);
-    const int nblk = (int)std::min<int64_t>(std::min<int64_t>(kMomentBlocks, T), std::max<int64_t>(GSE_MOMRES_TOTAL_BLOCKS / B, GSE_MOMRES_MIN_BLOCKS));
-    if (quarters)
-        hipLaunchKernelGGL(pf_moments_resampled_kernel<true>, dim3(nblk, B), dim3(kBlock), (size_t)(T + 1) * sizeof(double), st, x,
-                           w, ws.qsums[slot], ws.scan[slot], ws.partials, N, ld, T, ra);
-    else
-        hipLaunchKernelGGL(pf_moments_resampled_kernel<false>, dim3(nblk, B), dim3(kBlock), (size_t)(T + 1) * sizeof(double), st, x,
-                           w, ws.scan_sums[slot], ws.scan[slot], ws.partials, N, ld, T, ra);
+    // one wavefront per unit (a tile) and pass: no more workgroups than a quarter of the units (round 5: the rest only wrote
+    // zeros for the reduction to read); with the merge's tail inside the launch at most 256 per half (its last workgroup adds
+    // 32 partials per thread and half).  Half a tile per wavefront (GSE_MOMRES_SPLIT=2: twice the wavefronts waiting side by
+    // side) is SLOWER for a filter of 2^20 particles alone on the device: 21.8 us for 19.2 (14.7 for 13.8 without the tail).
+    int split = 1;
+    if (const char* e = getenv("GSE_MOMRES_SPLIT")) split = atoi(e) == 2 ? 2 : 1;      // (tuning knob)
+    int64_t cap = merge ? 256 * split : kMomentBlocks;
+    if (const char* e = getenv("GSE_MOMRES_CAP")) cap = std::min<int64_t>(cap, std::max(1, atoi(e)));      // (tuning knob)
+    const int nblk = (int)std::min<int64_t>(std::min<int64_t>(cap, ((int64_t)T * split + 3) / 4),
+                                            std::max<int64_t>(GSE_MOMRES_TOTAL_BLOCKS / B, GSE_MOMRES_MIN_BLOCKS));
+    MergeTail tail = {};
+    if (merge) pack_merge_tail(merge, tail);
+    if (getenv("GSE_MERGE_NOTAIL")) tail.flags = 0;                      // (timing experiments only: the results are not formed)
+    const dim3 grid(nblk, B);
+    const size_t dyn = (size_t)(T + 1) * sizeof(double);
+#define GSE_MOMRES_GO(Q_, S_, sums_)                                                                                            \
+    hipLaunchKernelGGL((pf_moments_resampled_kernel<Q_, S_>), grid, dim3(kBlock), dyn, st, x, w, sums_, ws.scan[slot], ws.partials, \
+                       N, ld, T, ra, ws.wstatus, tail, ws.counters)
+    if (quarters) {
+        if (split == 2) GSE_MOMRES_GO(true, 2, ws.qsums[slot]); else GSE_MOMRES_GO(true, 1, ws.qsums[slot]);
+    } else {
+        if (split == 2) GSE_MOMRES_GO(false, 2, ws.scan_sums[slot]); else GSE_MOMRES_GO(false, 1, ws.scan_sums[slot]);
+    }
+#undef GSE_MOMRES_GO
     if (hipGetLastError() != hipSuccess) return fail(GSE_ERR_HIP, "%s: pf_moments_resampled_kernel did not launch", fn);
+    return nblk;
+}
+
+#ifndef GSE_MOMENT_TOTAL_BLOCKS
+#define GSE_MOMENT_TOTAL_BLOCKS 1024
+#endif
+// the partial sums of gse_pf_moments (live particles and weights); returns the number of partials per filter, or an error code
+int launch_moments_partials(const char* fn, const float* x, const float* w, int64_t ld, int B, int64_t N, void* workspace,
+                            hipStream_t st) {
+    if (int rc = check_pf_geometry(fn, B, N, ld)) return rc;
+    if (!(x && w && workspace)) return fail(GSE_ERR_ARG, "%s: null argument", fn);
+    if (!(aligned16(x) && aligned16(w) && aligned16(workspace))) return fail(GSE_ERR_ARG, "%s: pointers must be 16-byte aligned", fn);
+    Workspace ws = carve_workspace(workspace, B, N);
+    // workgroups per filter: four per CU in total, so that with many filters each workgroup sweeps several tiles and the
+    // reduction at its end is paid less often (32 filters x 2^18 particles: 60 / 42 / 38 us with 4096 / 2048 / 1024
+    // workgroups in total -- 5.3 TB/s at 1024)
+    const int nblk = (int)std::min<int64_t>(std::min<int64_t>(kMomentBlocks, tiles_of(N)), std::max<int64_t>(GSE_MOMENT_TOTAL_BLOCKS / B, 32));
+    hipLaunchKernelGGL(pf_moments_kernel, dim3(nblk, B), dim3(kBlock), 0, st, x, w, ws.partials, N, ld);
+    if (hipGetLastError() != hipSuccess) return fail(GSE_ERR_HIP, "%s: pf_moments_kernel did not launch", fn);
     return nblk;
 }
 
@@ -322,6 +359,7 @@ int pf_step(uint32_t ops, const float* x_in, float* x_out, const float* w_in, fl
     a.smp_magic = a.smp_stride ? (uint32_t)((((uint64_t)1 << 32) + a.smp_stride - 1) / a.smp_stride) : 0u;
     GSE_REQUIRE(!(a.smp_in && a.smp_out) || a.smp_in != a.smp_out, "%s: SCAN_IN and SCAN_OUT must use different slots", fn);
     a.k_exact = nullptr;
+    a.wstatus = workspace ? ws.wstatus : nullptr;
     if ((ops & GSE_OP_WEIGHT_SCALE) && U && !G && !(ops & GSE_OP_UNIFORM_WEIGHTS)) {
         // an update without a resample in front of it: the scale's anchor over ALL particles, by a pass of its own
         // (scale_exact_kernel: the weights may span any number of binades by now, and 64 samples need not see the heavy ones)
@@ -577,21 +615,11 @@ int gse_debug_block_times(unsigned long long* out8192, long long* info8192) {
 
 int gse_pf_moments(const float* x, const float* w, int64_t ld, int B, int64_t N, double* out, void* workspace,
                    void* stream) {
-    if (int rc = check_pf_geometry("gse_pf_moments", B, N, ld)) return rc;
-    GSE_REQUIRE(x && w && out && workspace, "gse_pf_moments: null argument");
-    GSE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(workspace), "gse_pf_moments: pointers must be 16-byte aligned");
-    Workspace ws = carve_workspace(workspace, B, N);
-#ifndef GSE_MOMENT_TOTAL_BLOCKS
-#define GSE_MOMENT_TOTAL_BLOCKS 1024
-#endif
-    // workgroups per filter: four per CU in total, so that with many filters each workgroup sweeps several tiles and the
-    // reduction at its end is paid less often (32 filters x 2^18 particles: 60 / 42 / 38 us with 4096 / 2048 / 1024
-    // workgroups in total -- 5.3 TB/s at 1024)
-    const int nblk = (int)std::min<int64_t>(std::min<int64_t>(kMomentBlocks, tiles_of(N)), std::max<int64_t>(GSE_MOMENT_TOTAL_BLOCKS / B, 32));
+    GSE_REQUIRE(out, "gse_pf_moments: null argument");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pf_moments_kernel, dim3(nblk, B), dim3(kBlock), 0, st, x, w, ws.partials, N, ld);
-    GSE_LAUNCH_CHECK("pf_moments_kernel");
-    launch_moments_finish(ws.partials, nblk, 21, out, 26, B, x, GSE_NX * ld, ld, 21, GSE_NX, st);
+    const int nblk = launch_moments_partials("gse_pf_moments", x, w, ld, B, N, workspace, st);
+    if (nblk < 0) return nblk;
+    launch_moments_finish(carve_workspace(workspace, B, N).partials, nblk, 21, out, 26, B, x, GSE_NX * ld, ld, 21, GSE_NX, st);
     GSE_LAUNCH_CHECK("moments_finish_kernel");
     return GSE_OK;
 }

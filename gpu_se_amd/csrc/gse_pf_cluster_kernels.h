@@ -295,6 +295,7 @@ __global__ __launch_bounds__(kBlock) void pf_cluster_kernel(
     if (kGather) {
         double W;
         anc = cluster_gather(gl, qv, w_in + (int64_t)b * ld, qx_in + (int64_t)b * T * kBlock, N, ld, T, a.ra.r[b], j0, tid, W);
+        if (a.wstatus && blockIdx.x == 0 && tid == 0 && !(W < INFINITY)) a.wstatus[b] = GSE_WSTATUS_SUM_NOT_FINITE;
         if (island && blockIdx.x == 0 && tid == 0) {                     // shard bookkeeping (see gse_pf_resample)
             const double ws_b = a.wscale ? a.wscale[b] : 0.0;
             island[b] += log(W) + ws_b * 0.69314718055994530942;

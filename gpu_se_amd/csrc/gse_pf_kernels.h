@@ -34,6 +34,7 @@
 #pragma once
 
 #include "gse_host.h"
+#include "gse_merge_device.h"
 
 namespace gse {
 
@@ -58,6 +59,7 @@ struct StepArgs {
     // ... and for launches that update WITHOUT a resample in front (the weights may be anything by then): the best exponent over
     // ALL particles, left by scale_exact_kernel just before this launch ([B], biased by kExactBias; null: the samples decide)
     const uint32_t* k_exact;
+    uint32_t* wstatus;     // [B] sticky status words of the filters (workspace; GSE_WSTATUS_*), or null
 };
 constexpr int32_t kExactBias = 1 << 20;
 
@@ -754,6 +756,9 @@ __global__ __launch_bounds__(kBlock, GSE_STEP_MIN_WAVES) void pf_step_kernel(
         } else {
             W = totals[b];
         }
+        // a weight sum that is +inf or NaN (with GSE_OP_WEIGHT_SCALE: the stored weights overflowed): the resample below then
+        // copies particle 0 everywhere, as the reference's does -- but never silently (include/gse.h, GSE_WSTATUS_SUM_NOT_FINITE)
+        if (a.wstatus && tile_id == 0 && tid == 0 && !(W < INFINITY)) a.wstatus[b] = GSE_WSTATUS_SUM_NOT_FINITE;
         if (kDraw && draw_at == 1) draw_all();
         const double r = a.ra.r[b];
         // Weights that do not sum to a positive finite number: the reference's normalised cumsum is all-NaN and its
@@ -2018,26 +2023,58 @@ __global__ __launch_bounds__(kBlock) void pf_moments_kernel(const float* __restr
 // flight instead of four the kernel needs 124 registers for 204 (four wavefronts per SIMD for two): 55.6 -> 47.0 us per
 // tick of 32 x 2^18 particles.  Not better: twice the workgroups (52.2), the next step's inputs requested a step ahead
 // (48.7), full groups of 64 carried over the steps (48.5).
-#ifndef GSE_MOMRES_COMPACT
-#define GSE_MOMRES_COMPACT 1
-#endif
+// Round 5: the four quarters of a tile no longer take their turns (weights and prefixes requested, counted, the states of the
+// particles with offspring fetched, accumulated -- four dependent trips to memory per tile, which is what a filter of 2^20
+// particles alone spent its 14.5 us on: 2048 wavefronts with one tile each); a wavefront now requests the weights and prefixes of
+// the WHOLE tile at once, counts all sixteen particles of a lane, lists every particle with offspring of the tile, and works the
+// list off 128 at a time with both halves' states in flight.  Fuller groups of 64 too (a tile has ~170 such particles inside
+// a closed loop: three groups where the quarters made four).
 // kQuarters: the slot is in QUARTER FORMAT (gse_pf_cluster_kernels.h): tile_sums = [B][T][4] quarter sums, qx_all the quads'
 // exclusive prefixes inside their quarter; the tile sum and the tile-level prefix are formed as block_exclusive_scan forms them.
-template <bool kQuarters>
+// kSplit (1 or 2): a wavefront's unit of work is 1 / kSplit of a tile.  A filter ALONE on the device (gse_pf_merge_begin: one shard
+// of 2^20 particles) is a chain of dependent trips to memory with ONE wavefront per SIMD and tile; halving the unit doubles the
+// wavefronts that wait side by side.  The half that does not begin a tile finds the count below its first key by re-forming
+// the key before it (the last key of the previous quarter: that thread's weights and prefix, the same operations).
+template <bool kQuarters, int kSplit = 1>
 __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                       const double* __restrict__ tile_sums,
                                                                       const double* __restrict__ qx_all,
                                                                       double* __restrict__ partials, int64_t N, int64_t ld,
-                                                                      int T, const ResampleArgs ra) {
+                                                                      int T, const ResampleArgs ra,
+                                                                      uint32_t* __restrict__ wstatus, const MergeTail tail,
+                                                                      uint32_t* __restrict__ counter) {
     __shared__ double red[4 * 21];
-#if GSE_MOMRES_COMPACT
-    __shared__ int2 items[kBlock / 64][64 * kPerThread];           // per wavefront: (particle, offspring count)
-#endif
+    __shared__ int2 items[kBlock / 64][kTile / kSplit];          // per wavefront: (particle, offspring count) of one unit
+    __shared__ int last_s;
     extern __shared__ double pfx_m[];              // [T + 1]
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* xb = x + (int64_t)b * GSE_NX * ld;
     const float* wb = w + (int64_t)b * ld;
     const double* qx = qx_all + (int64_t)b * T * kBlock;
+    constexpr int kSubs = kTile / (64 * kPerThread) / kSplit;    // quarters of a tile per unit: 4 or 2
+    static_assert(kSplit == 1 || kSplit == 2, "a unit is a tile or half a tile");
+    // this wavefront's first unit: weights and prefixes requested before the tile prefix is built (they do not depend on it)
+    const int unit0 = blockIdx.x * (kBlock / 64) + wv, units = T * kSplit;
+    float4 wq[kSubs];
+    double ex[kSubs];
+    float4 wq_before = make_float4(0.f, 0.f, 0.f, 0.f);           // kSplit == 2, second half: the quad before the unit's first
+    double ex_before = 0.0;
+    auto request = [&](int unit) {
+        const int tq = unit / kSplit, sub0 = (unit % kSplit) * kSubs;
+#pragma unroll
+        for (int sub = 0; sub < kSubs; ++sub) {
+            const int t = (sub0 + sub) * 64 + lane;
+            const int64_t k0 = (int64_t)tq * kTile + (int64_t)t * kPerThread;
+            wq[sub] = load_weights4(wb, k0, N, ld);
+            ex[sub] = qx[tq * kBlock + t];
+        }
+        if (kSplit > 1 && sub0 > 0) {                             // (uniform addresses: one request for the wavefront)
+            const int t = sub0 * 64 - 1;
+            wq_before = load_weights4(wb, (int64_t)tq * kTile + (int64_t)t * kPerThread, N, ld);
+            ex_before = qx[tq * kBlock + t];
+        }
+    };
+    if (unit0 < units) request(unit0);
     // tile prefix (the arithmetic of the step kernel's gather stage)
     {
         const double* sums = tile_sums + (int64_t)b * T * (kQuarters ? 4 : 1);
@@ -2067,6 +2104,12 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
         __syncthreads();
     }
     const double W = pfx_m[T];
+    if (blockIdx.x == 0 && tid == 0) {
+        // the slot's weight sum beside the partials (column 21 of the first row: gse_pf_merge_begin forms the shard's
+        // log-weight from it), and the filter's sticky status when it is not a number the resample can use
+        partials[(int64_t)b * kMomentBlocks * kMomentWidth + 21] = W;
+        if (!(W < INFINITY)) wstatus[b] = GSE_WSTATUS_SUM_NOT_FINITE;
+    }
     double pv[GSE_NX];
 #pragma unroll
     for (int k = 0; k < GSE_NX; ++k) pv[k] = (double)xb[k * ld];          // pivot = particle 0
@@ -2077,34 +2120,66 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
     OffspringCount F;
     F.init(N, ra.r[b], valid ? W : 1.0);
     const double wu = (double)(float)(1.0 / (double)N);
-    // One WAVEFRONT per tile, four quarters of 64 quads one after the other: the count below a lane's first key comes from
-    // the lane before (DPP) and, for lane 0, from the previous quarter's last lane (kept in a scalar) -- no barrier, and the
-    // four wavefronts of the workgroup are at different tiles.  The states of a particle are fetched only if it has
-    // offspring: under the usual degenerate weights that is about one particle in a hundred, so the pass moves ~6 bytes
-    // per particle (weights and tile prefixes) instead of 26.
-    for (int tq = blockIdx.x * (kBlock / 64) + wv; valid && tq < T; tq += gridDim.x * (kBlock / 64)) {
+    auto add_particle = [&](const float (&xv)[GSE_NX], int count) {
+        const double wp = (double)count * wu;                            // (count 0: adds zeros)
+        double d[GSE_NX];
+#pragma unroll
+        for (int k = 0; k < GSE_NX; ++k) d[k] = (double)xv[k] - pv[k];
+        acc[0] += wp;
+        int c = 6;
+#pragma unroll
+        for (int k = 0; k < GSE_NX; ++k) {
+            const double wd = wp * d[k];
+            acc[1 + k] += wd;
+#pragma unroll
+            for (int l = k; l < GSE_NX; ++l) acc[c++] += wd * d[l];
+        }
+    };
+    // One WAVEFRONT per tile.  The count below a lane's first key comes from the lane before (DPP) and, for lane 0, from the
+    // previous quarter's last lane (kept in a scalar) -- no barrier, and the four wavefronts of the workgroup are at different
+    // tiles.  The states of a particle are fetched only if it has offspring: under the usual degenerate weights that is about
+    // one particle in a hundred, so the pass moves ~6 bytes per particle (weights and tile prefixes) instead of 26.
+    int2* mine = &items[wv][0];
+    for (int unit = unit0; valid && unit < units; unit += gridDim.x * (kBlock / 64)) {
+        if (unit != unit0) request(unit);
+        const int tq = unit / kSplit, sub0 = (unit % kSplit) * kSubs;
         const double P0 = pfx_m[tq], P1 = pfx_m[tq + 1];
         const int64_t tile_last = min((int64_t)(tq + 1) * kTile, N) - 1;
-        int32_t below = F(P0);                                           // (the previous tile's last key is pinned to P0)
-#pragma unroll 1
-        for (int sub = 0; sub < kTile / (64 * kPerThread); ++sub) {
-            const int t = sub * 64 + lane;
+        // the quarters before quarter q, as block_exclusive_scan adds them (quarter format)
+        auto quarter_base = [&](int q_at) {
+            const double* q = tile_sums + ((int64_t)b * T + tq) * 4;
+            double qb = 0.0;
+            if (q_at > 0) qb = q[0];
+            if (q_at > 1) qb += q[1];
+            if (q_at > 2) qb += q[2];
+            return qb;
+        };
+        double key_before = P0;                                          // (the previous tile's last key is pinned to P0)
+        if (kSplit > 1 && sub0 > 0) {
+            // the last key of the quarter before this unit, exactly as the wavefront that owns it forms it
+            const int t = sub0 * 64 - 1;
             const int64_t k0 = (int64_t)tq * kTile + (int64_t)t * kPerThread;
-            const float4 wq = load_weights4(wb, k0, N, ld);
-            double excl = qx[tq * kBlock + t];
-            if (kQuarters) {                           // (+ the quarters before this one, as block_exclusive_scan adds them)
-                const double* q = tile_sums + ((int64_t)b * T + tq) * 4;
-                double base = 0.0;
-                if (sub > 0) base = q[0];
-                if (sub > 1) base += q[1];
-                if (sub > 2) base += q[2];
-                excl = base + excl;
-            }
+            double exb = ex_before;
+            if (kQuarters) exb = quarter_base(sub0 - 1) + exb;
+            double sb = (k0 + 0 < N) ? (double)wq_before.x : 0.0;
+            sb = sb + ((k0 + 1 < N) ? (double)wq_before.y : 0.0);
+            sb = sb + ((k0 + 2 < N) ? (double)wq_before.z : 0.0);
+            sb = sb + ((k0 + 3 < N) ? (double)wq_before.w : 0.0);
+            key_before = (k0 + 3 >= tile_last) ? P1 : fmin(P0 + (exb + sb), P1);
+        }
+        int32_t below = F(key_before);
+        int base = 0;
+#pragma unroll
+        for (int sub = 0; sub < kSubs; ++sub) {
+            const int t = (sub0 + sub) * 64 + lane;
+            const int64_t k0 = (int64_t)tq * kTile + (int64_t)t * kPerThread;
+            double excl = ex[sub];
+            if (kQuarters) excl = quarter_base(sub0 + sub) + excl;
             double sc[kPerThread];
-            sc[0] = (k0 + 0 < N) ? (double)wq.x : 0.0;
-            sc[1] = sc[0] + ((k0 + 1 < N) ? (double)wq.y : 0.0);
-            sc[2] = sc[1] + ((k0 + 2 < N) ? (double)wq.z : 0.0);
-            sc[3] = sc[2] + ((k0 + 3 < N) ? (double)wq.w : 0.0);
+            sc[0] = (k0 + 0 < N) ? (double)wq[sub].x : 0.0;
+            sc[1] = sc[0] + ((k0 + 1 < N) ? (double)wq[sub].y : 0.0);
+            sc[2] = sc[1] + ((k0 + 2 < N) ? (double)wq[sub].z : 0.0);
+            sc[3] = sc[2] + ((k0 + 3 < N) ? (double)wq[sub].w : 0.0);
             double xs[kPerThread];
             int32_t fs[kPerThread];
             bool near[kPerThread];
@@ -2123,85 +2198,101 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
             int32_t prev = (int32_t)wave_shift_up1((uint32_t)fs[3]);
             if (lane == 0) prev = below;
             below = __builtin_amdgcn_readlane(fs[3], 63);
-            int32_t n_off[kPerThread];
+            // The particles with offspring -- one in six inside a closed loop -- are COMPACTED through the wavefront's list in
+            // LDS (ballots and population counts: the order is the particles' own, the sums do not depend on timing): taken
+            // where they stand, each of a lane's particles costs the whole wavefront the 60 fp64 instructions of the
+            // accumulation if any lane has offspring there, i.e. always.
 #pragma unroll
-            for (int p = 0; p < kPerThread; ++p)
-                n_off[p] = (k0 + p <= tile_last) ? fs[p] - (p == 0 ? prev : fs[(p + 3) % kPerThread]) : 0;
-#if GSE_MOMRES_COMPACT
-            // The particles with offspring -- one in six inside a closed loop -- are COMPACTED through the wavefront's list in LDS
-            // and worked off 64 at a time, every lane busy: taken where they stand, each of a lane's four particles costs the
-            // whole wavefront the 60 fp64 instructions of the accumulation if any lane has offspring there, i.e. always.
-            {
-                int2* mine = &items[wv][0];
-                int base = 0;
-#pragma unroll
-                for (int p = 0; p < kPerThread; ++p) {
-                    const unsigned long long m = __ballot(n_off[p] > 0);
-                    if (n_off[p] > 0)
-                        mine[base + __popcll(m & ((1ull << lane) - 1ull))] = make_int2((int)(k0 + p), n_off[p]);
-                    base += __popcll(m);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (int at = 0; at < base; at += 64) {
-                    const bool have = at + lane < base;
-                    const int2 it = have ? mine[at + lane] : make_int2(0, 0);
-                    float xv[GSE_NX];
-#pragma unroll
-                    for (int k = 0; k < GSE_NX; ++k) xv[k] = xb[k * ld + it.x];
-                    if (have) {
-                        const double wp = (double)it.y * wu;
-                        double d[GSE_NX];
-#pragma unroll
-                        for (int k = 0; k < GSE_NX; ++k) d[k] = (double)xv[k] - pv[k];
-                        acc[0] += wp;
-                        int c = 6;
-#pragma unroll
-                        for (int k = 0; k < GSE_NX; ++k) {
-                            const double wd = wp * d[k];
-                            acc[1 + k] += wd;
-#pragma unroll
-                            for (int l = k; l < GSE_NX; ++l) acc[c++] += wd * d[l];
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();                          // (the list is rewritten in the next step)
+            for (int p = 0; p < kPerThread; ++p) {
+                const int32_t n_off = (k0 + p <= tile_last) ? fs[p] - (p == 0 ? prev : fs[p - 1]) : 0;
+                const unsigned long long m = __ballot(n_off > 0);
+                if (n_off > 0) mine[base + __popcll(m & ((1ull << lane) - 1ull))] = make_int2((int)(k0 + p), n_off);
+                base += __popcll(m);
             }
-#else
-            float xv[kPerThread][GSE_NX];
-#pragma unroll
-            for (int p = 0; p < kPerThread; ++p)
-                if (n_off[p] > 0) {
-#pragma unroll
-                    for (int k = 0; k < GSE_NX; ++k) xv[p][k] = xb[k * ld + k0 + p];
-                }
-#pragma unroll
-            for (int p = 0; p < kPerThread; ++p)
-                if (n_off[p] > 0) {
-                    const double wp = (double)n_off[p] * wu;
-                    double d[GSE_NX];
-#pragma unroll
-                    for (int k = 0; k < GSE_NX; ++k) d[k] = (double)xv[p][k] - pv[k];
-                    acc[0] += wp;
-                    int c = 6;
-#pragma unroll
-                    for (int k = 0; k < GSE_NX; ++k) {
-                        const double wd = wp * d[k];
-                        acc[1 + k] += wd;
-#pragma unroll
-                        for (int l = k; l < GSE_NX; ++l) acc[c++] += wd * d[l];
-                    }
-                }
-#endif
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int at = 0; at < base; at += 128) {
+            const bool two = at + 64 < base;                             // (uniform)
+            const int2 it0 = (at + lane < base) ? mine[at + lane] : make_int2(0, 0);
+            const int2 it1 = (at + 64 + lane < base) ? mine[at + 64 + lane] : make_int2(0, 0);
+            float xv0[GSE_NX], xv1[GSE_NX];
+#pragma unroll
+            for (int k = 0; k < GSE_NX; ++k) xv0[k] = xb[k * ld + it0.x];
+            if (two) {
+#pragma unroll
+                for (int k = 0; k < GSE_NX; ++k) xv1[k] = xb[k * ld + it1.x];
+            }
+            add_particle(xv0, it0.y);
+            if (two) add_particle(xv1, it1.y);
+        }
+        __builtin_amdgcn_wave_barrier();                                  // (the list is rewritten for the next unit)
     }
     if (!valid && blockIdx.x == 0 && tid == 0) {
         // weights that do not sum to a positive finite number: every offspring copies particle 0 (see the gather stage)
         acc[0] = (double)N * wu;
     }
     double* out = partials + ((int64_t)b * kMomentBlocks + blockIdx.x) * kMomentWidth;
-    block_sums<21>(acc, red, [&](int c, double total) { out[c] = total; });
+    if (!(tail.flags & kMergeTailOn)) {                                  // (uniform)
+        block_sums<21>(acc, red, [&](int c, double total) { out[c] = total; });
+        return;
+    }
+    // ---- gse_pf_merge_begin (round 5): the LAST workgroup to get here finishes the partial sums and runs the merge's tail --
+    //      the shard's row of the merge buffer, and for a single shard the combination and the estimate -- instead of a second
+    //      launch (a kernel boundary costs ~3 us of drain and start; the whole estimate is to fit beside an 18 us cycle).
+    //      The partials cross XCDs (L2s that do not see each other): they are written and read as AGENT-scope atomics, which
+    //      go through to memory, each workgroup waits for its own stores before it draws its ticket (agent-scope atomic add),
+    //      and the last one therefore finds them all.  (Fences instead -- __threadfence on both sides -- write back and
+    //      invalidate the L2 in every workgroup: 32 us for the launch where this takes 19.)  The sums are added in a FIXED
+    //      order, whoever is last.  gridDim.x <= 256 kSplit (the host sees to it), B = 1.
+    block_sums<21>(acc, red, [&](int c, double total) {
+        __hip_atomic_store(out + c, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");               // (the stores have left: s_waitcnt, no cache maintenance)
+    __syncthreads();
+    if (tid == 0)
+        last_s = (__hip_atomic_fetch_add(counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1 : 0;
+    __syncthreads();
+    if (!last_s) return;
+    if (tid == 0) __hip_atomic_store(counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (ready for the next launch)
+    double* part = reinterpret_cast<double*>(&items[0][0]);             // [8][32] (the lists are spent)
+    double* sm = red;                                                    // [32] the shard's moments
+    double* sx = red + 32;                                               // [32] its row
+    {
+        const int c = tid & 31, g = tid >> 5;                            // 8 groups x 32 columns (21 used)
+        const double* pb = partials + (int64_t)b * kMomentBlocks * kMomentWidth;
+        const int nblk = (int)gridDim.x;
+        constexpr int kPer = 32 * kSplit;
+        double v[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int q = g + 8 * j;
+            v[j] = (c < 21 && q < nblk) ? __hip_atomic_load(pb + (int64_t)q * kMomentWidth + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : 0.0;
+        }
+#pragma unroll
+        for (int span = 1; span < kPer; span *= 2)
+#pragma unroll
+            for (int j = 0; j < kPer; j += 2 * span) v[j] += v[j + span];
+        part[g * 32 + c] = v[0];
+    }
+    for (int i = tid; i < tail.P * 22; i += kBlock)
+        if (i / 22 != tail.rank) tail.rows[i] = 0.0;
+    __syncthreads();
+    if (tid < 21) {
+        const double t = ((part[tid] + part[32 + tid]) + (part[64 + tid] + part[96 + tid])) +
+                         ((part[128 + tid] + part[160 + tid]) + (part[192 + tid] + part[224 + tid]));
+        sm[tid] = t;
+        tail.moments26[tid] = t;
+    }
+    if (tid >= 32 && tid < 32 + GSE_NX) {
+        const double pvt = (double)xb[(tid - 32) * ld];
+        sm[21 + tid - 32] = pvt;
+        tail.moments26[21 + tid - 32] = pvt;
+    }
+    __syncthreads();
+    if (tid < 64) merge_tail_wave(tail, sm, sx, W, tid);
 }
 
 // Fixed-order reduction of the per-workgroup partials -> out[b][0..width); appends pivot_count pivot values

@@ -23,6 +23,8 @@ struct PfLoopState {
     bool pend_gather = false, pend_predict = false;
     int gather_slot = -1, scan_slot = -1;
     bool samples_ok = false;                            // GSE_OP_SAMPLES: the slot's sample rows describe the particles
+    bool w_uniform = false;                             // every weight is 1 / N (a resample's copy ran and no update since):
+                                                        // an update without a copy in its launch may pass GSE_OP_UNIFORM_WEIGHTS
     gse_rng rng;
     const double* r_cur;
     hipStream_t st;
@@ -41,6 +43,7 @@ struct PfLoopState {
         }
         uint32_t ops = ((s->flags & GSE_PF_LOOP_WEIGHT_SCALE) && (update || pend_gather)) ? GSE_OP_WEIGHT_SCALE : 0u;
         const bool gather = pend_gather;
+        if (ops && update && !gather && w_uniform) ops |= GSE_OP_UNIFORM_WEIGHTS;      // (filter/particle.py _launch_step)
         const bool swap_x = gather || (ops && update && pend_predict);
         float* x_out = swap_x ? x_alt : x;
         const bool swap_w = gather || (ops && update);
@@ -56,11 +59,12 @@ struct PfLoopState {
             ops |= GSE_OP_UPDATE | (io_dev ? GSE_OP_Z_DEVICE : 0u) | GSE_OP_SCAN_OUT | (scan_out ? GSE_OP_SCAN_OUT_SLOT1 : 0u);
         }
         if (int rc = gse_pf_step(ops, x, x_out, w, w_out, nullptr, s->ld, s->B, s->N, u_cur, s->dt, z_cur, r_cur, s->state_pdf, &rng,
-                                 nullptr, s->measurement_pdf, nullptr, s->workspace, st))
+                                 nullptr, s->measurement_pdf, s->island, s->workspace, st))
             return rc;
         if (pend_predict) rng.step += 1;
         if (swap_x) std::swap(x, x_alt);
         if (swap_w) std::swap(w, w_alt);
+        if (update) w_uniform = false; else if (gather) w_uniform = true;
         samples_ok = update && (ops & GSE_OP_WEIGHT_SCALE);      // (nothing but these launches touches the particles while the loop runs)
         pend_gather = false;
         gather_slot = -1;
@@ -76,6 +80,7 @@ struct PfLoopState {
         float* x_out = swap_x ? x_alt : x;
         const bool swap_w = gather || ((ops & GSE_OP_WEIGHT_SCALE) && update);
         float* w_out = swap_w ? w_alt : w;
+        if ((ops & GSE_OP_WEIGHT_SCALE) && update && !gather && w_uniform) ops |= GSE_OP_UNIFORM_WEIGHTS;
         if (gather) ops |= GSE_OP_GATHER | GSE_OP_SCAN_IN | (gather_slot ? GSE_OP_SCAN_IN_SLOT1 : 0u);
         if (pend_predict) ops |= GSE_OP_PREDICT | (io_dev ? GSE_OP_U_DEVICE : 0u);
         int scan_out = -1;
@@ -84,11 +89,12 @@ struct PfLoopState {
             ops |= GSE_OP_UPDATE | (io_dev ? GSE_OP_Z_DEVICE : 0u) | GSE_OP_SCAN_OUT | (scan_out ? GSE_OP_SCAN_OUT_SLOT1 : 0u);
         }
         if (int rc = gse_pf_step(ops, x, x_out, w, w_out, nullptr, s->ld, s->B, s->N, u_cur, s->dt, z_cur, r_cur, s->state_pdf, &rng,
-                                 nullptr, s->measurement_pdf, nullptr, s->workspace, st))
+                                 nullptr, s->measurement_pdf, s->island, s->workspace, st))
             return rc;
         if (pend_predict) rng.step += 1;
         if (swap_x) std::swap(x, x_alt);
         if (swap_w) std::swap(w, w_alt);
+        if (update) w_uniform = false; else if (gather) w_uniform = true;
         pend_gather = false;
         gather_slot = -1;
         pend_predict = false;
@@ -125,6 +131,7 @@ extern "C" int gse_pf_closed_loop(gse_pf_loop_spec* s, void* stream) {
     f.u_cur = s->u;
     f.z_cur = s->z;
     f.st = (hipStream_t)stream;
+    f.w_uniform = s->w_uniform != 0;
     gse_rng plant_rng = s->plant_rng;
     gse_loop_tail tail = {};
     tail.law = s->law; tail.glue = s->glue; tail.u = s->u; tail.y_pred = s->y_pred; tail.known = s->known; tail.X = s->X;
@@ -182,6 +189,7 @@ extern "C" int gse_pf_closed_loop(gse_pf_loop_spec* s, void* stream) {
     s->gather_slot = f.gather_slot;
     s->scan_slot = f.scan_slot;
     s->samples_ok = f.samples_ok ? 1u : 0u;
+    s->w_uniform = f.w_uniform ? 1 : 0;
     s->rng.step = f.rng.step;
     if (f.pend_gather)
         for (int b = 0; b < B; ++b) s->r_pending[b] = f.r_cur[b];
@@ -212,6 +220,7 @@ extern "C" int gse_pf_cycles(gse_pf_loop_spec* s, int K, const double* u /* host
     f.pend_gather = s->pend_gather != 0;                    // (a resample the caller left pending rides the first launch)
     f.gather_slot = s->gather_slot;
     f.samples_ok = f.pend_gather && s->samples_ok != 0;
+    f.w_uniform = s->w_uniform != 0;
     if (f.pend_gather) f.r_cur = s->r_pending;
     for (int k = 0; k < K; ++k) {
         f.u_cur = u + (int64_t)k * B * 2;
@@ -231,6 +240,7 @@ extern "C" int gse_pf_cycles(gse_pf_loop_spec* s, int K, const double* u /* host
     s->gather_slot = f.gather_slot;
     s->scan_slot = -1;
     s->samples_ok = f.samples_ok ? 1u : 0u;
+    s->w_uniform = f.w_uniform ? 1 : 0;
     s->rng.step = f.rng.step;
     for (int b = 0; b < B; ++b) s->r_pending[b] = f.r_cur[b];
     return GSE_OK;

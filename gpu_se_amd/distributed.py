@@ -133,6 +133,8 @@ class ShardedParticleFilter:
     """
 
     collectives_issued = 0                                  # all-reduces / all-gathers / all-to-alls issued by this object
+    merge_cov_size = False                                  # merges also leave the covariance size in estimate_device[5] (a serial
+                                                            # Jacobi chain on the device: off unless a device consumer wants it)
     _shares_host = _side_stream = _shares_event = None      # (device groups only: see __init__)
     _shares_recorded = False
 
@@ -201,7 +203,7 @@ class ShardedParticleFilter:
         self.last_exact = None
         self._ends_index = None                             # device indices of the shard ends in the tile prefix (built once)
         self._merge_buf = torch.zeros((self.world, MERGE_WIDTH), dtype=torch.float64, device=self._merge_device)
-        self._dev_rows = self._dev_moments = self._dev_status = self._pivot_c = None      # device merge (merge_begin)
+        self._dev_rows = self._dev_moments = self._dev_status = self._pivot_c = self._dev_est = None   # device merge (merge_begin)
         self._merge_work, self._merge_pending = None, False
         self.collectives_issued = 0                         # all-reduces / all-gathers / all-to-alls this object has issued
 
@@ -244,6 +246,29 @@ class ShardedParticleFilter:
                 self._force_exact = False
                 return self._exact_resample(r)
         self.local.resample(r=r)
+
+    def run_cycles(self, us, zs, dt, rs=None):
+        """K island cycles predict -> update -> resample of this shard enqueued by ONE call (ParallelParticleFilter.run_cycles ->
+        gse_pf_cycles, which hands the shard's bookkeeping to every launch): the launches of K rounds of the three methods.
+        The island policy looks at the exchanged log-weights before the batch (an exact resample of the whole ensemble first,
+        if the shards have drifted apart) and the exchange that falls due inside the batch is issued behind it."""
+        K = len(us)
+        if K == 0:
+            return
+        multi = self.group is not None and self.world > 1
+        if multi:
+            self._consider_shares()
+            if self._force_exact:
+                self._force_exact = False
+                self._exact_resample(None)
+        copies = K - 1 + (1 if self.local._pend_gather else 0)      # resample copies the batch's launches execute
+        self.local.run_cycles(us, zs, dt, rs)
+        before = self._resamples
+        self._resamples += copies
+        if copies:
+            self._islands_apart = True
+        if multi and self._resamples // self.reduce_every != before // self.reduce_every:
+            self._exchange_shares()
 
     def _consider_shares(self):
         """One cycle after the shards' log-weights were exchanged: read them (the only synchronisation of the island
@@ -404,27 +429,58 @@ class ShardedParticleFilter:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         return merge_rows(buf.cpu().numpy(), self._pivot)
 
-    def merge_begin(self):
-        """Enqueue the posterior merge and return at once: the shard's moments (gse_pf_moments; a pending resample's copy
-        runs first, which is where the shard's log-weight absorbs the weight sum), its row of the merge buffer written ON THE
-        DEVICE (gse_merge_row: pivot shift, accumulated log-weight, binary exponent of the stored weights), and the
-        all-reduce of the [P][22] buffer -- asynchronous on RCCL, so that it overlaps whatever the caller enqueues next.
-        Nothing comes to the host (with the gloo backend of the CPU tests the buffer has to: gloo reduces host tensors)."""
-        f = self.local
-        f._flush()
-        dev = f._x.device
-        stream = torch.cuda.current_stream().cuda_stream
+    def _merge_buffers(self):
         if self._dev_rows is None:
+            import ctypes
+            dev = self.local._x.device
             self._dev_rows = torch.zeros((self.world, MERGE_WIDTH), dtype=torch.float64, device=dev)
             self._dev_moments = torch.zeros((2, 26), dtype=torch.float64, device=dev)      # [0] the shard's, [1] the ensemble's
+            self._dev_est = torch.zeros(6, dtype=torch.float64, device=dev)                # mean (5), covariance size
             self._dev_status = torch.zeros(1, dtype=torch.int32, device=dev)
             self._pivot_c = _lib.doubles(self._pivot, 5)
-        f._call("gse_pf_moments", f._x.data_ptr(), f._w.data_ptr(), f._ld, 1, f.N_particles, self._dev_moments[0].data_ptr(),
-                f._ws.data_ptr(), stream)
+            spec = self._merge_spec = _lib.MergeSpec()
+            spec.P, spec.rank = self.world, self.rank
+            for k in range(5):
+                spec.common_pivot[k] = float(self._pivot[k])
+            spec.rows, spec.moments26, spec.merged26 = (self._dev_rows.data_ptr(), self._dev_moments[0].data_ptr(),
+                                                        self._dev_moments[1].data_ptr())
+            spec.estimate6, spec.status = self._dev_est.data_ptr(), self._dev_status.data_ptr()
+            self._merge_spec_ref = ctypes.byref(spec)
+
+    def merge_begin(self, flushed=False, into=None):
+        """Enqueue the posterior merge and return at once (gse_pf_merge_begin, two launches).  When a resample is pending on the
+        scans the last update left -- the state between resample() and the next predict(), where the reference's loop asks for
+        its estimate (sim_base.py:258-262) -- NOTHING IS FLUSHED (round 5): the moments are those of the ensemble the resample
+        will produce, weighted by offspring counts (the resident loop's route: gse_pf_moments_resampled), the row's log-weight is
+        what the copy's launch will make of the shard's, and the copy itself keeps riding the next cycle's single launch.  One
+        kernel finishes the partial sums, writes this shard's row of the merge buffer ON THE DEVICE (pivot shift, accumulated
+        log-weight, binary exponent of the stored weights) and zeroes the other rows; then the all-reduce of the [P][22] buffer
+        -- asynchronous on RCCL, so that it overlaps whatever the caller enqueues next.  Without a group (one shard) that same
+        kernel also combines and estimates: two launches behind the cycle's one.  Nothing comes to the host (with the gloo
+        backend of the CPU tests the buffer has to: gloo reduces host tensors).
+        ``flushed=True``: round 4's route (the pending copy runs first, gse_pf_moments of the copied ensemble) -- kept as the
+        reference the new route is tested against.  ``into``: a device tensor of 26 doubles that receives the merged moments
+        instead of the object's own buffer (a loop that keeps a record per tick, as sim_base.py:287-296 does, hands in row t
+        and gets all its covariance sizes from ONE gse_moments_estimates call at the end)."""
+        f = self.local
+        pending = (not flushed and f._pend_gather and f._gather_slot is not None and f._pend_predict is None and
+                   f.N_particles <= (1 << 21))
+        if not pending:
+            f._flush()
+        self._merge_buffers()
+        spec = self._merge_spec
+        spec.flags = (_lib.GSE_MERGE_PENDING if pending else 0) | (_lib.GSE_MERGE_COV_SIZE if self.merge_cov_size else 0)
+        spec.slot = f._slot_arg(f._gather_slot) if pending else 0
+        spec.r = float(f._c_r[0])
+        spec.island = f._island.data_ptr()
+        spec.wscale = f._wscale.data_ptr() if f.weight_scale else None
+        if into is not None and not (into.is_cuda and into.dtype == torch.float64 and into.is_contiguous() and into.numel() == 26):
+            raise ValueError("into must be a contiguous CUDA tensor of 26 doubles")
+        self._merged_out = self._dev_moments[1] if into is None else into
+        spec.merged26 = self._merged_out.data_ptr()
+        _lib.call("gse_pf_merge_begin", f._x.data_ptr(), f._w.data_ptr(), f._ld, f.N_particles, self._merge_spec_ref,
+                  f._ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
         rows = self._dev_rows
-        rows.zero_()
-        _lib.call("gse_merge_row", self._dev_moments[0].data_ptr(), f._island.data_ptr(),
-                  f._wscale.data_ptr() if f.weight_scale else None, self._pivot_c, rows[self.rank].data_ptr(), stream)
         self._merge_work = None
         if self.group is not None:
             self.wait_collectives()
@@ -439,21 +495,33 @@ class ShardedParticleFilter:
 
     def merge_end(self):
         """The moments of the whole ensemble as a DEVICE tensor of 26 doubles (gse_pf_moments layout: what gse_loop_control and
-        gse_moments_estimates take), after merge_begin: the current stream waits for the all-reduce (no host wait), then one
-        small kernel combines the shards' rows (gse_merge_rows)."""
+        gse_moments_estimates take), after merge_begin: the current stream waits for the all-reduce (no host wait), then ONE
+        small kernel combines the shards' rows and forms the estimate (gse_merge_end; ``estimate_device`` holds mean and
+        covariance size).  A single shard without a group was combined by merge_begin's kernel already."""
         if not self._merge_pending:
             self.merge_begin()
         if self._merge_work is not None:
             self._merge_work.wait()                       # (stream-ordered: the host does not block)
             self._merge_work = None
-        _lib.call("gse_merge_rows", self._dev_rows.data_ptr(), self.world, self._pivot_c, self._dev_moments[1].data_ptr(),
-                  self._dev_status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if self.group is not None:
+            _lib.call("gse_merge_end", self._merge_spec_ref, torch.cuda.current_stream().cuda_stream)
         self._merge_pending = False
-        return self._dev_moments[1]
+        return self._merged_out
+
+    @property
+    def estimate_device(self):
+        """[mean (5), largest singular value of the covariance] of the last merge, a device tensor of 6 doubles (no copy)."""
+        return self._dev_est
 
     def _merged(self):
-        m = torch.cat([self.merge_end(), self._dev_status.to(torch.float64)]).cpu().numpy()    # the one copy of an estimate
-        if m[26] != 0:
+        f = self.local
+        m = torch.cat([self.merge_end(), self._dev_status.to(torch.float64), f._wstatus.to(torch.float64)]).cpu().numpy()
+        f._check_status(m[27:])                             # (a resample of this shard met a weight sum that is not finite)
+        status = int(m[26])
+        if status & _lib.GSE_MERGE_STATUS_OVERFLOW:
+            raise FloatingPointError("a shard's weight sum is not finite: the stored fp32 weights overflowed the launch's "
+                                     "power-of-two scale (GSE_OP_WEIGHT_SCALE)")
+        if status & _lib.GSE_MERGE_STATUS_NO_WEIGHT:
             raise FloatingPointError("every shard has zero weight (all likelihoods underflowed)")
         _, mean, cov = moments_to_mean_cov(m[0], m[1:6], m[6:21], m[21:26])
         return mean, cov

@@ -63,7 +63,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         self._w_sigma_c = (_lib.c_f * self._N_sigmas)(*[float(v) for v in w_sigma])
         self._w_sigma = DevArray.wrap(torch.as_tensor(w_sigma, device=dev))
 
-        self._ws = torch.empty(_lib.load().gse_workspace_bytes(B, n), dtype=torch.uint8, device=dev)
+        self._ws = torch.zeros(_lib.load().gse_workspace_bytes(B, n), dtype=torch.uint8, device=dev)
         self._moments = torch.empty((B, _lib.GSE_GSUKF_MOMENTS), dtype=torch.float64, device=dev)
         self._status = torch.zeros(1, dtype=torch.int32, device=dev)
         self._seed = gpu_se_amd._new_stream_seed()

@@ -100,6 +100,10 @@ class ParallelParticleFilter:
         at = lib.gse_workspace_weight_scale_offset(B, n)
         self._wscale = self._ws[at:at + 8 * B].view(torch.float64)
         self.weight_scale = True
+        # sticky status word per filter in the workspace (include/gse.h, GSE_WSTATUS_*): the kernels raise it when a resample
+        # meets a weight sum that is +inf or NaN; read where the host synchronises anyway (_check_status)
+        at = lib.gse_workspace_status_offset(B, n)
+        self._wstatus = self._ws[at:at + 4 * B].view(torch.int32)
         self._moments = torch.empty((B, 26), dtype=torch.float64, device=dev)
         self._tiles_valid = False
         self._island = None                                 # [2][B] fp64 shard bookkeeping (ShardedParticleFilter)
@@ -435,13 +439,20 @@ class ParallelParticleFilter:
         self._moments_host = None
         self._samples_ok = False
 
-    def _fold_weight_scale(self):
-        """Bring the stored weights to the scale 1 (what fp32 can hold of the true weights) and clear the exponent: a
-        caller who is handed the array, or assigns to it, deals in plain numbers."""
-        if self.weight_scale:
-            s = self._wscale
-            self._w.copy_((self._w.double() * torch.exp2(s)[:, None]).float())
-            s.zero_()
+    def _check_status(self, status=None):
+        """Turn a raised status word into an exception (and clear it).  ``status``: the words as a host array if the caller has
+        copied them already (with its own results: one synchronisation), else they are fetched here."""
+        if status is None:
+            status = self._wstatus.cpu().numpy()
+        status = numpy.asarray(status).astype(numpy.int64).reshape(-1)
+        if numpy.any(status & _lib.GSE_WSTATUS_SUM_NOT_FINITE):
+            self._wstatus.zero_()
+            bad = numpy.nonzero(status & _lib.GSE_WSTATUS_SUM_NOT_FINITE)[0].tolist()
+            raise FloatingPointError(
+                "a resample met weights whose sum is not finite (filter%s %s)%s: the ensemble has collapsed onto particle 0" % (
+                    "s" if len(bad) > 1 else "", bad,
+                    " -- the stored fp32 weights overflowed the launch's power-of-two scale: a particle weighed more than 2^127 "
+                    "times the 64 sample particles the scale is anchored on" if self.weight_scale else ""))
 
     @property
     def weight_log2_scale(self):
@@ -456,10 +467,19 @@ class ParallelParticleFilter:
 
     @property
     def weights(self):
+        """The weights as a device array (N,) / (B, N).  While the stored fp32 numbers ARE the weights (binary exponent 0:
+        always, unless a likelihood fell below 2^-40 since the last resample) this is a writable view of them, like the
+        reference's attribute.  With an exponent engaged the true weights are below fp32's range -- what the reference holds in
+        fp64 (filter/particle.py:103, :316) -- and an fp64 COPY of the true weights is handed out instead; the filter's state is
+        not touched (round 4 folded the exponent into the fp32 numbers here, which flushed every weight to zero and sent
+        the next resample to particle 0).  Synchronises."""
         self._flush()
-        self._fold_weight_scale()
+        n = self.N_particles
+        if self.weight_scale and bool((self._wscale != 0).any().item()):
+            v = self._w[:, :n].double() * torch.exp2(self._wscale)[:, None]
+            return DevArray.wrap(v[0] if self._B == 1 else v)
         self._handed_out()
-        v = self._w[:, :self.N_particles]
+        v = self._w[:, :n]
         return DevArray.wrap(v[0] if self._B == 1 else v)
 
     @weights.setter
@@ -581,7 +601,7 @@ class ParallelParticleFilter:
         ((K, B, 2) for a batch); rs: optional (K,) / (K, B) uniform numbers (default: the filter's own host stream, in the order
         resample() would draw them).  Philox noise, the built-in model, a 2-component measurement mixture, N <= 2^21."""
         if self._model is not None or isinstance(self.state_pdf, DeterministicGaussianSum) or self.measurement_pdf._Nd != 2 \
-                or self.N_particles > (1 << 21) or not self.lazy or self._island is not None or self.record_ancestors:
+                or self.N_particles > (1 << 21) or not self.lazy or self.record_ancestors:
             for k in range(len(us)):                        # (whatever gse_pf_cycles does not take: the methods themselves)
                 self.predict(us[k], dt)
                 self.update(us[k], zs[k])
@@ -614,6 +634,8 @@ class ParallelParticleFilter:
         spec.pend_gather = 1 if self._pend_gather else 0
         spec.gather_slot = self._gather_slot if self._pend_gather else -1
         spec.samples_ok = 1 if (self._pend_gather and self._samples_ok) else 0
+        spec.w_uniform = 1 if self._w_uniform else 0
+        spec.island = self._island.data_ptr() if self._island is not None else None     # (a shard: distributed.py)
         for b in range(B):
             spec.r_pending[b] = self._c_r[b]
         rc = self._lib.gse_pf_cycles(ctypes.byref(spec), K, u.ctypes.data, z.ctypes.data, stream_ptr(self._dev_index))
@@ -628,7 +650,7 @@ class ParallelParticleFilter:
         self._slot_fmt[self._gather_slot] = "q" if clustered else "t"
         self._tiles_valid, self._moments_host, self._want_index = False, None, False
         self._samples_ok = bool(spec.samples_ok)
-        self._w_uniform = False
+        self._w_uniform = bool(spec.w_uniform)
         for b in range(B):
             self._c_r[b] = spec.r_pending[b]
 
@@ -639,7 +661,9 @@ class ParallelParticleFilter:
         if self._moments_host is None:                      # nothing changed since the last estimate: reuse it
             self._call("gse_pf_moments", self._x.data_ptr(), self._w.data_ptr(), self._ld, self._B, self.N_particles,
                        self._moments.data_ptr(), self._ws.data_ptr(), stream_ptr())
-            self._moments_host = self._moments.cpu().numpy()
+            host = self._moments.cpu().numpy()
+            self._check_status()
+            self._moments_host = host
             if self.weight_scale:
                 # the kernel sums the STORED weights; the reference's quantities are un-normalised sums of the true ones
                 k = self._wscale.cpu().numpy()

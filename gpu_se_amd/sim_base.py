@@ -582,6 +582,7 @@ class BatchedSimulation:
         spec.schedule, spec.r = sched.ctypes.data, r_host.ctypes.data
         spec.us, spec.xs, spec.ys, spec.ys_meas, spec.moments = (t_.data_ptr() for t_ in (us, xs, ys, ys_meas, moments))
         spec.status = status.data_ptr()
+        spec.w_uniform = 1 if f._w_uniform else 0          # (the first update of a fresh filter needs no pass for its scale's anchor)
         _lib.check(lib.gse_pf_closed_loop(ctypes.byref(spec), stream))
         # the filter object carries on from where the loop left it
         if spec.x_current:
@@ -598,7 +599,7 @@ class BatchedSimulation:
         f._tiles_valid = False
         f._moments_host = None
         f._samples_ok = bool(spec.samples_ok)
-        f._w_uniform = False
+        f._w_uniform = bool(spec.w_uniform)
         if spec.pend_predict:
             f._pend_predict = (u, float(self.dt), None)
         for b in range(B):
@@ -681,6 +682,10 @@ class BatchedSimulation:
         device_s = ev0.elapsed_time(ev1) * 1e-3
         host = flat.cpu().numpy()
         est6 = estimates.cpu().numpy().reshape(ticks, B, 6)
+        if self.pf:
+            # a resample that met a weight sum that is not finite (the stored fp32 weights overflowed their power-of-two scale)
+            # has collapsed its rollout onto one particle: never silently (GSE_WSTATUS_SUM_NOT_FINITE; round 5)
+            self.f._check_status()
         clock.append(time.perf_counter())
         back, at = {}, 0
         for name, wdt in widths.items():

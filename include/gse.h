@@ -91,7 +91,9 @@ int         gse_stream_synchronize(void *stream, int spin);
 
 /* Bytes of device workspace the particle-filter / GS-UKF calls below need for (B, N): per filter the tile
  * sums, their prefix and the moment partials.  The workspace carries state only BETWEEN gse_*_update and a
- * gse_*_resample(..., GSE_RESAMPLE_TILES_VALID) that directly follows it. */
+ * gse_*_resample(..., GSE_RESAMPLE_TILES_VALID) that directly follows it -- plus three small per-filter words the library
+ * maintains across calls (weight-scale exponent, sticky status, the ticket counter of gse_pf_merge_begin): the owner
+ * ZERO-INITIALISES the workspace once, when it allocates it. */
 int64_t gse_workspace_bytes(int B, int64_t N);
 
 /* ---------------------------------------------------------------- particle filter ---------------- */
@@ -225,6 +227,15 @@ int gse_pf_resample_begin(const float *w, int64_t ld, int B, int64_t N, uint32_t
 #define GSE_SLOT_QUARTERS 2
 int gse_pf_slot_to_tiles(int B, int64_t N, int slot, void *workspace, void *stream);
 int64_t gse_workspace_weight_scale_offset(int B, int64_t N);   /* byte offset of scale[B] inside the workspace; < 0: bad B / N */
+/* Sticky status of every filter, uint32 [B] inside the workspace at this byte offset (round 5).  The kernels only ever RAISE bits,
+ * the caller reads them where it synchronises anyway and clears them:
+ *   GSE_WSTATUS_SUM_NOT_FINITE  a resample (its gather stage, gse_pf_resample_begin, gse_pf_moments_resampled) met weights whose
+ *                    sum is +inf or NaN.  With GSE_OP_WEIGHT_SCALE that is an OVERFLOW of the stored fp32 weights: a particle
+ *                    weighed 2^127 more than the launch's anchor (64 sample particles).  The resample itself then does what the
+ *                    reference's does with a NaN cumulative sum (every offspring copies particle 0, filter/particle.py:98) -- the
+ *                    ensemble collapses -- so the drivers turn this bit into FloatingPointError instead of carrying on. */
+#define GSE_WSTATUS_SUM_NOT_FINITE 1u
+int64_t gse_workspace_status_offset(int B, int64_t N);
 int gse_pf_step(uint32_t ops, const float *x_in, float *x_out, const float *w_in, float *w_out, int32_t *idx,
                 int64_t ld, int B, int64_t N, const double *u, double dt, const double *z, const double *r,
                 const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,
@@ -614,6 +625,12 @@ typedef struct gse_pf_loop_spec {
     int32_t pend_gather, pend_predict;           /* a resample's copy / a predict still to be launched */
     int32_t gather_slot, scan_slot;              /* scan slot the pending copy resamples from; slot of the current weights' scans */
     double r_pending[GSE_MAX_B];                 /* the uniform numbers of the pending resample */
+    /* in / out (round 5) */
+    double *island;                              /* [2][B] shard bookkeeping handed to every gse_pf_step (a SHARDED ensemble's
+                                                    cycles: gpu_se_amd/distributed.py), or NULL */
+    int32_t w_uniform, reserved2;                /* every weight is 1 / N (a resample's copy ran, no update since): the first
+                                                    update without a copy in its launch then passes GSE_OP_UNIFORM_WEIGHTS, as
+                                                    the class does; 0 if in doubt */
 } gse_pf_loop_spec;
 int gse_pf_closed_loop(gse_pf_loop_spec *spec /* host, in / out */, void *stream);
 /* K open-loop cycles predict(u_k, dt) -> update(u_k, z_k) -> resample(r_k) of the B filters in `spec` (its filter fields:
@@ -645,6 +662,44 @@ int gse_merge_row(const double *moments26, const double *log_island, const doubl
                   double *row /* [22] */, void *stream);
 int gse_merge_rows(const double *rows /* [P][22] */, int P, const double *common_pivot /* host */, double *moments26_out,
                    int32_t *status, void *stream);
+/* The same merge in TWO launches before the all-reduce and ONE behind it (round 5) -- what an estimate at the end of every
+ * cycle costs a shard (the reference's loop asks for one every tick, sim_base.py:262, :287-295):
+ * gse_pf_merge_begin: the shard's moments -- with GSE_MERGE_PENDING those of the ensemble the PENDING resample will produce
+ *   (spec->flags & GSE_MERGE_PENDING; gse_pf_moments_resampled: offspring-weighted, no particle is copied, the copy keeps riding the next cycle's single
+ *   launch; the row's log-weight is island[0] + log(sum of the slot's weights) + wscale ln 2, what the copy's launch will make
+ *   of island[0]), otherwise gse_pf_moments of the live weights -- then ONE kernel that finishes the partial sums, writes
+ *   this shard's row of rows[P][22] (gse_merge_row's arithmetic) and zeroes the other rows.  With P == 1 that kernel also
+ *   combines (gse_merge_rows) and writes merged26 / estimate6, and there is nothing left to do.
+ * gse_merge_end (P > 1, behind the all-reduce of rows): gse_merge_rows + the estimate in one launch.
+ * estimate6 = [mean (5), largest singular value of the covariance] as gse_moments_estimates gives them; the sixth only with
+ *   GSE_MERGE_COV_SIZE (the same cyclic Jacobi sweeps, 25 lanes to a 5 x 5 matrix, stopped when the off-diagonal has
+ *   vanished: a serial chain of fp64 divisions and roots that costs more than the rest of the merge -- a loop that records
+ *   merged26 per tick gets all its covariance sizes from ONE gse_moments_estimates call at the end, as the resident loops do).
+ * status[0]: bit 0 -- no shard has weight (every likelihood underflowed); bit 1 -- a shard's weight sum is inf or NaN (the
+ *   stored weights overflowed the launch's power-of-two scale, GSE_OP_WEIGHT_SCALE): such a shard is never silently dropped.
+ * One filter per call (B = 1: a shard).  Pointers device memory unless marked host. */
+#define GSE_MERGE_STATUS_NO_WEIGHT 1
+#define GSE_MERGE_STATUS_OVERFLOW 2
+#define GSE_MERGE_PENDING 1
+#define GSE_MERGE_COV_SIZE 2
+typedef struct gse_merge_spec {
+    int32_t P, rank;                 /* shards; this shard's row */
+    int32_t flags;                   /* GSE_MERGE_PENDING: moments of the pending resample's outcome (slot, r), else of the live
+                                        particles / weights; GSE_MERGE_COV_SIZE: estimate6[5] is wanted (else only the mean) */
+    int32_t slot;                    /* scan slot the pending resample reads (| GSE_SLOT_QUARTERS) */
+    double r;                        /* the pending resample's uniform number, in [0, 1) */
+    const double *island;            /* [2][1] shard bookkeeping of gse_pf_step, or NULL (log-weight 0) */
+    const double *wscale;            /* [1] binary exponent of the stored weights (GSE_OP_WEIGHT_SCALE), or NULL */
+    double common_pivot[5];          /* the pivot every rank shares */
+    double *rows;                    /* [P][22] merge buffer (what the ranks all-reduce) */
+    double *moments26;               /* [26] out: this shard's moments (gse_pf_moments layout) */
+    double *merged26;                /* [26] out: the whole ensemble's (S0 = 1, about common_pivot) */
+    double *estimate6;               /* [6] out, or NULL */
+    int32_t *status;                 /* [1] out */
+} gse_merge_spec;
+int gse_pf_merge_begin(const float *x /* [5][ld] */, const float *w /* [ld] */, int64_t ld, int64_t N,
+                       const gse_merge_spec *spec /* host */, void *workspace, void *stream);
+int gse_merge_end(const gse_merge_spec *spec /* host */, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Exact systematic resampling of an ensemble SHARDED over several GPUs: the result is, bit for

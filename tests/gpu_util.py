@@ -43,7 +43,7 @@ def product_mixtures():
 
 
 def workspace(B, N):
-    return torch.empty(_lib.load().gse_workspace_bytes(B, N), dtype=torch.uint8, device="cuda")
+    return torch.zeros(_lib.load().gse_workspace_bytes(B, N), dtype=torch.uint8, device="cuda")
 
 
 def adversarial_weights(n, rng):

@@ -38,7 +38,7 @@ def test_struct_layout_matches_header(lib):
 
 
 def test_loop_structs_match_the_header_as_a_c_compiler_lays_them_out(lib, tmp_path):
-    """gse_loop_spec and gse_loop_tail cross the boundary by pointer: size and every field offset of the ctypes mirrors
+    """gse_loop_spec, gse_loop_tail, gse_pf_loop_spec and gse_merge_spec cross the boundary by pointer: size and every field offset of the ctypes mirrors
     against include/gse.h compiled by gcc."""
     import os
     import shutil
@@ -46,7 +46,8 @@ def test_loop_structs_match_the_header_as_a_c_compiler_lays_them_out(lib, tmp_pa
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    structs = {"gse_loop_spec": lib.LoopSpec, "gse_loop_tail": lib.LoopTail}
+    structs = {"gse_loop_spec": lib.LoopSpec, "gse_loop_tail": lib.LoopTail, "gse_pf_loop_spec": lib.PfLoopSpec,
+               "gse_merge_spec": lib.MergeSpec}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gse.h"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

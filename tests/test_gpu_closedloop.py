@@ -165,10 +165,21 @@ def _sharded_worker(rank, world, port, out, n_local=1 << 15):
     # the posterior merge on the device (gse_merge_row -> all-reduce -> gse_merge_rows; nothing but the final 26 doubles comes
     # to the host) against the host merge of rounds 1-3 (rows packed and combined with NumPy): the same formulas; exp / log of
     # the shard shares come from two libraries, and the covariance undoes the pivot shift in another order
+    # (round 5) first the merge WITHOUT a flush: a resample is pending on both ranks, the moments are those of the ensembles the
+    # resamples will produce, the rows' log-weights what the copies' launches will make of the shards' -- nothing is copied
+    from gpu_se_amd.filter.particle import moments_to_mean_cov
+    assert spf.local._pend_gather
+    spf.merge_begin()
+    assert spf.local._pend_gather
+    pend = torch.cat([spf.merge_end(), spf.estimate_device]).cpu().numpy()
+    _, pend_mean, pend_cov = moments_to_mean_cov(pend[0], pend[1:6], pend[6:21], pend[21:26])
     host_mean, host_cov = spf._merged_host()
     dev_mean, dev_cov = spf._merged()
     np.testing.assert_allclose(dev_mean, host_mean, rtol=1e-14, atol=0)
     np.testing.assert_allclose(dev_cov, host_cov, rtol=1e-9, atol=1e-22)
+    np.testing.assert_allclose(pend_mean, host_mean, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(pend_cov, host_cov, rtol=1e-8, atol=1e-22)
+    np.testing.assert_allclose(pend[26:31], host_mean, rtol=1e-13, atol=0)          # gse_merge_end's estimate
     assert spf.collectives_issued >= 3
     est = spf.point_estimate()
     cov = spf.point_covariance()
@@ -442,7 +453,18 @@ def _rccl_worker(rank, world, port, out):
     # the posterior merge, on the device from end to end: the shard's row written by gse_merge_row, an ASYNCHRONOUS all-reduce
     # on RCCL, gse_merge_rows -- against the host merge of rounds 1-3 (one shard: its share is exp(0) = 1, so the mean is
     # the host's bit for bit; the covariance undoes the pivot shift in another order)
+    # (round 5) ... first without a flush: one more cycle leaves a resample pending, the merge takes the moments of the ensemble
+    # it will produce and the copy keeps riding the next launch; then the flushed merge of the same state
+    from gpu_se_amd.filter.particle import moments_to_mean_cov
+    spf.predict([0.06, 0.2], 0.1)
+    spf.update([0.06, 0.2], z)
+    spf.resample()
+    spf.merge_begin()
+    assert spf._merge_work is not None and spf.local._pend_gather
+    pend = spf.merge_end().cpu().numpy()
+    _, pend_mean, _ = moments_to_mean_cov(pend[0], pend[1:6], pend[6:21], pend[21:26])
     host_mean, host_cov = spf._merged_host()
+    np.testing.assert_allclose(pend_mean, host_mean, rtol=1e-13, atol=0)
     spf.merge_begin()
     assert spf._merge_work is not None                               # (issued with async_op=True on the nccl backend)
     moments = spf.merge_end()

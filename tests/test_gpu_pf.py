@@ -837,6 +837,12 @@ def test_weight_range_of_the_reference_after_a_measurement_jump(n, lazy):
         if cycle == 1:
             assert k[0] < -150 and o.weights.max() < 1e-50, (k, o.weights.max())
             assert w_plain.sum() == 0.0                                 # what plain fp32 weights make of this update
+            # reading the attribute now hands out the TRUE weights in fp64 and leaves the filter alone (round 5; round 4 folded
+            # the exponent into the fp32 numbers: all zero, and the resample below went to particle 0)
+            got = pf.weights.get()
+            assert got.dtype == np.float64 and 0 < got.max() < 1e-45
+            np.testing.assert_array_equal(got, np.ldexp(w[0].astype(np.float64), int(k[0])))
+            assert pf.weight_log2_scale[0] == k[0] and np.array_equal(pf._scaled_weights()[0], w)
         elif cycle == 0:
             assert k[0] == 0                                            # likelihoods fp32 holds: the launch is bit for bit
             np.testing.assert_array_equal(w[0], w_plain)                # what it is without the scale
@@ -983,8 +989,9 @@ def test_scale_of_an_update_without_a_resample_looks_at_every_particle(n, cluste
 
 
 def test_weight_scale_travels_with_the_accessors():
-    """``weights`` hands out plain numbers (the exponent folded in, what fp32 holds of them), assigning weights clears the
-    exponent, and the island bookkeeping of a shard (log of the TRUE weight sum) includes it."""
+    """``weights`` hands out the TRUE weights (fp64 while an exponent is engaged, the fp32 view otherwise) without touching the
+    filter, assigning weights clears the exponent, and the island bookkeeping of a shard (log of the TRUE weight sum) includes
+    it."""
     n = 8192
     pf, o, xss = _filter_and_reference_dtype_oracle(n, 78)
     pf._island = torch.zeros((2, 1), dtype=torch.float64, device="cuda")
@@ -1005,15 +1012,37 @@ def test_weight_scale_travels_with_the_accessors():
     isl = pf._island.cpu().numpy()
     np.testing.assert_allclose(isl[0, 0], np.log(true_sum), rtol=1e-12)
     np.testing.assert_allclose(isl[1, 0], true_sum, rtol=1e-12)
-    # a second update, then the accessor: plain fp32 numbers (here: flushed towards zero, as fp32 must), exponent cleared
+    # a second update, then the accessor (round 5): with an exponent engaged the true weights are below fp32's range, so an
+    # fp64 COPY of them is handed out -- what the reference holds after its first resample (filter/particle.py:103, :316) -- and
+    # the filter's state is not touched: the exponent stays, and the resample that follows finds the ancestors the stored
+    # weights call for (round 4 folded the exponent into the fp32 numbers here: every weight flushed to zero, every ancestor 0)
+    DeterministicGaussianSum.preload(noise)
+    pf.predict(u, 0.1)
+    pf.update(u, z)
+    k_before = pf.weight_log2_scale[0]
+    assert k_before < -40
+    w_stored, _ = pf._scaled_weights()
+    got = pf.weights.get()
+    assert got.dtype == np.float64 and pf.weight_log2_scale[0] == k_before
+    np.testing.assert_array_equal(got, np.ldexp(w_stored[0].astype(np.float64), int(k_before)))
+    assert 0 < got.max() < 1e-20
+    assert np.array_equal(pf._scaled_weights()[0], w_stored)
+    idx = pf.resample(r=0.6, return_index=True).get()
+    o.weights = w_stored[0].astype(np.float64)                      # (ancestors are invariant under the power of two)
+    np.testing.assert_array_equal(idx, o.resample(r=0.6, loop=False))
+    assert len(np.unique(idx)) > 10
+    # assigning plain numbers clears the exponent
     DeterministicGaussianSum.preload(noise)
     pf.predict(u, 0.1)
     pf.update(u, z)
     assert pf.weight_log2_scale[0] < -40
-    got = pf.weights.get()
-    assert pf.weight_log2_scale[0] == 0 and got.dtype == np.float32
     pf.weights = np.full(n, 1.0 / n, dtype=np.float32)
     assert pf.weight_log2_scale[0] == 0
+    # ... and while no exponent is engaged the attribute is the writable fp32 view it always was
+    v = pf.weights
+    assert v.get().dtype == np.float32
+    v[:] = 2.0 / n
+    assert pf.weights.get()[5] == np.float32(2.0 / n)
 
 
 # ------------------------------------------------------------------------------ four workgroups per tile (mid-size ensembles)
@@ -1117,8 +1146,9 @@ def test_cluster_cycle_on_adversarial_weights_and_in_batches():
     np.testing.assert_array_equal(a.point_estimate(), b_.point_estimate())
 
 
-@pytest.mark.parametrize("n,batch", [(1 << 14, None), (70001, None), (1 << 20, None), (9000, 3)])
-def test_run_cycles_equals_the_three_methods(n, batch):
+@pytest.mark.parametrize("n,batch,jump", [(1 << 14, None, False), (70001, None, False), (1 << 20, None, False), (9000, 3, False),
+                                          (1 << 14, None, True), (1 << 20, None, True), (9000, 3, True)])
+def test_run_cycles_equals_the_three_methods(n, batch, jump):
     """ParallelParticleFilter.run_cycles (gse_pf_cycles: K cycles enqueued from C++) against K rounds of predict / update /
     resample from Python: the same launches, so particles, weights and estimates bit for bit -- mid-size filters (cluster
     launches), 2^20 (the tile kernels), a batch; and the filter carries on identically afterwards."""
@@ -1140,6 +1170,11 @@ def test_run_cycles_equals_the_three_methods(n, batch):
     K, B = 9, batch or 1
     us = np.stack([rng.uniform(0.03, 0.09, (K, B)), rng.uniform(0.1, 0.3, (K, B))], axis=-1)
     zs = np.array(orc.bioreactor_g(xss))[None, None, :] + rng.normal(0, 0.3, (K, B, 2))
+    if jump:
+        # a measurement jump on the FIRST cycle (round 5): that launch updates without a copy in front of it, and
+        # the C++ loop now vouches for the uniform weights as the class does (GSE_OP_UNIFORM_WEIGHTS: the scale's anchor from the
+        # 64 samples instead of a pass over all particles) -- the same binary exponent, the same stored weights
+        zs[0, :, 0] += 300.0
     shape = (lambda v: v[0]) if batch is None else (lambda v: v)
     for part in (slice(0, 4), slice(4, 9)):                 # (the second call starts from a pending resample)
         a.run_cycles(us[part] if batch else us[part, 0], zs[part] if batch else zs[part, 0], 0.1)
@@ -1147,9 +1182,15 @@ def test_run_cycles_equals_the_three_methods(n, batch):
             b_.predict(shape(us[k]), 0.1)
             b_.update(shape(us[k]), shape(zs[k]))
             b_.resample()
+        if jump and part.start == 0:
+            assert np.array_equal(a.weight_log2_scale, b_.weight_log2_scale)
     np.testing.assert_array_equal(a.particles.get(), b_.particles.get())
     np.testing.assert_array_equal(a.weights.get(), b_.weights.get())
     for f in (a, b_):
         f.predict(shape(us[0]), 0.1)
         f.update(shape(us[0]), shape(zs[0]))
+    if jump:
+        assert np.all(a.weight_log2_scale < -100)
+    np.testing.assert_array_equal(a._scaled_weights()[0], b_._scaled_weights()[0])
+    np.testing.assert_array_equal(a.weight_log2_scale, b_.weight_log2_scale)
     np.testing.assert_array_equal(a.point_estimate(), b_.point_estimate())

@@ -34,7 +34,15 @@ done
 cd $R
 python tools/pmc_summary.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE > $O/${tag}_pmc_fetch_write.txt
 python tools/traffic.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE "profiles/${tag}_pmc_fetch_write.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 50)" > $O/${tag}_traffic.log 2>&1
-cp profiles/pmc_traffic.json $O/${tag}_pmc_traffic.json
+# ... and the same two passes at 2^21 particles (the per-rank size of BASELINE config 4), so that a line of that size has its traffic
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc21_${tag}_$C -- python3 $R/bench.py --steps 50 --warmup 10 --log2-particles 21 --no-extras --no-cpu-baseline > $O/pmc21_${tag}_$C.log 2>&1
+done
+cd $R
+python tools/pmc_summary.py gpurun_out/pmc21_${tag}_FETCH_SIZE gpurun_out/pmc21_${tag}_WRITE_SIZE > $O/${tag}_pmc_fetch_write_N2p21.txt
+python tools/traffic.py gpurun_out/pmc21_${tag}_FETCH_SIZE gpurun_out/pmc21_${tag}_WRITE_SIZE "profiles/${tag}_pmc_fetch_write_N2p21.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 50 --log2-particles 21)" 21 > $O/${tag}_traffic_N2p21.log 2>&1
+cp gpurun_out/pmc_traffic.json $O/${tag}_pmc_traffic.json
 echo "part 1 done"
 fi
 if [ "$part" = "2" ] || [ "$part" = "all" ]; then

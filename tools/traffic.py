@@ -1,5 +1,5 @@
 """HBM traffic of the cycle kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/pmc.sh) -> profiles/pmc_traffic.json.
-usage: traffic.py <fetch dir> <write dir> <source note>
+usage: traffic.py <fetch dir> <write dir> <source note> [log2 N = 20]      (one entry per size: {"by_n": {"1048576": {...}, ...}})
 
 Corrections as MI355X_MICROARCH.md (HBM / rocprofv3) prescribes: both counters are in KB; WRITE_SIZE is exact for the streaming
 stores of this kernel; FETCH_SIZE tallies 128-byte requests at 64 bytes on gfx950 -- x2 for wide coalesced reads, uncalibrated for
@@ -21,13 +21,14 @@ def averages(d):
 
 
 fetch, write = averages(sys.argv[1]), averages(sys.argv[2])
+log2n = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 cycle = next(k for k in fetch if "pf_step_kernel<true, true, false, true, 2, 3>" in k)
 moments = next((k for k in fetch if k.endswith("pf_moments_kernel")), None)
-n = 1 << 20
+n = 1 << log2n
 out = {
     "source": sys.argv[3] if len(sys.argv) > 3 else "",
     "csrc_sha256_16": bench.csrc_hash(),
-    "kernel": "pf_step_kernel<gather,predict,update,scan in+out>, N = 2^20, one launch = one cycle",
+    "kernel": "pf_step_kernel<gather,predict,update,scan in+out>, N = 2^%d, one launch = one cycle" % log2n,
     "launches": fetch[cycle][1],
     "WRITE_SIZE_KB": round(write[cycle][0], 1),
     "FETCH_SIZE_KB_raw": round(fetch[cycle][0], 1),
@@ -41,6 +42,14 @@ out = {
 if moments:
     out["check_pf_moments_kernel"] = {"FETCH_SIZE_KB_raw": round(fetch[moments][0], 1), "x2_bytes": int(fetch[moments][0] * 2048),
                                        "known_bytes": 24 * n}
+# merge into the per-size file (the scratch copy if an earlier pass of this run wrote one, else the committed one)
 path = os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
-json.dump(out, open(path, "w"), indent=1)
+doc = {"by_n": {}}
+for cand in (path, os.path.join(ROOT, "profiles", "pmc_traffic.json")):
+    if os.path.exists(cand):
+        old = json.load(open(cand))
+        doc = old if "by_n" in old else {"by_n": {str(1 << 20): old}}
+        break
+doc["by_n"][str(n)] = out
+json.dump(doc, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))
