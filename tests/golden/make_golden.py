@@ -23,6 +23,7 @@ Fixture list:
   G8 linear_model.npz   LinearModel.create_LinearModel of the bioreactor (get_parts wiring), dt_control in {1, 0.1}
   G10 closed_loop.npz   sim_base.Simulation.simulate (the reference's own loop text) on the NumPy classes: recorded random
                         inputs and every record of the loop, particle filter and GS-UKF, control every tick / every 10th
+  G11c loop_envelope_gsf.npz  256 more seeds of G11's gsf64_c01 (GS-UKF, control every tick): a sample for a two-sample test
   G11 loop_envelope.npz the reference's Simulation run to end_time = 50 for 32 seeds per configuration (statistical envelope
                         of the closed loop: ITSE, per-tick estimation error, outputs, inputs)
   G9 mpc_qp.npz         controller.MPC: the QP it hands to OSQP (H, q, A, l, u) for several horizons / bounds, and the
@@ -662,6 +663,31 @@ def gen_loop_envelope_large(seed=2222, seeds=16):
     save("loop_envelope_large.npz", **out)
 
 
+def gen_loop_envelope_gsf(seed=3333, seeds=256):
+    """G11c (round 5): ``seeds`` more independent runs of the reference's own loop for ONE configuration, the Gaussian-sum UKF
+    with 64 Gaussians and control every tick (gsf64_c01 of G11, whose 32 seeds put the standard error of the median ITSE at
+    4e4 -- too coarse to say whether a device median of 1.4e6 or 1.6e6 is the reference's): a sample large enough for a
+    two-sample test against the Philox-driven device loop (tests/test_gpu_mpc.py).  Stored per run: ITSE, solved fraction, the
+    estimation error of the two controlled outputs per tick.  loop_envelope_gsf.npz."""
+    import multiprocessing
+    tag, cfg = "gsf64_c01", (64, 0.1, 0.1, 50, False)
+    jobs = [(tag,) + cfg + (seed + s,) for s in range(seeds)]
+    runs = []
+    with multiprocessing.Pool(min(7, os.cpu_count() or 1), initializer=_patch_loop_environment) as pool:
+        for k, r in enumerate(pool.imap_unordered(_envelope_worker, jobs)):
+            runs.append(r[1:5])
+            if (k + 1) % 32 == 0:
+                print("  gsf envelope %d/%d" % (k + 1, len(jobs)), flush=True)
+    runs.sort(key=lambda r: r[0])
+    out = {"names": numpy.array([tag]), tag + "_cfg": numpy.array([cfg[0], cfg[1], cfg[2], cfg[3], float(cfg[4])]),
+           tag + "_seeds": numpy.array([r[0] for r in runs]), tag + "_performance": numpy.array([r[1] for r in runs]),
+           tag + "_mpc_frac": numpy.array([r[2] for r in runs]), tag + "_err": numpy.array([r[3] for r in runs])}
+    p = out[tag + "_performance"]
+    print("  %s: %d seeds, ITSE median %.4g (10%% %.4g, 90%% %.4g), mean %.4g, sd %.4g" % (
+        tag, len(p), numpy.median(p), *numpy.quantile(p, [0.1, 0.9]), p.mean(), p.std()), flush=True)
+    save("loop_envelope_gsf.npz", **out)
+
+
 def gen_loop_envelope(seed=1111, seeds=32):
     """G11: the reference's own Simulation (sim_base.py:207-309, the protocol of
     results/pf_closedloop/bioreactor_performance_pf.py:19-58: end_time = 50, dt_predict = 0.1) run to the end on its NumPy
@@ -733,3 +759,5 @@ if __name__ == "__main__":
         gen_loop_envelope()
     if "envelope_large" in which:
         gen_loop_envelope_large()
+    if "envelope_gsf" in which:
+        gen_loop_envelope_gsf()
