@@ -124,6 +124,29 @@ def exact_resample_plan(J, spans, rank):
     return send, recv
 
 
+class TorchComm:
+    """The collectives ShardedParticleFilter needs, on a torch.distributed group (backend "nccl" is RCCL on ROCm).  Anything
+    with these five methods and three attributes can stand in for it -- the tests drive eight shards from eight THREADS of one
+    process through such a stand-in (tests/gpu_util.ThreadComm: a GPU box admits six processes on its card, BASELINE config 4
+    has eight ranks)."""
+
+    def __init__(self, group):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.backend = dist.get_backend(group)
+
+    def all_reduce(self, tensor, async_op=False):
+        """In-place sum over the ranks; with async_op a work object whose wait() orders the current stream behind it."""
+        return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def all_gather(self, parts, tensor):
+        dist.all_gather(parts, tensor, group=self.group)
+
+    def all_to_all_single(self, dst, src, recv, send):
+        self._comm.all_to_all_single(dst, src, recv, send)
+
+
 class ShardedParticleFilter:
     """One big particle filter whose particles live on all ranks of ``group``.
 
@@ -140,9 +163,11 @@ class ShardedParticleFilter:
 
     def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, group=None, merge_device=None,
                  reduce_every=32, even_split=False):
+        # (``group``: a torch.distributed group, or any object with TorchComm's interface)
+        self._comm = None if group is None else (group if hasattr(group, "all_to_all_single") else TorchComm(group))
         self.group = group
-        self.world = dist.get_world_size(group) if group is not None else 1
-        self.rank = dist.get_rank(group) if group is not None else 0
+        self.world = self._comm.world if group is not None else 1
+        self.rank = self._comm.rank if group is not None else 0
         self.N_particles = int(N_particles)
         # shards on tile boundaries whenever every rank can have a tile of its own: exact resampling (and with it the
         # island policy below) needs that of every shard but the last
@@ -160,7 +185,7 @@ class ShardedParticleFilter:
         self._pivot = numpy.asarray(x0.weights, dtype=numpy.float64) @ numpy.asarray(x0.means, dtype=numpy.float64) \
             / float(numpy.sum(x0.weights))
         # the collective runs where the backend wants its tensors: device for nccl/RCCL, host for gloo (CPU tests)
-        backend = dist.get_backend(group) if group is not None else None
+        backend = self._comm.backend if group is not None else None
         self._merge_device = merge_device or (dev if backend in (None, "nccl") else torch.device("cpu"))
         self._pending = None
         # The weight-sum all-reduce is bookkeeping (island weights travel as log-weights and are only combined when
@@ -213,7 +238,7 @@ class ShardedParticleFilter:
         every rank."""
         from gpu_se_amd import sim_base
         from gpu_se_amd.model import Bioreactor
-        world = dist.get_world_size(group) if group is not None else 1
+        world = (group.world if hasattr(group, "all_to_all_single") else dist.get_world_size(group)) if group is not None else 1
         xss = Bioreactor.find_SS(numpy.array([0.06, 0.2]), numpy.array([260 / 180, 640 / 24.6, 1000 / 116, 0, 0]))
         state_pdf, measurement_pdf = sim_base.get_noise()
         x0, _ = sim_base.get_noise()
@@ -315,7 +340,7 @@ class ShardedParticleFilter:
             # (with scaled weights -- GSE_OP_WEIGHT_SCALE -- a shard's live weights also carry a binary exponent of their own)
             mine_log = torch.zeros(P, dtype=torch.float64, device=self._merge_device)
             mine_log[self.rank:self.rank + 1].copy_(f._island[0] + (f._wscale * 0.6931471805599453 if f.weight_scale else 0.0))
-            dist.all_reduce(mine_log, op=dist.ReduceOp.SUM, group=self.group)
+            self._comm.all_reduce(mine_log)
             self.collectives_issued += 1
             mine_log = mine_log.to(dev)
             scale = torch.exp(mine_log[self.rank] - mine_log.max()).to(torch.float32)      # (exactly 1 on the heaviest shard)
@@ -367,14 +392,14 @@ class ShardedParticleFilter:
         padded = torch.zeros((width,), dtype=mine.dtype, device=self._merge_device)
         padded[:mine.numel()] = mine.to(self._merge_device)
         parts = [torch.empty_like(padded) for _ in counts]
-        dist.all_gather(parts, padded, group=self.group)
+        self._comm.all_gather(parts, padded)
         self.collectives_issued += 1
         return torch.cat([p[:k] for p, k in zip(parts, counts)])
 
     def _all_to_all_rows(self, rows, send, recv):
         src = rows.to(self._merge_device).contiguous()
         dst = torch.empty((sum(recv), rows.shape[1]), dtype=rows.dtype, device=self._merge_device)
-        dist.all_to_all_single(dst, src, output_split_sizes=recv, input_split_sizes=send, group=self.group)
+        self._comm.all_to_all_single(dst, src, recv, send)
         self.collectives_issued += 1
         return dst
 
@@ -390,7 +415,7 @@ class ShardedParticleFilter:
             self._shares[self.rank:self.rank + 1].copy_(self.local._island[0])
         else:
             self._shares[self.rank] = float(self.local._island[0, 0].item())
-        self._pending = dist.all_reduce(self._shares, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending = self._comm.all_reduce(self._shares, async_op=True)
         self.collectives_issued += 1
         self._shares_cycle = self._resamples
         if self._shares_event is not None:
@@ -426,7 +451,7 @@ class ShardedParticleFilter:
         buf = self._merge_buf
         buf.zero_()
         buf[self.rank] = torch.as_tensor(row, dtype=torch.float64, device=self._merge_device)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        self._comm.all_reduce(buf)
         return merge_rows(buf.cpu().numpy(), self._pivot)
 
     def _merge_buffers(self):
@@ -485,10 +510,10 @@ class ShardedParticleFilter:
         if self.group is not None:
             self.wait_collectives()
             if self._merge_device.type == "cuda":
-                self._merge_work = dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._merge_work = self._comm.all_reduce(rows, async_op=True)
             else:
                 host_rows = rows.cpu()
-                dist.all_reduce(host_rows, op=dist.ReduceOp.SUM, group=self.group)
+                self._comm.all_reduce(host_rows)
                 rows.copy_(host_rows)
             self.collectives_issued += 1
         self._merge_pending = True
