@@ -285,11 +285,26 @@ def gsukf_block(torch, sizes=(64, 4096, 1 << 16, 1 << 18)):
             cycle(i)
         reps = 300
         t0 = time.perf_counter()
-        dev = time_method_events(torch, cycle, reps)
+        dev_methods = time_method_events(torch, cycle, reps)
+        wall_methods = (time.perf_counter() - t0) / reps
+        # ... and the same cycles enqueued by ONE call (run_cycles -> gse_gsukf_cycles, round 5: the class's launches from C++)
+        us_k, zs_k = np.tile(np.asarray(u, dtype=np.float64), (reps, 1)), np.tile(np.asarray(z, dtype=np.float64), (reps, 1))
+        gf.run_cycles(us_k[:50], zs_k[:50], 0.1)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        gf.run_cycles(us_k, zs_k, 0.1)
+        e1.record()
+        torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / reps
+        dev = e0.elapsed_time(e1) * 1e-3 / reps
         est = gf.point_estimate()
         assert np.all(np.isfinite(est)), est
-        entry = {"device_us_per_cycle": round(dev * 1e6, 2), "wall_us_per_cycle": round(wall * 1e6, 2)}
+        entry = {"device_us_per_cycle": round(dev * 1e6, 2), "wall_us_per_cycle": round(wall * 1e6, 2),
+                 "wall_over_device": round(wall / dev, 3),
+                 "by_three_method_calls": {"device_us_per_cycle": round(dev_methods * 1e6, 2),
+                                           "wall_us_per_cycle": round(wall_methods * 1e6, 2)}}
         if n <= 64:
             entry["bound"] = "launch latency (one launch, one workgroup): no roofline fraction"
         elif n <= 4096:

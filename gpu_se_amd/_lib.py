@@ -97,6 +97,18 @@ GSE_PF_LOOP_WEIGHT_SCALE = 1
 GSE_PF_LOOP_CLUSTER = 2
 
 
+class GsukfCyclesSpec(ctypes.Structure):
+    """struct gse_gsukf_cycles_spec (include/gse.h)."""
+    _fields_ = [("B", c_i32), ("regime", c_i32), ("N", c_i64), ("dt", c_d), ("mu", c_vp * 2), ("P", c_vp * 2), ("w", c_vp * 2),
+                ("idx", c_vp), ("workspace", c_vp), ("status", c_vp), ("w_sigma", c_vp), ("state_pdf", c_vp),
+                ("measurement_pdf", c_vp), ("rng", Rng), ("r", c_vp),
+                ("bank_current", c_i32), ("w_current", c_i32), ("pend_resample", c_i32), ("pend_gather", c_i32),
+                ("sums_valid", c_i32), ("sums_slot", c_i32), ("r_pending", c_d * GSE_MAX_B)]
+
+
+GSE_GSUKF_REGIME_CYCLE, GSE_GSUKF_REGIME_LANES, GSE_GSUKF_REGIME_TWO = 0, 1, 2
+
+
 class MergeSpec(ctypes.Structure):
     """struct gse_merge_spec (include/gse.h)."""
     _fields_ = [("P", c_i32), ("rank", c_i32), ("flags", c_i32), ("slot", c_i32), ("r", c_d), ("island", c_vp), ("wscale", c_vp),
@@ -172,6 +184,7 @@ PROTOTYPES = {
     "gse_gsukf_gather_rows_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp]),
     "gse_gsukf_predict_update_from_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_d,
                                                            c_vp, P_F, P_MIX, P_RNG, c_vp, P_MIX, c_vp, c_u32, c_vp]),
+    "gse_gsukf_cycles": (ctypes.c_int, [ctypes.POINTER(GsukfCyclesSpec), ctypes.c_int, c_vp, c_vp, c_vp]),
     "gse_gsukf_moments26": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
     "gse_gsukf_sigma_points_model": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
     "gse_gsukf_predict_model": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_i64, P_D, c_d, P_F, P_MIX, P_RNG, c_vp, c_vp, c_vp]),

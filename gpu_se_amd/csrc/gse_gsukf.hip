@@ -513,4 +513,76 @@ int gse_gsukf_moments_model(void* model, const float* mu, const float* P, const 
     return gsukf_moments(m_, mu, P, w, B, N, out, workspace, stream);
 }
 
+// K open-loop cycles of B banks enqueued from C++: filter/gs_ukf.py's deferred stages restated for its three regimes on the entry
+// points above (include/gse.h).  What the class's predict / update / resample launch, in their order.
+int gse_gsukf_cycles(gse_gsukf_cycles_spec* s, int K, const double* u, const double* z, void* stream) {
+    GSE_REQUIRE(s && u && z && K >= 1, "gse_gsukf_cycles: bad argument");
+    GSE_REQUIRE(s->B >= 1 && s->B <= GSE_MAX_B && s->N >= 1, "gse_gsukf_cycles: bad B / N");
+    GSE_REQUIRE(s->mu[0] && s->P[0] && s->w[0] && s->status && s->w_sigma && s->state_pdf && s->measurement_pdf && s->r,
+                "gse_gsukf_cycles: null argument");
+    GSE_REQUIRE(s->regime == GSE_GSUKF_REGIME_CYCLE || (s->mu[1] && s->P[1] && s->w[1] && s->workspace),
+                "gse_gsukf_cycles: this regime needs the second buffers and the workspace");
+    GSE_REQUIRE(s->regime != GSE_GSUKF_REGIME_TWO || s->idx, "gse_gsukf_cycles: the two-launch regime needs idx");
+    GSE_REQUIRE(s->regime != GSE_GSUKF_REGIME_CYCLE || s->N <= 64, "gse_gsukf_cycles: GSE_GSUKF_REGIME_CYCLE takes at most 64 Gaussians");
+    const int B = s->B;
+    const int64_t N = s->N;
+    float *mu = s->mu[0], *mu_alt = s->mu[1], *P = s->P[0], *P_alt = s->P[1], *w = s->w[0], *w_alt = s->w[1];
+    bool pend_resample = s->pend_resample != 0, pend_gather = s->pend_gather != 0, sums_valid = s->sums_valid != 0;
+    int slot = s->sums_slot;
+    const double* r_pend = s->r_pending;
+    gse_rng rng = s->rng;
+    for (int k = 0; k < K; ++k) {
+        const double *uk = u + (int64_t)k * B * GSE_NU, *zk = z + (int64_t)k * B * GSE_NY, *rk = s->r + (int64_t)k * B;
+        if (s->regime == GSE_GSUKF_REGIME_CYCLE) {
+            if (int rc = gse_gsukf_cycle(mu, P, w, nullptr, B, N, uk, s->dt, zk, rk, s->w_sigma, s->state_pdf, &rng, nullptr,
+                                         s->measurement_pdf, s->status, stream))
+                return rc;
+            rng.step += 1;
+            continue;
+        }
+        // predict(u, dt) is deferred; update(u, z) launches predict + update, with whatever the last resample left to it
+        if (s->regime == GSE_GSUKF_REGIME_LANES && pend_resample) {
+            if (int rc = gse_gsukf_cycle_lanes(mu, P, w, mu_alt, P_alt, w_alt, nullptr, B, N, uk, s->dt, zk, r_pend, s->w_sigma,
+                                               s->state_pdf, &rng, nullptr, s->measurement_pdf, s->status, s->workspace,
+                                               slot ? GSE_IO_SUMS_SLOT1 : 0u, stream))
+                return rc;
+            std::swap(mu, mu_alt); std::swap(P, P_alt); std::swap(w, w_alt);
+            pend_resample = false;
+            sums_valid = true;
+            slot = 1 - slot;
+        } else {
+            const int32_t* idx = pend_gather ? s->idx : nullptr;
+            float *out_m = idx ? mu_alt : mu, *out_c = idx ? P_alt : P;
+            if (int rc = gse_gsukf_predict_update_sums(mu, P, idx, out_m, out_c, w, B, N, uk, s->dt, zk, s->w_sigma, s->state_pdf,
+                                                       &rng, nullptr, s->measurement_pdf, s->status, s->workspace, 0u, stream))
+                return rc;
+            if (idx) { std::swap(mu, mu_alt); std::swap(P, P_alt); }
+            pend_gather = false;
+            sums_valid = true;
+            slot = 0;
+        }
+        rng.step += 1;
+        // resample(r)
+        if (s->regime == GSE_GSUKF_REGIME_LANES) {
+            pend_resample = true;                              // nothing to launch: the next cycle's launch finds the ancestors
+            r_pend = rk;
+        } else {
+            if (int rc = gse_gsukf_resample_begin_slot(w, w_alt, s->idx, B, N, rk, s->workspace, slot, stream)) return rc;
+            std::swap(w, w_alt);
+            sums_valid = false;
+            pend_gather = true;
+        }
+    }
+    s->bank_current = (mu == s->mu[0]) ? 0 : 1;
+    s->w_current = (w == s->w[0]) ? 0 : 1;
+    s->pend_resample = pend_resample ? 1 : 0;
+    s->pend_gather = pend_gather ? 1 : 0;
+    s->sums_valid = sums_valid ? 1 : 0;
+    s->sums_slot = slot;
+    s->rng.step = rng.step;
+    if (pend_resample)
+        for (int b = 0; b < B; ++b) s->r_pending[b] = r_pend[b];
+    return GSE_OK;
+}
+
 }  // extern "C"

@@ -444,6 +444,74 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         if wanted:
             return DevArray.wrap(idx[0] if B == 1 else idx)
 
+    def run_cycles(self, us, zs, dt, rs=None):
+        """K cycles predict(us[k], dt) -> update(us[k], zs[k]) -> resample() enqueued by ONE call (gse_gsukf_cycles: the loop over
+        the three methods that results/gsf_openloop/gsf_run_seq.py:16-134 runs from Python, restated in C++ for the class's
+        three regimes): the same launches, hence the same banks, weights and ancestors as K rounds of the methods, without the
+        interpreter's 20-50 us per cycle between them -- which is more than the device needs up to 2^17 Gaussians.  us, zs:
+        (K, 2) host arrays ((K, B, 2) for a batch); rs: optional (K,) / (K, B) uniform numbers (default: the filter's own host
+        stream, in the order resample() would draw them).  Philox noise, the built-in model."""
+        n, B, K = self.N_particles, self._B, len(us)
+        native = (self._model is None and not isinstance(self.state_pdf, DeterministicGaussianSum) and self.lazy and
+                  not self.record_ancestors and self._sums_ok and K > 0 and
+                  (self._fusable or self._cycle_lanes or (self._fuse_pu and n > _lib.GSE_SMALL_RESAMPLE_MAX)))
+        if not native:
+            for k in range(K):                              # (whatever gse_gsukf_cycles does not take: the methods themselves)
+                self.predict(us[k], dt)
+                self.update(us[k], zs[k])
+                self.resample(r=None if rs is None else rs[k])
+            return
+        if self._pend_predict is not None or self._pend_update is not None:
+            self._flush()
+        regime = (_lib.GSE_GSUKF_REGIME_CYCLE if self._fusable else
+                  _lib.GSE_GSUKF_REGIME_LANES if self._cycle_lanes else _lib.GSE_GSUKF_REGIME_TWO)
+        if regime != _lib.GSE_GSUKF_REGIME_LANES and self._pend_resample is not None:
+            self._flush()
+        if regime == _lib.GSE_GSUKF_REGIME_LANES and self._pend_gather is not None:
+            self._flush()                                   # (ancestors somebody asked for: copy the rows first)
+        u = numpy.ascontiguousarray(numpy.broadcast_to(numpy.asarray(us, dtype=numpy.float64).reshape(K, -1, 2), (K, B, 2)))
+        z = numpy.ascontiguousarray(numpy.broadcast_to(numpy.asarray(zs, dtype=numpy.float64).reshape(K, -1, 2), (K, B, 2)))
+        if rs is None:
+            r = numpy.array([self._host_rng.random(B) if B > 1 else [self._host_rng.random()] for _ in range(K)])
+        else:
+            r = numpy.broadcast_to(numpy.asarray(rs, dtype=numpy.float64).reshape(K, -1), (K, B))
+        r = numpy.ascontiguousarray(r, dtype=numpy.float64)
+        addr = lambda obj: ctypes.cast(ctypes.pointer(obj), ctypes.c_void_p).value
+        if regime == _lib.GSE_GSUKF_REGIME_TWO and self._idx_buf is None:
+            self._idx_buf = torch.empty((B, n), dtype=torch.int32, device=self._w.device)
+        if self._pend_gather is not None and self._pend_gather is not self._idx_buf:
+            self._flush()                                   # (the caller keeps that index array: do not write over it)
+        spec = _lib.GsukfCyclesSpec()
+        spec.B, spec.regime, spec.N, spec.dt = B, regime, n, float(dt)
+        spec.mu[0], spec.mu[1] = self._means.data_ptr(), self._means_alt.data_ptr()
+        spec.P[0], spec.P[1] = self._covs.data_ptr(), self._covs_alt.data_ptr()
+        spec.w[0], spec.w[1] = self._w.data_ptr(), self._w_alt.data_ptr()
+        spec.idx = self._idx_buf.data_ptr() if self._idx_buf is not None else None
+        spec.workspace, spec.status = self._ws.data_ptr(), self._status.data_ptr()
+        spec.w_sigma = ctypes.cast(self._w_sigma_c, ctypes.c_void_p).value
+        spec.state_pdf, spec.measurement_pdf = addr(self.state_pdf._pod()), addr(self.measurement_pdf._pod())
+        spec.rng = _lib.Rng(seed=self._seed, step=self._step, filter_offset=self._filter_offset)
+        spec.r = r.ctypes.data
+        spec.pend_resample = 1 if self._pend_resample is not None else 0
+        spec.pend_gather = 1 if self._pend_gather is not None else 0
+        spec.sums_valid, spec.sums_slot = (1 if self._sums_valid else 0), self._sums_slot
+        for b in range(B):
+            spec.r_pending[b] = self._c_r_pend[b]
+        rc = self._lib.gse_gsukf_cycles(ctypes.byref(spec), K, u.ctypes.data, z.ctypes.data, stream_ptr())
+        if rc:
+            _lib.check(rc)
+        if spec.bank_current:
+            self._means, self._means_alt = self._means_alt, self._means
+            self._covs, self._covs_alt = self._covs_alt, self._covs
+        if spec.w_current:
+            self._w, self._w_alt = self._w_alt, self._w
+        self._step = int(spec.rng.step)
+        self._pend_resample = True if spec.pend_resample else None
+        self._pend_gather = self._idx_buf if spec.pend_gather else None
+        self._sums_valid, self._sums_slot = bool(spec.sums_valid), int(spec.sums_slot)
+        for b in range(B):
+            self._c_r_pend[b] = spec.r_pending[b]
+
     # ------------------------------------------------------------------ estimates
     def _moment_sums_all(self):
         """Per bank (sum w, w @ mu, sum w P + sum w (mu - mean)(mu - mean)^T) from one device pass (synchronises)."""

@@ -149,9 +149,23 @@ def performance(ys, r, ts):
 def performance_rollouts(ys, r, ts):
     """performance() of B rollouts at once: ys, r (ticks, B, outputs) -> (B,)."""
     se = (numpy.asarray(ys) - numpy.asarray(r)) ** 2 * numpy.asarray(ts)[:, None, None]
-    flat = se.reshape(len(ts), -1)
-    per = numpy.array([simps(flat[:, k], ts) for k in range(flat.shape[1])]).reshape(se.shape[1], se.shape[2])
-    return per.sum(axis=1)
+    # all columns at once, each summed along its own contiguous row: the additions (NumPy's pairwise order) of simps() on one
+    # column, so the same bits -- without 2 B Python calls of it (1.7 ms of a 9.4 ms loop of 32 rollouts)
+    cols = numpy.ascontiguousarray(se.reshape(len(ts), -1).T)
+    x = numpy.asarray(ts, dtype=float)
+
+    def pairs(y, xx):
+        h0, h1 = numpy.diff(xx)[0::2], numpy.diff(xx)[1::2]
+        hs, hp, hq = h0 + h1, h0 * h1, h0 / h1
+        terms = hs / 6.0 * (y[:, 0:-2:2] * (2.0 - 1.0 / hq) + y[:, 1:-1:2] * (hs * hs / hp) + y[:, 2::2] * (2.0 - hq))
+        return numpy.ascontiguousarray(terms).sum(axis=1)
+    if cols.shape[1] % 2 == 1:
+        per = pairs(cols, x)
+    else:
+        first = pairs(cols[:, :-1], x[:-1]) + 0.5 * (x[-1] - x[-2]) * (cols[:, -1] + cols[:, -2])
+        last = 0.5 * (x[1] - x[0]) * (cols[:, 1] + cols[:, 0]) + pairs(cols[:, 1:], x[1:])
+        per = 0.5 * (first + last)
+    return per.reshape(se.shape[1], se.shape[2]).sum(axis=1)
 
 
 class InjectedNoise:
@@ -562,8 +576,7 @@ class BatchedSimulation:
         B = self.B
         f._flush()
         # the uniform numbers of the resamples: the class's own host stream, in the order resample() would draw them
-        r_host = numpy.ascontiguousarray(numpy.array([f._host_rng.random(B) if B > 1 else [f._host_rng.random()]
-                                                      for _ in range(max(n_control, 1))], dtype=numpy.float64).reshape(-1, B))
+        r_host = numpy.ascontiguousarray(f._host_rng.random((max(n_control, 1), B)))      # (= that many calls of random(B))
         _, law, _keep_law = K._device_law()
         glue = K.loop_glue(_U_FALLBACK)
         addr = lambda obj: ctypes.cast(ctypes.pointer(obj), ctypes.c_void_p).value
@@ -623,21 +636,11 @@ class BatchedSimulation:
         ticks, B = len(self.ts), self.B
         # the schedule of sim_base.py:250, :255 and the uniform numbers of the resamples (the class's own host stream, in the
         # order resample() would draw them)
-        sched = numpy.zeros(ticks, dtype=numpy.uint8)
-        t_next_control, t_next_predict = 0, 0
-        control_ticks = [0]
-        for t in range(1, ticks):
-            if self.ts[t] > t_next_predict:
-                sched[t] |= 1
-                t_next_predict += self.dt_predict
-            if self.ts[t] > t_next_control:
-                sched[t] |= 2
-                control_ticks.append(t)
-                t_next_control += self.dt_control
+        sched, control_ticks = self._schedule()
         n_control = len(control_ticks) - 1
         f._flush()
-        r_host = numpy.array([f._host_rng.random(B) for _ in range(n_control)], dtype=numpy.float64).reshape(max(n_control, 1), B) \
-            if n_control else numpy.zeros((1, B))
+        # (one call: the generator fills the array in the order n_control calls of random(B) would)
+        r_host = f._host_rng.random((n_control, B)) if n_control else numpy.zeros((1, B))
         dev = X.device
         sched_d = torch.as_tensor(sched, device=dev)
         r_d = torch.as_tensor(numpy.ascontiguousarray(r_host), device=dev)

@@ -371,6 +371,42 @@ int gse_gsukf_cycle_lanes(const float *mu_in, const float *P_in, const float *w_
                           const float *w_sigma, const gse_mixture *state_pdf, const gse_rng *rng, const float *noise,
                           const gse_mixture *measurement_pdf, int32_t *status, void *workspace, uint32_t where, void *stream);
 
+/* K open-loop cycles predict(u_k, dt) -> update(u_k, z_k) -> resample(r_k) of B banks enqueued from C++ (round 5): the loop
+ * results/gsf_openloop/gsf_run_seq.py:16-134 runs over the three methods from Python -- where the host spends 20-50 us per
+ * cycle between the calls, more than the device needs up to 2^17 Gaussians -- restated on the entry points above, in the
+ * class's three regimes (filter/gs_ukf.py of this build): the same launches with the same arguments in the same order, hence the
+ * same banks, weights and ancestors bit for bit.
+ *   GSE_GSUKF_REGIME_CYCLE  (N <= 64)      one gse_gsukf_cycle per cycle, in place;
+ *   GSE_GSUKF_REGIME_LANES  (gse_gsukf_cycle_lanes' range) one gse_gsukf_cycle_lanes per cycle (the resample of cycle k rides
+ *                           the launch of cycle k + 1; the first cycle, with no resample pending: gse_gsukf_predict_update_sums);
+ *   GSE_GSUKF_REGIME_TWO    (beyond)       gse_gsukf_predict_update_sums (+ the pending row copy) and
+ *                           gse_gsukf_resample_begin_slot per cycle.
+ * Philox noise, the built-in model.  u, z: HOST [K][B][2]; spec->r: HOST [K][B].  The trailing fields of the spec are in / out:
+ * what is pending on entry (a resample whose ancestors are still to be found, or whose row copy is) and on return. */
+#define GSE_GSUKF_REGIME_CYCLE 0
+#define GSE_GSUKF_REGIME_LANES 1
+#define GSE_GSUKF_REGIME_TWO 2
+typedef struct gse_gsukf_cycles_spec {
+    int32_t B, regime;
+    int64_t N;
+    double dt;
+    float *mu[2], *P[2], *w[2];                  /* the bank's buffer pairs [B][N][5], [B][N][5][5], [B][N]; [0] holds the bank */
+    int32_t *idx;                                /* [B][N] ancestors (regime TWO) */
+    void *workspace;                             /* gse_workspace_bytes(B, N) */
+    int32_t *status;                             /* [1] counts covariances that could not be factorised */
+    const float *w_sigma;                        /* host [11] */
+    const gse_mixture *state_pdf, *measurement_pdf;          /* host */
+    gse_rng rng;                                 /* step = that of the next predict (in / out) */
+    const double *r;                             /* HOST [K][B] */
+    /* in / out */
+    int32_t bank_current, w_current;             /* out: which of mu[] / P[] and of w[] holds the bank now */
+    int32_t pend_resample;                       /* LANES: a resample whose ancestors the next launch finds (r_pending) */
+    int32_t pend_gather;                         /* TWO: ancestors in idx, the row copy rides the next launch */
+    int32_t sums_valid, sums_slot;               /* the workspace holds the quarter sums of the current weights, in this slot */
+    double r_pending[GSE_MAX_B];
+} gse_gsukf_cycles_spec;
+int gse_gsukf_cycles(gse_gsukf_cycles_spec *spec /* host, in / out */, int K, const double *u, const double *z, void *stream);
+
 /* gse_gsukf_moments in the particle filter's layout -- rows of 26 doubles { S0, S1[5], S2[15] + C[15], p[5] }, so that
  * S2 - S1 e^T - e S1^T + S0 e e^T is the whole covariance (filter/gs_ukf.py:442-449): what gse_loop_control and the host
  * post-processing of a closed loop (sim_base.py:243-309) take from either estimator. */

@@ -589,3 +589,54 @@ def test_batch_of_banks_with_injected_noise_tracks_the_oracle():
         assert_mean_close(batch.means.get()[b], o.means, prior_cov, rel_sigma=2e-4)
         assert_cov_close(batch.covariances.get()[b], o.covariances, 2e-4)
         np.testing.assert_allclose(batch.weights.get()[b], o.weights, rtol=2e-3)
+
+
+# ------------------------------------------------------------------------------ K cycles enqueued from C++
+@pytest.mark.parametrize("n,batch", [(7, None), (64, None), (300, None), (4096, None), (1 << 16, None), (1 << 18, None),
+                                     (5000, None), (64, 5), (2048, 3), (1 << 14, 2)])
+def test_gsukf_run_cycles_equals_the_three_methods(n, batch):
+    """ParallelGaussianSumUnscentedKalmanFilter.run_cycles (gse_gsukf_cycles: K cycles enqueued from C++, round 5) against K
+    rounds of predict / update / resample from Python -- the loop of results/gsf_openloop/gsf_run_seq.py:16-134: the same
+    launches in the class's three regimes (<= 64 Gaussians: one workgroup per bank; up to 2^17: one lane per Gaussian, one
+    launch per cycle; beyond: two launches), so banks, weights and estimates bit for bit; a second batch starts from what the
+    first left pending; and the filter carries on identically afterwards.  5000 Gaussians with B = 1 is outside the
+    one-launch range (not a multiple of... the two-launch regime); batches share every launch."""
+    banks = []
+    for _ in range(2):
+        if batch is None:
+            banks.append(make(n))
+        else:
+            rng0 = np.random.default_rng(5)
+            means = (orc.steady_state()[None, None, :] * (1 + 0.01 * rng0.standard_normal((batch, n, 5)))).astype(np.float32)
+            banks.append(make_batch(batch, n, means))
+    a, b_ = banks
+    rng = np.random.default_rng(3)
+    xss = orc.steady_state()
+    K, B = 9, batch or 1
+    us = np.stack([rng.uniform(0.03, 0.09, (K, B)), rng.uniform(0.1, 0.3, (K, B))], axis=-1)
+    zs = np.array(orc.bioreactor_g(xss))[None, None, :] + rng.normal(0, 0.3, (K, B, 2))
+    shape = (lambda v: v[0]) if batch is None else (lambda v: v)
+    for part in (slice(0, 4), slice(4, 9)):                 # (the second call starts from what the first left pending)
+        a.run_cycles(us[part] if batch else us[part, 0], zs[part] if batch else zs[part, 0], 0.1)
+        for k in range(part.start, part.stop):
+            b_.predict(shape(us[k]), 0.1)
+            b_.update(shape(us[k]), shape(zs[k]))
+            b_.resample()
+        assert (a._pend_resample is None) == (b_._pend_resample is None)
+        assert (a._pend_gather is None) == (b_._pend_gather is None)
+    assert a._step == b_._step
+    np.testing.assert_array_equal(a.means.get(), b_.means.get())
+    np.testing.assert_array_equal(a.covariances.get(), b_.covariances.get())
+    np.testing.assert_array_equal(host_w(a), host_w(b_))
+    for f in (a, b_):
+        f.predict(shape(us[0]), 0.1)
+        f.update(shape(us[0]), shape(zs[0]))
+        f.resample()
+    np.testing.assert_array_equal(a.point_estimate(), b_.point_estimate())
+    np.testing.assert_array_equal(a.means.get(), b_.means.get())
+    assert int(a._status.item()) == 0
+
+
+def host_w(f):
+    f._flush()
+    return f._w.cpu().numpy()
