@@ -522,6 +522,28 @@ __device__ __forceinline__ void block_sums(double (&v)[kCount], double* lds, Emi
     }
 }
 
+// block_sums with the wavefront totals formed by data-parallel-primitive moves (wave_inclusive_scan's six steps: lane 63 ends up
+// with the total) instead of six butterfly exchanges through the LDS crossbar per value: 21 values cost 3.2 us that way in a
+// kernel whose whole job is 13 (the resampled-moments pass of a shard's merge, round 5).  Another association of the same
+// 64 numbers than block_sums: callers that must agree bit for bit with each other use the same one.
+template <int kCount, class Emit>
+__device__ __forceinline__ void block_sums_dpp(double (&v)[kCount], double* lds, Emit emit) {
+    static_assert(kCount <= 64, "one thread per value adds the wavefront totals");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < kCount; ++c) v[c] = wave_inclusive_scan(v[c], lane);
+    __syncthreads();                      // protect lds against a previous use
+    if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < kCount; ++c) lds[wv * kCount + c] = v[c];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < kCount) {
+        const int c = threadIdx.x;
+        emit(c, (lds[c] + lds[kCount + c]) + (lds[2 * kCount + c] + lds[3 * kCount + c]));
+    }
+}
+
 // Fixed-order reduction of a filter's per-workgroup moment partials -> out[b][0 .. width); appends pivot_count pivot values.
 // 1024 threads: thread (g, c) = (tid / 64, tid % 64) adds the partials q = g, g + 16, ... of column c into 8 interleaved
 // accumulators (8 loads in flight), folds them pairwise, and the 16 group totals are folded pairwise after one barrier: a

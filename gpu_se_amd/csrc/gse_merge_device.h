@@ -156,7 +156,7 @@ __device__ __forceinline__ int merge_rows_wave(const double* rows, int P, const 
         if (p < P) {
             const double la = rows[p * 22], s0 = rows[p * 22 + 1];
             const bool live = (s0 > 0.0) && (fabs(la) < INFINITY) && (s0 < INFINITY);
-            if (live) lw = la + log(s0);
+            if (live) lw = (P == 1) ? 0.0 : la + log(s0);             // (P == 1: only "is there a live shard" is asked of top)
             if (!(s0 < INFINITY) || !(la < INFINITY)) b = 1;
         }
 #pragma unroll
@@ -173,7 +173,8 @@ __device__ __forceinline__ int merge_rows_wave(const double* rows, int P, const 
             const double la = rows[p * 22], s0 = rows[p * 22 + 1];
             live_p = ((s0 > 0.0) && (fabs(la) < INFINITY) && (s0 < INFINITY)) ? 1 : 0;
             if (live_p) {
-                a_p = exp((la + log(s0)) - top);
+                // (one shard: (la + log(s0)) - top is 0.0 and exp of it 1.0, exactly: no need to ask)
+                a_p = (P == 1) ? 1.0 : exp((la + log(s0)) - top);
                 s0_p = s0;
             }
         }
@@ -217,10 +218,11 @@ inline void pack_merge_tail(const gse_merge_spec* spec, MergeTail& t) {
 }
 #endif
 
-// The first wavefront of the finishing workgroup: sm[26] (LDS) holds the shard's moments, W the slot's weight sum (pending).
+// The first wavefront of the finishing workgroup: sm[26] (LDS) holds the shard's moments, log_w = log of the slot's weight sum
+// (pending; formed by the caller while its loads are in flight).
 // Forms the shard's row (rows[rank], other rows are the caller's to zero); a single shard (P == 1) is combined and estimated.
 // sm and sx: >= 32 doubles of LDS each; sm is overwritten with the merged moments.
-__device__ __forceinline__ void merge_tail_wave(const MergeTail& a, double* sm, double* sx, double W, int lane) {
+__device__ __forceinline__ void merge_tail_wave(const MergeTail& a, double* sm, double* sx, double log_w, int lane) {
     double la = 0.0, wsd = 0.0;
     if (lane == 0) {
         la = a.island ? a.island[0] : 0.0;
@@ -228,7 +230,7 @@ __device__ __forceinline__ void merge_tail_wave(const MergeTail& a, double* sm, 
         if (a.flags & GSE_MERGE_PENDING) {
             // the moments are those of the resampled ensemble (weights 1 / N); the copy's launch will add this to island[0]
             // (pf_step_kernel's gather stage: island[b] += log(W) + wscale ln 2)
-            la += log(W) + wsd * 0.69314718055994530942;
+            la += log_w + wsd * 0.69314718055994530942;
         }
     }
     la = __shfl(la, 0, 64);

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * kFinishGroups) void merge_finish_kernel(const 
     for (int i = tid; i < a.tail.P * 22; i += 64 * kFinishGroups)
         if (i / 22 != a.tail.rank) a.tail.rows[i] = 0.0;
     __syncthreads();
-    if (tid < 64) merge_tail_wave(a.tail, sm, sx, 1.0, tid);
+    if (tid < 64) merge_tail_wave(a.tail, sm, sx, 0.0, tid);      // (never pending here: no weight sum to absorb)
 }
 
 __global__ __launch_bounds__(64) void merge_end_kernel(const double* __restrict__ rows, int P, const Pivot5 common, int flags,

@@ -595,6 +595,11 @@ int gse_pf_shard_gather(const float* x_in, int64_t ld, int64_t N_local, const do
 
 #ifdef GSE_STAMPS
 // diagnostic build only: copy the phase stamps of the last fused launches to the host (synchronises)
+int gse_debug_mstamps(unsigned long long* out32) {
+    GSE_HIP_CHECK(hipDeviceSynchronize());
+    GSE_HIP_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_mstamps), sizeof(unsigned long long) * 32));
+    return GSE_OK;
+}
 int gse_debug_stamps(unsigned long long* out32) {
     GSE_HIP_CHECK(hipDeviceSynchronize());
     GSE_HIP_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32));

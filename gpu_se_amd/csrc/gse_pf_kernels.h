@@ -106,9 +106,19 @@ __device__ unsigned long long g_stamps[32];
             g_stamps[i] = t_;                                                     \
         }                                                                         \
     } while (0)
+__device__ unsigned long long g_mstamps[32];              // ... of the resampled-moments kernel (workgroup GSE_STAMPS / the last one)
+#define GSE_MSTAMP(i, cond)                                                       \
+    do {                                                                          \
+        if ((cond) && blockIdx.y == 0 && threadIdx.x == 0) {                      \
+            unsigned long long t_;                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            g_mstamps[i] = t_;                                                    \
+        }                                                                         \
+    } while (0)
 #else
 #define GSE_STAMP(i)
 #define GSE_BLOCK_TIME(which)
+#define GSE_MSTAMP(i, cond)
 #endif
 #ifndef GSE_PRIO
 #define GSE_PRIO 4               // gather variants: issue priority by phase.  0: none; 1: memory phases high, the noise draw
@@ -2074,6 +2084,7 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
             ex_before = qx[tq * kBlock + t];
         }
     };
+    GSE_MSTAMP(0, blockIdx.x == GSE_STAMPS);
     if (unit0 < units) request(unit0);
     // tile prefix (the arithmetic of the step kernel's gather stage)
     {
@@ -2104,6 +2115,7 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
         __syncthreads();
     }
     const double W = pfx_m[T];
+    GSE_MSTAMP(1, blockIdx.x == GSE_STAMPS);
     if (blockIdx.x == 0 && tid == 0) {
         // the slot's weight sum beside the partials (column 21 of the first row: gse_pf_merge_begin forms the shard's
         // log-weight from it), and the filter's sticky status when it is not a number the resample can use
@@ -2213,6 +2225,10 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        GSE_MSTAMP(2, blockIdx.x == GSE_STAMPS);
+#ifdef GSE_STAMPS
+        if (blockIdx.x == GSE_STAMPS && blockIdx.y == 0 && threadIdx.x == 0) g_mstamps[16] = (unsigned long long)base;
+#endif
         for (int at = 0; at < base; at += 128) {
             const bool two = at + 64 < base;                             // (uniform)
             const int2 it0 = (at + lane < base) ? mine[at + lane] : make_int2(0, 0);
@@ -2229,13 +2245,14 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
         }
         __builtin_amdgcn_wave_barrier();                                  // (the list is rewritten for the next unit)
     }
+    GSE_MSTAMP(3, blockIdx.x == GSE_STAMPS);
     if (!valid && blockIdx.x == 0 && tid == 0) {
         // weights that do not sum to a positive finite number: every offspring copies particle 0 (see the gather stage)
         acc[0] = (double)N * wu;
     }
     double* out = partials + ((int64_t)b * kMomentBlocks + blockIdx.x) * kMomentWidth;
     if (!(tail.flags & kMergeTailOn)) {                                  // (uniform)
-        block_sums<21>(acc, red, [&](int c, double total) { out[c] = total; });
+        block_sums_dpp<21>(acc, red, [&](int c, double total) { out[c] = total; });
         return;
     }
     // ---- gse_pf_merge_begin (round 5): the LAST workgroup to get here finishes the partial sums and runs the merge's tail --
@@ -2246,15 +2263,19 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
     //      and the last one therefore finds them all.  (Fences instead -- __threadfence on both sides -- write back and
     //      invalidate the L2 in every workgroup: 32 us for the launch where this takes 19.)  The sums are added in a FIXED
     //      order, whoever is last.  gridDim.x <= 256 kSplit (the host sees to it), B = 1.
-    block_sums<21>(acc, red, [&](int c, double total) {
+    block_sums_dpp<21>(acc, red, [&](int c, double total) {
         __hip_atomic_store(out + c, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     });
+    GSE_MSTAMP(4, blockIdx.x == GSE_STAMPS);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");               // (the stores have left: s_waitcnt, no cache maintenance)
     __syncthreads();
+    GSE_MSTAMP(5, blockIdx.x == GSE_STAMPS);
     if (tid == 0)
         last_s = (__hip_atomic_fetch_add(counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1 : 0;
     __syncthreads();
+    GSE_MSTAMP(6, blockIdx.x == GSE_STAMPS);
     if (!last_s) return;
+    GSE_MSTAMP(8, true);
     if (tid == 0) __hip_atomic_store(counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (ready for the next launch)
     double* part = reinterpret_cast<double*>(&items[0][0]);             // [8][32] (the lists are spent)
     double* sm = red;                                                    // [32] the shard's moments
@@ -2271,12 +2292,15 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
             v[j] = (c < 21 && q < nblk) ? __hip_atomic_load(pb + (int64_t)q * kMomentWidth + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                         : 0.0;
         }
+        // (the one transcendental of the tail -- the shard's log-weight absorbs log(W) -- while those loads are in flight)
+        if (tid == 0) red[64] = (tail.flags & GSE_MERGE_PENDING) ? log(W) : 0.0;
 #pragma unroll
         for (int span = 1; span < kPer; span *= 2)
 #pragma unroll
             for (int j = 0; j < kPer; j += 2 * span) v[j] += v[j + span];
         part[g * 32 + c] = v[0];
     }
+    GSE_MSTAMP(9, true);
     for (int i = tid; i < tail.P * 22; i += kBlock)
         if (i / 22 != tail.rank) tail.rows[i] = 0.0;
     __syncthreads();
@@ -2292,7 +2316,9 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
         tail.moments26[21 + tid - 32] = pvt;
     }
     __syncthreads();
-    if (tid < 64) merge_tail_wave(tail, sm, sx, W, tid);
+    GSE_MSTAMP(10, true);
+    if (tid < 64) merge_tail_wave(tail, sm, sx, red[64], tid);
+    GSE_MSTAMP(11, true);
 }
 
 // Fixed-order reduction of the per-workgroup partials -> out[b][0..width); appends pivot_count pivot values
