@@ -144,7 +144,7 @@ class TorchComm:
         dist.all_gather(parts, tensor, group=self.group)
 
     def all_to_all_single(self, dst, src, recv, send):
-        self._comm.all_to_all_single(dst, src, recv, send)
+        dist.all_to_all_single(dst, src, output_split_sizes=recv, input_split_sizes=send, group=self.group)
 
 
 class ShardedParticleFilter:
@@ -193,6 +193,7 @@ class ShardedParticleFilter:
         # ~25 us of host time, more than a whole cycle of device work at N = 2^20.
         self.reduce_every = max(1, int(reduce_every))
         self._resamples = 0
+        self._exchange_due = False                          # the next update() issues the exchange of the shards' log-weights
         # Island policy: the shards' accumulated log-weights are exchanged with that same all-reduce (P doubles, slot p
         # written by rank p); when the effective number of islands falls below ess_fraction * P the NEXT resample is an
         # exact one over the whole ensemble, which levels the shards (every rank sees the same numbers one cycle later,
@@ -254,12 +255,12 @@ class ShardedParticleFilter:
         """Local update.  The launch that carries the update also executes a pending resample-gather, which is where
         the shard's log-weight absorbs the weight sum; with more than one rank that sum is then all-reduced
         asynchronously (RCCL) -- nothing waits for it until wait_collectives() / an estimate."""
-        resampled = self.local._pend_gather
         self.local.update(u, z)
-        if resampled:
-            self._resamples += 1
-            self._islands_apart = True
-            if self.group is not None and self.world > 1 and self._resamples % self.reduce_every == 0:
+        if self._exchange_due:
+            # (the resample was counted when it was called -- round 5: whoever ran its copy, this launch or a flush before it,
+            #  the shard's log-weight has absorbed the weight sum by now)
+            self._exchange_due = False
+            if self.group is not None and self.world > 1:
                 self._exchange_shares()
 
     def resample(self, r=None, exact=False):
@@ -271,12 +272,15 @@ class ShardedParticleFilter:
                 self._force_exact = False
                 return self._exact_resample(r)
         self.local.resample(r=r)
+        self._resamples += 1
+        self._islands_apart = True
+        self._exchange_due = self._resamples % self.reduce_every == 0
 
     def run_cycles(self, us, zs, dt, rs=None):
         """K island cycles predict -> update -> resample of this shard enqueued by ONE call (ParallelParticleFilter.run_cycles ->
         gse_pf_cycles, which hands the shard's bookkeeping to every launch): the launches of K rounds of the three methods.
         The island policy looks at the exchanged log-weights before the batch (an exact resample of the whole ensemble first,
-        if the shards have drifted apart) and the exchange that falls due inside the batch is issued behind it."""
+        if the shards have drifted apart) and an exchange that falls due inside the batch is issued by the next update()."""
         K = len(us)
         if K == 0:
             return
@@ -286,14 +290,13 @@ class ShardedParticleFilter:
             if self._force_exact:
                 self._force_exact = False
                 self._exact_resample(None)
-        copies = K - 1 + (1 if self.local._pend_gather else 0)      # resample copies the batch's launches execute
         self.local.run_cycles(us, zs, dt, rs)
         before = self._resamples
-        self._resamples += copies
-        if copies:
-            self._islands_apart = True
-        if multi and self._resamples // self.reduce_every != before // self.reduce_every:
-            self._exchange_shares()
+        self._resamples += K                                   # (counted where resample() counts them: at the call)
+        self._islands_apart = True
+        # an exchange that falls due inside the batch is issued by the next update(), like one that falls due on its last resample
+        # (the copy of that resample -- where the shard's log-weight absorbs the weight sum -- rides that update's launch)
+        self._exchange_due = self._exchange_due or (self._resamples // self.reduce_every != before // self.reduce_every)
 
     def _consider_shares(self):
         """One cycle after the shards' log-weights were exchanged: read them (the only synchronisation of the island

@@ -181,6 +181,7 @@ def _exact_worker(rank, world, port, out):
     # the host logic of ShardedParticleFilter._exact_resample, with NumPy standing in for the four kernels
     shard = object.__new__(gd.ShardedParticleFilter)
     shard.group, shard.world, shard.rank, shard._merge_device = dist.group.WORLD, world, rank, torch.device("cpu")
+    shard._comm = gd.TorchComm(dist.group.WORLD)
     tiles = [-(-c // 1024) for _, c in spans]
     mine = np.add.reduceat(ws, np.arange(0, cnt, 1024))
     sums = shard._all_gather_uneven(torch.as_tensor(mine), tiles).numpy()
