@@ -221,6 +221,7 @@ PROTOTYPES = {
     "gse_merge_rows": (ctypes.c_int, [c_vp, ctypes.c_int, P_D, c_vp, c_vp, c_vp]),
     "gse_pf_merge_begin": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.POINTER(MergeSpec), c_vp, c_vp]),
     "gse_merge_end": (ctypes.c_int, [ctypes.POINTER(MergeSpec), c_vp]),
+    "gse_island_absorb": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "gse_plant_step_injected": (ctypes.c_int, [c_vp, c_vp, c_d, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
 }
 

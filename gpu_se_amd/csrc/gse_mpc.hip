@@ -265,6 +265,37 @@ __global__ __launch_bounds__(64 * kFinishGroups) void merge_finish_kernel(const 
     if (tid < 64) merge_tail_wave(a.tail, sm, sx, 0.0, tid);      // (never pending here: no weight sum to absorb)
 }
 
+// A shard's accumulated log-weight absorbs the sum of its live weights (what the particle filter's gather stage does inside
+// its launch, pf_step_kernel: island[b] += log(W)) -- as a call of its own for estimators whose resample does not carry the
+// bookkeeping (the sharded Gaussian-sum filter): ONE workgroup adds the N fp32 weights in fp64, in a fixed order.
+__global__ __launch_bounds__(1024) void island_absorb_kernel(const float* __restrict__ w, int64_t N, double* __restrict__ log_island,
+                                                             double* __restrict__ sum_out) {
+    __shared__ double part[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i0 = tid; i0 < N; i0 += 4096) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = i0 + (int64_t)j * 1024;
+            if (i < N) a[j] += (double)w[i];
+        }
+    }
+    const double v = wave_sum((a[0] + a[1]) + (a[2] + a[3]));
+    if (lane == 0) part[wv] = v;
+    __syncthreads();
+    if (tid == 0) {
+        double t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = part[k];
+#pragma unroll
+        for (int span = 1; span < 16; span *= 2)
+#pragma unroll
+            for (int k = 0; k < 16; k += 2 * span) t[k] += t[k + span];
+        log_island[0] += log(t[0]);
+        if (sum_out) sum_out[0] = t[0];
+    }
+}
+
 __global__ __launch_bounds__(64) void merge_end_kernel(const double* __restrict__ rows, int P, const Pivot5 common, int flags,
                                                        double* __restrict__ merged26, double* __restrict__ estimate6,
                                                        int32_t* __restrict__ status) {
@@ -456,6 +487,13 @@ int gse_pf_merge_begin(const float* x, const float* w, int64_t ld, int64_t N, co
     pack_merge_tail(spec, a.tail);
     hipLaunchKernelGGL(merge_finish_kernel, dim3(1), dim3(64 * kFinishGroups), 0, st, a);
     GSE_LAUNCH_CHECK("merge_finish_kernel");
+    return GSE_OK;
+}
+
+int gse_island_absorb(const float* w, int64_t N, double* log_island, double* sum_out, void* stream) {
+    GSE_REQUIRE(w && log_island && N >= 1, "gse_island_absorb: bad argument");
+    hipLaunchKernelGGL(island_absorb_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, N, log_island, sum_out);
+    GSE_LAUNCH_CHECK("island_absorb_kernel");
     return GSE_OK;
 }
 

@@ -26,7 +26,7 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     _parallel_resample = _KernelLauncher(_parallel_resample)
 
-    def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, _batch=1):
+    def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, _batch=1, element_offset=0):
         # the bioreactor functions run the kernels shipped in the library; any other (f, g) is translated and its kernels
         # are compiled for the device at run time (gs_ukf.py:243-275 hands them to Numba)
         self._lib, self._model = _model_library(f, g)
@@ -46,7 +46,13 @@ class ParallelGaussianSumUnscentedKalmanFilter:
             raise ValueError("batch size must be in 1..%d" % _lib.GSE_MAX_B)
         dev = device()
 
-        self._means = x0.draw((B, n)).as_subclass(torch.Tensor).reshape(B, n, self._Nx).contiguous()     # (gs_ukf.py:50)
+        # (element_offset: global index of this bank's first Gaussian when it is a SHARD of a larger bank -- its prior rows and
+        #  its sigma-point noise are then those the whole bank draws for these Gaussians: gpu_se_amd/distributed.py)
+        self._element_offset = int(element_offset)
+        if self._element_offset and B != 1:
+            raise ValueError("a shard is one bank")
+        self._means = x0.draw((B, n), _element_offset=self._element_offset).as_subclass(torch.Tensor) \
+            .reshape(B, n, self._Nx).contiguous()                                                         # (gs_ukf.py:50)
         cov0 = torch.as_tensor(numpy.asarray(state_pdf.covariances[0], dtype=numpy.float32), device=dev)
         self._covs = cov0[None, None, :, :].repeat(B, n, 1, 1).contiguous()                               # (:52)
         self._w = torch.full((B, n), 1.0 / n, dtype=torch.float32, device=dev)                            # (:54)
@@ -274,7 +280,8 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         if self._replay is not None:
             self._noise, self._replay = self._replay, None
             return None, None, self._noise.data_ptr()
-        rng = _lib.Rng(seed=self._seed, step=self._step, filter_offset=self._filter_offset)
+        rng = _lib.Rng(seed=self._seed, step=self._step, filter_offset=self._filter_offset,
+                       element_offset=self._element_offset * self._N_sigmas)
         self._step += 1
         return ctypes.byref(self.state_pdf._pod()), ctypes.byref(rng), None
 
@@ -490,7 +497,8 @@ class ParallelGaussianSumUnscentedKalmanFilter:
         spec.workspace, spec.status = self._ws.data_ptr(), self._status.data_ptr()
         spec.w_sigma = ctypes.cast(self._w_sigma_c, ctypes.c_void_p).value
         spec.state_pdf, spec.measurement_pdf = addr(self.state_pdf._pod()), addr(self.measurement_pdf._pod())
-        spec.rng = _lib.Rng(seed=self._seed, step=self._step, filter_offset=self._filter_offset)
+        spec.rng = _lib.Rng(seed=self._seed, step=self._step, filter_offset=self._filter_offset,
+                       element_offset=self._element_offset * self._N_sigmas)
         spec.r = r.ctypes.data
         spec.pend_resample = 1 if self._pend_resample is not None else 0
         spec.pend_gather = 1 if self._pend_gather is not None else 0

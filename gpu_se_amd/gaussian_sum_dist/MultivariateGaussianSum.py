@@ -103,7 +103,7 @@ class MultivariateGaussianSum:
         _lib.call(fn, t.data_ptr(), m, ctypes.byref(pod), out.data_ptr(), stream_ptr())
         return DevArray.wrap(out)
 
-    def draw(self, shape=(1,)):
+    def draw(self, shape=(1,), _element_offset=0):
         """Samples, device array (*shape x Nx) fp32 (MultivariateGaussianSum.py:65-97).  The component of
         every sample is drawn independently (the reference lays components out in contiguous blocks --
         each row has the same distribution); Philox4x32-10 + Box-Muller + the Cholesky factor."""
@@ -111,7 +111,8 @@ class MultivariateGaussianSum:
             shape = (shape,)
         size = int(numpy.prod(shape))
         out = torch.empty((size, self._Nx), dtype=torch.float32, device=device())
-        pod, rng = self._pod(), self._rng()
+        # (_element_offset: global index of the first sample -- a shard of a larger draw takes ITS rows of it)
+        pod, rng = self._pod(), self._rng(element_offset=int(_element_offset))
         _lib.call("gse_mixture_draw", out.data_ptr(), size, 0, ctypes.byref(pod), ctypes.byref(rng), stream_ptr())
         return DevArray.wrap(out.reshape(shape + (self._Nx,)))
 

@@ -736,6 +736,11 @@ typedef struct gse_merge_spec {
 int gse_pf_merge_begin(const float *x /* [5][ld] */, const float *w /* [ld] */, int64_t ld, int64_t N,
                        const gse_merge_spec *spec /* host */, void *workspace, void *stream);
 int gse_merge_end(const gse_merge_spec *spec /* host */, void *stream);
+/* log_island[0] += log(sum of w[0 .. N)) (fp64 sum in a fixed order; sum_out[0], optional, receives the sum): the island
+ * bookkeeping of a shard whose resample does not carry it -- the sharded Gaussian-sum filter calls this right before a local
+ * resample, the particle filter's gather stage does the same inside its launch (gse_pf_step's island argument). */
+int gse_island_absorb(const float *w, int64_t N, double *log_island /* [1] in / out */, double *sum_out /* [1] or NULL */,
+                      void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Exact systematic resampling of an ensemble SHARDED over several GPUs: the result is, bit for
