@@ -45,7 +45,10 @@ __device__ __forceinline__ void per_iteration_uniform(MpcLawDev& l) {
 //   3. otherwise that row joins the set (lane |W|) and the dual coordinate sweeps (Hildreth, as below) run over the set from
 //      the multipliers they had, until the stopping rule of the small solver holds;
 // and so on: every pass adds a row the previous optimum violated, so the dual objective rises strictly and no set repeats.
-// Not converged (status 1, the caller's fallback): more than 64 rows active together, or sweeps exhausted.  Nothing is kept
+// Every pass first sheds the rows whose multipliers have returned to zero (round 5; ADVICE round 4: they used to keep their
+// lanes, so a QP with fewer than 64 rows active at the optimum could still fill the set on the way there and fall to the
+// fallback input).
+// Not converged (status 1, the caller's fallback): more than 64 rows active together, or sweeps / passes exhausted.  Nothing is kept
 // in LDS (the callers have none to spare): the rows are re-formed from the law's matrices in every pass -- a few thousand
 // independent loads per rollout and pass, served by the L2.
 __device__ __noinline__ int mpc_solve_large(const MpcLawDev& law, double theta_lane, int lane, double& out) {
@@ -57,7 +60,7 @@ __device__ __noinline__ int mpc_solve_large(const MpcLawDev& law, double theta_l
     double th[GSE_MPC_MAX_THETA];
 #pragma unroll
     for (int k = 0; k < GSE_MPC_MAX_THETA; ++k) th[k] = __shfl(theta_lane, k, 64);
-    for (int pass = 0; pass <= 64; ++pass) {
+    for (int pass = 0; pass <= 4 * 64; ++pass) {          // (every pass adds a row the last optimum violated; evictions make room)
         // 1. the most violated row outside the working set
         double worst = 0.0, worst_c = 0.0, worst_c0 = 0.0;
         int worst_row = -1;
@@ -92,7 +95,32 @@ __device__ __noinline__ int mpc_solve_large(const MpcLawDev& law, double theta_l
             if (ob > best || (ob == best && ol < best_lane)) { best = ob; best_lane = ol; }
         }
         if (!(best > 0.0)) { converged = 1; break; }
-        if (nW == 64) break;
+        {
+            // Before a row joins (round 5): rows whose multiplier has returned to zero and that sit strictly inside their bounds
+            // only occupy a lane -- they joined on the way and the optimum over the set has left them.  They leave (rows
+            // outside the set again, with zero multipliers: feasible, and step 1 watches them) and the ranks close.  Shedding
+            // them in EVERY pass, not only when the set is full, also keeps the set near the number of active rows -- a set
+            // with many slack rows more than the problem has dimensions is rank-deficient, and the coordinate sweeps crawl
+            // on it (a 40-dimensional projection with 52 rows in the set: 20 000 sweeps did not finish one pass).
+            const bool keep = lane < nW && !(nu == 0.0 && c > lo && c < hi);
+            const unsigned long long km = __ballot(keep);
+            const int kept = __popcll(km);
+            if (kept < nW) {
+                unsigned long long left = km;
+                int src = -1;
+                for (int t = 0; t <= lane; ++t) {             // the lane-th kept lane (none for lane >= kept)
+                    src = __ffsll((long long)left) - 1;
+                    left &= left - 1;
+                }
+                const int from = src < 0 ? lane : src;
+                myrow = __shfl(myrow, from, 64);
+                nu = __shfl(nu, from, 64); c = __shfl(c, from, 64); c0 = __shfl(c0, from, 64);
+                lo = __shfl(lo, from, 64); hi = __shfl(hi, from, 64); sii = __shfl(sii, from, 64);
+                if (lane >= kept) { myrow = -1; nu = 0.0; c = 0.0; c0 = 0.0; lo = -INFINITY; hi = INFINITY; sii = 1.0; }
+                nW = kept;
+            }
+        }
+        if (nW == 64) break;                              // 64 rows, every one active or on a bound: more than this solver holds
         // 2. that row joins the working set on lane nW
         const int r = __shfl(worst_row, best_lane, 64);
         const double rc = __shfl(worst_c, best_lane, 64), rc0 = __shfl(worst_c0, best_lane, 64);

@@ -382,3 +382,73 @@ def test_moments_estimates_kernel_against_numpy():
         np.testing.assert_allclose(got[k, :5], mean, rtol=1e-14, atol=1e-14)
         sv = np.linalg.svd(cov, compute_uv=False)[0]
         np.testing.assert_allclose(got[k, 5], sv, rtol=1e-10, atol=1e-300)
+
+
+def test_working_set_sheds_rows_whose_multipliers_returned_to_zero():
+    """ADVICE round 4 (gse_loop_device.h, mpc_solve_large): the working set of at most 64 rows only ever grew, so a QP with
+    fewer than 64 rows active at the optimum could fill it ON THE WAY and fall to the fallback input.  Projection of a far point
+    onto a random polytope in 40 dimensions (1000 half-spaces): the walk adds about 2 x 40 rows before it stops on ~40 active
+    ones -- round 4's solver reports "not solved" on these (its set is full after 64 additions: emulated below), round 5's evicts
+    the rows that have gone slack and converges.  Checked against SciPy's non-negative least squares on the same problem
+    (least-distance programming, Lawson & Hanson), through gse_mpc_step itself with a hand-made law."""
+    import ctypes
+    from scipy.optimize import nnls
+    from gpu_se_amd import _lib
+    from gpu_se_amd.controller import _Law
+    rng = np.random.default_rng(5)
+    d, m = 40, 1000
+    dev = dict(dtype=torch.float64, device="cuda")
+    for trial in range(3):
+        A = rng.normal(size=(m, d))
+        A /= np.linalg.norm(A, axis=1, keepdims=True)
+        b = 0.2 + rng.random(m)
+        p = rng.normal(size=d) * 12
+        # min 1/2 |x - p|^2  s.t.  A x <= b:   c0 = A p,  S = A A^T,  x = p - A^T nu;  the law reports x[0:8] and x[8:16]
+        law = dict(Gc=np.zeros((m, 1)), gc0=A @ p, S=A @ A.T, lo=np.full(m, -np.inf), hi=b,
+                   Gu=np.zeros((8, 1)), gu0=p[:8], Tu=A[:, :8].T.copy(), Gy=np.zeros((8, 1)), gy0=p[8:16], Ty=A[:, 8:16].T.copy())
+        keep = {k: torch.as_tensor(np.ascontiguousarray(v), **dev) for k, v in law.items()}
+        c_law = _Law()
+        c_law.n_theta, c_law.n_u, c_law.n_y, c_law.n_rows = 1, 8, 8, m
+        c_law.max_sweeps, c_law.eps_abs, c_law.eps_rel = 20000, 1e-12, 1e-12
+        for k, t in keep.items():
+            setattr(c_law, k, t.data_ptr())
+        theta = torch.zeros((1, 1), **dev)
+        du0, y1 = torch.zeros((1, 8), **dev), torch.zeros((1, 8), **dev)
+        status = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+        _lib.call("gse_mpc_step", ctypes.byref(c_law), theta.data_ptr(), 1, du0.data_ptr(), y1.data_ptr(), status.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+        assert status.item() == 0, trial
+        got = np.concatenate([du0.cpu().numpy()[0], y1.cpu().numpy()[0]])
+        # least-distance programming by non-negative least squares (Lawson & Hanson): min |x - p| s.t. -A (x - p) >= A p - b
+        E = np.vstack([-A.T, (A @ p - b)[None, :]])
+        f = np.zeros(d + 1)
+        f[d] = 1.0
+        uu, _ = nnls(E, f, maxiter=20000)
+        rr = E @ uu - f
+        x_ref = p - rr[:d] / rr[d]
+        assert np.max(A @ x_ref - b) < 1e-9
+        np.testing.assert_allclose(got, x_ref[:16], rtol=0, atol=1e-8)
+        active = int(np.sum(b - A @ x_ref < 1e-7))
+        assert 30 <= active < 64, active
+        # round 4's rule on the same walk (most violated row joins, nothing leaves): the set fills before the walk ends
+        W, nu = [], np.zeros(m)
+        S, c0 = law["S"], law["gc0"]
+        for _ in range(70):
+            c = c0 - S @ nu
+            viol = c - b
+            viol[W] = -1.0
+            i = int(np.argmax(viol))
+            if viol[i] <= 1e-10 or len(W) == 64:
+                break
+            W.append(i)
+            Wi = np.array(W)
+            SW, nW = S[np.ix_(Wi, Wi)], nu[Wi].copy()
+            for sweep in range(20000):
+                for a in range(len(Wi)):
+                    r = (c0[Wi[a]] - SW[a] @ nW) + SW[a, a] * nW[a]
+                    nW[a] = max((r - b[Wi[a]]) / SW[a, a], 0.0)
+                cW = c0[Wi] - SW @ nW
+                if np.max(np.where(nW > 0, np.abs(cW - b[Wi]), np.maximum(cW - b[Wi], 0))) <= 1e-12:
+                    break
+            nu[Wi] = nW
+        assert len(W) == 64 and np.max(c0 - S @ nu - b) > 1e-6          # full, and rows outside it still violated
