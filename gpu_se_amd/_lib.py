@@ -58,6 +58,16 @@ class Mixture(ctypes.Structure):
                 ("inv_cov", ((c_d * GSE_NX) * GSE_NX) * GSE_MAX_ND)]
 
 
+GSE_N_MAX_NX = 8
+
+
+class MixtureN(ctypes.Structure):
+    """struct gse_mixture_n (include/gse.h): a mixture of up to 8 dimensions, as the dimension-generic kernels take it."""
+    _fields_ = [("nd", c_i32), ("n", c_i32), ("cumw", c_f * GSE_MAX_ND), ("cw", c_d * GSE_MAX_ND),
+                ("mean", (c_f * GSE_N_MAX_NX) * GSE_MAX_ND), ("chol", ((c_f * GSE_N_MAX_NX) * GSE_N_MAX_NX) * GSE_MAX_ND),
+                ("inv", ((c_d * GSE_N_MAX_NX) * GSE_N_MAX_NX) * GSE_MAX_ND)]
+
+
 class Rng(ctypes.Structure):
     """struct gse_rng (include/gse.h)."""
     _fields_ = [("seed", c_u64), ("step", c_u64), ("element_offset", c_u64),
@@ -149,6 +159,10 @@ PROTOTYPES = {
     "gse_model_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, c_u64, ctypes.c_char_p, ctypes.c_char_p,
                                         ctypes.c_char_p, ctypes.POINTER(c_vp)]),
     "gse_model_destroy": (ctypes.c_int, [c_vp]),
+    "gse_generic_model_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_u64, ctypes.c_char_p,
+                                                ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(c_vp)]),
+    "gse_model_launch": (ctypes.c_int, [c_vp, ctypes.c_char_p, c_u32, c_u32, c_u32, c_u32, c_u32, c_u32, c_u32,
+                                        ctypes.POINTER(c_vp), c_vp]),
     "gse_model_prepare": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
     "gse_model_compile_check": (c_i64, [c_vp, ctypes.c_char_p]),
     "gse_model_kernels": (c_i64, [c_vp]),
@@ -203,6 +217,8 @@ PROTOTYPES = {
     "gse_mixture_pdf_f32": (ctypes.c_int, [c_vp, c_i64, P_MIX, c_vp, c_vp]),
     "gse_mixture_pdf_f64": (ctypes.c_int, [c_vp, c_i64, P_MIX, c_vp, c_vp]),
     "gse_mixture_draw": (ctypes.c_int, [c_vp, c_i64, c_i64, P_MIX, P_RNG, c_vp]),
+    "gse_mixture_draw_n": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(MixtureN), P_RNG, c_vp]),
+    "gse_mixture_pdf_n": (ctypes.c_int, [c_vp, c_i64, ctypes.POINTER(MixtureN), c_vp, c_vp]),
     "gse_cumsum_normalised": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "gse_systematic_index": (ctypes.c_int, [c_vp, c_vp, c_i64, c_d, c_vp]),
     "gse_rng_raw": (ctypes.c_int, [c_vp, c_i64, P_RNG, c_u32, c_vp]),

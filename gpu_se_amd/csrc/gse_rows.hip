@@ -3,6 +3,7 @@
 // systematic index from a cumulative sum, and the raw RNG words.  The filters themselves use the fused
 // kernels in gse_pf.hip / gse_gsukf.hip; these exist for API completeness and for the parity tests.
 #include "gse_rows_kernels.h"
+#include "gse_generic_kernels.h"
 #include "gse_rtc.h"
 
 #include <string.h>
@@ -93,6 +94,29 @@ __global__ __launch_bounds__(kBlock) void systematic_index_kernel(const double* 
         if (c[mid] < u) lo = mid + 1; else hi = mid;
     }
     idx[i] = lo;
+}
+
+// MultivariateGaussianSum.draw / .pdf for mixtures of more than GSE_NX dimensions (gse_generic_kernels.h)
+struct MixtureNArgs {
+    gse_mixture_n m;
+    RngKey rng;
+};
+
+__global__ __launch_bounds__(kBlock) void mixture_draw_n_kernel(float* __restrict__ out, int64_t M, const MixtureNArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    float e[kGMaxNx];
+    generic_draw_n(a.m, a.rng, (uint64_t)i, e);
+    for (int k = 0; k < a.m.n; ++k) out[i * a.m.n + k] = e[k];
+}
+
+__global__ __launch_bounds__(kBlock) void mixture_pdf_n_kernel(const double* __restrict__ e, int64_t M, const MixtureNArgs a,
+                                                               double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    double v[kGMaxNx];
+    for (int k = 0; k < kGMaxNx; ++k) v[k] = (k < a.m.n) ? e[i * a.m.n + k] : 0.0;
+    out[i] = generic_pdf_n(a.m, v);
 }
 
 static int pack_pdfn(PdfN& p, const gse_mixture& m) {
@@ -219,6 +243,35 @@ int gse_rng_raw(uint32_t* out, int64_t M, const gse_rng* rng, uint32_t purpose, 
     const RngKey key = make_rng_key(*rng, purpose);
     hipLaunchKernelGGL(rng_raw_kernel, dim3(blocks_for(M)), dim3(kBlock), 0, (hipStream_t)stream, out, M, key);
     GSE_LAUNCH_CHECK("rng_raw_kernel");
+    return GSE_OK;
+}
+
+static int check_mixture_n(const char* fn, const gse_mixture_n* m) {
+    GSE_REQUIRE(m, "%s: null mixture", fn);
+    GSE_REQUIRE(m->nd >= 1 && m->nd <= GSE_MAX_ND && m->n >= 1 && m->n <= GSE_N_MAX_NX, "%s: mixture of %d components in %d "
+                "dimensions (at most %d, %d)", fn, m->nd, m->n, GSE_MAX_ND, GSE_N_MAX_NX);
+    return GSE_OK;
+}
+
+int gse_mixture_draw_n(float* out, int64_t M, const gse_mixture_n* m, const gse_rng* rng, void* stream) {
+    GSE_REQUIRE(out && rng && M >= 1, "gse_mixture_draw_n: bad argument");
+    if (int rc = check_mixture_n("gse_mixture_draw_n", m)) return rc;
+    MixtureNArgs a;
+    a.m = *m;
+    a.rng = make_rng_key(*rng, kPurposeDraw);
+    hipLaunchKernelGGL(mixture_draw_n_kernel, dim3(blocks_for(M)), dim3(kBlock), 0, (hipStream_t)stream, out, M, a);
+    GSE_LAUNCH_CHECK("mixture_draw_n_kernel");
+    return GSE_OK;
+}
+
+int gse_mixture_pdf_n(const double* e, int64_t M, const gse_mixture_n* m, double* out, void* stream) {
+    GSE_REQUIRE(e && out && M >= 1, "gse_mixture_pdf_n: bad argument");
+    if (int rc = check_mixture_n("gse_mixture_pdf_n", m)) return rc;
+    MixtureNArgs a;
+    a.m = *m;
+    a.rng = RngKey{};
+    hipLaunchKernelGGL(mixture_pdf_n_kernel, dim3(blocks_for(M)), dim3(kBlock), 0, (hipStream_t)stream, e, M, a, out);
+    GSE_LAUNCH_CHECK("mixture_pdf_n_kernel");
     return GSE_OK;
 }
 

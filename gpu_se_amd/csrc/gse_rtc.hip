@@ -67,7 +67,8 @@ int open_rtc(const char* path) {
 struct UserModel {
     std::string header;                 // the generated model (user_increment / user_output, GSE_USER_NX, GSE_USER_NU)
     std::string include_csrc, include_abi;
-    int nx = 0, nu = 0;
+    int nx = 0, nu = 0, ny = 2;
+    bool generic = false;               // a model beyond the fast path's bounds: its kernels are gse_generic_kernels.h
     uint64_t tag = 0;
     std::map<std::string, hipFunction_t> functions;
     std::vector<hipModule_t> modules;
@@ -81,9 +82,10 @@ static int compile_instance(UserModel* m, const char* name_expression, std::vect
     // one translation unit per kernel instance: the model header (registered as an in-memory include), then the kernels
     // (the GS-UKF kernels are a translation unit of their own: a particle-filter instance does not pay for parsing them)
     const bool gsukf = strstr(name_expression, "gse::gsukf_") != nullptr;
-    const std::string source = std::string("#define GSE_USER_MODEL \"gse_user_model.h\"\n") +
-                               (gsukf ? "#include \"gse_gsukf_kernels.h\"\n"
-                                      : "#include \"gse_pf_kernels.h\"\n#include \"gse_rows_kernels.h\"\n");
+    const std::string source = m->generic
+        ? std::string("#define GSE_GENERIC_MODEL \"gse_user_model.h\"\n#include \"gse_generic_kernels.h\"\n")
+        : std::string("#define GSE_USER_MODEL \"gse_user_model.h\"\n") +
+              (gsukf ? "#include \"gse_gsukf_kernels.h\"\n" : "#include \"gse_pf_kernels.h\"\n#include \"gse_rows_kernels.h\"\n");
     const char* header_names[] = {"gse_user_model.h"};
     const char* header_texts[] = {m->header.c_str()};
     rtc_program prog = nullptr;
@@ -176,6 +178,38 @@ int gse_model_create(const char* model_header, int nx, int nu, uint64_t tag, con
     m->tag = tag;
     *model_out = m;
     return GSE_OK;
+}
+
+// A model beyond the fast path's bounds (up to 8 states, 4 inputs, 4 outputs): its kernels are those of gse_generic_kernels.h,
+// compiled with the model's dimensions as constants and launched by name through gse_model_launch.
+int gse_generic_model_create(const char* model_header, int nx, int nu, int ny, uint64_t tag, const char* include_csrc,
+                             const char* include_abi, const char* hiprtc_path, void** model_out) {
+    GSE_REQUIRE(model_header && include_csrc && include_abi && model_out, "gse_generic_model_create: null argument");
+    GSE_REQUIRE(nx >= 1 && nx <= 8 && nu >= 1 && nu <= 4 && ny >= 1 && ny <= 4,
+                "gse_generic_model_create: nx = %d, nu = %d, ny = %d out of range (8, 4, 4)", nx, nu, ny);
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (int rc = open_rtc(hiprtc_path)) return rc;
+    }
+    UserModel* m = new UserModel;
+    m->header = model_header;
+    m->include_csrc = include_csrc;
+    m->include_abi = include_abi;
+    m->nx = nx; m->nu = nu; m->ny = ny;
+    m->generic = true;
+    m->tag = tag;
+    *model_out = m;
+    return GSE_OK;
+}
+
+// Launch a kernel of the model's translation unit by its C++ name (compiled on first use): params = one pointer per kernel
+// argument, as hipModuleLaunchKernel takes them.
+int gse_model_launch(void* model, const char* name_expression, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx, uint32_t by,
+                     uint32_t bz, uint32_t dynamic_lds, void** params, void* stream) {
+    GSE_REQUIRE(model && name_expression && params && gx >= 1 && gy >= 1 && gz >= 1 && bx >= 1 && by >= 1 && bz >= 1 &&
+                    (uint64_t)bx * by * bz <= 1024, "gse_model_launch: bad argument");
+    return launch_user_kernel(static_cast<UserModel*>(model), name_expression, dim3(gx, gy, gz), dim3(bx, by, bz), dynamic_lds,
+                              (hipStream_t)stream, params);
 }
 
 int gse_model_destroy(void* model) {

@@ -26,6 +26,18 @@ class ParallelGaussianSumUnscentedKalmanFilter:
 
     _parallel_resample = _KernelLauncher(_parallel_resample)
 
+    def __new__(cls, f, g, *args, **kwargs):
+        # (as ParallelParticleFilter.__new__: models beyond the fast kernels' bounds get the dimension-generic class)
+        from gpu_se_amd.model import Bioreactor
+        if cls is ParallelGaussianSumUnscentedKalmanFilter and not (f is Bioreactor.homeostatic_DEs and g is Bioreactor.static_outputs):
+            from gpu_se_amd import usermodel
+            if usermodel.needs_generic_kernels(f, g):
+                from gpu_se_amd.filter.generic import GenericGaussianSumFilter
+                if kwargs.get("element_offset") or kwargs.get("_batch", 1) != 1:
+                    raise NotImplementedError("shards and batches run the fast kernels' models only")
+                return GenericGaussianSumFilter(f, g, *args)
+        return object.__new__(cls)
+
     def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, _batch=1, element_offset=0):
         # the bioreactor functions run the kernels shipped in the library; any other (f, g) is translated and its kernels
         # are compiled for the device at run time (gs_ukf.py:243-275 hands them to Numba)

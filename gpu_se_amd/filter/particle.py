@@ -69,6 +69,18 @@ class ParallelParticleFilter:
 
     _parallel_resample = _KernelLauncher(_parallel_resample)
 
+    def __new__(cls, f, g, *args, **kwargs):
+        # a user model beyond the fast kernels' bounds (more than 5 states / 2 inputs, other than 2 outputs; round 5): the
+        # dimension-generic class takes over (filter/generic.py) -- the reference's constructor takes any model Numba compiles
+        if cls is ParallelParticleFilter and not (f is Bioreactor.homeostatic_DEs and g is Bioreactor.static_outputs):
+            from gpu_se_amd import usermodel
+            if usermodel.needs_generic_kernels(f, g):
+                from gpu_se_amd.filter.generic import GenericParticleFilter
+                if kwargs.get("element_offset") or kwargs.get("_batch", 1) != 1:
+                    raise NotImplementedError("shards and batches run the fast kernels' models only")
+                return GenericParticleFilter(f, g, *args)
+        return object.__new__(cls)
+
     def __init__(self, f, g, N_particles, x0, state_pdf, measurement_pdf, element_offset=0, _batch=1):
         lib, self._model = _model_library(f, g)
         self._lib = lib

@@ -37,9 +37,13 @@ class MultivariateGaussianSum:
         # fp64 inverse of the covariances as given, fp32 constants from the fp32 covariances (:33-37)
         self._inverse_covariances = numpy.linalg.inv(numpy.asarray(covariances, dtype=numpy.float64))
         self._Nd, self._Nx = means.shape
-        if not (1 <= self._Nd <= _lib.GSE_MAX_ND and 1 <= self._Nx <= _lib.GSE_NX):
+        if not (1 <= self._Nd <= _lib.GSE_MAX_ND and 1 <= self._Nx <= _lib.GSE_N_MAX_NX):
             raise ValueError("MultivariateGaussianSum on the HIP device supports Nd <= %d, Nx <= %d (got %d, %d)"
-                             % (_lib.GSE_MAX_ND, _lib.GSE_NX, self._Nd, self._Nx))
+                             % (_lib.GSE_MAX_ND, _lib.GSE_N_MAX_NX, self._Nd, self._Nx))
+        # (more than GSE_NX = 5 dimensions -- the noise of a user model of 6 .. 8 states, round 5 --: draw and pdf go through
+        #  gse_mixture_draw_n / gse_mixture_pdf_n, the dimension-generic kernels' mixture; _pod(), the fast kernels' struct, is
+        #  not available for those)
+        self._wide = self._Nx > _lib.GSE_NX
         self._constants = ((2 * numpy.pi) ** (-self._Nx / 2)
                            / numpy.sqrt(numpy.linalg.det(self.covariances))).astype(numpy.float32)
         self._seed = gpu_se_amd._new_stream_seed()
@@ -58,7 +62,28 @@ class MultivariateGaussianSum:
         self._pod_cache = (key, pod)
         return pod
 
+    def _pod_n(self):
+        """struct gse_mixture_n for the CURRENT attribute values (any dimension up to 8)."""
+        m = _lib.MixtureN()
+        n = self._Nx
+        m.nd, m.n = self._Nd, n
+        w = numpy.asarray(self.weights, dtype=numpy.float32)
+        cum = numpy.cumsum(w, dtype=numpy.float32) / numpy.float32(w.sum(dtype=numpy.float32))
+        means = numpy.asarray(self.means, dtype=numpy.float32).reshape(self._Nd, n)
+        chol = numpy.linalg.cholesky(numpy.asarray(self.covariances, dtype=numpy.float64)).astype(numpy.float32)
+        for d in range(self._Nd):
+            m.cumw[d] = float(cum[d])
+            m.cw[d] = float(numpy.float64(numpy.float32(self._constants[d])) * numpy.float64(w[d]))
+            for i in range(n):
+                m.mean[d][i] = float(means[d, i])
+                for j in range(n):
+                    m.chol[d][i][j] = float(chol[d, i, j])
+                    m.inv[d][i][j] = float(self._inverse_covariances[d, i, j])
+        return m
+
     def _build_pod(self):
+        if self._wide:
+            raise ValueError("a mixture of %d dimensions has no fast-kernel struct (gse_mixture: Nx <= %d)" % (self._Nx, _lib.GSE_NX))
         m = _lib.Mixture()
         m.nd, m.nx = self._Nd, self._Nx
         means = numpy.asarray(self.means, dtype=numpy.float32).reshape(self._Nd, self._Nx)
@@ -98,6 +123,10 @@ class MultivariateGaussianSum:
             raise ValueError("pdf: points have %d columns, the mixture has Nx = %d" % (t.shape[-1], self._Nx))
         m = t.shape[0]
         out = torch.empty(m, dtype=torch.float64, device=t.device)
+        if self._wide:
+            t = t.to(torch.float64).contiguous()
+            _lib.call("gse_mixture_pdf_n", t.data_ptr(), m, ctypes.byref(self._pod_n()), out.data_ptr(), stream_ptr())
+            return DevArray.wrap(out)
         pod = self._pod()
         fn = "gse_mixture_pdf_f32" if t.dtype == torch.float32 else "gse_mixture_pdf_f64"
         _lib.call(fn, t.data_ptr(), m, ctypes.byref(pod), out.data_ptr(), stream_ptr())
@@ -112,6 +141,10 @@ class MultivariateGaussianSum:
         size = int(numpy.prod(shape))
         out = torch.empty((size, self._Nx), dtype=torch.float32, device=device())
         # (_element_offset: global index of the first sample -- a shard of a larger draw takes ITS rows of it)
+        if self._wide:
+            rng = self._rng(element_offset=int(_element_offset))
+            _lib.call("gse_mixture_draw_n", out.data_ptr(), size, ctypes.byref(self._pod_n()), ctypes.byref(rng), stream_ptr())
+            return DevArray.wrap(out.reshape(shape + (self._Nx,)))
         pod, rng = self._pod(), self._rng(element_offset=int(_element_offset))
         _lib.call("gse_mixture_draw", out.data_ptr(), size, 0, ctypes.byref(pod), ctypes.byref(rng), stream_ptr())
         return DevArray.wrap(out.reshape(shape + (self._Nx,)))

@@ -15,9 +15,11 @@ Accepted form
         ...                     #   a if cond else b, comparisons, min / max / abs / exp / log / sqrt / sin / cos / tanh / pow
         return dx1 * dt, dx2 * dt
     def g(x, u): ... return y1, y2
-    1 <= Nx <= 5 states, 1 <= Nu <= 2 inputs, Ny = 2 outputs (the kernels' measurement density is two-dimensional).
-Anything else (loops, calls to other functions, attribute access other than numpy. / math.) raises ``ModelError`` --
-there is no CPU fallback.
+    1 <= Nx <= 5 states, 1 <= Nu <= 2 inputs, Ny = 2 outputs: the fast kernels (state-major rows of five, a two-dimensional
+    measurement density).  Beyond that -- up to 8 states, 4 inputs, 1 .. 4 outputs (round 5) -- the dimension-generic kernels of
+    csrc/gse_generic_kernels.h run the same algorithms (gpu_se_amd/filter/generic.py): correct and parallel, not tuned.
+Anything else (loops, calls to other functions, attribute access other than numpy. / math.; more than 8 states) raises
+``ModelError`` -- there is no CPU fallback.
 
 Arithmetic: every expression is evaluated in fp64 on the fp32-stored state, without FMA contraction, and the new state is
 rounded to fp32 once -- what the reference's device code does when the expression mixes array elements with Python
@@ -51,7 +53,9 @@ class ModelError(NotImplementedError):
 class _Translator:
     """One Python function -> a list of C++ statements and the expressions it returns."""
 
-    def __init__(self, fn, param_roles):
+    def __init__(self, fn, param_roles, max_x=None, max_u=None):
+        self.max_x = MAX_NX if max_x is None else max_x
+        self.max_u = MAX_NU if max_u is None else max_u
         try:
             src = textwrap.dedent(inspect.getsource(fn))
         except (OSError, TypeError) as e:
@@ -82,7 +86,7 @@ class _Translator:
                          % (self.fn.name, getattr(node, "lineno", 0), what))
 
     def element(self, role, index, node):
-        limit = MAX_NX if role == "x" else MAX_NU
+        limit = self.max_x if role == "x" else self.max_u
         if not 0 <= index < limit:
             self.fail(node, "%s[%d]" % (role, index))
         self.used[role] = max(self.used[role], index + 1)
@@ -227,6 +231,114 @@ def translate(f, g):
         "    " + "\n    ".join(body_g),
         "}", ""])
     return nx, nu, text
+
+
+G_MAX_NX, G_MAX_NU, G_MAX_NY = 8, 4, 4
+
+
+def model_dimensions(f, g):
+    """(nx, nu, ny) of a pair of model functions (translated with the generic bounds)."""
+    tf, tg = _Translator(f, ("x", "u", "dt"), G_MAX_NX, G_MAX_NU), _Translator(g, ("x", "u"), G_MAX_NX, G_MAX_NU)
+    return len(tf.returns), max(tf.used["u"], tg.used["u"], 1), len(tg.returns)
+
+
+def needs_generic_kernels(f, g):
+    """True when (f, g) is outside the fast kernels' bounds (5 states, 2 inputs, exactly 2 outputs) but inside the generic
+    ones'; outside both: ModelError."""
+    nx, nu, ny = model_dimensions(f, g)
+    if nx <= MAX_NX and nu <= MAX_NU and ny == NY:
+        return False
+    if not (1 <= nx <= G_MAX_NX and 1 <= nu <= G_MAX_NU and 1 <= ny <= G_MAX_NY):
+        raise ModelError("a model of %d states, %d inputs, %d outputs is beyond the generic kernels' bounds (%d, %d, %d)"
+                         % (nx, nu, ny, G_MAX_NX, G_MAX_NU, G_MAX_NY))
+    return True
+
+
+def translate_generic(f, g):
+    """(nx, nu, ny, header text) for the dimension-generic kernels (csrc/gse_generic_kernels.h)."""
+    tf, tg = _Translator(f, ("x", "u", "dt"), G_MAX_NX, G_MAX_NU), _Translator(g, ("x", "u"), G_MAX_NX, G_MAX_NU)
+    nx, ny = len(tf.returns), len(tg.returns)
+    nu = max(tf.used["u"], tg.used["u"], 1)
+    if not 1 <= nx <= G_MAX_NX or max(tf.used["x"], tg.used["x"]) > nx:
+        raise ModelError("f must return one increment per state (1..%d states); it returns %d and the functions read %d states"
+                         % (G_MAX_NX, nx, max(tf.used["x"], tg.used["x"])))
+    if not 1 <= ny <= G_MAX_NY:
+        raise ModelError("g must return 1..%d outputs; it returns %d" % (G_MAX_NY, ny))
+    names = ["x_%d" % k for k in range(nx)] + ["u_%d" % k for k in range(nu)]
+    prologue = ["const double x_%d = x_[%d];" % (k, k) for k in range(nx)] + \
+               ["const double u_%d = u_[%d];" % (k, k) for k in range(nu)] + [" ".join("(void)%s;" % n for n in names)]
+    body_f = prologue + tf.lines + ["dx_[%d] = %s;" % (k, tf.returns[k]) for k in range(nx)]
+    body_g = prologue + tg.lines + ["y_[%d] = (float)(%s);" % (k, tg.returns[k]) for k in range(ny)]
+    text = "\n".join([
+        "// generated by gpu_se_amd/usermodel.py from %s / %s (generic kernels) -- do not edit" % (f.__name__, g.__name__),
+        "#pragma once",
+        "#define GSE_G_NX %d" % nx, "#define GSE_G_NU %d" % nu, "#define GSE_G_NY %d" % ny,
+        "__device__ __forceinline__ void generic_increment(const double (&x_)[%d], const double (&u_)[%d], double dt_, "
+        "double (&dx_)[%d]) {" % (nx, nu, nx),
+        "#pragma clang fp contract(off)",
+        "    " + "\n    ".join(body_f),
+        "}",
+        "__device__ __forceinline__ void generic_output(const double (&x_)[%d], const double (&u_)[%d], float (&y_)[%d]) {"
+        % (nx, nu, ny),
+        "#pragma clang fp contract(off)",
+        "    const double dt_ = 0.0; (void)dt_;",
+        "    " + "\n    ".join(body_g),
+        "}", ""])
+    return nx, nu, ny, text
+
+
+class GenericModel:
+    """A user model beyond the fast kernels' bounds: its kernels (csrc/gse_generic_kernels.h) are compiled in the process by
+    hiprtc with the model's dimensions as constants, one kernel at a time on first launch, and launched by name."""
+
+    def __init__(self, f, g):
+        import torch
+        self.nx, self.nu, self.ny, text = translate_generic(f, g)
+        self.text = text
+        h = hashlib.sha256(text.encode())
+        with open(os.path.join(build.CSRC, "gse_generic_kernels.h"), "rb") as fh:
+            h.update(fh.read())
+        self.tag = int(h.hexdigest()[:15], 16) | 1
+        base = _lib.load()
+        handle = ctypes.c_void_p()
+        rtc = os.path.join(os.path.dirname(torch.__file__), "lib", "libhiprtc.so")
+        if not os.path.exists(rtc):
+            rtc = "/opt/rocm/lib/libhiprtc.so"
+        _lib.check(base.gse_generic_model_create(text.encode(), self.nx, self.nu, self.ny, self.tag, build.CSRC.encode(),
+                                                 os.path.join(build.ROOT, "include").encode(), rtc.encode(), ctypes.byref(handle)))
+        self._base, self._handle = base, handle
+
+    def launch(self, name, n_threads, block, args, stream):
+        """Launch kernel ``name`` (a C++ name inside gse::) over n_threads threads in workgroups of ``block``; args: ctypes
+        objects, one per kernel argument (kept alive by the caller until the call returns -- the launch copies them)."""
+        params = (ctypes.c_void_p * len(args))(*[ctypes.cast(ctypes.pointer(a), ctypes.c_void_p).value for a in args])
+        grid = max(1, -(-int(n_threads) // block))
+        _lib.check(self._base.gse_model_launch(self._handle, ("gse::" + name).encode(), grid, 1, 1, block, 1, 1, 0, params, stream))
+
+    def compile_check(self, name):
+        """Compile only (works without a device): size of the code object in bytes."""
+        n = self._base.gse_model_compile_check(self._handle, ("gse::" + name).encode())
+        if n < 0:
+            _lib.check(int(n))
+        return int(n)
+
+    def __del__(self):
+        handle, self._handle = getattr(self, "_handle", None), None
+        if handle is not None and getattr(self, "_base", None) is not None:
+            try:
+                self._base.gse_model_destroy(handle)
+            except Exception:
+                pass
+
+
+_generic_cache = {}
+
+
+def compile_generic_model(f, g):
+    key = (f, g)
+    if key not in _generic_cache:
+        _generic_cache[key] = GenericModel(f, g)
+    return _generic_cache[key]
 
 
 USER_DIR = os.path.join(build.LIBDIR, "user")

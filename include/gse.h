@@ -473,6 +473,18 @@ uint64_t gse_model_tag(void);
 int gse_model_create(const char *model_header, int nx, int nu, uint64_t tag, const char *include_csrc,
                      const char *include_abi, const char *hiprtc_path, void **model_out);
 int gse_model_destroy(void *model);
+/* Models BEYOND the fast path's bounds (round 5): up to 8 states, 4 inputs, 4 outputs.  Their header defines GSE_G_NX / GSE_G_NU /
+ * GSE_G_NY, generic_increment() and generic_output(); their kernels are the dimension-generic ones of
+ * gpu_se_amd/csrc/gse_generic_kernels.h (both filters: one thread per particle / Gaussian, rows of NX floats), compiled by
+ * hiprtc with those constants.  gse_model_launch starts a kernel of a model's translation unit by its C++ name, e.g.
+ * "gse::generic_pf_predict_kernel<false>" (compiled on first use): `params` holds one pointer per kernel argument, as
+ * hipModuleLaunchKernel takes them.  The Python classes of gpu_se_amd/filter/generic.py drive these kernels the way the
+ * reference drives its Numba kernels -- from Python -- with the resample's cumulative weights and ancestors from the entry
+ * points above (gse_cumsum_normalised, gse_systematic_index), which do not depend on the model. */
+int gse_generic_model_create(const char *model_header, int nx, int nu, int ny, uint64_t tag, const char *include_csrc,
+                             const char *include_abi, const char *hiprtc_path, void **model_out);
+int gse_model_launch(void *model, const char *name_expression, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx,
+                     uint32_t by, uint32_t bz, uint32_t dynamic_lds, void **params, void *stream);
 /* Compile and load a kernel instance now, e.g. "gse::pf_step_kernel<true, true, false, true, 2, 3>" (otherwise: first use). */
 int gse_model_prepare(void *model, const char *name_expression);
 /* Compile only -- works without a device; returns the size of the code object in bytes, or a negative status. */
@@ -493,6 +505,22 @@ int gse_mixture_pdf_f64(const double *e, int64_t M, const gse_mixture *m, double
  * ld > 0 state-major [nx][ld] (the layout gse_pf_* uses; this is how the filters draw their prior). */
 int gse_mixture_draw(float *out, int64_t M, int64_t ld, const gse_mixture *m, const gse_rng *rng,
                      void *stream);
+/* The same two for mixtures of MORE than GSE_NX dimensions (round 5: user models of up to 8 states run the dimension-generic
+ * kernels, gpu_se_amd/filter/generic.py): the mixture as the generic kernels take it -- normalised cumulative weights for the
+ * draw, constant x weight and inverse covariance for the density.  Element i of a draw takes Philox blocks sub = 0, 1, ... of
+ * element rng->element_offset + i: pair p = words (2p, 2p + 1) is one Box-Muller pair = normals 2p, 2p + 1, the word behind
+ * the pairs selects the component; sample = mean + L n.  e / out rows are [M][n]. */
+#define GSE_N_MAX_NX 8
+typedef struct gse_mixture_n {
+    int32_t nd, n;                              /* components (<= GSE_MAX_ND), dimension (<= GSE_N_MAX_NX) */
+    float   cumw[GSE_MAX_ND];                   /* normalised cumulative weights */
+    double  cw[GSE_MAX_ND];                     /* (2 pi)^(-n/2) / sqrt(det Sigma_d) (fp32) x weight_d */
+    float   mean[GSE_MAX_ND][GSE_N_MAX_NX];
+    float   chol[GSE_MAX_ND][GSE_N_MAX_NX][GSE_N_MAX_NX];   /* lower Cholesky factor of Sigma_d */
+    double  inv[GSE_MAX_ND][GSE_N_MAX_NX][GSE_N_MAX_NX];    /* Sigma_d^-1 */
+} gse_mixture_n;
+int gse_mixture_draw_n(float *out, int64_t M, const gse_mixture_n *m /* host */, const gse_rng *rng, void *stream);
+int gse_mixture_pdf_n(const double *e, int64_t M, const gse_mixture_n *m /* host */, double *out, void *stream);
 /* torch.cumsum + "/= cumsum[-1]" of resample (filter/particle.py:301-304): w [N] fp32 -> c [N] fp64. */
 int gse_cumsum_normalised(const float *w, double *c, int64_t N, void *workspace, void *stream);
 /* _parallel_resample (filter/particle.py:223-263): idx[i] = first k with c[k] >= (i + r)/N.  idx int64. */

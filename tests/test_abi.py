@@ -47,7 +47,8 @@ def test_loop_structs_match_the_header_as_a_c_compiler_lays_them_out(lib, tmp_pa
         pytest.skip("no gcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     structs = {"gse_loop_spec": lib.LoopSpec, "gse_loop_tail": lib.LoopTail, "gse_pf_loop_spec": lib.PfLoopSpec,
-               "gse_merge_spec": lib.MergeSpec, "gse_gsukf_cycles_spec": lib.GsukfCyclesSpec}
+               "gse_merge_spec": lib.MergeSpec, "gse_gsukf_cycles_spec": lib.GsukfCyclesSpec,
+               "gse_mixture_n": lib.MixtureN}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gse.h"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -69,3 +69,45 @@ def test_library_builds_for_a_user_model():
                                  None, None, None) < 0
     assert b"bad ops mask" in model.lib.gse_last_error()
     assert usermodel.compile_model(um.two_state_f, um.two_state_g, backend="hipcc") is model          # cached
+
+
+def test_models_beyond_the_fast_bounds_get_the_generic_kernels():
+    """Round 5: up to 8 states / 4 inputs / 4 outputs through the dimension-generic kernels (csrc/gse_generic_kernels.h), compiled
+    by hiprtc with the model's dimensions as constants -- no device needed for the compilation itself."""
+    assert usermodel.model_dimensions(um.six_state_f, um.six_state_g) == (6, 3, 3)
+    assert usermodel.needs_generic_kernels(um.six_state_f, um.six_state_g)
+    assert not usermodel.needs_generic_kernels(um.two_state_f, um.two_state_g)
+    assert usermodel.needs_generic_kernels(um.two_state_f, _one_output)              # one output: not the fast kernels' two
+    nx, nu, ny, text = usermodel.translate_generic(um.six_state_f, um.six_state_g)
+    assert (nx, nu, ny) == (6, 3, 3)
+    for piece in ("#define GSE_G_NX 6", "#define GSE_G_NU 3", "#define GSE_G_NY 3", "generic_increment", "generic_output",
+                  "fp contract(off)", "fmin("):
+        assert piece in text
+    model = usermodel.compile_generic_model(um.six_state_f, um.six_state_g)
+    assert usermodel.compile_generic_model(um.six_state_f, um.six_state_g) is model
+    for name in ("generic_pf_predict_kernel<false>", "generic_pf_update_kernel", "generic_gsukf_predict_kernel<true>",
+                 "generic_gsukf_update_kernel", "generic_moments_kernel"):
+        assert model.compile_check(name) > 10000
+    with pytest.raises(usermodel.ModelError, match="outside the supported form|beyond"):
+        usermodel.needs_generic_kernels(_nine_state_f, um.six_state_g)
+
+
+def _nine_state_f(x, u, dt):
+    return x[0] * dt, x[1] * dt, x[2] * dt, x[3] * dt, x[4] * dt, x[5] * dt, x[6] * dt, x[7] * dt, x[8] * dt
+
+
+def test_wide_mixture_host_side():
+    """A MultivariateGaussianSum of 6 dimensions keeps the reference's host attributes and packs the generic kernels' struct."""
+    from gpu_se_amd import gaussian_sum_dist as gsd
+    cov = np.array([np.diag([1e-2, 2e-2, 1e-2, 3e-2, 1e-2, 2e-2]), np.diag([1e-2] * 6) + 1e-3])
+    m = gsd.MultivariateGaussianSum(means=np.zeros((2, 6)), covariances=cov, weights=np.array([0.7, 0.9]))
+    assert (m._Nd, m._Nx, m._wide) == (2, 6, True)
+    pod = m._pod_n()
+    assert pod.nd == 2 and pod.n == 6 and abs(pod.cumw[0] - 0.7 / 1.6) < 1e-6 and abs(pod.cumw[1] - 1.0) < 1e-6
+    np.testing.assert_allclose(np.array(pod.chol[1])[:6, :6], np.linalg.cholesky(cov[1]), rtol=1e-6)
+    np.testing.assert_allclose(np.array(pod.inv[0])[:6, :6], np.linalg.inv(cov[0]), rtol=1e-12)
+    np.testing.assert_allclose(pod.cw[1], (2 * np.pi) ** -3 / np.sqrt(np.linalg.det(cov[1])) * 0.9, rtol=1e-6)
+    with pytest.raises(ValueError, match="no fast-kernel struct"):
+        m._pod()
+    with pytest.raises(ValueError):
+        gsd.MultivariateGaussianSum(means=np.zeros((1, 9)), covariances=np.array([np.eye(9)]), weights=np.array([1.0]))

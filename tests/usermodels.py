@@ -39,3 +39,22 @@ def loop_f(x, u, dt):
     for v in x:
         out.append(v * dt)
     return tuple(out)
+
+
+# ------------------------------------------------------------------------------ beyond the fast kernels' bounds (round 5)
+def six_state_f(x, u, dt):
+    """Six states, three inputs: a chain of first-order lags with a saturating product and a clipped decay."""
+    x1, x2, x3, x4, x5, x6 = x
+    r = x2 * x3 / (1.0 + x3)
+    d1 = (-0.1 * x1 + u[0]) * dt
+    d2 = (x1 - 0.2 * x2) * dt
+    d3 = (r - 0.05 * x3) * dt
+    d4 = (0.3 * x5 - x4 * u[1]) * dt
+    d5 = (u[2] - 0.3 * x5) * dt
+    d6 = (0.01 * x1 - 0.1 * min(x6, 2.0)) * dt
+    return d1, d2, d3, d4, d5, d6
+
+
+def six_state_g(x, u):
+    """Three outputs (one of them reads an input)."""
+    return x[0] + x[1], x[2] * x[3], x[5] + 0.1 * u[2]
