@@ -2045,6 +2045,9 @@ __global__ __launch_bounds__(kBlock) void pf_moments_kernel(const float* __restr
 // of 2^20 particles) is a chain of dependent trips to memory with ONE wavefront per SIMD and tile; halving the unit doubles the
 // wavefronts that wait side by side.  The half that does not begin a tile finds the count below its first key by re-forming
 // the key before it (the last key of the previous quarter: that thread's weights and prefix, the same operations).
+#ifndef GSE_MOMRES_PREFETCH
+#define GSE_MOMRES_PREFETCH 1    // unit i + 1's weights and prefixes requested before unit i's list is worked off
+#endif
 template <bool kQuarters, int kSplit = 1>
 __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                       const double* __restrict__ tile_sums,
@@ -2065,8 +2068,10 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
     static_assert(kSplit == 1 || kSplit == 2, "a unit is a tile or half a tile");
     // this wavefront's first unit: weights and prefixes requested before the tile prefix is built (they do not depend on it)
     const int unit0 = blockIdx.x * (kBlock / 64) + wv, units = T * kSplit;
-    float4 wq[kSubs];
-    double ex[kSubs];
+    // (requests go into the `next` set: a wavefront with several units -- many filters sharing the launch -- asks for unit i + 1
+    //  while it works unit i's list off, round 5)
+    float4 wq[kSubs], wq_next[kSubs];
+    double ex[kSubs], ex_next[kSubs];
     float4 wq_before = make_float4(0.f, 0.f, 0.f, 0.f);           // kSplit == 2, second half: the quad before the unit's first
     double ex_before = 0.0;
     auto request = [&](int unit) {
@@ -2075,8 +2080,8 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
         for (int sub = 0; sub < kSubs; ++sub) {
             const int t = (sub0 + sub) * 64 + lane;
             const int64_t k0 = (int64_t)tq * kTile + (int64_t)t * kPerThread;
-            wq[sub] = load_weights4(wb, k0, N, ld);
-            ex[sub] = qx[tq * kBlock + t];
+            wq_next[sub] = load_weights4(wb, k0, N, ld);
+            ex_next[sub] = qx[tq * kBlock + t];
         }
         if (kSplit > 1 && sub0 > 0) {                             // (uniform addresses: one request for the wavefront)
             const int t = sub0 * 64 - 1;
@@ -2152,8 +2157,10 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
     // tiles.  The states of a particle are fetched only if it has offspring: under the usual degenerate weights that is about
     // one particle in a hundred, so the pass moves ~6 bytes per particle (weights and tile prefixes) instead of 26.
     int2* mine = &items[wv][0];
-    for (int unit = unit0; valid && unit < units; unit += gridDim.x * (kBlock / 64)) {
-        if (unit != unit0) request(unit);
+    const int unit_stride = gridDim.x * (kBlock / 64);
+    for (int unit = unit0; valid && unit < units; unit += unit_stride) {
+#pragma unroll
+        for (int sub = 0; sub < kSubs; ++sub) { wq[sub] = wq_next[sub]; ex[sub] = ex_next[sub]; }
         const int tq = unit / kSplit, sub0 = (unit % kSplit) * kSubs;
         const double P0 = pfx_m[tq], P1 = pfx_m[tq + 1];
         const int64_t tile_last = min((int64_t)(tq + 1) * kTile, N) - 1;
@@ -2222,6 +2229,8 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
                 base += __popcll(m);
             }
         }
+        if (GSE_MOMRES_PREFETCH && kSplit == 1 && unit + unit_stride < units)
+            request(unit + unit_stride);                                                 // (in flight while the list is worked off)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2244,6 +2253,7 @@ __global__ __launch_bounds__(kBlock) void pf_moments_resampled_kernel(const floa
             if (two) add_particle(xv1, it1.y);
         }
         __builtin_amdgcn_wave_barrier();                                  // (the list is rewritten for the next unit)
+        if ((kSplit > 1 || !GSE_MOMRES_PREFETCH) && unit + unit_stride < units) request(unit + unit_stride);
     }
     GSE_MSTAMP(3, blockIdx.x == GSE_STAMPS);
     if (!valid && blockIdx.x == 0 && tid == 0) {
