@@ -755,7 +755,7 @@ def main():
                 "value": round(float(world) * n * steps / elapsed_est / UNIT_PARTICLES, 2),
                 "unit": "cycles/s per 2^20 particles", "ms_per_step": round(elapsed_est / steps * 1e3, 5),
                 "collectives_in_timed_region": int(collectives_est),
-                "launches_per_cycle": 2 if world == 1 else 3,
+                "launches_per_cycle": 3 if use_dist else 2,      # (+ the all-reduce's own kernel with a process group)
                 "frac_of_164B_per_particle": round(164.0 * n * steps / elapsed_est / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "every cycle ends in the posterior merge over all ranks, nothing flushed: the cycle's one launch, then "
                         "gse_pf_merge_begin (moments of the ensemble the pending resample will produce; the launch's last workgroup "
