@@ -574,9 +574,12 @@ def main():
     #      (combination + estimate); a single shard is combined by the first launch.  The merged moments of every cycle go to
     #      a record row; the covariance sizes of all rows come from one gse_moments_estimates call at the end of the region, as
     #      in the resident closed loops.  Stream-ordered, nothing comes to the host.  Same bracket as above.
-    io2 = make_inputs(steps + 5, dt, seed=11)
-    record = torch.zeros((steps + 5, 26), dtype=torch.float64, device="cuda")
-    sizes = torch.zeros((steps + 5, 6), dtype=torch.float64, device="cuda")
+    # (its own count of timed cycles, at least 200: at the driver's K = 20 the region's two ends and the one call that turns the
+    #  recorded rows into covariance sizes would be a quarter of what is measured -- `fresh_prior` does the same for the kernel)
+    est_steps = max(steps, 200)
+    io2 = make_inputs(est_steps + 5, dt, seed=11)
+    record = torch.zeros((est_steps + 5, 26), dtype=torch.float64, device="cuda")
+    sizes = torch.zeros((est_steps + 5, 6), dtype=torch.float64, device="cuda")
     from gpu_se_amd import _lib as _gl
 
     def cycle_with_estimate(i):
@@ -586,11 +589,11 @@ def main():
         pf.resample()
         pf.merge_begin(into=record[i])
         pf.merge_end()
-        if i == steps + 4:
-            _gl.call("gse_moments_estimates", record.data_ptr(), steps + 5, sizes.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if i == est_steps + 4:
+            _gl.call("gse_moments_estimates", record.data_ptr(), est_steps + 5, sizes.data_ptr(), torch.cuda.current_stream().cuda_stream)
     for i in range(5):
         cycle_with_estimate(i)
-    elapsed_est, collectives_est = bracket(cycle_with_estimate, 5, steps, pf)
+    elapsed_est, collectives_est = bracket(cycle_with_estimate, 5, est_steps, pf)
     est_rows = sizes.cpu().numpy()
     assert np.all(np.isfinite(est_rows)) and np.all(est_rows[:, 5] > 0), "merged estimates are not finite"
     assert np.allclose(est_rows[-1, :5], pf.estimate_device.cpu().numpy()[:5], rtol=1e-12)
@@ -752,11 +755,12 @@ def main():
             "particles_per_s": round(particle_cycles, 1),
             "collectives_in_timed_region": int(collectives_timed),
             "with_estimate_every_cycle": {
-                "value": round(float(world) * n * steps / elapsed_est / UNIT_PARTICLES, 2),
-                "unit": "cycles/s per 2^20 particles", "ms_per_step": round(elapsed_est / steps * 1e3, 5),
+                "value": round(float(world) * n * est_steps / elapsed_est / UNIT_PARTICLES, 2),
+                "unit": "cycles/s per 2^20 particles", "ms_per_step": round(elapsed_est / est_steps * 1e3, 5),
+                "timed_cycles": est_steps,
                 "collectives_in_timed_region": int(collectives_est),
                 "launches_per_cycle": 3 if use_dist else 2,      # (+ the all-reduce's own kernel with a process group)
-                "frac_of_164B_per_particle": round(164.0 * n * steps / elapsed_est / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_of_164B_per_particle": round(164.0 * n * est_steps / elapsed_est / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "every cycle ends in the posterior merge over all ranks, nothing flushed: the cycle's one launch, then "
                         "gse_pf_merge_begin (moments of the ensemble the pending resample will produce; the launch's last workgroup "
                         "finishes them and writes the shard's row), all-reduce of [P][22] doubles (RCCL, async), gse_merge_end "
