@@ -429,8 +429,13 @@ class BatchedSimulation:
         dev = f._w.device
         ticks = len(self.ts)
         f64 = dict(dtype=torch.float64, device=dev)
-        X = torch.as_tensor(self.X, **f64).contiguous()
-        u = torch.as_tensor(self.us[0], **f64).contiguous()             # the current input of every rollout
+        # (the loop's initial values in ONE host -> device copy: state, input, outputs, the estimator's measurement)
+        ys0 = numpy.asarray(self.ys[0], dtype=numpy.float64).reshape(B, 5)
+        init = torch.as_tensor(numpy.ascontiguousarray(numpy.concatenate(
+            [numpy.asarray(self.X, dtype=numpy.float64).reshape(B, 5), numpy.asarray(self.us[0], dtype=numpy.float64).reshape(B, 2),
+             ys0, ys0[:, _OUTPUTS]], axis=1)), **f64)
+        X = init[:, 0:5].contiguous()
+        u = init[:, 5:7].contiguous()                                    # the current input of every rollout
         # every per-tick record lives in ONE device buffer (carved below) and comes back in one copy at the end
         widths = dict(us=2, xs=5, ys=5, ys_meas=5, moments=26)
         flat = torch.zeros((ticks * B * sum(widths.values()),), **f64)
@@ -439,10 +444,9 @@ class BatchedSimulation:
             hist[name] = flat[at:at + ticks * B * wdt].view(ticks, B, wdt)
             at += ticks * B * wdt
         us, xs, ys, ys_meas, moments = (hist[k] for k in ("us", "xs", "ys", "ys_meas", "moments"))
-        z = torch.zeros((B, 2), **f64)
+        z = init[:, 12:14].contiguous()
         us[0], xs[0] = u, X
-        ys[0] = ys_meas[0] = torch.as_tensor(self.ys[0], **f64)
-        z.copy_(ys_meas[0][:, _OUTPUTS])
+        ys[0] = ys_meas[0] = init[:, 7:12]
         y_pred, known, _ = K.loop_state(B, dev)
         status = torch.zeros((ticks, B), dtype=torch.int32, device=dev)      # one row per tick, written by the controller
         n_control, last_control = 0, -1
@@ -541,6 +545,15 @@ class BatchedSimulation:
                 record_moments(t)
         return self._finish_resident(lib, torch, time, flat, widths, moments, status, control_ticks, n_control, ev0, ev1, clock,
                                      f64, stream)
+
+    @property
+    def moments(self):
+        """The estimator's moment rows of a resident run, (ticks, B, 26) doubles (gse_pf_moments layout), fetched from the device
+        on first use."""
+        if getattr(self, "_moments_host", None) is None and getattr(self, "_moments_device", None) is not None:
+            self._moments_host = self._moments_device.cpu().numpy()
+            self._moments_device = None
+        return getattr(self, "_moments_host", None)
 
     def _schedule(self):
         """(schedule [ticks] uint8: bit 0 a predict is due, bit 1 the controller acts -- sim_base.py:250, :255; control ticks)."""
@@ -683,7 +696,11 @@ class BatchedSimulation:
         torch.cuda.synchronize()
         clock.append(time.perf_counter())
         device_s = ev0.elapsed_time(ev1) * 1e-3
-        host = flat.cpu().numpy()
+        # (the moment rows -- 26 of a tick's 43 doubles, kept for whoever wants them -- stay on the device until somebody asks:
+        #  ``moments`` fetches them; the records the reference's loop keeps come back now, in one copy)
+        eager = ticks * B * sum(wdt for name, wdt in widths.items() if name != "moments")
+        assert list(widths)[-1] == "moments"
+        host = flat[:eager].cpu().numpy()
         est6 = estimates.cpu().numpy().reshape(ticks, B, 6)
         if self.pf:
             # a resample that met a weight sum that is not finite (the stored fp32 weights overflowed their power-of-two scale)
@@ -692,9 +709,11 @@ class BatchedSimulation:
         clock.append(time.perf_counter())
         back, at = {}, 0
         for name, wdt in widths.items():
+            if name == "moments":
+                continue
             back[name] = host[at:at + ticks * B * wdt].reshape(ticks, B, wdt)
             at += ticks * B * wdt
-        self.moments = back["moments"]                # (kept: rows of 26 doubles per tick and rollout)
+        self._moments_device, self._moments_host = moments, None      # (rows of 26 doubles per tick and rollout: see ``moments``)
         self.us, self.xs, self.ys, self.ys_meas = back["us"], back["xs"], back["ys"], back["ys_meas"]
         self.X = self.xs[-1].copy()
         est = est6[..., :5]
