@@ -619,6 +619,21 @@ def main():
         el4, coll4 = bracket(cycle4, warmup, steps, pf4)
         est4 = pf4.point_estimate()
         assert np.all(np.isfinite(est4)), est4
+        # ... and the same shape with the posterior merge at the end of every cycle (what a loop around config 4 would run)
+        rec4 = torch.zeros((est_steps + 5, 26), dtype=torch.float64, device="cuda")
+        io4e = make_inputs(est_steps + 5, dt, seed=22)
+
+        def cycle4_est(i):
+            u, z = io4e[i]
+            pf4.predict(u, dt)
+            pf4.update(u, z)
+            pf4.resample()
+            pf4.merge_begin(into=rec4[i])
+            pf4.merge_end()
+        for i in range(5):
+            cycle4_est(i)
+        el4e, coll4e = bracket(cycle4_est, 5, est_steps, pf4)
+        assert np.all(np.isfinite(rec4[-1].cpu().numpy()))
         config4 = {"workload": "PF N=2^%d particles sharded over %d ranks (2^21 per rank%s), island resampling, posterior merge at "
                                "the end" % (21 + int(np.log2(world)) if (world & (world - 1)) == 0 else 0, world,
                                             ": BASELINE config 4" if world == 8 else ""),
@@ -626,7 +641,10 @@ def main():
                    "ms_per_step": round(el4 / steps * 1e3, 5), "ensemble_cycles_per_s": round(steps / el4, 2),
                    "value": round(float(world) * n4 * steps / el4 / UNIT_PARTICLES, 2), "unit": "cycles/s per 2^20 particles",
                    "collectives_in_timed_region": int(coll4), "exact_resamples": pf4.exact_resamples,
-                   "frac_vs_reference_passes": round(140.0 * n4 * steps / el4 / 1e9 / HBM_PEAK_GBS, 4)}
+                   "frac_vs_reference_passes": round(140.0 * n4 * steps / el4 / 1e9 / HBM_PEAK_GBS, 4),
+                   "with_estimate_every_cycle": {"ms_per_step": round(el4e / est_steps * 1e3, 5), "timed_cycles": est_steps,
+                                                 "collectives_in_timed_region": int(coll4e),
+                                                 "frac_of_164B_per_particle": round(164.0 * n4 * est_steps / el4e / 1e9 / HBM_PEAK_GBS, 4)}}
         del pf4
         # config 5: 256 closed-loop rollouts x 2^18 particles on 8 GPUs = 32 rollouts per rank, independent replicas (seed =
         # base + rank), no collective until the final gather of the ITSE scalars
