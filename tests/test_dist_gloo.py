@@ -260,3 +260,65 @@ def test_island_policy_reads_the_shares_at_a_fixed_lag():
         assert shard.shares_lag == lag
     shard._shares_event = None                                # host groups (gloo): the old one-cycle lag
     assert shard.shares_lag == 1
+
+
+# ------------------------------------------------------------------------------ the comm interface (round 5)
+def _comm_ops(comm, rank, world):
+    """The five collectives of gpu_se_amd.distributed.TorchComm's interface on small host tensors: what a rank ends up with."""
+    t = torch.zeros(world, dtype=torch.float64)
+    t[rank] = rank + 1.5
+    work = comm.all_reduce(t, async_op=True)
+    work.wait()
+    s = torch.full((3,), float(rank))
+    comm.all_reduce(s)
+    parts = [torch.empty(2) for _ in range(world)]
+    comm.all_gather(parts, torch.tensor([float(rank), 10.0 * rank]))
+    send = [(rank + q) % 3 + 1 for q in range(world)]
+    recv = [(p + rank) % 3 + 1 for p in range(world)]
+    src = torch.arange(sum(send), dtype=torch.float32).reshape(-1, 1).repeat(1, 5) + 100 * rank
+    dst = torch.empty((sum(recv), 5), dtype=torch.float32)
+    comm.all_to_all_single(dst, src, recv, send)
+    return t.tolist(), s.tolist(), [p.tolist() for p in parts], dst[:, 0].tolist(), (comm.rank, comm.world, comm.backend)
+
+
+def _comm_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out[rank] = _comm_ops(gd.TorchComm(dist.group.WORLD), rank, world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_comm_interface_over_gloo_and_between_threads():
+    """ShardedParticleFilter / ShardedGaussianSumFilter talk to their peers through five methods (gpu_se_amd.distributed.TorchComm
+    on a torch.distributed group; round 5).  The -m gpu tests drive EIGHT shards from eight threads of one process through a
+    stand-in with the same interface (tests/gpu_util.ThreadComm: a GPU box admits six processes on its card) -- here the two are
+    held to each other on the CPU: world size 2 over gloo (processes) and world size 2 and 8 between threads give every rank the
+    same sums, the same gathered parts and the same all-to-all pieces."""
+    import threading
+    from tests.gpu_util import ThreadComm, ThreadWorld
+    manager = mp.Manager()
+    out = manager.dict()
+    mp.spawn(_comm_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for world in (2, 8):
+        shared = ThreadWorld(world)
+        got = {}
+        threads = [threading.Thread(target=lambda r=r: got.__setitem__(r, _comm_ops(ThreadComm(shared, r), r, world))) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert sorted(got) == list(range(world))
+        for r in range(world):
+            red, s, parts, a2a, ident = got[r]
+            assert red == [p + 1.5 for p in range(world)] and s == [float(sum(range(world)))] * 3
+            assert parts == [[float(p), 10.0 * p] for p in range(world)] and ident == (r, world, "thread")
+            want = []
+            for p in range(world):                                  # rank p sends rows [lo, lo + cnt) of its source to rank r
+                sendp = [(p + q) % 3 + 1 for q in range(world)]
+                lo = sum(sendp[:r])
+                want += [float(100 * p + k) for k in range(lo, lo + sendp[r])]
+            assert a2a == want
+            if world == 2:
+                assert out[r][:4] == got[r][:4] and out[r][4] == (r, 2, "gloo")
